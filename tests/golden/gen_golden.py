@@ -1,0 +1,308 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors by RUNNING THE REFERENCE'S OWN CODE in this container.
+
+    python tests/golden/gen_golden.py            # writes tests/golden/*.npz
+
+Imports the reference's hot-path modules from /root/reference through `refshim.py` (stand-ins for the
+un-installed detectron2/fvcore/timm/torchvision names; nothing is copied), feeds them synthetic
+inputs/weights produced by `synth.py` (so the tests can regenerate the same inputs without the
+reference), and stores inputs (small cases) and expected outputs (full tensors or digests).
+The reference cannot travel to the GPU box; these fixtures can.
+
+What each file pins:
+  msda_core.npz   a6   ms_deform_attn_core_pytorch fwd + autograd grads; ops/test.py cases (seed 3)
+  pe_sine.npz     a3   PositionEmbeddingSine
+  sem_mix.npz     a1   channel_weighted_block + the SEM mix line (maskformer_model.py:345-352)
+  head.npz        a2,a4,a5,a7-a13  MaskFormerHead forward at BT=5, R50-S4 shapes, eval mode
+  criterion.npz   a14-a16 matcher indices + 39 losses (S4 / all-frames / AVSS variants) + grad digests
+  inference.npz   a17  inference tail
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import refshim  # noqa: E402
+import synth  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def save(name, out):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {os.path.getsize(path) / 1e6:.2f} MB, {len(out)} arrays")
+
+
+# ----------------------------------------------------------------------------------------------------
+def gen_msda_core(R):
+    out = {}
+    core = R.ms_deform_attn_core_pytorch
+
+    def run_case(tag, value, shapes, loc, w, grad_out=None, full=True, dtype=torch.float64):
+        value = value.to(dtype).requires_grad_(True)
+        loc = loc.to(dtype).requires_grad_(True)
+        w = w.to(dtype).requires_grad_(True)
+        o = core(value, shapes, loc, w)
+        if grad_out is None:
+            grad_out = synth.synth_tensor(tag + ".grad_out", tuple(o.shape), 0).to(dtype)
+        gv, gl, gw = torch.autograd.grad(o, (value, loc, w), grad_out.to(dtype))
+        if full:
+            out[f"{tag}/value"] = value.detach().numpy()
+            out[f"{tag}/loc"] = loc.detach().numpy()
+            out[f"{tag}/w"] = w.detach().numpy()
+            out[f"{tag}/shapes"] = shapes.numpy()
+            out[f"{tag}/grad_out"] = grad_out.numpy()
+            out[f"{tag}/out"] = o.detach().numpy()
+            out[f"{tag}/grad_value"] = gv.numpy()
+            out[f"{tag}/grad_loc"] = gl.numpy()
+            out[f"{tag}/grad_w"] = gw.numpy()
+        else:
+            for nm, t in (("out", o), ("grad_value", gv), ("grad_loc", gl), ("grad_w", gw)):
+                synth.pack(f"{tag}/{nm}", synth.digest(t, f"{tag}/{nm}"), out)
+
+    # --- the reference's own unit-test cases: ops/test.py:24-31 (N,M,D=1,2,2; Lq,L,P=2,2,2; seed 3) ---
+    N, M, D = 1, 2, 2
+    Lq, L, P = 2, 2, 2
+    shapes = torch.as_tensor([(6, 4), (3, 2)], dtype=torch.long)
+    S = int(shapes.prod(1).sum())
+    torch.manual_seed(3)
+
+    def draw(ch):
+        value = torch.rand(N, S, M, ch) * 0.01
+        loc = torch.rand(N, Lq, M, L, P, 2)
+        w = torch.rand(N, Lq, M, L, P) + 1e-5
+        w = w / w.sum(-1, keepdim=True).sum(-2, keepdim=True)
+        return value, loc, w
+
+    v, l, w = draw(D)  # check_forward_equal_with_pytorch_double  (test.py:34-53)
+    run_case("t_double", v, shapes, l, w, dtype=torch.float64)
+    v, l, w = draw(D)  # check_forward_equal_with_pytorch_float   (test.py:56-71)
+    run_case("t_float", v, shapes, l, w, dtype=torch.float32)
+    for ch in [30, 32, 64, 71, 1025]:  # check_gradient_numerical    (test.py:74-96)
+        v, l, w = draw(ch)
+        run_case(f"t_grad{ch}", v, shapes, l, w, dtype=torch.float64)
+
+    # --- edge cases: samples on / outside the border (zero padding, .cuh:290-296) ---
+    shapes_e = torch.as_tensor([(5, 7), (2, 3)], dtype=torch.long)
+    S_e = int(shapes_e.prod(1).sum())
+    v = synth.synth_tensor("edge.value", (2, S_e, 2, 4), 0)
+    pts = torch.tensor([0.0, 1.0, 0.5, -0.01, 1.01, 5.0, -3.0, 0.5 / 7, 1 - 0.5 / 7, 0.999999, 1e-7, 0.25])
+    xs, ys = torch.meshgrid(pts, pts, indexing="ij")
+    grid = torch.stack([xs.reshape(-1), ys.reshape(-1)], -1)  # [144,2]
+    Lq_e = 9
+    loc = grid.view(1, Lq_e, 2, 2, 4, 2).repeat(2, 1, 1, 1, 1, 1).contiguous()
+    loc[1] = loc[1].flip(1)
+    w = synth.synth_tensor("edge.w", (2, Lq_e, 2, 2, 4), 0, kind="unit") + 0.1
+    w = w / w.sum((-1, -2), keepdim=True)
+    run_case("edge", v, shapes_e, loc, w, dtype=torch.float64)
+
+    # --- production shape (R50-S4 @224: S=Lq=1029, M=8, D=32, L=3, P=4), BT=2, digests only ---
+    shapes_p = torch.as_tensor([(7, 7), (14, 14), (28, 28)], dtype=torch.long)
+    B, S_p = 2, 1029
+    v = synth.synth_tensor("prod.value", (B, S_p, 8, 32), 0)
+    refp = synth.synth_tensor("prod.ref", (B, S_p, 1, 1, 1, 2), 0, kind="unit")
+    off = synth.synth_tensor("prod.off", (B, S_p, 8, 3, 4, 2), 0, scale=2.5)
+    norm = torch.stack([shapes_p[:, 1], shapes_p[:, 0]], -1).float()
+    loc = refp + off / norm[None, None, None, :, None, :]
+    w = torch.softmax(synth.synth_tensor("prod.w", (B, S_p, 8, 12), 0), -1).view(B, S_p, 8, 3, 4)
+    run_case("prod", v, shapes_p, loc, w, full=False, dtype=torch.float32)
+    out["prod/shapes"] = shapes_p.numpy()
+    save("msda_core.npz", out)
+
+
+# ----------------------------------------------------------------------------------------------------
+def gen_pe(R):
+    out = {}
+    pe = R.PositionEmbeddingSine(128, normalize=True)
+    for hw in (7, 14, 28, 56):
+        x = torch.zeros(1, 256, hw, hw)
+        p = pe(x)
+        if hw <= 7:
+            out[f"pe{hw}/full"] = p.numpy()
+        synth.pack(f"pe{hw}", synth.digest(p, f"pe{hw}"), out)
+    x = torch.zeros(2, 8, 5, 9)  # non-square, batch 2
+    out["pe5x9/full"] = pe(x).numpy()
+    save("pe_sine.npz", out)
+
+
+def gen_sem_mix(R):
+    out = {}
+    for dim in (256, 512):
+        blk = R.channel_weighted_block(dim)
+        spec = [(k, tuple(v.shape)) for k, v in blk.state_dict().items()]
+        blk.load_state_dict({k: synth.synth_param(f"sem{dim}." + k, s) for k, s in spec})
+        f = synth.synth_tensor(f"sem{dim}.f", (3, dim, 6, 5), 0)
+        p = synth.synth_tensor(f"sem{dim}.p", (3, dim, 6, 5), 0)
+        with torch.no_grad():
+            s = blk(p)
+            mixed = f + s * p  # maskformer_model.py:352
+        out[f"sem{dim}/spec"] = np.array(json.dumps(spec))
+        out[f"sem{dim}/gate"] = s.numpy()
+        out[f"sem{dim}/mixed"] = mixed.numpy()
+    save("sem_mix.npz", out)
+
+
+# ----------------------------------------------------------------------------------------------------
+from gen_inputs import BT, HEAD_SEED, head_inputs, make_targets  # noqa: E402
+
+
+def clone_outputs(o):
+    return {
+        "pred_logits": o["pred_logits"], "pred_masks": o["pred_masks"],
+        "aux_outputs": [dict(a) for a in o["aux_outputs"]],
+        "middles_attn_mask": list(o["middles_attn_mask"]),
+    }
+
+
+def gen_head_and_criterion(R):
+    out = {}
+    head = refshim.build_head(num_classes=2)
+    head.eval()
+    spec = [(k, tuple(v.shape)) for k, v in head.state_dict().items()]
+    sd = synth.synth_state_dict(spec, HEAD_SEED)
+    head.load_state_dict(sd)
+    out["spec"] = np.array(json.dumps(spec))
+
+    feats, audio = head_inputs()
+    for v in feats.values():
+        v.requires_grad_(True)
+    audio.requires_grad_(True)
+
+    # record the per-head attention masks (transformer_decoder.py:502-507)
+    rec = {"attn": [], "attn_live": []}
+    fph = head.predictor.forward_prediction_heads
+
+    def wrapped(output, mask_features, attn_mask_target_size):
+        c, m, a = fph(output, mask_features, attn_mask_target_size)
+        rec["attn"].append(a.clone())  # as produced by the head
+        rec["attn_live"].append(a)  # mutated in place by the row-reset of the NEXT layer (:458)
+        return c, m, a
+    head.predictor.forward_prediction_heads = wrapped
+
+    # ---- MaskFormerHead.layers, step by step (mask_former_head.py:141-159) ----
+    mask_features, enc_feat, multi_scale = head.pixel_decoder.forward_features(dict(feats))
+    synth.pack("pd/mask_features", synth.digest(mask_features, "pd/mask_features"), out)
+    for i, m in enumerate(multi_scale):
+        synth.pack(f"pd/ms{i}", synth.digest(m, f"pd/ms{i}"), out)
+    fused = head.fusion_module({"res2": mask_features}, audio)
+    fv, fa = fused["visual"]["res2"], fused["audio"]
+    synth.pack("fuse/visual", synth.digest(fv, "fuse/visual"), out)
+    out["fuse/audio"] = fa.detach().numpy()
+    a256 = head.audio_transformation(fa)
+    out["fuse/audio256"] = a256.detach().numpy()
+    pred = head.predictor(multi_scale, a256, fv, None)
+
+    logits = [a["pred_logits"] for a in pred["aux_outputs"]] + [pred["pred_logits"]]
+    masks = [a["pred_masks"] for a in pred["aux_outputs"]] + [pred["pred_masks"]]
+    out["dec/pred_logits"] = torch.stack(logits).detach().numpy()  # [10,BT,100,3]
+    for i, m in enumerate(masks):
+        synth.pack(f"dec/pred_masks{i}", synth.digest(m, f"dec/pred_masks{i}"), out)
+    out["dec/attn_true_count"] = np.array([int(a.sum()) for a in rec["attn"]], dtype=np.int64)
+    out["dec/attn_used_true_count"] = np.array([int(a.sum()) for a in rec["attn_live"]], dtype=np.int64)
+    # packed bits of head#0's mask for frame 0, head 0  [100, 49]
+    out["dec/attn0_bits"] = np.packbits(rec["attn"][0][0].numpy().astype(np.uint8))
+    assert len(pred["middles_attn_mask"]) == 9
+    save("head.npz", out)
+
+    # ---- inference tail (maskformer_model.py:393-402, 460-464) ----
+    inf = {}
+    with torch.no_grad():
+        up = F.interpolate(pred["pred_masks"], size=(224, 224), mode="bilinear", align_corners=False)
+        sem = torch.stack([torch.einsum("qc,qhw->chw", F.softmax(c, dim=-1)[..., :-1], m.sigmoid())
+                           for c, m in zip(pred["pred_logits"], up)])
+    synth.pack("sem_seg", synth.digest(sem, "sem_seg"), inf)
+    inf["sem_seg_frame0_ds"] = sem[0, :, ::8, ::8].numpy()
+    save("inference.npz", inf)
+
+    # ---- criterion (criterion.py:233-287 / criterion_ss.py:238-289) ----
+    crit = {}
+    weights = {"loss_ce": 2.0, "loss_mask": 5.0, "loss_dice": 5.0, "loss_cosine": 10.0}
+    wd = dict(weights)
+    for i in range(9):
+        wd.update({f"{k}_{i}": v for k, v in weights.items()})
+    matcher = R.HungarianMatcher(cost_class=2.0, cost_mask=5.0, cost_dice=5.0, num_points=12544)
+
+    def mk(cls):
+        return cls(2, matcher=matcher, weight_dict=wd, eos_coef=0.1, losses=["labels", "masks"],
+                   num_points=12544, oversample_ratio=3.0, importance_sample_ratio=0.75)
+
+    grad_params = [
+        "predictor.query_feat.weight", "predictor.mask_embed.layers.2.weight",
+        "predictor.transformer_cross_attention_layers.0.multihead_attn.in_proj_weight",
+        "pixel_decoder.transformer.encoder.layers.0.self_attn.sampling_offsets.weight",
+        "pixel_decoder.transformer.encoder.layers.5.self_attn.value_proj.weight",
+        "pixel_decoder.input_proj.0.0.weight", "pixel_decoder.layer_1.weight",
+        "fusion_module.b_attn.attn_list.0.v_proj.weight", "fusion_module.b_attn.gamma_a",
+        "fusion_module.b_attn.attn_list.0.values_v_proj.weight",
+        "audio_transformation.embeddings.0.weight", "predictor.class_embed.weight",
+    ]
+    named = dict(head.named_parameters())
+
+    for mode, cls in (("s4", R.SetCriterion), ("all", R.SetCriterion), ("ss", R.SetCriterion_SS)):
+        criterion = mk(cls)
+        torch.manual_seed(11)
+        o = clone_outputs(pred)
+        if mode == "ss":
+            gt_flag = torch.tensor([1, 0, 1, 1, 0])
+            vid_flag = torch.ones(5)
+            t_all = make_targets("all")
+            targets = [t_all[i] for i in range(5) if gt_flag[i] == 1]
+            losses = criterion(o, targets, vid_flag, gt_flag)
+            crit["ss/gt_flag"] = gt_flag.numpy()
+        else:
+            targets = make_targets(mode)
+            losses = criterion(o, targets)
+        keys = sorted(losses.keys())
+        assert len(keys) == 39, len(keys)
+        crit[f"{mode}/keys"] = np.array(json.dumps(keys))
+        crit[f"{mode}/values"] = np.array([float(losses[k]) for k in keys], dtype=np.float64)
+        total = sum(losses[k] * wd[k] for k in keys)  # maskformer_model.py:384-391
+        crit[f"{mode}/total"] = np.float64(float(total))
+        # matcher indices of the final layer, same RNG state as inside forward
+        torch.manual_seed(11)
+        o2 = clone_outputs(pred)
+        if mode == "s4":
+            sel = torch.arange(0, BT, 5)
+            fin = {"pred_logits": o2["pred_logits"][sel], "pred_masks": o2["pred_masks"][sel]}
+        elif mode == "ss":
+            sel = torch.where(gt_flag == 1)[0]
+            fin = {"pred_logits": o2["pred_logits"][sel], "pred_masks": o2["pred_masks"][sel]}
+        else:
+            fin = {"pred_logits": o2["pred_logits"], "pred_masks": o2["pred_masks"]}
+        idx = matcher(fin, targets)
+        crit[f"{mode}/match_src"] = np.stack([i.numpy() for i, _ in idx])
+        crit[f"{mode}/match_tgt"] = np.stack([j.numpy() for _, j in idx])
+        if mode in ("s4", "all"):
+            gi = list(feats.values()) + [audio] + [named[n] for n in grad_params]
+            grads = torch.autograd.grad(total, gi, retain_graph=True, allow_unused=True)
+            names = [f"feat.{k}" for k in feats] + ["feat.audio"] + grad_params
+            for n, g in zip(names, grads):
+                synth.pack(f"{mode}/grad/{n}", synth.digest(g, f"{mode}/grad/{n}"), crit)
+    crit["grad_params"] = np.array(json.dumps(grad_params))
+    save("criterion.npz", crit)
+
+
+def main():
+    R = refshim.ref()
+    which = sys.argv[1:] or ["msda", "pe", "sem", "head"]
+    with torch.no_grad():
+        pass
+    if "msda" in which:
+        gen_msda_core(R)
+    if "pe" in which:
+        with torch.no_grad():
+            gen_pe(R)
+    if "sem" in which:
+        gen_sem_mix(R)
+    if "head" in which:
+        gen_head_and_criterion(R)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,124 @@
+"""Deterministic synthetic weights / inputs / digests shared by the golden generator and the tests.
+
+Test tooling only.  Nothing here comes from the reference: state-dict *names and shapes* are recorded
+in the fixtures by `gen_golden.py`; the values are produced here from a name-derived seed so that the
+39 M-parameter head never has to be committed.  Large expected outputs are stored as *digests*
+(a fixed pseudo-random sample of entries + mean + L2 norm) instead of full tensors.
+"""
+import hashlib
+import math
+
+import numpy as np
+import torch
+
+
+def _seed_of(name: str, seed: int) -> int:
+    h = hashlib.sha256(f"{seed}:{name}".encode()).digest()
+    return int.from_bytes(h[:8], "little")
+
+
+def rng_of(name: str, seed: int = 0) -> np.random.Generator:
+    return np.random.default_rng(_seed_of(name, seed))
+
+
+def synth_tensor(name, shape, seed=0, kind="normal", scale=1.0, dtype=torch.float32):
+    g = rng_of(name, seed)
+    if kind == "normal":
+        a = g.standard_normal(size=shape, dtype=np.float32) * scale
+    elif kind == "uniform":  # U(-scale, scale)
+        a = (g.random(size=shape, dtype=np.float32) * 2.0 - 1.0) * scale
+    elif kind == "unit":  # U(0,1)
+        a = g.random(size=shape, dtype=np.float32)
+    else:
+        raise ValueError(kind)
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dtype)
+
+
+def synth_param(name, shape, seed=0):
+    """Value rule per parameter name.  Chosen so that every term of the hot path is numerically
+    visible in the outputs (e.g. layer-scale gammas are O(0.3) instead of the 1e-4 init, the
+    deformable offsets get a real weight matrix instead of zeros)."""
+    shape = tuple(shape)
+    leaf = name.split(".")[-1]
+    if "gamma" in name:  # b_attn.gamma_a, b_attn.gamma_v_list.0
+        return 0.3 + 0.1 * synth_tensor(name, shape, seed)
+    if name.endswith("sampling_offsets.bias"):
+        # the 8-direction / 1..P-pixel pattern of ms_deform_attn.py:68-84 plus noise
+        n_heads, n_points = 8, 4
+        n_levels = shape[0] // (n_heads * n_points * 2)
+        thetas = torch.arange(n_heads, dtype=torch.float32) * (2.0 * math.pi / n_heads)
+        grid = torch.stack([thetas.cos(), thetas.sin()], -1)
+        grid = (grid / grid.abs().max(-1, keepdim=True)[0]).view(n_heads, 1, 1, 2).repeat(1, n_levels, n_points, 1)
+        for i in range(n_points):
+            grid[:, :, i, :] *= i + 1
+        return grid.reshape(-1) + 0.25 * synth_tensor(name, shape, seed)
+    if name.endswith("sampling_offsets.weight"):
+        return synth_tensor(name, shape, seed, scale=0.05)
+    if name.endswith("attention_weights.weight"):
+        return synth_tensor(name, shape, seed, scale=0.1)
+    if ("norm" in name or name.endswith(".1.weight") or name.endswith(".1.bias")) and len(shape) == 1:
+        # LayerNorm / GroupNorm affine (input_proj.{i}.1 is the GroupNorm)
+        if leaf == "weight":
+            return 1.0 + 0.1 * synth_tensor(name, shape, seed)
+        return 0.1 * synth_tensor(name, shape, seed)
+    if len(shape) >= 2:
+        if leaf == "weight" and ("query_feat" in name or "query_embed" in name or "level_embed" in name or "audio_pos" in name):
+            return synth_tensor(name, shape, seed)  # nn.Embedding ~ N(0,1)
+        if name.endswith("level_embed"):
+            return synth_tensor(name, shape, seed)
+        fan_out = shape[0] * int(np.prod(shape[2:])) if len(shape) > 2 else shape[0]
+        fan_in = shape[1] * int(np.prod(shape[2:])) if len(shape) > 2 else shape[1]
+        bound = math.sqrt(6.0 / (fan_in + fan_out))
+        return synth_tensor(name, shape, seed, kind="uniform", scale=bound)
+    if leaf == "empty_weight":
+        raise KeyError(name)
+    return 0.02 * synth_tensor(name, shape, seed)  # biases
+
+
+def synth_state_dict(spec, seed=0):
+    """spec: iterable of (name, shape) -> {name: tensor}"""
+    return {n: synth_param(n, s, seed) for n, s in spec}
+
+
+def digest_indices(numel, k, name):
+    g = rng_of("digest:" + name, 1234)
+    k = min(k, numel)
+    return np.sort(g.choice(numel, size=k, replace=False)) if numel > k else np.arange(numel)
+
+
+def digest(t: torch.Tensor, name: str, k: int = 4096):
+    """-> dict of numpy arrays: sample (at fixed pseudo-random flat indices), mean, l2, shape."""
+    t = t.detach().to(torch.float64).reshape(-1).cpu()
+    idx = digest_indices(t.numel(), k, name)
+    return {
+        "sample": t[torch.from_numpy(idx)].numpy().astype(np.float32 if k else np.float64),
+        "mean": np.float64(t.mean().item()),
+        "l2": np.float64(t.norm().item()),
+        "numel": np.int64(t.numel()),
+    }
+
+
+def check_digest(t: torch.Tensor, d, name: str, rtol: float, atol: float, k: int = 4096, frac_bad: float = 0.0):
+    """Assert tensor `t` reproduces digest `d` (as returned by digest() / loaded from npz with prefix)."""
+    got = digest(t, name, k)
+    assert int(got["numel"]) == int(d["numel"]), f"{name}: numel {got['numel']} != {d['numel']}"
+    a, b = got["sample"].astype(np.float64), np.asarray(d["sample"]).astype(np.float64)
+    err = np.abs(a - b)
+    tol = atol + rtol * np.abs(b)
+    bad = float((err > tol).mean())
+    assert bad <= frac_bad, f"{name}: {bad * 100:.3f}% of sampled entries exceed tol (max err {err.max():.3e})"
+    scale = max(abs(float(d["l2"])), 1e-12)
+    if frac_bad == 0.0:
+        assert abs(float(got["l2"]) - float(d["l2"])) <= (rtol * 10) * scale + atol, \
+            f"{name}: l2 {got['l2']} vs {d['l2']}"
+    return float(err.max())
+
+
+def pack(prefix, d, out):
+    for k, v in d.items():
+        out[f"{prefix}/{k}"] = np.asarray(v)
+
+
+def unpack(prefix, z):
+    p = prefix + "/"
+    return {k[len(p):]: z[k] for k in z.files if k.startswith(p)}
