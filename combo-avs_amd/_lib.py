@@ -1,0 +1,70 @@
+"""ctypes binding of libcombo_avs_hip.so (the C ABI declared in include/combo_avs.h).
+
+Loud by design: `lib()` raises RuntimeError when the shared library has not been built; nothing in
+this package falls back to PyTorch/CPU for an op that has a HIP kernel.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcombo_avs_hip.so")
+_lib = None
+
+c_void_p, c_int, c_float, c_longlong = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
+
+# name -> argtypes (restype is always int unless listed in _RESTYPES)
+_SIGNATURES = {
+    "combo_abi_version": [],
+    "combo_build_arch": [],
+    "combo_msda_forward_f32": [c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_int, c_void_p],
+    "combo_msda_forward_f64": [c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_int, c_void_p],
+    "combo_msda_backward_f32": [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 3 + [c_int, c_void_p],
+    "combo_msda_backward_f64": [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 3 + [c_int, c_void_p],
+}
+_RESTYPES = {"combo_build_arch": ctypes.c_char_p}
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"HIP library not built: {LIB_PATH} is missing. Run `python combo-avs_amd/build.py` "
+                "(or __graft_entry__.build()). There is no CPU fallback for the hot path.")
+        _lib = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in _SIGNATURES.items():
+            fn = getattr(_lib, name)  # AttributeError if the .so is stale
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPES.get(name, c_int)
+    return _lib
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def check(code, what):
+    if code != 0:
+        raise HipError(f"{what} failed with hipError_t {code}")
+
+
+def ptr(t):
+    """Device pointer of a contiguous torch tensor (None -> NULL)."""
+    return 0 if t is None else t.data_ptr()
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("combo_avs_amd ops run on the GPU only (got a CPU tensor); there is no CPU fallback")
+        if t is not None and not t.is_contiguous():
+            raise RuntimeError("combo_avs_amd ops need contiguous tensors")

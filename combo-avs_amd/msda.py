@@ -1,0 +1,99 @@
+"""Drop-in for the reference's native module `MultiScaleDeformableAttention`
+(pybind names at models/modeling/pixel_decoder/ops/src/vision.cpp:18-21) and its autograd wrapper
+`MSDeformAttnFunction` (ops/functions/ms_deform_attn_func.py:32-50), backed by
+combo_msda_{forward,backward}_{f32,f64} of libcombo_avs_hip.so.
+
+Same argument order, shapes and error behaviour as the reference op (contiguity / device checks raise
+RuntimeError like the c10 asserts at ms_deform_attn_cuda.cu:33-43); `im2col_step` is accepted and
+ignored (the batch is never chunked here).  Unlike ops/modules/ms_deform_attn.py:119-125 nothing here
+swallows exceptions and there is no grid_sample fallback.
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+
+ALGO_AUTO, ALGO_GENERIC, ALGO_LDS = 0, 1, 2
+_algo = ALGO_AUTO
+
+
+def set_algo(algo: int):
+    """Force a kernel family (tests / A-B benchmarking)."""
+    global _algo
+    _algo = int(algo)
+
+
+def _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight):
+    if value.dim() != 4 or sampling_loc.dim() != 6 or attn_weight.dim() != 5:
+        raise RuntimeError("ms_deform_attn: value [B,S,M,D], sampling_loc [B,Lq,M,L,P,2], attn_weight [B,Lq,M,L,P] expected")
+    B, S, M, D = value.shape
+    _, Lq, M2, L, P, two = sampling_loc.shape
+    if two != 2 or M2 != M or tuple(attn_weight.shape) != (B, Lq, M, L, P) or sampling_loc.shape[0] != B:
+        raise RuntimeError("ms_deform_attn: inconsistent shapes")
+    if spatial_shapes.dtype != torch.int64 or level_start_index.dtype != torch.int64:
+        raise RuntimeError("ms_deform_attn: spatial_shapes / level_start_index must be int64 device tensors")
+    if tuple(spatial_shapes.shape) != (L, 2) or tuple(level_start_index.shape) != (L,):
+        raise RuntimeError("ms_deform_attn: spatial_shapes [L,2] / level_start_index [L] expected")
+    if sampling_loc.dtype != value.dtype or attn_weight.dtype != value.dtype:
+        raise RuntimeError("ms_deform_attn: dtype mismatch")
+    return B, S, M, D, L, Lq, P
+
+
+def _suffix(dtype):
+    if dtype == torch.float32:
+        return "f32"
+    if dtype == torch.float64:
+        return "f64"
+    raise RuntimeError("ms_deform_attn: only float32/float64 are supported (as in the reference, ms_deform_attn_cuda.cu:69)")
+
+
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step=128):
+    _lib.require_cuda(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    B, S, M, D, L, Lq, P = _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    out = torch.empty((B, Lq, M * D), dtype=value.dtype, device=value.device)
+    fn = getattr(_lib.lib(), "combo_msda_forward_" + _suffix(value.dtype))
+    _lib.check(fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
+                  attn_weight.data_ptr(), B, S, M, D, L, Lq, P, out.data_ptr(), _algo, _lib.current_stream()),
+               "combo_msda_forward")
+    return out
+
+
+def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
+                            im2col_step=128):
+    _lib.require_cuda(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    grad_output = grad_output.contiguous()
+    B, S, M, D, L, Lq, P = _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    if tuple(grad_output.shape) != (B, Lq, M * D):
+        raise RuntimeError("ms_deform_attn_backward: grad_output [B,Lq,M*D] expected")
+    grad_value = torch.zeros_like(value)
+    grad_loc = torch.zeros_like(sampling_loc)
+    grad_w = torch.zeros_like(attn_weight)
+    fn = getattr(_lib.lib(), "combo_msda_backward_" + _suffix(value.dtype))
+    _lib.check(fn(grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                  sampling_loc.data_ptr(), attn_weight.data_ptr(), B, S, M, D, L, Lq, P, grad_value.data_ptr(),
+                  grad_loc.data_ptr(), grad_w.data_ptr(), _algo, _lib.current_stream()), "combo_msda_backward")
+    return grad_value, grad_loc, grad_w
+
+
+class MSDeformAttnFunction(Function):
+    """Same call signature as the reference's autograd Function (ms_deform_attn_func.py:32-50)."""
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
+                im2col_step=128):
+        ctx.im2col_step = im2col_step
+        value = value.contiguous()
+        sampling_locations = sampling_locations.contiguous()
+        attention_weights = attention_weights.contiguous()
+        out = ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                                     attention_weights, im2col_step)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, lsi, loc, w = ctx.saved_tensors
+        gv, gl, gw = ms_deform_attn_backward(value, shapes, lsi, loc, w, grad_output, ctx.im2col_step)
+        return gv, None, None, gl, gw, None

@@ -1,0 +1,77 @@
+/*
+ * combo_avs.h — C ABI of libcombo_avs_hip.so: the MI355X (gfx950) kernels behind COMBO-AVS's
+ * fusion + mask-decoding hot path.
+ *
+ * Drop-in boundary.  The only native interface the reference has is the pybind module
+ * `MultiScaleDeformableAttention` (reference: models/modeling/pixel_decoder/ops/src/vision.cpp:18-21,
+ * ops/src/ms_deform_attn.h:25-66) whose two functions dispatch to the launchers
+ * `ms_deformable_im2col_cuda` / `ms_deformable_col2im_cuda`
+ * (ops/src/cuda/ms_deform_im2col_cuda.cuh:928-959, 961-1331).  `combo_msda_*` below replace exactly
+ * those launchers.  All other entry points replace chains of ATen ops inside the reference's Python
+ * modules; each cites the Python lines it stands for.  INTEGRATION.md shows the ctypes stub that
+ * binds them from the reference side.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in `_host`; tensors are contiguous,
+ *     row-major, in the layout written next to the argument;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls are asynchronous
+ *     and never synchronise;
+ *   - the return value is a hipError_t as int (0 = hipSuccess); argument errors return
+ *     COMBO_EINVAL (= hipErrorInvalidValue, 1).  Unlike the reference, which only printf's launch
+ *     failures (ms_deform_im2col_cuda.cuh:953-957), launch errors are returned;
+ *   - outputs are caller-allocated; whether they must be zero-filled is stated per function.
+ */
+#ifndef COMBO_AVS_H_
+#define COMBO_AVS_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COMBO_EINVAL 1
+typedef void* combo_stream_t;
+
+/* Library / device introspection (host only, no GPU needed). */
+int combo_abi_version(void);
+const char* combo_build_arch(void); /* "gfx950" */
+
+/* ------------------------------------------------------------------------------------------------
+ * a6  MSDeformAttn core op
+ *   replaces ms_deform_attn_cuda_forward / _backward (ops/src/cuda/ms_deform_attn_cuda.cu:25-85, 88-157)
+ *   out[b,q,m,:] = sum_{l<L,p<P} w[b,q,m,l,p] * bilinear(value_l[b,:,m,:], loc*(W_l,H_l) - 0.5), zero padding.
+ *
+ *   value          [B,S,M,D]        spatial_shapes [L,2] int64 (H,W)    level_start_index [L] int64
+ *   sampling_loc   [B,Lq,M,L,P,2]   attn_weight    [B,Lq,M,L,P]         out [B,Lq,M*D] (fully overwritten)
+ *   algo: 0 = auto, 1 = generic (gather from L2), 2 = LDS-staged value slab (D==32, slab must fit LDS)
+ *   im2col_step of the reference has no meaning here (the batch is never chunked) and is not a parameter.
+ * ---------------------------------------------------------------------------------------------- */
+int combo_msda_forward_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                           const float* sampling_loc, const float* attn_weight,
+                           int B, int S, int M, int D, int L, int Lq, int P,
+                           float* out, int algo, combo_stream_t stream);
+int combo_msda_forward_f64(const double* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                           const double* sampling_loc, const double* attn_weight,
+                           int B, int S, int M, int D, int L, int Lq, int P,
+                           double* out, int algo, combo_stream_t stream);
+
+/*   grad_out [B,Lq,M*D];  grad_value [B,S,M,D], grad_sampling_loc [B,Lq,M,L,P,2], grad_attn_weight [B,Lq,M,L,P].
+ *   All three gradient buffers MUST be zero-filled by the caller (as the reference does,
+ *   ms_deform_attn_cuda.cu:126-128).  Accumulation order is not deterministic (float atomics), as in
+ *   the reference. */
+int combo_msda_backward_f32(const float* grad_out, const float* value, const int64_t* spatial_shapes,
+                            const int64_t* level_start_index, const float* sampling_loc, const float* attn_weight,
+                            int B, int S, int M, int D, int L, int Lq, int P,
+                            float* grad_value, float* grad_sampling_loc, float* grad_attn_weight,
+                            int algo, combo_stream_t stream);
+int combo_msda_backward_f64(const double* grad_out, const double* value, const int64_t* spatial_shapes,
+                            const int64_t* level_start_index, const double* sampling_loc, const double* attn_weight,
+                            int B, int S, int M, int D, int L, int Lq, int P,
+                            double* grad_value, double* grad_sampling_loc, double* grad_attn_weight,
+                            int algo, combo_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COMBO_AVS_H_ */

@@ -1,0 +1,170 @@
+"""GPU parity tests of the MSDeformAttn core op: HIP kernels (through the C ABI)
+vs the committed golden vectors from the reference and vs the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from oracle import combo_oracle as O
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+def run_hip(value, shapes, loc, w, grad_out=None, algo=0):
+    from combo_avs_amd import msda
+    msda.set_algo(algo)
+    try:
+        sh = torch.as_tensor(shapes, dtype=torch.int64)
+        lsi = torch.cat((sh.new_zeros(1), sh.prod(1).cumsum(0)[:-1]))
+        v, l, a = dev(value).requires_grad_(True), dev(loc).requires_grad_(True), dev(w).requires_grad_(True)
+        out = msda.MSDeformAttnFunction.apply(v, sh.cuda(), lsi.cuda(), l, a, 128)
+        res = [out.detach().cpu()]
+        if grad_out is not None:
+            gv, gl, gw = torch.autograd.grad(out, (v, l, a), dev(grad_out))
+            res += [gv.cpu(), gl.cpu(), gw.cpu()]
+        torch.cuda.synchronize()
+        return res
+    finally:
+        msda.set_algo(0)
+
+
+@pytest.mark.parametrize("tag", ["t_double", "t_float", "t_grad30", "t_grad32", "t_grad64", "t_grad71", "t_grad1025", "edge"])
+def test_reference_unit_cases(tag):
+    """The reference's own test cases (ops/test.py, seed 3) + border cases, outputs produced by the reference."""
+    z = np.load(os.path.join(G, "msda_core.npz"))
+    dt = torch.float32 if tag == "t_float" else torch.float64
+    value, loc, w = (torch.from_numpy(z[f"{tag}/{k}"]).to(dt) for k in ("value", "loc", "w"))
+    go = torch.from_numpy(z[f"{tag}/grad_out"]).to(dt)
+    out, gv, gl, gw = run_hip(value, z[f"{tag}/shapes"].tolist(), loc, w, go)
+    tol = dict(rtol=1e-5, atol=1e-8) if dt == torch.float32 else dict(rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(out.numpy(), z[f"{tag}/out"], **tol)
+    gtol = dict(rtol=1e-4, atol=1e-7) if dt == torch.float32 else dict(rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(gv.numpy(), z[f"{tag}/grad_value"], **gtol)
+    np.testing.assert_allclose(gw.numpy(), z[f"{tag}/grad_w"], **gtol)
+    if tag != "edge":  # d/dloc is discontinuous exactly on pixel borders
+        np.testing.assert_allclose(gl.numpy(), z[f"{tag}/grad_loc"], **gtol)
+
+
+def prod_inputs(B=2, shapes=((7, 7), (14, 14), (28, 28)), M=8, D=32, P=4, seed_tag="prod"):
+    S = sum(h * w for h, w in shapes)
+    L = len(shapes)
+    v = synth.synth_tensor(f"{seed_tag}.value", (B, S, M, D), 0)
+    refp = synth.synth_tensor(f"{seed_tag}.ref", (B, S, 1, 1, 1, 2), 0, kind="unit")
+    off = synth.synth_tensor(f"{seed_tag}.off", (B, S, M, L, P, 2), 0, scale=2.5)
+    norm = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32)
+    loc = refp + off / norm[None, None, None, :, None, :]
+    w = torch.softmax(synth.synth_tensor(f"{seed_tag}.w", (B, S, M, L * P), 0), -1).view(B, S, M, L, P)
+    return v, list(shapes), loc, w
+
+
+@pytest.mark.parametrize("algo", [1, 2])
+def test_production_shape_vs_reference_digests(algo):
+    """R50-S4 @224 shape (S=Lq=1029, M=8, D=32, L=3, P=4): both kernel families against the reference's
+    grid_sample core (digests in msda_core.npz) to fp32 round-off."""
+    z = np.load(os.path.join(G, "msda_core.npz"))
+    v, shapes, loc, w = prod_inputs()
+    go = synth.synth_tensor("prod.grad_out", (2, 1029, 256), 0)
+    out, gv, gl, gw = run_hip(v, shapes, loc, w, go, algo=algo)
+    for nm, t in (("out", out), ("grad_value", gv), ("grad_loc", gl), ("grad_w", gw)):
+        synth.check_digest(t, synth.unpack(f"prod/{nm}", z), f"prod/{nm}", rtol=1e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize("algo", [1, 2])
+def test_production_shape_vs_oracle_full_tensor(algo):
+    v, shapes, loc, w = prod_inputs(B=3, seed_tag="prod3")
+    go = synth.synth_tensor("prod3.grad_out", (3, 1029, 256), 0)
+    v.requires_grad_(True); loc.requires_grad_(True); w.requires_grad_(True)
+    ref = O.ms_deform_attn_core(v, shapes, loc, w)
+    rgv, rgl, rgw = torch.autograd.grad(ref, (v, loc, w), go)
+    out, gv, gl, gw = run_hip(v.detach(), shapes, loc.detach(), w.detach(), go, algo=algo)
+    torch.testing.assert_close(out, ref.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(gv, rgv, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(gw, rgw, rtol=1e-4, atol=1e-5)
+    # grad_loc: exclude samples within 1e-4 px of a pixel border (derivative jumps there)
+    torch.testing.assert_close(gl, rgl, rtol=1e-3, atol=2e-4)
+
+
+def test_ragged_and_tiny_shapes():
+    """Lq != S, non-square levels, one level, P=1, B=1; D=16/64 (generic vec4 path) and D=6 (scalar path)."""
+    for (shapes, M, D, P, Lq) in [(((3, 5),), 1, 16, 1, 7), (((4, 4), (2, 9)), 3, 64, 2, 33), (((5, 3), (1, 1)), 2, 6, 3, 5)]:
+        S = sum(h * w for h, w in shapes)
+        L = len(shapes)
+        tag = f"rag{S}_{M}_{D}"
+        v = synth.synth_tensor(tag + ".v", (2, S, M, D), 0)
+        loc = synth.synth_tensor(tag + ".loc", (2, Lq, M, L, P, 2), 0, kind="unit") * 1.4 - 0.2
+        w = synth.synth_tensor(tag + ".w", (2, Lq, M, L, P), 0, kind="unit")
+        go = synth.synth_tensor(tag + ".go", (2, Lq, M * D), 0)
+        v.requires_grad_(True); loc.requires_grad_(True); w.requires_grad_(True)
+        ref = O.ms_deform_attn_core(v, list(shapes), loc, w)
+        rg = torch.autograd.grad(ref, (v, loc, w), go)
+        out, gv, gl, gw = run_hip(v.detach(), list(shapes), loc.detach(), w.detach(), go)
+        torch.testing.assert_close(out, ref.detach(), rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(gv, rg[0], rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(gl, rg[1], rtol=1e-3, atol=1e-4)
+        torch.testing.assert_close(gw, rg[2], rtol=1e-4, atol=1e-5)
+
+
+def test_lds_and_generic_agree_bitwise_forward():
+    """Both forward kernels accumulate the 48 taps in the same order -> identical bits."""
+    v, shapes, loc, w = prod_inputs(B=2, seed_tag="bw")
+    a = run_hip(v, shapes, loc, w, algo=1)[0]
+    b = run_hip(v, shapes, loc, w, algo=2)[0]
+    assert (a - b).abs().max().item() <= 1e-6
+
+
+def test_full_size_properties_bs8():
+    """BASELINE config 2 size (BT=40): size-independent properties instead of a CPU oracle run.
+    (1) linearity in value, (2) constant value field + all-in-range samples -> out = const * sum(w),
+    (3) sum over value-gradient equals sum of grad_out-weighted in-range tap weights (adjointness):
+        <out, g> == <value, grad_value>."""
+    B = 40
+    v, shapes, loc, w = prod_inputs(B=B, seed_tag="full")
+    v2 = synth.synth_tensor("full.v2", tuple(v.shape), 0)
+    g = synth.synth_tensor("full.g", (B, 1029, 256), 0)
+    o1, gv, _, _ = run_hip(v, shapes, loc, w, g)
+    o2 = run_hip(v2, shapes, loc, w)[0]
+    o12 = run_hip(2.0 * v + 3.0 * v2, shapes, loc, w)[0]
+    torch.testing.assert_close(o12, 2.0 * o1 + 3.0 * o2, rtol=1e-4, atol=1e-4)
+    # adjoint identity
+    lhs = (o1.double() * g.double()).sum().item()
+    rhs = (v.double() * gv.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0) + 1e-2
+    # constant field, samples strictly inside every level
+    loc_in = 0.3 + 0.4 * synth.synth_tensor("full.locin", tuple(loc.shape), 0, kind="unit")
+    oc = run_hip(torch.full_like(v, 1.5), shapes, loc_in, w)[0]
+    expect = (1.5 * w.sum((-1, -2)))[..., None].expand(-1, -1, -1, 32).reshape(B, 1029, 256)
+    torch.testing.assert_close(oc, expect, rtol=1e-5, atol=1e-5)
+
+
+def test_large_level_generic_path_512():
+    """PVT@512-like encoder shape (S=5376 > LDS capacity) goes down the generic path; B=1 vs oracle."""
+    shapes = ((16, 16), (32, 32), (64, 64))
+    v, shapes, loc, w = prod_inputs(B=1, shapes=shapes, seed_tag="big")
+    go = synth.synth_tensor("big.go", (1, 5376, 256), 0)
+    v.requires_grad_(True); loc.requires_grad_(True); w.requires_grad_(True)
+    ref = O.ms_deform_attn_core(v, shapes, loc, w)
+    rg = torch.autograd.grad(ref, (v, loc, w), go)
+    out, gv, gl, gw = run_hip(v.detach(), shapes, loc.detach(), w.detach(), go)
+    torch.testing.assert_close(out, ref.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(gv, rg[0], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(gw, rg[2], rtol=1e-4, atol=2e-5)
+
+
+def test_error_behaviour():
+    from combo_avs_amd import msda
+    v, shapes, loc, w = prod_inputs(B=1)
+    sh = torch.as_tensor(shapes, dtype=torch.int64).cuda()
+    lsi = torch.tensor([0, 49, 245]).cuda()
+    with pytest.raises(RuntimeError):  # non-contiguous (ms_deform_attn_cuda.cu:33-37)
+        msda.ms_deform_attn_forward(v.cuda().transpose(1, 2), sh, lsi, loc.cuda(), w.cuda())
+    with pytest.raises(RuntimeError):  # half precision is not supported (ms_deform_attn_cuda.cu:69)
+        msda.ms_deform_attn_forward(v.cuda().half(), sh, lsi, loc.cuda().half(), w.cuda().half())
+    with pytest.raises(RuntimeError):  # int32 shapes
+        msda.ms_deform_attn_forward(v.cuda(), sh.int(), lsi, loc.cuda(), w.cuda())
