@@ -31,6 +31,9 @@ def exported_symbols():
 def lib():
     global _lib
     if _lib is None:
+        # torch bundles its own libamdhip64.so.7; load it FIRST so that this library binds to the same
+        # HIP runtime instance as torch's allocator/streams (same SONAME -> first one loaded wins).
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"HIP library not built: {LIB_PATH} is missing. Run `python combo-avs_amd/build.py` "
