@@ -228,16 +228,30 @@ msda_bwd_serial(const T* __restrict__ gout, const T* __restrict__ value, const i
 
 // -------------------------------------------------------------------------------------------------
 // LDS-staged forward, D == 32, fp32.
-//   grid  = B*M*QT workgroups (QT query tiles per (frame, head)), block = 512 threads = 8 waves
+//   grid  = B*M*QT workgroups (QT query tiles per (frame, head)), block = NW waves (NW = 8 or 12,
+//           whatever fits next to the slab)
 //   LDS   = slab (S+1 rows x 128 B, row S is all-zero and is where out-of-range taps point)
-//           + 8 waves x QW*LP x (float4 weights + uint2 packed row indices)
+//           + NW waves x QW*LP x (float4 weights + uint2 packed row indices)
+//   staging uses the LDS-DMA path (global_load_lds_dwordx4: 8 rows = 1 KiB per wave instruction, no
+//   VGPR round trip, all requests in flight at once).
 // -------------------------------------------------------------------------------------------------
-constexpr int kFwdThreads = 512;
-constexpr int kFwdWaves = kFwdThreads / 64;
-constexpr int kQW = 8;  // queries per wave iteration (8 lanes x 4 channels each in the gather phase)
+constexpr int kQW = 8;       // queries per wave iteration (8 lanes x 4 channels each in the gather phase)
+constexpr int kMaxLP = 16;   // L*P supported by the LDS kernels
+constexpr int kFwdPre = (kQW * kMaxLP + 63) / 64;
 
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+  // blocks are dispatched round-robin over the 8 XCDs (private L2s): give each XCD a contiguous chunk
+  // of the logical index space so that the heads / query tiles of one frame share an L2.  Bijective.
+  const int q = n >> 3, r = n & 7, xcd = id & 7, j = id >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
 
-__global__ void __launch_bounds__(kFwdThreads)
+__device__ __forceinline__ void dma16(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+__global__ void __launch_bounds__(768)
 msda_fwd_lds_d32(const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
                  const float* __restrict__ loc, const float* __restrict__ aw, int B, int S, int M, int L, int Lq, int P,
                  int QT, float* __restrict__ out) {
@@ -245,28 +259,29 @@ msda_fwd_lds_d32(const float* __restrict__ value, const int64_t* __restrict__ sh
   constexpr int D = 32;
   float* slab = reinterpret_cast<float*>(smem);
   const int LP = L * P;
+  const int NW = blockDim.x >> 6;
   const int slab_bytes = (S + 1) * D * 4;
   float4* wts_all = reinterpret_cast<float4*>(smem + slab_bytes);
-  uint2* offs_all = reinterpret_cast<uint2*>(smem + slab_bytes + kFwdWaves * kQW * LP * 16);
+  uint2* offs_all = reinterpret_cast<uint2*>(smem + slab_bytes + NW * kQW * LP * 16);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int qt = blockIdx.x % QT;
-  const int bm = blockIdx.x / QT;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int qt = logical % QT;
+  const int bm = logical / QT;
   const int m = bm % M, b = bm / M;
 
   // ---- stage the (b, m) slab: rows of 128 B at stride M*D*4 in global -> contiguous rows in LDS ----
   {
-    const float* vb = value + ((long long)b * S * M + m) * D;
-    const int chunk = tid & 7;
-    for (int r = tid >> 3; r < S; r += kFwdThreads / 8) {
-      const float4 v = *reinterpret_cast<const float4*>(vb + (long long)r * M * D + chunk * 4);
-      *reinterpret_cast<float4*>(slab + r * D + chunk * 4) = v;
+    const float* vb = value + ((long long)b * S * M + m) * D + (lane & 7) * 4;
+    for (int r0 = wave * 8; r0 < S; r0 += NW * 8) {  // 8 rows per wave instruction
+      const int r = r0 + (lane >> 3);
+      if (r < S) dma16(vb + (long long)r * M * D, slab + r0 * D);
     }
     if (tid < 8) *reinterpret_cast<float4*>(slab + S * D + tid * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  __syncthreads();
 
-  // level table (wave-uniform values; tiny)
+  // level table (wave-uniform values; tiny) - loaded while the DMA is in flight
   int lvH[kMaxLevels], lvW[kMaxLevels], lvS[kMaxLevels];
 #pragma unroll
   for (int l = 0; l < kMaxLevels; ++l) {
@@ -280,17 +295,39 @@ msda_fwd_lds_d32(const float* __restrict__ value, const int64_t* __restrict__ sh
   const int qbeg = (int)(((long long)Lq * qt) / QT), qend = (int)(((long long)Lq * (qt + 1)) / QT);
   const int npairs = kQW * LP;
 
-  for (int q0 = qbeg + wave * kQW; q0 < qend; q0 += kFwdWaves * kQW) {
-    // ---- coordinate phase: one lane per (query, point) ----
-    for (int i = lane; i < npairs; i += 64) {
+  // software prefetch of the sampling locations / weights of the next wave iteration
+  float2 pxy[kFwdPre];
+  float pa[kFwdPre];
+  auto prefetch = [&](int q0) {
+#pragma unroll
+    for (int j = 0; j < kFwdPre; ++j) {
+      const int i = lane + j * 64;
       const int ql = i / LP, pt = i - ql * LP;
       const int q = q0 + ql;
-      float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
-      unsigned r01 = (unsigned)S | ((unsigned)S << 16), r23 = r01;
-      if (q < qend) {
+      pxy[j] = make_float2(-8.f, -8.f);
+      pa[j] = 0.f;
+      if (i < npairs && q < qend) {
         const long long e = (((long long)b * Lq + q) * M + m) * LP + pt;
-        const float2 xy = *reinterpret_cast<const float2*>(loc + e * 2);
-        const float a = aw[e];
+        pxy[j] = *reinterpret_cast<const float2*>(loc + e * 2);
+        pa[j] = aw[e];
+      }
+    }
+  };
+  int q0 = qbeg + wave * kQW;
+  if (q0 < qend) prefetch(q0);
+  __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes the slab
+
+  for (; q0 < qend; q0 += NW * kQW) {
+    // ---- coordinate phase: one lane per (query, point) ----
+#pragma unroll
+    for (int j = 0; j < kFwdPre; ++j) {
+      const int i = lane + j * 64;
+      if (i < npairs) {
+        const int ql = i / LP, pt = i - ql * LP;
+        float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
+        unsigned r01 = (unsigned)S | ((unsigned)S << 16), r23 = r01;
+        const float2 xy = pxy[j];
+        const float a = pa[j];
         const int l = pt / P;
         int H = lvH[0], W = lvW[0], st = lvS[0];
 #pragma unroll
@@ -311,10 +348,11 @@ msda_fwd_lds_d32(const float* __restrict__ value, const int64_t* __restrict__ sh
           r23 = r2 | (r3 << 16);
           wv = make_float4(hh * hw * a, hh * lw * a, lh * hw * a, lh * lw * a);
         }
+        wts[i] = wv;
+        offs[i] = make_uint2(r01, r23);
       }
-      wts[i] = wv;
-      offs[i] = make_uint2(r01, r23);
     }
+    if (q0 + NW * kQW < qend) prefetch(q0 + NW * kQW);  // in flight during the gather phase
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -346,43 +384,231 @@ msda_fwd_lds_d32(const float* __restrict__ value, const int64_t* __restrict__ sh
 }
 
 // -------------------------------------------------------------------------------------------------
-// LDS-staged backward, D == 32, fp32.
-//   grid  = B*M*2 workgroups: (frame, head, 16-channel half); block = 1024 threads = 16 waves
-//   LDS   = value half-slab (S+1 rows x 64 B) + gradient half-slab of the same size (zero-filled)
-//   lane  = 4 channels of one (query, point) pair; 4 lanes per pair, 16 pairs per wave iteration
-//   grad_loc / grad_attn_weight get the two halves' partial sums through two global float atomics
-//   (two addends onto a zero-filled buffer: order-independent, hence deterministic);
-//   grad_value is accumulated with LDS float atomics and written once with plain stores.
+// LDS-staged backward, D == 32, fp32: two kernels, no floating-point atomics anywhere.
+//
+// Measured on MI355X (tools/ubench/lds_atomic*.hip): ds_add_f32 retires ONE LANE per 3 cycles per CU
+// (192 cycles per wave instruction, independent of addresses and of the number of waves) while
+// ds_add_u32 retires a whole wave instruction in 4-8 cycles.  global_atomic_add_f32 is ~14 G/s chip-wide.
+// Hence:
+//   msda_bwd_value_lds_d32  - grad_value.  One workgroup per (frame, head, 16-channel half).  The
+//       scatter-add runs on a 32-bit FIXED-POINT accumulator slab in LDS (ds_add_u32), with one scale
+//       per channel chosen from a pre-pass: scale_c = 2^30 / (max_q |grad_out[q,c]| * sum_{q,p} |w|),
+//       which bounds every partial sum below 2^30.  Integer adds commute, so grad_value is bitwise
+//       DETERMINISTIC (the reference's float atomicAdd is not).  Resolution: 2^-30 of the bound, i.e.
+//       ~1e-6 x max|grad_out| for softmax weights at Lq = 1029.  The slab is flushed once with plain
+//       coalesced stores; grad_value needs no zero-fill.  `value` is not read at all.
+//   msda_bwd_locw_lds_d32   - grad_sampling_loc, grad_attn_weight.  Forward-shaped: value slab staged
+//       in LDS, coordinate phase -> per-wave scratch, gather phase computes the 4 tap dot products with
+//       grad_out, reduces over the 8 channel-lanes with xor shuffles and stores plainly.
 // -------------------------------------------------------------------------------------------------
-constexpr int kBwdThreads = 1024;
+constexpr int kBwdVThreads = 512;
 
-__global__ void __launch_bounds__(kBwdThreads)
-msda_bwd_lds_d32(const float* __restrict__ gout, const float* __restrict__ value, const int64_t* __restrict__ shapes,
-                 const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ aw, int B,
-                 int S, int M, int L, int Lq, int P, float* __restrict__ gvalue, float* __restrict__ gloc,
-                 float* __restrict__ gaw) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int D = 32, HD = 16;
-  float* vs = reinterpret_cast<float*>(smem);   // [S+1][16]
-  float* gs = vs + (S + 1) * HD;                // [S+1][16]
+// One pass over all (query, point) samples of (b, m).  4 lanes (cg = 0..3) serve one query; 16 queries per
+// wave iteration, `mult` apart.  PASS 0: scatter |a * tapweight| (rounded UP, fixed point) into wsum[row]
+// -> an upper bound W_r of everything that can ever be added to a row.  PASS 1: scatter the gradient itself
+// in fixed point with the per-row scale 2^30 / W_r (and grad_out normalised per channel to [-1, 1]).
+template <int PASS>
+__device__ __forceinline__ void bwd_value_pass(const float* __restrict__ gout, const int64_t* __restrict__ shapes,
+                                               const int64_t* __restrict__ lsi, const float* __restrict__ loc,
+                                               const float* __restrict__ aw, int b, int m, int half, int S, int M,
+                                               int L, int Lq, int P, int mult, int wave, int lane, float wscale,
+                                               const float (&inv_mx)[4], int* __restrict__ acc,
+                                               int* __restrict__ wsum) {
+  constexpr int D = 32, HD = 16, NW = kBwdVThreads / 64;
   const int LP = L * P;
-  const int tid = threadIdx.x;
-  const int half = blockIdx.x & 1;
-  const int bm = blockIdx.x >> 1;
+  const int cg = lane & 3, slot = lane >> 2, rot = slot & 3;
+  const float* rowscale = reinterpret_cast<const float*>(wsum);
+  const int chunks = (Lq + 15) / 16;
+  for (int ci = wave; ci < chunks; ci += NW) {
+    const int n = ci * 16 + slot;
+    const bool live = n < Lq;
+    const int q = live ? (int)(((long long)n * mult) % Lq) : 0;
+    const long long qm = ((long long)b * Lq + q) * M + m;
+    float tgr[4] = {0.f, 0.f, 0.f, 0.f};
+    int coff[4] = {0, 1, 2, 3};
+    if constexpr (PASS == 1) {
+      const float4 tg = *reinterpret_cast<const float4*>(gout + qm * D + half * HD + cg * 4);
+      // normalised grad_out, channels in this lane's rotated walk order (spreads the LDS banks)
+      const float tgs[4] = {tg.x * inv_mx[0], tg.y * inv_mx[1], tg.z * inv_mx[2], tg.w * inv_mx[3]};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        coff[j] = (j + rot) & 3;
+        tgr[j] = tgs[0];
+#pragma unroll
+        for (int c = 1; c < 4; ++c)
+          if (coff[j] == c) tgr[j] = tgs[c];
+      }
+    }
+    float2 xy[kMaxLP];
+    float av[kMaxLP];
+#pragma unroll
+    for (int pt = 0; pt < kMaxLP; ++pt) {
+      xy[pt] = make_float2(-8.f, -8.f);
+      av[pt] = 0.f;
+      if (pt < LP && live) {
+        xy[pt] = *reinterpret_cast<const float2*>(loc + (qm * LP + pt) * 2);
+        av[pt] = aw[qm * LP + pt];
+      }
+    }
+#pragma unroll
+    for (int pt = 0; pt < kMaxLP; ++pt) {
+      if (pt < LP) {
+        const int l = pt / P;
+        const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)lsi[l];
+        const float h_im = xy[pt].y * H - 0.5f, w_im = xy[pt].x * W - 0.5f;
+        if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+          const float hf = floorf(h_im), wf = floorf(w_im);
+          const int h0 = (int)hf, w0 = (int)wf;
+          const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+          const bool t_ok = h0 >= 0, b_ok = h0 + 1 <= H - 1, l_ok = w0 >= 0, r_ok = w0 + 1 <= W - 1;
+          const int base = st + h0 * W + w0;
+          const int r[4] = {(t_ok && l_ok) ? base : S, (t_ok && r_ok) ? base + 1 : S, (b_ok && l_ok) ? base + W : S,
+                            (b_ok && r_ok) ? base + W + 1 : S};
+          const float a = av[pt];
+          const float wt[4] = {hh * hw * a, hh * lw * a, lh * hw * a, lh * lw * a};
+          if constexpr (PASS == 0) {
+            // lane cg handles tap cg
+            float wk = wt[0];
+            int rk = r[0];
+#pragma unroll
+            for (int k = 1; k < 4; ++k)
+              if (cg == k) { wk = wt[k]; rk = r[k]; }
+            __hip_atomic_fetch_add(wsum + rk, __float2int_ru(fabsf(wk) * wscale), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              int* gp = acc + r[k] * HD + cg * 4;  // row S is a dummy sink for out-of-range taps
+              const float ws = wt[k] * rowscale[r[k]];
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                __hip_atomic_fetch_add(gp + coff[j], __float2int_rn(ws * tgr[j]), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kBwdVThreads)
+msda_bwd_value_lds_d32(const float* __restrict__ gout, const int64_t* __restrict__ shapes,
+                       const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ aw,
+                       int B, int S, int M, int L, int Lq, int P, int mult, float* __restrict__ gvalue) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int D = 32, HD = 16, NW = kBwdVThreads / 64;
+  int* acc = reinterpret_cast<int*>(smem);                         // [S+1][16] fixed point
+  int* wsum = acc + (S + 1) * HD;                                  // [S+1] weight bound -> row scale
+  float* red = reinterpret_cast<float*>(wsum + ((S + 1 + 3) & ~3));  // [NW][20] block-reduction scratch
+  const int LP = L * P;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int half = logical & 1;
+  const int bm = logical >> 1;
+  const int m = bm % M, b = bm / M;
+  const int cg = tid & 3;  // this lane's 4 channels: half*16 + cg*4 ..
+
+  for (int r = tid >> 2; r <= S; r += kBwdVThreads / 4)
+    *reinterpret_cast<int4*>(acc + r * HD + cg * 4) = make_int4(0, 0, 0, 0);
+  for (int r = tid; r <= S; r += kBwdVThreads) wsum[r] = 0;
+
+  // ---- pre-pass: per-channel max |grad_out| over the queries of (b, m), and sum |attention weight| ----
+  float mx[4] = {0.f, 0.f, 0.f, 0.f};
+  float sa = 0.f;
+  bool nan = false;
+  for (int q = tid >> 2; q < Lq; q += kBwdVThreads / 4) {
+    const float4 t = *reinterpret_cast<const float4*>(gout + (((long long)b * Lq + q) * M + m) * D + half * HD + cg * 4);
+    mx[0] = fmaxf(mx[0], fabsf(t.x)); mx[1] = fmaxf(mx[1], fabsf(t.y));
+    mx[2] = fmaxf(mx[2], fabsf(t.z)); mx[3] = fmaxf(mx[3], fabsf(t.w));
+    nan |= !(t.x == t.x) || !(t.y == t.y) || !(t.z == t.z) || !(t.w == t.w);  // fmaxf drops NaNs
+  }
+  for (int i = tid; i < Lq * LP; i += kBwdVThreads) {
+    const int q = i / LP, pt = i - q * LP;
+    sa += fabsf(aw[(((long long)b * Lq + q) * M + m) * LP + pt]);
+  }
+#pragma unroll
+  for (int s = 4; s < 64; s <<= 1)  // lanes with equal cg
+#pragma unroll
+    for (int c = 0; c < 4; ++c) mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], s));
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) sa += __shfl_xor(sa, s);
+  const bool wave_nan = __any(nan);
+  if (lane < 4) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[wave * 20 + lane * 4 + c] = mx[c];
+  }
+  if (lane == 0) { red[wave * 20 + 16] = sa; red[wave * 20 + 17] = wave_nan ? 1.f : 0.f; }
+  __syncthreads();
+  float mxc[4], inv_mx[4];
+  float tot = 0.f, bad = 0.f;
+  for (int w = 0; w < NW; ++w) { tot += red[w * 20 + 16]; bad += red[w * 20 + 17]; }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float mm = 0.f;
+    for (int w = 0; w < NW; ++w) mm = fmaxf(mm, red[w * 20 + cg * 4 + c]);
+    if (bad != 0.f || !(mm < 3.0e38f) || !(tot < 3.0e38f)) mm = __builtin_nanf("");
+    mxc[c] = mm;
+    inv_mx[c] = (mm > 0.f) ? 1.f / mm : (mm == mm ? 0.f : mm);
+  }
+  // weights are accumulated with scale 2^30 / sum|a| (every row sum <= sum|a|)
+  const float wscale = tot > 0.f ? 1073741824.f / tot : 0.f;
+  const float inv_wscale = tot > 0.f ? tot * (1.f / 1073741824.f) : 0.f;
+
+  float dummy[4] = {0.f, 0.f, 0.f, 0.f};
+  bwd_value_pass<0>(gout, shapes, lsi, loc, aw, b, m, half, S, M, L, Lq, P, mult, wave, lane, wscale, dummy, acc, wsum);
+  __syncthreads();
+  // W_r (upper bound, rounded up) -> per-row fixed-point scale 2^30 / W_r, stored in place as float
+  for (int r = tid; r <= S; r += kBwdVThreads) {
+    const float wr = (float)wsum[r] * inv_wscale * 1.0001f;
+    reinterpret_cast<float*>(wsum)[r] = wr > 0.f ? 1073741824.f / wr : 0.f;
+  }
+  __syncthreads();
+  bwd_value_pass<1>(gout, shapes, lsi, loc, aw, b, m, half, S, M, L, Lq, P, mult, wave, lane, wscale, inv_mx, acc, wsum);
+  __syncthreads();
+  {
+    float* gb = gvalue + ((long long)b * S * M + m) * D + half * HD + cg * 4;
+    const float* rowscale = reinterpret_cast<const float*>(wsum);
+    for (int r = tid >> 2; r < S; r += kBwdVThreads / 4) {
+      const int4 v = *reinterpret_cast<const int4*>(acc + r * HD + cg * 4);
+      const float rs = rowscale[r];
+      const float f = rs > 0.f ? 1.f / rs : 0.f;
+      *reinterpret_cast<float4*>(gb + (long long)r * M * D) =
+          make_float4((float)v.x * f * mxc[0], (float)v.y * f * mxc[1], (float)v.z * f * mxc[2], (float)v.w * f * mxc[3]);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(768)
+msda_bwd_locw_lds_d32(const float* __restrict__ gout, const float* __restrict__ value,
+                      const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+                      const float* __restrict__ loc, const float* __restrict__ aw, int B, int S, int M, int L, int Lq,
+                      int P, int QT, float* __restrict__ gloc, float* __restrict__ gaw) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int D = 32;
+  float* slab = reinterpret_cast<float*>(smem);
+  const int LP = L * P;
+  const int NW = blockDim.x >> 6;
+  const int slab_bytes = (S + 1) * D * 4;
+  float4* par_all = reinterpret_cast<float4*>(smem + slab_bytes);  // (lh, lw, a*W, a*H)
+  uint2* offs_all = reinterpret_cast<uint2*>(smem + slab_bytes + NW * kQW * LP * 16);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int qt = logical % QT;
+  const int bm = logical / QT;
   const int m = bm % M, b = bm / M;
 
   {
-    const float* vb = value + ((long long)b * S * M + m) * D + half * HD;
-    const int chunk = tid & 3;
-    for (int r = tid >> 2; r <= S; r += kBwdThreads / 4) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < S) v = *reinterpret_cast<const float4*>(vb + (long long)r * M * D + chunk * 4);
-      *reinterpret_cast<float4*>(vs + r * HD + chunk * 4) = v;
-      *reinterpret_cast<float4*>(gs + r * HD + chunk * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* vb = value + ((long long)b * S * M + m) * D + (lane & 7) * 4;
+    for (int r0 = wave * 8; r0 < S; r0 += NW * 8) {
+      const int r = r0 + (lane >> 3);
+      if (r < S) dma16(vb + (long long)r * M * D, slab + r0 * D);
     }
+    if (tid < 8) *reinterpret_cast<float4*>(slab + S * D + tid * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  __syncthreads();
-
   int lvH[kMaxLevels], lvW[kMaxLevels], lvS[kMaxLevels];
 #pragma unroll
   for (int l = 0; l < kMaxLevels; ++l) {
@@ -390,71 +616,96 @@ msda_bwd_lds_d32(const float* __restrict__ gout, const float* __restrict__ value
     lvW[l] = l < L ? (int)shapes[2 * l + 1] : 1;
     lvS[l] = l < L ? (int)lsi[l] : 0;
   }
-
-  const int cg = tid & 3;
-  const int npairs = Lq * LP;                       // pairs of this (b, m)
-  const int pairs_per_iter = kBwdThreads / 4;       // 256
-  const int iters = (npairs + pairs_per_iter - 1) / pairs_per_iter;
-  for (int it = 0; it < iters; ++it) {
-    const int pi = it * pairs_per_iter + (tid >> 2);
-    const bool live = pi < npairs;
-    const int pic = live ? pi : 0;
-    const int q = pic / LP, pt = pic - q * LP;
-    const long long e = (((long long)b * Lq + q) * M + m) * LP + pt;
-    const float2 xy = *reinterpret_cast<const float2*>(loc + e * 2);
-    const float a = aw[e];
-    float4 tg = *reinterpret_cast<const float4*>(gout + (((long long)b * Lq + q) * M + m) * D + half * HD + cg * 4);
-    const int l = pt / P;
-    int H = lvH[0], W = lvW[0], st = lvS[0];
-#pragma unroll
-    for (int k = 1; k < kMaxLevels; ++k)
-      if (l == k) { H = lvH[k]; W = lvW[k]; st = lvS[k]; }
-    const float h_im = xy.y * H - 0.5f, w_im = xy.x * W - 0.5f;
-    float g_w = 0.f, g_x = 0.f, g_y = 0.f;
-    if (live && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
-      const float hf = floorf(h_im), wf = floorf(w_im);
-      const int h0 = (int)hf, w0 = (int)wf;
-      const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-      const bool t_ok = h0 >= 0, b_ok = h0 + 1 <= H - 1, l_ok = w0 >= 0, r_ok = w0 + 1 <= W - 1;
-      const int base = st + h0 * W + w0;
-      const int r[4] = {(t_ok && l_ok) ? base : S, (t_ok && r_ok) ? base + 1 : S, (b_ok && l_ok) ? base + W : S,
-                        (b_ok && r_ok) ? base + W + 1 : S};
-      const float wt[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
-      const float dh[4] = {-hw, -lw, hw, lw};
-      const float dw[4] = {-hh, hh, -lh, lh};
-      const float tga[4] = {tg.x * a, tg.y * a, tg.z * a, tg.w * a};
-      float sv = 0.f, sx = 0.f, sy = 0.f;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float4 v = *reinterpret_cast<const float4*>(vs + r[k] * HD + cg * 4);
-        const float dot = tg.x * v.x + tg.y * v.y + tg.z * v.z + tg.w * v.w;
-        sv += wt[k] * dot;
-        sy += dh[k] * dot;
-        sx += dw[k] * dot;
-        float* gp = gs + r[k] * HD + cg * 4;  // row S is a dummy sink for out-of-range taps
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-          __hip_atomic_fetch_add(gp + c, wt[k] * tga[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-      g_w = sv;
-      g_x = sx * a * W;
-      g_y = sy * a * H;
-    }
-    g_w += __shfl_xor(g_w, 1); g_x += __shfl_xor(g_x, 1); g_y += __shfl_xor(g_y, 1);
-    g_w += __shfl_xor(g_w, 2); g_x += __shfl_xor(g_x, 2); g_y += __shfl_xor(g_y, 2);
-    if (live && cg == 0) {
-      atomic_add_relaxed(gaw + e, g_w);
-      atomic_add_relaxed(gloc + e * 2, g_x);
-      atomic_add_relaxed(gloc + e * 2 + 1, g_y);
-    }
-  }
+  float4* par = par_all + wave * kQW * LP;
+  uint2* offs = offs_all + wave * kQW * LP;
+  const int qbeg = (int)(((long long)Lq * qt) / QT), qend = (int)(((long long)Lq * (qt + 1)) / QT);
+  const int npairs = kQW * LP;
   __syncthreads();
-  {
-    float* gb = gvalue + ((long long)b * S * M + m) * D + half * HD;
-    const int chunk = tid & 3;
-    for (int r = tid >> 2; r < S; r += kBwdThreads / 4)
-      *reinterpret_cast<float4*>(gb + (long long)r * M * D + chunk * 4) =
-          *reinterpret_cast<const float4*>(gs + r * HD + chunk * 4);
+
+  for (int q0 = qbeg + wave * kQW; q0 < qend; q0 += NW * kQW) {
+    for (int i = lane; i < npairs; i += 64) {
+      const int ql = i / LP, pt = i - ql * LP;
+      const int q = q0 + ql;
+      float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+      unsigned r01 = (unsigned)S | ((unsigned)S << 16), r23 = r01;
+      if (q < qend) {
+        const long long e = (((long long)b * Lq + q) * M + m) * LP + pt;
+        const float2 xy = *reinterpret_cast<const float2*>(loc + e * 2);
+        const float a = aw[e];
+        const int l = pt / P;
+        int H = lvH[0], W = lvW[0], st = lvS[0];
+#pragma unroll
+        for (int k = 1; k < kMaxLevels; ++k)
+          if (l == k) { H = lvH[k]; W = lvW[k]; st = lvS[k]; }
+        const float h_im = xy.y * H - 0.5f, w_im = xy.x * W - 0.5f;
+        if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+          const float hf = floorf(h_im), wf = floorf(w_im);
+          const int h0 = (int)hf, w0 = (int)wf;
+          const bool t_ok = h0 >= 0, b_ok = h0 + 1 <= H - 1, l_ok = w0 >= 0, r_ok = w0 + 1 <= W - 1;
+          const int base = st + h0 * W + w0;
+          const unsigned r0 = (t_ok && l_ok) ? (unsigned)base : (unsigned)S;
+          const unsigned r1 = (t_ok && r_ok) ? (unsigned)(base + 1) : (unsigned)S;
+          const unsigned r2 = (b_ok && l_ok) ? (unsigned)(base + W) : (unsigned)S;
+          const unsigned r3 = (b_ok && r_ok) ? (unsigned)(base + W + 1) : (unsigned)S;
+          r01 = r0 | (r1 << 16);
+          r23 = r2 | (r3 << 16);
+          pv = make_float4(h_im - hf, w_im - wf, a * W, a * H);
+        }
+      }
+      par[i] = pv;
+      offs[i] = make_uint2(r01, r23);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+      const int g = lane >> 3, cg = lane & 7;
+      const int q = q0 + g;
+      const int qc = q < qend ? q : qbeg;
+      const long long qm = ((long long)b * Lq + qc) * M + m;
+      const float4 tg = *reinterpret_cast<const float4*>(gout + qm * D + cg * 4);
+      const float* sl = slab + cg * 4;
+      float keep_w[2] = {0.f, 0.f}, keep_x[2] = {0.f, 0.f}, keep_y[2] = {0.f, 0.f};
+      for (int pt = 0; pt < LP; ++pt) {
+        const uint2 o = offs[g * LP + pt];
+        const float4 pp = par[g * LP + pt];
+        const float4 v0 = *reinterpret_cast<const float4*>(sl + (o.x & 0xffffu) * D);
+        const float4 v1 = *reinterpret_cast<const float4*>(sl + (o.x >> 16) * D);
+        const float4 v2 = *reinterpret_cast<const float4*>(sl + (o.y & 0xffffu) * D);
+        const float4 v3 = *reinterpret_cast<const float4*>(sl + (o.y >> 16) * D);
+        const float d0 = tg.x * v0.x + tg.y * v0.y + tg.z * v0.z + tg.w * v0.w;
+        const float d1 = tg.x * v1.x + tg.y * v1.y + tg.z * v1.z + tg.w * v1.w;
+        const float d2 = tg.x * v2.x + tg.y * v2.y + tg.z * v2.z + tg.w * v2.w;
+        const float d3 = tg.x * v3.x + tg.y * v3.y + tg.z * v3.z + tg.w * v3.w;
+        const float lh = pp.x, lw = pp.y, hh = 1.f - lh, hw = 1.f - lw;
+        float sw = hh * hw * d0 + hh * lw * d1 + lh * hw * d2 + lh * lw * d3;  // d out / d w
+        float sy = (-hw * d0 - lw * d1 + hw * d2 + lw * d3) * pp.w;              // * a * H
+        float sx = (-hh * d0 + hh * d1 - lh * d2 + lh * d3) * pp.z;              // * a * W
+#pragma unroll
+        for (int s = 1; s < 8; s <<= 1) {
+          sw += __shfl_xor(sw, s);
+          sx += __shfl_xor(sx, s);
+          sy += __shfl_xor(sy, s);
+        }
+        // lane cg keeps points cg and cg+8 -> coalesced stores below
+        if ((pt & 7) == cg) {
+          if (pt < 8) { keep_w[0] = sw; keep_x[0] = sx; keep_y[0] = sy; }
+          else { keep_w[1] = sw; keep_x[1] = sx; keep_y[1] = sy; }
+        }
+      }
+      if (q < qend) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int pt = cg + 8 * h;
+          if (pt < LP) {
+            gaw[qm * LP + pt] = keep_w[h];
+            *reinterpret_cast<float2*>(gloc + (qm * LP + pt) * 2) = make_float2(keep_x[h], keep_y[h]);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -468,8 +719,10 @@ inline bool check_common(int B, int S, int M, int D, int L, int Lq, int P) {
   return B > 0 && S > 0 && M > 0 && D > 0 && L > 0 && L <= kMaxLevels && Lq > 0 && P > 0;
 }
 
-size_t fwd_lds_bytes(int S, int L, int P) { return (size_t)(S + 1) * 128 + (size_t)kFwdWaves * kQW * L * P * 24; }
-size_t bwd_lds_bytes(int S) { return (size_t)(S + 1) * 64 * 2; }
+size_t fwd_lds_bytes(int S, int L, int P, int nw) { return (size_t)(S + 1) * 128 + (size_t)nw * kQW * L * P * 24; }
+size_t bwd_value_lds_bytes(int S) {
+  return (size_t)(S + 1) * 64 + (size_t)((S + 1 + 3) & ~3) * 4 + (size_t)(kBwdVThreads / 64) * 20 * 4;
+}
 constexpr size_t kLdsLimit = 160 * 1024;
 
 template <typename T>
@@ -478,14 +731,16 @@ int msda_forward(const T* value, const int64_t* shapes, const int64_t* lsi, cons
   if (!value || !shapes || !lsi || !loc || !aw || !out || !check_common(B, S, M, D, L, Lq, P)) return COMBO_EINVAL;
   if ((long long)B * Lq * M * D >= (1LL << 31) * 8) return COMBO_EINVAL;
   bool lds_ok = false;
-  if constexpr (sizeof(T) == 4) lds_ok = (D == 32) && S < 65535 && fwd_lds_bytes(S, L, P) <= kLdsLimit;
+  if constexpr (sizeof(T) == 4)
+    lds_ok = (D == 32) && S < 65535 && L * P <= kMaxLP && fwd_lds_bytes(S, L, P, 8) <= kLdsLimit;
   if (algo == 2 && !lds_ok) return COMBO_EINVAL;
   if constexpr (sizeof(T) == 4) {
     if (lds_ok && algo != 1) {
       // enough workgroups to fill 256 CUs a few times; each re-stages the slab from L2 (cheap)
+      const int nw = fwd_lds_bytes(S, L, P, 12) <= kLdsLimit ? 12 : 8;
       int QT = 1;
-      while ((long long)B * M * QT < 1024 && QT < 8 && Lq / (QT * 2) >= kFwdWaves * kQW) QT *= 2;
-      const size_t lds = fwd_lds_bytes(S, L, P);
+      while ((long long)B * M * QT < 1024 && QT < 8 && Lq / (QT * 2) >= nw * kQW) QT *= 2;
+      const size_t lds = fwd_lds_bytes(S, L, P, nw);
       static bool attr_set = false;
       if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_fwd_lds_d32),
@@ -493,7 +748,7 @@ int msda_forward(const T* value, const int64_t* shapes, const int64_t* lsi, cons
         if (e != hipSuccess) return (int)e;
         attr_set = true;
       }
-      hipLaunchKernelGGL(msda_fwd_lds_d32, dim3(B * M * QT), dim3(kFwdThreads), lds, stream, value, shapes, lsi, loc,
+      hipLaunchKernelGGL(msda_fwd_lds_d32, dim3(B * M * QT), dim3(nw * 64), lds, stream, value, shapes, lsi, loc,
                          aw, B, S, M, L, Lq, P, QT, out);
       return (int)hipGetLastError();
     }
@@ -527,19 +782,34 @@ int msda_backward(const T* gout, const T* value, const int64_t* shapes, const in
   if (!gout || !value || !shapes || !lsi || !loc || !aw || !gv || !gl || !gw || !check_common(B, S, M, D, L, Lq, P))
     return COMBO_EINVAL;
   bool lds_ok = false;
-  if constexpr (sizeof(T) == 4) lds_ok = (D == 32) && bwd_lds_bytes(S) <= kLdsLimit;
+  if constexpr (sizeof(T) == 4)
+    lds_ok = (D == 32) && S < 65535 && L * P <= kMaxLP && fwd_lds_bytes(S, L, P, 8) <= kLdsLimit;
   if (algo == 2 && !lds_ok) return COMBO_EINVAL;
   if constexpr (sizeof(T) == 4) {
     if (lds_ok && algo != 1) {
       static bool attr_set = false;
       if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_lds_d32),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_value_lds_d32),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_locw_lds_d32),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
       }
-      hipLaunchKernelGGL(msda_bwd_lds_d32, dim3(B * M * 2), dim3(kBwdThreads), bwd_lds_bytes(S), stream, gout, value,
-                         shapes, lsi, loc, aw, B, S, M, L, Lq, P, gv, gl, gw);
+      // query stride: ~Lq/16 and coprime with Lq, so the 16 queries of one wave instruction are far apart
+      int mult = Lq / 16 + 1;
+      auto gcd = [](int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; };
+      while (gcd(mult, Lq) != 1) ++mult;
+      hipLaunchKernelGGL(msda_bwd_value_lds_d32, dim3(B * M * 2), dim3(kBwdVThreads), bwd_value_lds_bytes(S), stream,
+                         gout, shapes, lsi, loc, aw, B, S, M, L, Lq, P, mult, gv);
+      hipError_t e1 = hipGetLastError();
+      if (e1 != hipSuccess) return (int)e1;
+      const int nw = fwd_lds_bytes(S, L, P, 12) <= kLdsLimit ? 12 : 8;
+      int QT = 1;
+      while ((long long)B * M * QT < 1024 && QT < 8 && Lq / (QT * 2) >= nw * kQW) QT *= 2;
+      hipLaunchKernelGGL(msda_bwd_locw_lds_d32, dim3(B * M * QT), dim3(nw * 64), fwd_lds_bytes(S, L, P, nw), stream,
+                         gout, value, shapes, lsi, loc, aw, B, S, M, L, Lq, P, QT, gl, gw);
       return (int)hipGetLastError();
     }
   }
