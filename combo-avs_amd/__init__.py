@@ -9,3 +9,7 @@ library is missing (see _lib.py).
 __version__ = "0.1.0"
 
 from . import _lib  # noqa: F401
+
+from .config import (CfgNode, add_audio_config, add_fuse_config, add_maskformer2_config, combo_cfg, get_cfg)  # noqa: E402,F401
+from .registry import (BACKBONE_REGISTRY, META_ARCH_REGISTRY, SEM_SEG_HEADS_REGISTRY,  # noqa: E402,F401
+                       TRANSFORMER_DECODER_REGISTRY)

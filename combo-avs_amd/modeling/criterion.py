@@ -1,0 +1,170 @@
+"""SetCriterion / SetCriterion_SS, mirroring models/modeling/criterion.py and
+criterion_ss.py: same constructor, same 39 loss keys, same frame-selection rules.
+
+MI355X notes: no `.cuda()` literals (criterion.py:218,225,244 cannot run on CPU); the `num_masks` all-reduce
+stays a device tensor (no `.item()` sync, :262-265); all 10 decoder outputs are matched with one D2H copy
+(matcher.match_layers); `point_source` injects the random points (tests replay the reference's stream).
+"""
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+from torch import nn
+
+from ..ops.points import point_sample
+from .matcher import default_point_source
+
+
+def dice_loss(inputs, targets, num_masks):
+    inputs = inputs.sigmoid().flatten(1)
+    numerator = 2 * (inputs * targets).sum(-1)
+    denominator = inputs.sum(-1) + targets.sum(-1)
+    return (1 - (numerator + 1) / (denominator + 1)).sum() / num_masks
+
+
+def sigmoid_ce_loss(inputs, targets, num_masks):
+    return F.binary_cross_entropy_with_logits(inputs, targets, reduction="none").mean(1).sum() / num_masks
+
+
+def calculate_uncertainty(logits):
+    assert logits.shape[1] == 1
+    return -(torch.abs(logits))
+
+
+def get_uncertain_point_coords_with_randomness(coarse_logits, num_points, oversample_ratio, importance_sample_ratio, ps):
+    """detectron2 PointRend importance sampling with uncertainty = -|logit| (criterion.py:159-165)."""
+    num_boxes = coarse_logits.shape[0]
+    num_sampled = int(num_points * oversample_ratio)
+    point_coords = ps(num_boxes, num_sampled)
+    point_logits = point_sample(coarse_logits, point_coords)
+    point_uncertainties = calculate_uncertainty(point_logits)
+    num_uncertain_points = int(importance_sample_ratio * num_points)
+    num_random_points = num_points - num_uncertain_points
+    idx = torch.topk(point_uncertainties[:, 0, :], k=num_uncertain_points, dim=1)[1]
+    shift = num_sampled * torch.arange(num_boxes, dtype=torch.long, device=coarse_logits.device)
+    idx = idx + shift[:, None]
+    point_coords = point_coords.view(-1, 2)[idx.view(-1), :].view(num_boxes, num_uncertain_points, 2)
+    if num_random_points > 0:
+        point_coords = torch.cat([point_coords, ps(num_boxes, num_random_points)], dim=1)
+    return point_coords
+
+
+class SetCriterion(nn.Module):
+    def __init__(self, num_classes, matcher, weight_dict, eos_coef, losses, num_points, oversample_ratio,
+                 importance_sample_ratio, n_frame=5):
+        super().__init__()
+        self.num_classes, self.matcher, self.weight_dict = num_classes, matcher, weight_dict
+        self.eos_coef, self.losses = eos_coef, losses
+        empty_weight = torch.ones(self.num_classes + 1)
+        empty_weight[-1] = self.eos_coef
+        self.register_buffer("empty_weight", empty_weight)
+        self.num_points, self.oversample_ratio = num_points, oversample_ratio
+        self.importance_sample_ratio = importance_sample_ratio
+        self.n_frame = n_frame  # hard-coded 5 in the reference (criterion.py:243,284)
+        self.point_source = None  # test hook
+
+    # ---- individual losses -----------------------------------------------------------------------------
+    def loss_labels(self, outputs, targets, indices, num_masks):
+        src_logits = outputs["pred_logits"].float()
+        idx = self._get_src_permutation_idx(indices)
+        target_classes_o = torch.cat([t["labels"][J.to(t["labels"].device)] for t, (_, J) in zip(targets, indices)])
+        target_classes = torch.full(src_logits.shape[:2], self.num_classes, dtype=torch.int64, device=src_logits.device)
+        target_classes[idx] = target_classes_o
+        return {"loss_ce": F.cross_entropy(src_logits.transpose(1, 2), target_classes, self.empty_weight)}
+
+    def loss_masks(self, outputs, targets, indices, num_masks):
+        ps = self.point_source or default_point_source(outputs["pred_masks"].device)
+        src_idx = self._get_src_permutation_idx(indices)
+        src_masks = outputs["pred_masks"][src_idx]
+        target_masks = torch.cat([t["masks"][J.to(t["masks"].device)] for t, (_, J) in zip(targets, indices)]).to(src_masks)
+        src_masks, target_masks = src_masks[:, None], target_masks[:, None]
+        with torch.no_grad():
+            point_coords = get_uncertain_point_coords_with_randomness(
+                src_masks.float(), self.num_points, self.oversample_ratio, self.importance_sample_ratio, ps)
+            point_labels = point_sample(target_masks, point_coords).squeeze(1)
+        point_logits = point_sample(src_masks, point_coords).squeeze(1)
+        return {"loss_mask": sigmoid_ce_loss(point_logits, point_labels, num_masks),
+                "loss_dice": dice_loss(point_logits, point_labels, num_masks)}
+
+    @staticmethod
+    def _get_src_permutation_idx(indices):
+        batch_idx = torch.cat([torch.full_like(src, i) for i, (src, _) in enumerate(indices)])
+        src_idx = torch.cat([src for (src, _) in indices])
+        return batch_idx, src_idx
+
+    def get_loss(self, loss, outputs, targets, indices, num_masks):
+        loss_map = {"labels": self.loss_labels, "masks": self.loss_masks}
+        assert loss in loss_map, f"do you really want to compute {loss} loss?"
+        return loss_map[loss](outputs, targets, indices, num_masks)
+
+    def get_similarity_loss(self, middle_attn_mask, cosine_weight=None, n_frame=5):
+        """criterion.py:208-231: c_f = 1 - cos(m_f, m_{f+1}); sum_f c_f exp(-c_f); / clips / (n_frame-1)."""
+        bs, n_query, HW = middle_attn_mask.shape
+        bs = bs // n_frame
+        m = middle_attn_mask.reshape(bs, n_frame, n_query * HW).float()
+        x1, x2 = m[:, :-1], m[:, 1:]
+        cos = (x1 * x2).sum(-1) / torch.sqrt(((x1 * x1).sum(-1) + 1e-12) * ((x2 * x2).sum(-1) + 1e-12))
+        c = 1 - cos  # [bs, n_frame-1]
+        if cosine_weight is None:
+            c = c * torch.exp(-c)
+        else:
+            c = c * cosine_weight[None, : n_frame - 1]
+        return {"loss_cosine": c.sum() / bs / (n_frame - 1)}
+
+    # ---- frame selection ---------------------------------------------------------------------------------
+    def _select(self, outputs, index):
+        sel = {"pred_logits": outputs["pred_logits"].index_select(0, index),
+               "pred_masks": outputs["pred_masks"].index_select(0, index)}
+        sel["aux_outputs"] = [{k: v.index_select(0, index) for k, v in a.items()} for a in outputs.get("aux_outputs", [])]
+        if "middles_attn_mask" in outputs:
+            sel["middles_attn_mask"] = outputs["middles_attn_mask"]  # NOT sub-selected (criterion.py:241-254)
+        return sel
+
+    def _num_masks(self, targets, device):
+        num_masks = torch.as_tensor([sum(len(t["labels"]) for t in targets)], dtype=torch.float, device=device)
+        world = 1
+        if dist.is_available() and dist.is_initialized():
+            dist.all_reduce(num_masks)
+            world = dist.get_world_size()
+        return torch.clamp(num_masks / world, min=1)  # stays on the device: no .item() sync
+
+    def _losses(self, outputs, targets):
+        layers = [{"pred_logits": outputs["pred_logits"], "pred_masks": outputs["pred_masks"]}] + list(outputs.get("aux_outputs", []))
+        ps = self.point_source
+        if ps is None:
+            all_indices = self.matcher.match_layers(layers, targets)  # one host sync for all 10 outputs
+        else:  # replay mode: keep the reference's RNG order (matcher, then losses, per layer)
+            all_indices = None
+        num_masks = self._num_masks(targets, outputs["pred_logits"].device)
+        losses = {}
+        for li, lo in enumerate(layers):
+            indices = all_indices[li] if all_indices is not None else self.matcher(lo, targets, ps)
+            indices = [(i.to(lo["pred_logits"].device), j) for i, j in indices]
+            sfx = "" if li == 0 else f"_{li - 1}"
+            for loss in self.losses:
+                for k, v in self.get_loss(loss, lo, targets, indices, num_masks).items():
+                    losses[k + sfx] = v
+        if "middles_attn_mask" in outputs:
+            for i, mid in enumerate(outputs["middles_attn_mask"]):
+                losses[f"loss_cosine_{i}"] = self.get_similarity_loss(mid, None, n_frame=self.n_frame)["loss_cosine"]
+        return losses
+
+    def forward(self, outputs, targets):
+        if len(outputs["pred_logits"]) != len(targets):  # S4 training: GT on the first frame of each clip only
+            index = torch.arange(0, len(outputs["pred_logits"]), 5, device=outputs["pred_logits"].device)
+            outputs = self._select(outputs, index)
+        return self._losses(outputs, targets)
+
+    def __repr__(self):
+        body = [f"matcher: {self.matcher.__repr__(_repr_indent=8)}", f"losses: {self.losses}",
+                f"weight_dict: {self.weight_dict}", f"num_classes: {self.num_classes}", f"eos_coef: {self.eos_coef}",
+                f"num_points: {self.num_points}", f"oversample_ratio: {self.oversample_ratio}",
+                f"importance_sample_ratio: {self.importance_sample_ratio}"]
+        return "\n".join(["Criterion " + self.__class__.__name__] + [" " * 4 + line for line in body])
+
+
+class SetCriterion_SS(SetCriterion):
+    """AVSS variant: frames are chosen by gt_temporal_mask_flag (criterion_ss.py:246-257)."""
+
+    def forward(self, outputs, targets, vid_temporal_mask_flag, gt_temporal_mask_flag):
+        index = torch.where(gt_temporal_mask_flag == 1)[0].to(outputs["pred_logits"].device)
+        return self._losses(self._select(outputs, index), targets)

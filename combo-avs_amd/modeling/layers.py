@@ -1,0 +1,77 @@
+"""Small building blocks shared by the head modules."""
+import math
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+_PE_CACHE = {}
+
+
+def position_embedding_sine(b, h, w, device, num_pos_feats=128, temperature=10000.0, dtype=torch.float32):
+    """PositionEmbeddingSine(normalize=True) of the reference (position_encoding.py:29-48).
+    Input independent, so it is computed once per (h, w, device) and cached (the reference recomputes it
+    7 times per forward).  Returns [1, 2*num_pos_feats, h, w]; callers broadcast over the batch."""
+    key = (h, w, str(device), num_pos_feats)
+    pe = _PE_CACHE.get(key)
+    if pe is None:
+        eps, scale = 1e-6, 2 * math.pi
+        y = torch.arange(1, h + 1, dtype=torch.float32, device=device).view(h, 1).expand(h, w)
+        x = torch.arange(1, w + 1, dtype=torch.float32, device=device).view(1, w).expand(h, w)
+        y = y / (float(h) + eps) * scale
+        x = x / (float(w) + eps) * scale
+        i = torch.arange(num_pos_feats, dtype=torch.float32, device=device)
+        dim_t = temperature ** (2 * torch.div(i, 2, rounding_mode="floor") / num_pos_feats)
+        px, py = x[:, :, None] / dim_t, y[:, :, None] / dim_t
+        px = torch.stack((px[:, :, 0::2].sin(), px[:, :, 1::2].cos()), dim=3).flatten(2)
+        py = torch.stack((py[:, :, 0::2].sin(), py[:, :, 1::2].cos()), dim=3).flatten(2)
+        pe = torch.cat((py, px), dim=2).permute(2, 0, 1).unsqueeze(0).contiguous()
+        _PE_CACHE[key] = pe
+    return pe.to(dtype)
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d + optional norm + optional activation; parameters are named like detectron2's wrapper
+    (`<name>.weight`, `<name>.norm.weight`) so reference checkpoints load 1:1."""
+
+    def __init__(self, *args, norm=None, activation=None, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.norm = norm
+        self.activation = activation
+
+    def forward(self, x):
+        x = F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+        if self.norm is not None:
+            x = self.norm(x)
+        if self.activation is not None:
+            x = self.activation(x)
+        return x
+
+
+def get_norm(norm, out_channels):
+    if norm is None or norm == "":
+        return None
+    if norm == "GN":
+        return nn.GroupNorm(32, out_channels)
+    raise ValueError(f"unsupported norm {norm!r}")
+
+
+def c2_xavier_fill(module):
+    nn.init.kaiming_uniform_(module.weight, a=1)
+    if module.bias is not None:
+        nn.init.constant_(module.bias, 0)
+
+
+class MLP(nn.Module):
+    """transformer_decoder.py:207-219"""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers):
+        super().__init__()
+        self.num_layers = num_layers
+        h = [hidden_dim] * (num_layers - 1)
+        self.layers = nn.ModuleList(nn.Linear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
+
+    def forward(self, x):
+        for i, layer in enumerate(self.layers):
+            x = F.relu(layer(x)) if i < self.num_layers - 1 else layer(x)
+        return x

@@ -1,0 +1,252 @@
+"""MSDeformAttn pixel decoder, mirroring
+models/modeling/pixel_decoder/msdeformattn.py and ops/modules/ms_deform_attn.py of the reference:
+same class names, constructor arguments, parameter names and `forward_features` contract.
+
+MI355X notes: the deformable core runs on the hand-written HIP kernels (`combo_avs_amd.msda`), there is no
+grid_sample fallback and no bare `except` (ms_deform_attn.py:119-125 of the reference hides kernel failures);
+position encodings and reference points are cached per resolution; tokens stay [BT, S, 256] row-major
+(one 128-B row per head) which is the layout the LDS-staged kernels consume.
+"""
+import math
+from typing import Dict
+
+import numpy as np
+import torch
+from torch import nn
+from torch.nn import functional as F
+from torch.nn.init import constant_, normal_, xavier_uniform_
+
+from ..msda import MSDeformAttnFunction
+from ..registry import SEM_SEG_HEADS_REGISTRY, ShapeSpec
+from .layers import Conv2d, c2_xavier_fill, get_norm, position_embedding_sine
+
+
+class MSDeformAttn(nn.Module):
+    """ops/modules/ms_deform_attn.py:32-129"""
+
+    def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
+        super().__init__()
+        if d_model % n_heads != 0:
+            raise ValueError(f"d_model must be divisible by n_heads, but got {d_model} and {n_heads}")
+        self.im2col_step = 128
+        self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
+        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
+        self.value_proj = nn.Linear(d_model, d_model)
+        self.output_proj = nn.Linear(d_model, d_model)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        constant_(self.sampling_offsets.weight.data, 0.0)
+        thetas = torch.arange(self.n_heads, dtype=torch.float32) * (2.0 * math.pi / self.n_heads)
+        grid_init = torch.stack([thetas.cos(), thetas.sin()], -1)
+        grid_init = (grid_init / grid_init.abs().max(-1, keepdim=True)[0]).view(self.n_heads, 1, 1, 2)
+        grid_init = grid_init.repeat(1, self.n_levels, self.n_points, 1)
+        for i in range(self.n_points):
+            grid_init[:, :, i, :] *= i + 1
+        with torch.no_grad():
+            self.sampling_offsets.bias = nn.Parameter(grid_init.view(-1))
+        constant_(self.attention_weights.weight.data, 0.0)
+        constant_(self.attention_weights.bias.data, 0.0)
+        xavier_uniform_(self.value_proj.weight.data)
+        constant_(self.value_proj.bias.data, 0.0)
+        xavier_uniform_(self.output_proj.weight.data)
+        constant_(self.output_proj.bias.data, 0.0)
+
+    def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
+                input_padding_mask=None, offset_normalizer=None):
+        N, Len_q, _ = query.shape
+        N, Len_in, _ = input_flatten.shape
+        value = self.value_proj(input_flatten)
+        if input_padding_mask is not None:
+            value = value.masked_fill(input_padding_mask[..., None], float(0))
+        value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
+        sampling_offsets = self.sampling_offsets(query).view(N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
+        attention_weights = self.attention_weights(query).view(N, Len_q, self.n_heads, self.n_levels * self.n_points)
+        attention_weights = F.softmax(attention_weights, -1).view(N, Len_q, self.n_heads, self.n_levels, self.n_points)
+        if reference_points.shape[-1] != 2:
+            raise ValueError(f"Last dim of reference_points must be 2, but get {reference_points.shape[-1]} instead.")
+        if offset_normalizer is None:
+            offset_normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
+        sampling_locations = (reference_points[:, :, None, :, None, :]
+                              + sampling_offsets / offset_normalizer[None, None, None, :, None, :])
+        output = MSDeformAttnFunction.apply(value.float(), input_spatial_shapes, input_level_start_index,
+                                            sampling_locations.float(), attention_weights.float(), self.im2col_step)
+        return self.output_proj(output.to(query.dtype))
+
+
+class MSDeformAttnTransformerEncoderLayer(nn.Module):
+    """msdeformattn.py:98-134 (post-norm, dropout = MASK_FORMER.DROPOUT = 0 in every shipped config)"""
+
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4, n_heads=8, n_points=4):
+        super().__init__()
+        self.self_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.dropout2 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout3 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+
+    def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None, normalizer=None):
+        src2 = self.self_attn(src + pos, reference_points, src, spatial_shapes, level_start_index, padding_mask, normalizer)
+        src = self.norm1(src + self.dropout1(src2))
+        src2 = self.linear2(self.dropout2(F.relu(self.linear1(src))))
+        return self.norm2(src + self.dropout3(src2))
+
+
+class MSDeformAttnTransformerEncoder(nn.Module):
+    def __init__(self, encoder_layer_fn, num_layers):
+        super().__init__()
+        self.layers = nn.ModuleList([encoder_layer_fn() for _ in range(num_layers)])
+        self.num_layers = num_layers
+
+    @staticmethod
+    def get_reference_points(spatial_shapes_list, device):
+        """msdeformattn.py:144-157 with valid_ratios == 1 -> [1, S, L, 2]"""
+        pts = []
+        for (H, W) in spatial_shapes_list:
+            ry = (torch.arange(H, dtype=torch.float32, device=device) + 0.5) / H
+            rx = (torch.arange(W, dtype=torch.float32, device=device) + 0.5) / W
+            gy, gx = torch.meshgrid(ry, rx, indexing="ij")
+            pts.append(torch.stack((gx.reshape(-1), gy.reshape(-1)), -1))
+        ref = torch.cat(pts, 0)
+        return ref[None, :, None, :].expand(1, -1, len(spatial_shapes_list), -1).contiguous()
+
+
+class MSDeformAttnTransformerEncoderOnly(nn.Module):
+    """msdeformattn.py:23-95"""
+
+    def __init__(self, d_model=256, nhead=8, num_encoder_layers=6, dim_feedforward=1024, dropout=0.1,
+                 activation="relu", num_feature_levels=4, enc_n_points=4):
+        super().__init__()
+        self.d_model, self.nhead = d_model, nhead
+        self.encoder = MSDeformAttnTransformerEncoder(
+            lambda: MSDeformAttnTransformerEncoderLayer(d_model, dim_feedforward, dropout, activation,
+                                                        num_feature_levels, nhead, enc_n_points),
+            num_encoder_layers)
+        self.level_embed = nn.Parameter(torch.Tensor(num_feature_levels, d_model))
+        self._geom = {}
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for m in self.modules():
+            if isinstance(m, MSDeformAttn):
+                m._reset_parameters()
+        normal_(self.level_embed)
+
+    def _geometry(self, shapes_list, device):
+        key = (tuple(shapes_list), str(device))
+        g = self._geom.get(key)
+        if g is None:
+            spatial_shapes = torch.as_tensor(shapes_list, dtype=torch.long, device=device)
+            level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+            ref = MSDeformAttnTransformerEncoder.get_reference_points(shapes_list, device)
+            normalizer = torch.tensor([[w, h] for h, w in shapes_list], dtype=torch.float32, device=device)
+            g = (spatial_shapes, level_start_index, ref, normalizer)
+            self._geom[key] = g
+        return g
+
+    def forward(self, srcs, pos_embeds):
+        """srcs: list of [B,C,h,w]; pos_embeds: list of [1,C,h,w].  Returns (memory [B,S,C], shapes, start)."""
+        shapes_list = [(int(s.shape[2]), int(s.shape[3])) for s in srcs]
+        spatial_shapes, level_start_index, ref, normalizer = self._geometry(shapes_list, srcs[0].device)
+        src = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
+        pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[l].view(1, 1, -1)
+                         for l, p in enumerate(pos_embeds)], 1)
+        ref = ref.expand(src.shape[0], -1, -1, -1)
+        out = src
+        for layer in self.encoder.layers:
+            out = layer(out, pos, ref, spatial_shapes, level_start_index, None, normalizer)
+        return out, spatial_shapes, level_start_index, shapes_list
+
+
+@SEM_SEG_HEADS_REGISTRY.register()
+class MSDeformAttnPixelDecoder(nn.Module):
+    """msdeformattn.py:168-359"""
+
+    def __init__(self, input_shape: Dict[str, ShapeSpec], *, transformer_dropout: float, transformer_nheads: int,
+                 transformer_dim_feedforward: int, transformer_enc_layers: int, conv_dim: int, mask_dim: int,
+                 norm=None, transformer_in_features=("res3", "res4", "res5"), common_stride: int = 4):
+        super().__init__()
+        transformer_input_shape = {k: v for k, v in input_shape.items() if k in transformer_in_features}
+        input_shape = sorted(input_shape.items(), key=lambda x: x[1].stride)
+        self.in_features = [k for k, v in input_shape]
+        self.feature_strides = [v.stride for k, v in input_shape]
+        self.feature_channels = [v.channels for k, v in input_shape]
+        transformer_input_shape = sorted(transformer_input_shape.items(), key=lambda x: x[1].stride)
+        self.transformer_in_features = [k for k, v in transformer_input_shape]
+        transformer_in_channels = [v.channels for k, v in transformer_input_shape]
+        self.transformer_feature_strides = [v.stride for k, v in transformer_input_shape]
+        self.transformer_num_feature_levels = len(self.transformer_in_features)
+        chans = transformer_in_channels[::-1] if self.transformer_num_feature_levels > 1 else [transformer_in_channels[-1]]
+        self.input_proj = nn.ModuleList(
+            [nn.Sequential(nn.Conv2d(c, conv_dim, kernel_size=1), nn.GroupNorm(32, conv_dim)) for c in chans])
+        for proj in self.input_proj:
+            nn.init.xavier_uniform_(proj[0].weight, gain=1)
+            nn.init.constant_(proj[0].bias, 0)
+        self.transformer = MSDeformAttnTransformerEncoderOnly(
+            d_model=conv_dim, dropout=transformer_dropout, nhead=transformer_nheads,
+            dim_feedforward=transformer_dim_feedforward, num_encoder_layers=transformer_enc_layers,
+            num_feature_levels=self.transformer_num_feature_levels)
+        self.conv_dim = conv_dim
+        self.mask_dim = mask_dim
+        self.mask_features = Conv2d(conv_dim, mask_dim, kernel_size=1, stride=1, padding=0)
+        c2_xavier_fill(self.mask_features)
+        self.maskformer_num_feature_levels = 3
+        self.common_stride = common_stride
+        stride = min(self.transformer_feature_strides)
+        self.num_fpn_levels = int(np.log2(stride) - np.log2(self.common_stride))
+        lateral_convs, output_convs = [], []
+        use_bias = norm == ""
+        for idx, in_channels in enumerate(self.feature_channels[: self.num_fpn_levels]):
+            lateral_conv = Conv2d(in_channels, conv_dim, kernel_size=1, bias=use_bias, norm=get_norm(norm, conv_dim))
+            output_conv = Conv2d(conv_dim, conv_dim, kernel_size=3, stride=1, padding=1, bias=use_bias,
+                                 norm=get_norm(norm, conv_dim), activation=F.relu)
+            c2_xavier_fill(lateral_conv)
+            c2_xavier_fill(output_conv)
+            self.add_module(f"adapter_{idx + 1}", lateral_conv)
+            self.add_module(f"layer_{idx + 1}", output_conv)
+            lateral_convs.append(lateral_conv)
+            output_convs.append(output_conv)
+        self.lateral_convs = lateral_convs[::-1]
+        self.output_convs = output_convs[::-1]
+
+    @classmethod
+    def from_config(cls, cfg, input_shape):
+        return dict(
+            input_shape={k: v for k, v in input_shape.items() if k in cfg.MODEL.SEM_SEG_HEAD.IN_FEATURES},
+            conv_dim=cfg.MODEL.SEM_SEG_HEAD.CONVS_DIM, mask_dim=cfg.MODEL.SEM_SEG_HEAD.MASK_DIM,
+            norm=cfg.MODEL.SEM_SEG_HEAD.NORM, transformer_dropout=cfg.MODEL.MASK_FORMER.DROPOUT,
+            transformer_nheads=cfg.MODEL.MASK_FORMER.NHEADS,
+            transformer_dim_feedforward=1024,  # hidden constant of the reference (msdeformattn.py:308-309)
+            transformer_enc_layers=cfg.MODEL.SEM_SEG_HEAD.TRANSFORMER_ENC_LAYERS,
+            transformer_in_features=cfg.MODEL.SEM_SEG_HEAD.DEFORMABLE_TRANSFORMER_ENCODER_IN_FEATURES,
+            common_stride=cfg.MODEL.SEM_SEG_HEAD.COMMON_STRIDE)
+
+    def forward_features(self, features):
+        """-> (mask_features [BT,mask_dim,H/4,W/4], out[0], multi_scale_features[3]); fp32 like the reference
+        (msdeformattn.py:315: autocast disabled, inputs .float())."""
+        with torch.autocast(device_type="cuda", enabled=False):
+            srcs, pos = [], []
+            for idx, f in enumerate(self.transformer_in_features[::-1]):
+                x = features[f].float()
+                srcs.append(self.input_proj[idx](x))
+                pos.append(position_embedding_sine(1, x.shape[2], x.shape[3], x.device, self.conv_dim // 2))
+            y, spatial_shapes, level_start_index, shapes_list = self.transformer(srcs, pos)
+            bs = y.shape[0]
+            out, start = [], 0
+            for (H, W) in shapes_list:
+                out.append(y[:, start:start + H * W].transpose(1, 2).reshape(bs, -1, H, W))
+                start += H * W
+            for idx, f in enumerate(self.in_features[: self.num_fpn_levels][::-1]):
+                x = features[f].float()
+                cur_fpn = self.lateral_convs[idx](x)
+                y = cur_fpn + F.interpolate(out[-1], size=cur_fpn.shape[-2:], mode="bilinear", align_corners=False)
+                out.append(self.output_convs[idx](y))
+            multi_scale_features = out[: self.maskformer_num_feature_levels]
+            return self.mask_features(out[-1]), out[0], multi_scale_features

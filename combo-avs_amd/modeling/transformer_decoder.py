@@ -1,0 +1,233 @@
+"""Audio-seeded masked transformer decoder, mirroring
+models/modeling/transformer_decoder/transformer_decoder.py: same class names, constructor arguments,
+parameter names (so reference checkpoints load 1:1) and the same output dict.
+
+MI355X notes: activations are batch-first [BT, Q, C] / token-major [BT, hw, C] (the reference is sequence-first);
+position encodings are cached; the boolean attention mask is kept as ONE [BT, Q, hw] tensor and broadcast over
+the 8 heads instead of being materialised 8x (transformer_decoder.py:504); the "fully blocked row" reset
+(:458, a nonzero()+index_put => host sync in the reference) is a sync-free logical op; mask logits come from a
+token-major pixel embedding so the contraction is a K-contiguous NT GEMM.
+"""
+import logging
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from ..registry import TRANSFORMER_DECODER_REGISTRY
+from .layers import MLP, position_embedding_sine
+
+
+class _MHAParams(nn.Module):
+    """Parameter container with nn.MultiheadAttention's names (in_proj_weight/in_proj_bias/out_proj.*)."""
+
+    def __init__(self, d_model, nhead):
+        super().__init__()
+        self.embed_dim, self.num_heads = d_model, nhead
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d_model, d_model))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d_model))
+        self.out_proj = nn.Linear(d_model, d_model)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.constant_(self.out_proj.bias, 0.0)
+
+    def forward(self, query, key, value, blocked=None):
+        """batch-first: query [B,Lq,E], key/value [B,Lk,E]; blocked: bool [B,Lq,Lk], True = masked out."""
+        E, H = self.embed_dim, self.num_heads
+        B, Lq, _ = query.shape
+        Lk = key.shape[1]
+        W, b = self.in_proj_weight, self.in_proj_bias
+        q = F.linear(query, W[:E], b[:E]).view(B, Lq, H, E // H).transpose(1, 2)
+        k = F.linear(key, W[E:2 * E], b[E:2 * E]).view(B, Lk, H, E // H).transpose(1, 2)
+        v = F.linear(value, W[2 * E:], b[2 * E:]).view(B, Lk, H, E // H).transpose(1, 2)
+        mask = None if blocked is None else (~blocked)[:, None]  # SDPA: True = may attend
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
+        return self.out_proj(o.transpose(1, 2).reshape(B, Lq, E))
+
+
+class SelfAttentionLayer(nn.Module):
+    def __init__(self, d_model, nhead, dropout=0.0, activation="relu", normalize_before=False):
+        super().__init__()
+        assert not normalize_before and dropout == 0.0, "shipped configs: PRE_NORM False, dropout 0"
+        self.self_attn = _MHAParams(d_model, nhead)
+        self.norm = nn.LayerNorm(d_model)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, tgt, query_pos):
+        qk = tgt + query_pos
+        return self.norm(tgt + self.self_attn(qk, qk, tgt))  # transformer_decoder.py:50-58
+
+
+class CrossAttentionLayer(nn.Module):
+    def __init__(self, d_model, nhead, dropout=0.0, activation="relu", normalize_before=False):
+        super().__init__()
+        assert not normalize_before and dropout == 0.0
+        self.multihead_attn = _MHAParams(d_model, nhead)
+        self.norm = nn.LayerNorm(d_model)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, tgt, memory, blocked, pos, query_pos):
+        tgt2 = self.multihead_attn(tgt + query_pos, memory + pos, memory, blocked)  # :99-118
+        return self.norm(tgt + tgt2)
+
+
+class FFNLayer(nn.Module):
+    def __init__(self, d_model, dim_feedforward=2048, dropout=0.0, activation="relu", normalize_before=False):
+        super().__init__()
+        assert not normalize_before and dropout == 0.0
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm = nn.LayerNorm(d_model)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, tgt):
+        return self.norm(tgt + self.linear2(F.relu(self.linear1(tgt))))  # :178-182
+
+
+@TRANSFORMER_DECODER_REGISTRY.register()
+class MultiScaleMaskedTransformerDecoder(nn.Module):
+    _version = 2
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        version = local_metadata.get("version", None)
+        if version is None or version < 2:  # transformer_decoder.py:226-245
+            for k in list(state_dict.keys()):
+                if "static_query" in k:
+                    state_dict[k.replace("static_query", "query_feat")] = state_dict.pop(k)
+                    logging.getLogger(__name__).warning("Weight format of %s have changed! Applying automatic conversion now ...",
+                                                        self.__class__.__name__)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+
+    def __init__(self, in_channels, mask_classification=True, *, num_classes: int, hidden_dim: int, num_queries: int,
+                 num_frames: int, queries_fuse_type: str, audio_out_dim: int, nheads: int, dim_feedforward: int,
+                 dec_layers: int, pre_norm: bool, mask_dim: int, enforce_input_project: bool, dataset_name: str,
+                 use_cosine_loss: bool):
+        super().__init__()
+        assert mask_classification, "Only support mask classification model"
+        self.mask_classification = mask_classification
+        self.hidden_dim = hidden_dim
+        self.num_heads, self.num_layers = nheads, dec_layers
+        self.queries_fuse_type, self.audio_out_dim = queries_fuse_type, audio_out_dim
+        self.transformer_self_attention_layers = nn.ModuleList()
+        self.transformer_cross_attention_layers = nn.ModuleList()
+        self.transformer_ffn_layers = nn.ModuleList()
+        for _ in range(self.num_layers):
+            self.transformer_self_attention_layers.append(SelfAttentionLayer(hidden_dim, nheads, 0.0, normalize_before=pre_norm))
+            self.transformer_cross_attention_layers.append(CrossAttentionLayer(hidden_dim, nheads, 0.0, normalize_before=pre_norm))
+            self.transformer_ffn_layers.append(FFNLayer(hidden_dim, dim_feedforward, 0.0, normalize_before=pre_norm))
+        self.decoder_norm = nn.LayerNorm(hidden_dim)
+        self.num_queries = num_queries
+        query_feat_dim = hidden_dim - audio_out_dim if queries_fuse_type == "dim" else hidden_dim
+        self.query_feat = nn.Embedding(num_queries, query_feat_dim)
+        self.query_embed = nn.Embedding(num_queries, hidden_dim)
+        self.num_feature_levels = 3
+        self.level_embed = nn.Embedding(self.num_feature_levels, hidden_dim)
+        self.input_proj = nn.ModuleList()
+        for _ in range(self.num_feature_levels):
+            if in_channels != hidden_dim or enforce_input_project:
+                conv = nn.Conv2d(in_channels, hidden_dim, kernel_size=1)
+                nn.init.kaiming_uniform_(conv.weight, a=1)
+                nn.init.constant_(conv.bias, 0)
+                self.input_proj.append(conv)
+            else:
+                self.input_proj.append(nn.Sequential())
+        self.class_embed = nn.Linear(hidden_dim, num_classes + 1)
+        self.mask_embed = MLP(hidden_dim, hidden_dim, mask_dim, 3)
+        self.dataset_name = dataset_name
+        self.use_cosine_loss = use_cosine_loss
+
+    @classmethod
+    def from_config(cls, cfg, in_channels, mask_classification):
+        assert cfg.MODEL.MASK_FORMER.DEC_LAYERS >= 1
+        return dict(
+            in_channels=in_channels, mask_classification=mask_classification,
+            num_classes=cfg.MODEL.SEM_SEG_HEAD.NUM_CLASSES, hidden_dim=cfg.MODEL.MASK_FORMER.HIDDEN_DIM,
+            num_queries=cfg.MODEL.MASK_FORMER.NUM_OBJECT_QUERIES, num_frames=cfg.MODEL.FUSE_CONFIG.NUM_FRAMES,
+            queries_fuse_type=cfg.MODEL.FUSE_CONFIG.QUERIES_FUSE_TYPE, audio_out_dim=cfg.MODEL.FUSE_CONFIG.AUDIO_OUT_DIM,
+            nheads=cfg.MODEL.MASK_FORMER.NHEADS, dim_feedforward=cfg.MODEL.MASK_FORMER.DIM_FEEDFORWARD,
+            dec_layers=cfg.MODEL.MASK_FORMER.DEC_LAYERS - 1, pre_norm=cfg.MODEL.MASK_FORMER.PRE_NORM,
+            enforce_input_project=cfg.MODEL.MASK_FORMER.ENFORCE_INPUT_PROJ, mask_dim=cfg.MODEL.SEM_SEG_HEAD.MASK_DIM,
+            dataset_name=cfg.DATASETS.TRAIN[0][:5], use_cosine_loss=cfg.MODEL.MASK_FORMER.COSINE_WEIGHT > 0)
+
+    def scramble_audio(self, audio_features, bt):
+        """transformer_decoder.py:437 `audio.repeat(1,Q,1).reshape(Q,-1,C)` is NOT a transpose: query q of frame b
+        gets the audio token of frame (q*BT+b)//Q.  Reproduced as an index gather, batch-first [BT,Q,C]."""
+        Q = self.num_queries
+        key = (bt, str(audio_features.device))
+        idx = getattr(self, "_scramble_idx", {}).get(key)
+        if idx is None:
+            q = torch.arange(Q, device=audio_features.device)[None, :]
+            b = torch.arange(bt, device=audio_features.device)[:, None]
+            idx = torch.div(q * bt + b, Q, rounding_mode="floor")  # [BT,Q]
+            if not hasattr(self, "_scramble_idx"):
+                self._scramble_idx = {}
+            self._scramble_idx[key] = idx
+        return audio_features[:, 0][idx]  # [BT,Q,C]
+
+    def forward(self, x, audio_features, mask_features, mask=None):
+        bt, c_m, h_m, w_m = mask_features.shape
+        assert len(x) == self.num_feature_levels
+        del mask
+        mf_tok = mask_features.permute(0, 2, 3, 1).reshape(bt, h_m * w_m, c_m)  # free for channels_last input
+        src, pos, size_list = [], [], []
+        for i in range(self.num_feature_levels):
+            size_list.append(tuple(x[i].shape[-2:]))
+            p = position_embedding_sine(1, x[i].shape[2], x[i].shape[3], x[i].device, self.hidden_dim // 2)
+            pos.append(p.flatten(2).transpose(1, 2))  # [1,hw,C]
+            s = self.input_proj[i](x[i]).flatten(2) + self.level_embed.weight[i][None, :, None]
+            src.append(s.transpose(1, 2))  # [BT,hw,C]
+        query_embed = self.query_embed.weight.unsqueeze(0)  # [1,Q,C]
+        output = self.query_feat.weight.unsqueeze(0).expand(bt, -1, -1)
+        if self.queries_fuse_type == "add":
+            output = output + self.scramble_audio(audio_features, bt)
+        elif self.queries_fuse_type == "dim":
+            output = torch.cat([output, self.scramble_audio(audio_features, bt)], dim=-1)
+        elif self.queries_fuse_type == "all":
+            output = self.scramble_audio(audio_features, bt)
+        predictions_class, predictions_mask, middles = [], [], []
+        outputs_class, outputs_mask, blocked = self.forward_prediction_heads(output, mf_tok, (h_m, w_m), size_list[0])
+        predictions_class.append(outputs_class)
+        predictions_mask.append(outputs_mask)
+        if self.use_cosine_loss:
+            middles.append(outputs_mask.reshape(bt, self.num_queries, -1))
+        for i in range(self.num_layers):
+            lvl = i % self.num_feature_levels
+            blocked = blocked & ~blocked.all(dim=-1, keepdim=True)  # :458, sync-free
+            output = self.transformer_cross_attention_layers[i](output, src[lvl], blocked, pos[lvl], query_embed)
+            output = self.transformer_self_attention_layers[i](output, query_embed)
+            output = self.transformer_ffn_layers[i](output)
+            outputs_class, outputs_mask, blocked = self.forward_prediction_heads(
+                output, mf_tok, (h_m, w_m), size_list[(i + 1) % self.num_feature_levels])
+            predictions_class.append(outputs_class)
+            predictions_mask.append(outputs_mask)
+            if self.use_cosine_loss and i != self.num_layers - 1:
+                middles.append(outputs_mask.reshape(bt, self.num_queries, -1))
+        assert len(predictions_class) == self.num_layers + 1
+        return {
+            "pred_logits": predictions_class[-1], "pred_masks": predictions_mask[-1],
+            "aux_outputs": [{"pred_logits": a, "pred_masks": b} for a, b in zip(predictions_class[:-1], predictions_mask[:-1])],
+            "middles_attn_mask": middles,
+        }
+
+    def forward_prediction_heads(self, output, mf_tok, hw, attn_mask_target_size):
+        """:493-509 -> (class logits [BT,Q,K+1], mask logits [BT,Q,H,W], blocked bool [BT,Q,h*w])"""
+        from ..ops import masklogit
+        dec = self.decoder_norm(output)
+        outputs_class = self.class_embed(dec)
+        mask_embed = self.mask_embed(dec)
+        outputs_mask, blocked = masklogit.mask_logits_and_attn_mask(mask_embed, mf_tok, hw, attn_mask_target_size)
+        return outputs_class, outputs_mask, blocked
