@@ -42,7 +42,7 @@ class ConvBN(nn.Conv2d):
     def forward(self, x):
         scale, shift = self.norm.scale_shift()
         w = self.weight * scale[:, None, None, None]
-        return F.conv2d(x, w.to(x.dtype), shift.to(x.dtype), self.stride, self.padding)
+        return F.conv2d(x, w, shift, self.stride, self.padding)  # autocast (if enabled) picks the compute dtype
 
 
 class Bottleneck(nn.Module):

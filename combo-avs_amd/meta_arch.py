@@ -134,17 +134,19 @@ class MaskFormer(nn.Module):
         image_size = tuple(images.shape[-2:])
         audio_log_mels = torch.cat([b["audio_log_mel"].to(dev, non_blocking=True) for b in batched_inputs], dim=0)
         images = self._pad((images.float() - self.pixel_mean) / self.pixel_std)  # maskformer_model.py:324-325
-        with torch.no_grad():
-            audio_feature = self.audio_backbone(audio_log_mels.to(self.backbone_dtype)).float()  # :327-328
+        amp = torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.backbone_dtype == torch.bfloat16)
+        with torch.no_grad(), amp:
+            audio_feature = self.audio_backbone(audio_log_mels).float()  # :327-328
         audio_feature = audio_feature.unsqueeze(1)
         if self.is_avss_data:
             audio_feature = audio_feature[vid_flag.bool()]
-        bdt = self.backbone_dtype
-        features = self.backbone(images.to(bdt))
+        with amp:
+            features = self.backbone(images)
         if self.use_pre_sam:
             pre = torch.cat([b["pre_masks"].to(dev, non_blocking=True) for b in batched_inputs], dim=0)
             pre = self._pad((pre.float() - self.pixel_mean) / self.pixel_std)
-            pre_sam_features = self.pre_sam_backbone(pre.to(bdt))
+            with amp:
+                pre_sam_features = self.pre_sam_backbone(pre)
             features = sem_mix(features, pre_sam_features, self.scale_factor_module)  # :345-352
         outputs = self.sem_seg_head(features, audio_feature)
         if self.training:

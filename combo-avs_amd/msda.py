@@ -16,6 +16,37 @@ from . import _lib
 
 ALGO_AUTO, ALGO_GENERIC, ALGO_LDS = 0, 1, 2
 _algo = ALGO_AUTO
+_timing = None  # {"fwd": [(start_event, end_event)], "bwd": [...]} while bench.py measures kernel durations
+
+
+def start_timing():
+    """Record HIP events (on the launch stream) around every core-op launch until stop_timing()."""
+    global _timing
+    _timing = {"fwd": [], "bwd": []}
+
+
+def stop_timing():
+    """-> {"fwd_us": [...], "bwd_us": [...]} per-launch durations in microseconds (synchronises)."""
+    global _timing
+    t, _timing = _timing, None
+    torch.cuda.synchronize()
+    return {k + "_us": [s.elapsed_time(e) * 1e3 for s, e in v] for k, v in (t or {"fwd": [], "bwd": []}).items()}
+
+
+class _Timed:
+    def __init__(self, kind):
+        self.kind = kind
+
+    def __enter__(self):
+        if _timing is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+
+    def __exit__(self, *a):
+        if _timing is not None:
+            self.e.record()
+            _timing[self.kind].append((self.s, self.e))
 
 
 def set_algo(algo: int):
@@ -53,9 +84,10 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     B, S, M, D, L, Lq, P = _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
     out = torch.empty((B, Lq, M * D), dtype=value.dtype, device=value.device)
     fn = getattr(_lib.lib(), "combo_msda_forward_" + _suffix(value.dtype))
-    _lib.check(fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
-                  attn_weight.data_ptr(), B, S, M, D, L, Lq, P, out.data_ptr(), _algo, _lib.current_stream()),
-               "combo_msda_forward")
+    with _Timed("fwd"):
+        rc = fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
+                attn_weight.data_ptr(), B, S, M, D, L, Lq, P, out.data_ptr(), _algo, _lib.current_stream())
+    _lib.check(rc, "combo_msda_forward")
     return out
 
 
@@ -70,9 +102,11 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     grad_loc = torch.zeros_like(sampling_loc)
     grad_w = torch.zeros_like(attn_weight)
     fn = getattr(_lib.lib(), "combo_msda_backward_" + _suffix(value.dtype))
-    _lib.check(fn(grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
-                  sampling_loc.data_ptr(), attn_weight.data_ptr(), B, S, M, D, L, Lq, P, grad_value.data_ptr(),
-                  grad_loc.data_ptr(), grad_w.data_ptr(), _algo, _lib.current_stream()), "combo_msda_backward")
+    with _Timed("bwd"):
+        rc = fn(grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                sampling_loc.data_ptr(), attn_weight.data_ptr(), B, S, M, D, L, Lq, P, grad_value.data_ptr(),
+                grad_loc.data_ptr(), grad_w.data_ptr(), _algo, _lib.current_stream())
+    _lib.check(rc, "combo_msda_backward")
     return grad_value, grad_loc, grad_w
 
 
