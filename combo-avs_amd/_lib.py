@@ -20,6 +20,8 @@ _SIGNATURES = {
     "combo_msda_forward_f64": [c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_int, c_void_p],
     "combo_msda_backward_f32": [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 3 + [c_int, c_void_p],
     "combo_msda_backward_f64": [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 3 + [c_int, c_void_p],
+    "combo_attn_mask_f32": [c_void_p] + [c_int] * 6 + [c_void_p, c_void_p],
+    "combo_adamw_f32": [c_void_p] * 4 + [c_longlong, c_void_p] + [c_float] * 7 + [c_void_p],
 }
 _RESTYPES = {"combo_build_arch": ctypes.c_char_p}
 

@@ -128,24 +128,99 @@ class SetCriterion(nn.Module):
         return torch.clamp(num_masks / world, min=1)  # stays on the device: no .item() sync
 
     def _losses(self, outputs, targets):
+        """All decoder outputs (final + aux) are processed TOGETHER: one batched cost computation + one D2H copy for
+        the 10 x F assignment problems, one batched importance-sampling / point-sampling / loss evaluation for the
+        10 x (matched masks), one batched cosine loss.  Random points are drawn in the reference's order
+        (per output: matcher points frame by frame, then the 3x-oversampled and the extra uniform loss points,
+        criterion.py:259-277) so that an injected `point_source` replays the reference exactly."""
         layers = [{"pred_logits": outputs["pred_logits"], "pred_masks": outputs["pred_masks"]}] + list(outputs.get("aux_outputs", []))
-        ps = self.point_source
-        if ps is None:
-            all_indices = self.matcher.match_layers(layers, targets)  # one host sync for all 10 outputs
-        else:  # replay mode: keep the reference's RNG order (matcher, then losses, per layer)
-            all_indices = None
-        num_masks = self._num_masks(targets, outputs["pred_logits"].device)
+        dev = outputs["pred_logits"].device
+        ps = self.point_source or default_point_source(dev)
+        L, F_ = len(layers), len(targets)
+        logits = torch.stack([lo["pred_logits"] for lo in layers]).float()  # [L,F,Q,K+1]
+        masks = torch.stack([lo["pred_masks"] for lo in layers])  # [L,F,Q,h,w]
+        Q = logits.shape[2]
+        G = [int(t["labels"].shape[0]) for t in targets]
+        Gmax, Nm = max(G), sum(G)
+        P = self.num_points
+        n_over = int(P * self.oversample_ratio)
+        n_unc = int(self.importance_sample_ratio * P)
+        n_rand = P - n_unc
+        # ---- random points, reference order -----------------------------------------------------------------
+        mpts, over, extra = [], [], []
+        for _ in range(L):
+            mpts.append(torch.cat([ps(1, P) for _ in range(F_)], 0))  # [F,P,2]
+            over.append(ps(Nm, n_over))
+            if n_rand > 0:
+                extra.append(ps(Nm, n_rand))
+        mpts = torch.stack(mpts).view(L * F_, P, 2)
+        over = torch.stack(over).view(L * Nm, n_over, 2)
+        extra = torch.stack(extra).view(L * Nm, n_rand, 2) if n_rand > 0 else None
+        # ---- Hungarian matching: batched costs, one host sync -------------------------------------------------
+        H, W = targets[0]["masks"].shape[-2:]
+        gt = torch.zeros(F_, Gmax, H, W, device=dev)
+        lab = torch.zeros(F_, Gmax, dtype=torch.int64, device=dev)
+        for f, t in enumerate(targets):
+            gt[f, : G[f]] = t["masks"].to(gt)
+            lab[f, : G[f]] = t["labels"]
+        with torch.no_grad():
+            C = self.matcher.batched_cost(logits.view(L * F_, Q, -1), masks.view(L * F_, Q, *masks.shape[-2:]).float(),
+                                          lab.repeat(L, 1), gt.repeat(L, 1, 1, 1), mpts)  # [L*F,Q,Gmax]
+            C_host = C.cpu().numpy()  # the only device->host sync of the criterion
+        src_q = torch.empty(L, Nm, dtype=torch.int64)
+        tgt_g = torch.empty(L, Nm, dtype=torch.int64)
+        frame = torch.cat([torch.full((g,), f, dtype=torch.int64) for f, g in enumerate(G)])
+        for l in range(L):
+            off = 0
+            for f in range(F_):
+                i, j = self.matcher.solve([C_host[l * F_ + f, :, : G[f]]])[0]
+                src_q[l, off:off + G[f]] = i
+                tgt_g[l, off:off + G[f]] = j
+                off += G[f]
+        self.last_indices = (src_q, tgt_g, frame)
+        src_q, tgt_g, frame = src_q.to(dev), tgt_g.to(dev), frame.to(dev)
+        num_masks = self._num_masks(targets, dev)
+        # ---- classification loss (criterion.py:121-135), per output ---------------------------------------------
+        target_classes = torch.full((L, F_, Q), self.num_classes, dtype=torch.int64, device=dev)
+        lidx = torch.arange(L, device=dev)[:, None].expand(L, Nm)
+        target_classes[lidx, frame[None].expand(L, Nm), src_q] = lab[frame[None].expand(L, Nm), tgt_g]
+        nll = F.cross_entropy(logits.view(L * F_ * Q, -1), target_classes.view(-1), reduction="none").view(L, -1)
+        wgt = self.empty_weight[target_classes].view(L, -1)
+        loss_ce = (nll * wgt).sum(1) / wgt.sum(1)
+        # ---- mask losses (criterion.py:137-186), all outputs at once ----------------------------------------------
+        src = masks[lidx, frame[None].expand(L, Nm), src_q].reshape(L * Nm, 1, *masks.shape[-2:])
+        tgt = gt[frame[None].expand(L, Nm), tgt_g].reshape(L * Nm, 1, H, W)
+        with torch.no_grad():
+            unc = -point_sample(src.float(), over).abs()[:, 0]  # calculate_uncertainty
+            idx = torch.topk(unc, k=n_unc, dim=1)[1]
+            coords = torch.gather(over, 1, idx[..., None].expand(-1, -1, 2))
+            if extra is not None:
+                coords = torch.cat([coords, extra], dim=1)
+            point_labels = point_sample(tgt, coords).squeeze(1)
+        point_logits = point_sample(src, coords).squeeze(1).float()
+        bce = F.binary_cross_entropy_with_logits(point_logits, point_labels, reduction="none").mean(1).view(L, Nm)
+        sg = point_logits.sigmoid()
+        dice = (1 - (2 * (sg * point_labels).sum(-1) + 1) / (sg.sum(-1) + point_labels.sum(-1) + 1)).view(L, Nm)
+        loss_mask = bce.sum(1) / num_masks
+        loss_dice = dice.sum(1) / num_masks
         losses = {}
-        for li, lo in enumerate(layers):
-            indices = all_indices[li] if all_indices is not None else self.matcher(lo, targets, ps)
-            indices = [(i.to(lo["pred_logits"].device), j) for i, j in indices]
-            sfx = "" if li == 0 else f"_{li - 1}"
-            for loss in self.losses:
-                for k, v in self.get_loss(loss, lo, targets, indices, num_masks).items():
-                    losses[k + sfx] = v
-        if "middles_attn_mask" in outputs:
-            for i, mid in enumerate(outputs["middles_attn_mask"]):
-                losses[f"loss_cosine_{i}"] = self.get_similarity_loss(mid, None, n_frame=self.n_frame)["loss_cosine"]
+        for l in range(L):
+            sfx = "" if l == 0 else f"_{l - 1}"
+            losses["loss_ce" + sfx] = loss_ce[l]
+            losses["loss_mask" + sfx] = loss_mask[l]
+            losses["loss_dice" + sfx] = loss_dice[l]
+        # ---- frame-to-frame cosine loss on the intermediate mask logits (criterion.py:208-231, 282-286) -----------
+        if "middles_attn_mask" in outputs and len(outputs["middles_attn_mask"]):
+            mid = torch.stack(outputs["middles_attn_mask"])  # [9,BT,Q,HW]
+            n9, bt = mid.shape[0], mid.shape[1]
+            nf = self.n_frame
+            m = mid.reshape(n9, bt // nf, nf, -1).float()
+            x1, x2 = m[:, :, :-1], m[:, :, 1:]
+            cos = (x1 * x2).sum(-1) / torch.sqrt(((x1 * x1).sum(-1) + 1e-12) * ((x2 * x2).sum(-1) + 1e-12))
+            c = 1 - cos
+            lc = (c * torch.exp(-c)).sum((1, 2)) / (bt // nf) / (nf - 1)
+            for i in range(n9):
+                losses[f"loss_cosine_{i}"] = lc[i]
         return losses
 
     def forward(self, outputs, targets):

@@ -52,6 +52,23 @@ class HungarianMatcher(nn.Module):
                                     targets[b]["masks"], pc, self.cost_class, self.cost_mask, self.cost_dice))
         return costs
 
+    @torch.no_grad()
+    def batched_cost(self, logits, masks, labels, gt, points):
+        """Cost tensors of N = (outputs x frames) assignment problems at once.
+        logits [N,Q,K+1], masks [N,Q,h,w], labels [N,Gmax] (padded), gt [N,Gmax,H,W] (zero padded), points [N,P,2]
+        -> [N,Q,Gmax] (columns beyond a frame's real G are garbage and are sliced away by the caller)."""
+        prob = logits.softmax(-1)
+        cost_class = -torch.gather(prob, 2, labels[:, None, :].expand(-1, prob.shape[1], -1))
+        o = point_sample(masks, points)  # [N,Q,P]
+        t = point_sample(gt, points)  # [N,Gmax,P]
+        hw = o.shape[-1]
+        pos, neg = F.softplus(-o), F.softplus(o)
+        tT = t.transpose(1, 2)
+        cost_mask = (torch.bmm(pos, tT) + torch.bmm(neg, 1 - tT)) / hw
+        s = o.sigmoid()
+        cost_dice = 1 - (2 * torch.bmm(s, tT) + 1) / (s.sum(-1)[:, :, None] + t.sum(-1)[:, None, :] + 1)
+        return self.cost_mask * cost_mask + self.cost_class * cost_class + self.cost_dice * cost_dice
+
     @staticmethod
     def solve(costs_host):
         out = []

@@ -206,7 +206,7 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
             middles.append(outputs_mask.reshape(bt, self.num_queries, -1))
         for i in range(self.num_layers):
             lvl = i % self.num_feature_levels
-            blocked = blocked & ~blocked.all(dim=-1, keepdim=True)  # :458, sync-free
+            # `blocked` already has the fully-blocked-row reset of :458 applied (fused in the mask kernel)
             output = self.transformer_cross_attention_layers[i](output, src[lvl], blocked, pos[lvl], query_embed)
             output = self.transformer_self_attention_layers[i](output, query_embed)
             output = self.transformer_ffn_layers[i](output)

@@ -50,7 +50,13 @@ class FlatAdamW:
         entries = param_groups(model, base_lr, weight_decay, backbone_multiplier, weight_decay_norm, weight_decay_embed)
         entries.sort(key=lambda e: (e[2], e[3]))  # stable: contiguous (lr, wd) segments
         self.entries = entries
-        total = sum(e[0].numel() for e in entries)
+        # every (lr, wd) segment starts on a 16-byte boundary (vectorised fused AdamW kernel)
+        total, prev = 0, None
+        for p, _, lr, wd in entries:
+            if prev is not None and prev != (lr, wd):
+                total = (total + 3) // 4 * 4
+            prev = (lr, wd)
+            total += p.numel()
         dev = entries[0][0].device
         self.flat_param = torch.empty(total, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(total, dtype=grad_dtype, device=dev)
@@ -58,8 +64,11 @@ class FlatAdamW:
         self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
         self.segments = []  # (start, end, lr, wd)
         off = 0
+        self.flat_param.zero_()
         for p, name, lr, wd in entries:
             n = p.numel()
+            if self.segments and not (self.segments[-1][2] == lr and self.segments[-1][3] == wd):
+                off = (off + 3) // 4 * 4
             self.flat_param[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.flat_param[off:off + n].view_as(p)
             p.grad = self.flat_grad[off:off + n].view_as(p)

@@ -71,6 +71,26 @@ int combo_msda_backward_f64(const double* grad_out, const double* value, const i
                             double* grad_value, double* grad_sampling_loc, double* grad_attn_weight,
                             int algo, combo_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * a13 (tail)  next-layer attention mask
+ *   replaces F.interpolate(outputs_mask, size, bilinear, align_corners=False).sigmoid() < 0.5 and the
+ *   "fully blocked row" reset (models/modeling/transformer_decoder/transformer_decoder.py:502-507, :458).
+ *   logits [N,H,W] fp32 (N = frames x queries), blocked [N,h*w] bytes (1 = masked out).  The same mask serves all
+ *   8 heads (the reference repeats it 8x).  reset_full_rows != 0 applies the :458 rule.
+ * ---------------------------------------------------------------------------------------------- */
+int combo_attn_mask_f32(const float* logits, int N, int H, int W, int h, int w, int reset_full_rows,
+                        unsigned char* blocked, combo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (f)1  optimiser: fused gradient clip + AdamW on a flat fp32 segment
+ *   replaces FullModelGradientClippingOptimizer.step (train_net.py:205-221): p *= 1-lr*wd; m,v EMAs of
+ *   clip_coef*g; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps).  clip_coef: device scalar (NULL = 1).
+ *   All four arrays are 16-byte aligned, length n.
+ * ---------------------------------------------------------------------------------------------- */
+int combo_adamw_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n,
+                    const float* clip_coef, float lr, float weight_decay, float beta1, float beta2, float eps,
+                    float bias_correction1, float bias_correction2, combo_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

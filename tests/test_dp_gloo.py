@@ -1,0 +1,94 @@
+"""CPU, world_size 2, gloo: the data-parallel host logic (flat gradient buffer, ONE all-reduce, averaging, global-norm
+clip, grouped AdamW) gives the same parameters as a single process that sees the whole batch and uses the optimiser
+the reference builds (train_net.py:147-226).  Also covers the criterion's `num_masks` all-reduce."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model():
+    torch.manual_seed(3)
+    return torch.nn.ModuleDict({
+        "backbone": torch.nn.Sequential(torch.nn.Linear(12, 10), torch.nn.LayerNorm(10)),
+        "sem_seg_head": torch.nn.Sequential(torch.nn.Linear(10, 4)),
+        "emb": torch.nn.Embedding(3, 4)})
+
+
+def _loss(m, x, y):
+    out = m["sem_seg_head"](m["backbone"](x)) + m["emb"].weight[0]
+    return ((out - y) ** 2).mean() * 100
+
+
+def _worker(rank, world, port, ret):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.modeling.criterion import SetCriterion
+    from combo_avs_amd.trainer import FlatAdamW
+    m = _model()
+    opt = FlatAdamW(m, base_lr=1e-2, weight_decay=0.05, backbone_multiplier=0.1, clip_value=0.01)
+    g = torch.Generator().manual_seed(7)
+    for it in range(4):
+        x, y = torch.randn(8, 12, generator=g), torch.randn(8, 4, generator=g)
+        xs, ys = x[rank::world], y[rank::world]  # clip i -> rank i mod world
+        opt.zero_grad()
+        _loss(m, xs, ys).backward()
+        opt.all_reduce_grads()
+        opt.step()
+    # num_masks: sum over ranks / world, clamped at 1 (criterion.py:261-265)
+    crit = SetCriterion(2, matcher=None, weight_dict={}, eos_coef=0.1, losses=[], num_points=4, oversample_ratio=3.0,
+                        importance_sample_ratio=0.75)
+    nm = crit._num_masks([{"labels": torch.zeros(1 + 2 * rank)}], torch.device("cpu"))
+    if rank == 0:
+        ret["params"] = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        ret["num_masks"] = float(nm)
+        ret["numel"] = opt.numel
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_equals_single_process_reference_optimizer():
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.trainer import param_groups
+    m = _model()
+    groups = [{"params": [p], "lr": lr, "weight_decay": wd} for p, _, lr, wd in param_groups(m, 1e-2, 0.05)]
+    ref = torch.optim.AdamW(groups, 1e-2)
+    g = torch.Generator().manual_seed(7)
+    for it in range(4):
+        x, y = torch.randn(8, 12, generator=g), torch.randn(8, 4, generator=g)
+        ref.zero_grad()
+        # DDP semantics: mean over ranks of per-rank mean losses == mean over the whole batch (equal shards)
+        _loss(m, x, y).backward()
+        torch.nn.utils.clip_grad_norm_([p for gr in groups for p in gr["params"]], 0.01)
+        ref.step()
+    for k, v in m.state_dict().items():
+        torch.testing.assert_close(ret["params"][k], v, rtol=1e-5, atol=1e-7, msg=k)
+    assert ret["num_masks"] == 2.0  # (1 + 3) / 2
+
+
+def test_param_group_rules():
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.trainer import param_groups
+    m = _model()
+    rules = {n: (lr, wd) for _, n, lr, wd in param_groups(m, 1e-4, 0.05)}
+    assert rules["backbone.0.weight"] == (1e-5, 0.05)       # "backbone" in module name -> lr x 0.1
+    assert rules["backbone.1.weight"] == (1e-5, 0.0)        # LayerNorm -> WEIGHT_DECAY_NORM = 0
+    assert rules["sem_seg_head.0.bias"] == (1e-4, 0.05)
+    assert rules["emb.weight"] == (1e-4, 0.0)               # nn.Embedding -> WEIGHT_DECAY_EMBED = 0

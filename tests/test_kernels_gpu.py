@@ -1,0 +1,67 @@
+"""GPU parity of the small fused kernels: next-layer attention mask (row a13 tail) and clip+AdamW ((f)1)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("H,W,h,w", [(56, 56, 7, 7), (56, 56, 14, 14), (56, 56, 28, 28), (128, 128, 16, 16), (56, 40, 9, 13), (8, 8, 8, 8)])
+def test_attn_mask_matches_interpolate_sigmoid(H, W, h, w):
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.ops import masklogit
+    torch.manual_seed(0)
+    bt, Q = 3, 100
+    logits = torch.randn(bt, Q, H, W, device="cuda") * 3
+    logits[0, 5] = -2.0 - torch.rand(H, W, device="cuda")  # fully blocked row -> reset to all-False (:458)
+    logits[1, 7] = 4.0  # nothing blocked
+    logits[2, 9, : H // 2] = -5.0
+    am = F.interpolate(logits, size=(h, w), mode="bilinear", align_corners=False)
+    ref = (am.sigmoid() < 0.5).flatten(2)
+    raw = masklogit.attn_mask(logits, (h, w), reset_full_rows=False)
+    near0 = am.flatten(2).abs() < 1e-6  # threshold ties may legitimately differ
+    assert ((raw != ref) & ~near0).sum().item() == 0
+    ref_reset = ref.clone()
+    ref_reset[torch.where(ref_reset.sum(-1) == ref_reset.shape[-1])] = False
+    got = masklogit.attn_mask(logits, (h, w), reset_full_rows=True)
+    assert ((got != ref_reset) & ~near0).sum().item() == 0
+    assert not got[0, 5].any() and ref[0, 5].all()
+
+
+def test_fused_adamw_matches_torch_optimizer():
+    """FlatAdamW (one flat buffer, fused HIP clip+AdamW, reference grouping rules) vs torch.optim.AdamW +
+    clip_grad_norm_ as train_net.py:147-226 of the reference builds it."""
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.trainer import FlatAdamW, param_groups
+    torch.manual_seed(0)
+
+    def make():
+        torch.manual_seed(1)
+        m = torch.nn.ModuleDict({
+            "backbone": torch.nn.Sequential(torch.nn.Linear(33, 17), torch.nn.LayerNorm(17)),
+            "pre_sam_backbone": torch.nn.Linear(17, 9),
+            "head": torch.nn.Sequential(torch.nn.Linear(9, 5), torch.nn.GroupNorm(1, 5)),
+            "emb": torch.nn.Embedding(7, 5)}).cuda()
+        return m
+
+    def loss_fn(m, x):
+        y = m["head"](m["pre_sam_backbone"](m["backbone"](x)))
+        return (y * m["emb"].weight[:y.shape[0]].sum(0)).pow(2).sum() * 50
+
+    a, b = make(), make()
+    groups = [{"params": [p], "lr": lr, "weight_decay": wd} for p, _, lr, wd in param_groups(b, 1e-3, 0.05)]
+    assert sorted({(g["lr"], g["weight_decay"]) for g in groups}) == [(1e-4, 0.0), (1e-4, 0.05), (1e-3, 0.0), (1e-3, 0.05)]
+    ref = torch.optim.AdamW(groups, 1e-3)
+    opt = FlatAdamW(a, base_lr=1e-3, weight_decay=0.05, backbone_multiplier=0.1, clip_value=0.01)
+    for it in range(5):
+        x = torch.randn(6, 33, device="cuda")
+        opt.zero_grad()
+        loss_fn(a, x).backward()
+        opt.all_reduce_grads()
+        opt.step()
+        ref.zero_grad()
+        loss_fn(b, x).backward()
+        torch.nn.utils.clip_grad_norm_([p for g in groups for p in g["params"]], 0.01)
+        ref.step()
+    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        torch.testing.assert_close(pa, pb, rtol=1e-5, atol=1e-7, msg=n)
