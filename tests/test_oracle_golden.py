@@ -195,3 +195,27 @@ def test_criterion_losses_and_grads(head_run, mode):
         synth.check_digest(g, d, f"{mode}/grad/{n}", rtol=5e-3, atol=5e-3 * scale + 1e-9, frac_bad=0.01)
     for p in grad_params:
         P[p].requires_grad_(False)
+
+
+# ---------------------------------------------------------------------------------------- plain-C core-op oracle
+@pytest.mark.parametrize("tag", ["t_double", "t_float", "t_grad30", "t_grad32", "t_grad71", "edge"])
+def test_c_oracle_reference_unit_cases(tag):
+    from oracle import msda_c
+    z = load("msda_core.npz")
+    dt = np.float32 if tag == "t_float" else np.float64
+    value, loc, w = (z[f"{tag}/{k}"].astype(dt) for k in ("value", "loc", "w"))
+    shapes = z[f"{tag}/shapes"]
+    tol = dict(rtol=1e-5, atol=1e-8) if dt == np.float32 else dict(rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(msda_c.forward(value, shapes, loc, w), z[f"{tag}/out"], **tol)
+    gv, gl, gw = msda_c.backward(z[f"{tag}/grad_out"].astype(dt), value, shapes, loc, w)
+    np.testing.assert_allclose(gv, z[f"{tag}/grad_value"], **tol)
+    np.testing.assert_allclose(gw, z[f"{tag}/grad_w"], **tol)
+    if tag != "edge":
+        np.testing.assert_allclose(gl, z[f"{tag}/grad_loc"], **tol)
+
+
+def test_c_oracle_equals_torch_oracle_production_shape():
+    from oracle import msda_c
+    v, shapes, loc, w = prod_inputs()
+    out = O.ms_deform_attn_core(v, shapes, loc, w)
+    np.testing.assert_allclose(msda_c.forward(v.numpy(), shapes, loc.numpy(), w.numpy()), out.numpy(), rtol=1e-5, atol=1e-5)
