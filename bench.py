@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--clips", type=int, default=8, help="clips per GPU (BASELINE config 2: 8)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"], help="host-PyTorch backbone compute dtype")
+    ap.add_argument("--head-dtype", default="fp32", choices=["bf16", "fp32"], help="dense layers of the head")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -110,6 +111,8 @@ def main():
     model = build_model(cfg).to(dev).train()
     if args.dtype == "bf16":
         model.backbone_dtype = torch.bfloat16
+    if args.head_dtype == "bf16":
+        model.head_dtype = torch.bfloat16
     opt = FlatAdamW(model, base_lr=cfg.SOLVER.BASE_LR, weight_decay=cfg.SOLVER.WEIGHT_DECAY,
                     backbone_multiplier=cfg.SOLVER.BACKBONE_MULTIPLIER, clip_value=cfg.SOLVER.CLIP_GRADIENTS.CLIP_VALUE)
     T, H, W = 5, 224, 224

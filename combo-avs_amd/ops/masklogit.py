@@ -21,6 +21,7 @@ def mask_logits_and_attn_mask(mask_embed, mf_tok, hw, target_size):
     """mask_embed [BT,Q,C], mf_tok [BT,HW,C] token-major -> (logits [BT,Q,H,W], blocked bool [BT,Q,h*w]).
     The returned mask already has fully-blocked rows reset (it is only ever consumed by the next layer)."""
     bt, Q, _ = mask_embed.shape
-    logits = torch.bmm(mask_embed, mf_tok.transpose(1, 2)).view(bt, Q, hw[0], hw[1])
+    with torch.autocast("cuda", enabled=False):  # mask logits are always produced in fp32
+        logits = torch.bmm(mask_embed.float(), mf_tok.float().transpose(1, 2)).view(bt, Q, hw[0], hw[1])
     blocked = attn_mask(logits.detach().float().contiguous(), target_size, True)
     return logits, blocked

@@ -72,6 +72,37 @@ int combo_msda_backward_f64(const double* grad_out, const double* value, const i
                             int algo, combo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * a8-a9  bilateral audio-visual fusion, token stage (C == 256 channels, 8 heads)
+ *   replaces, for one fused level, LayerNorm_v + BiMultiHeadAttention's visual-side chain + the layer-scale residual
+ *   (fusion_module/utils/fuse_helper.py:155-237 and :320-332) in its algebraically collapsed form:
+ *     xn = LN(x); s[h,i] = (xn_i+pos_i).u[b,h]+c[b,h] (clamped +-5e4); p = softmax_i(s);
+ *     y_i = xn_i + gamma_v*(sum_h p[h,i]*dropv[h,i]*z[b,h] + b_ov); pooled[b,h] = sum_i p[h,i]*dropa[h,i]*xn_i; spa = sum_i p*dropa
+ *   x,y [B,N,C] token-major; pos [N,C]; u,z [B,8,C]; c [B,8]; scores [B,8,N] and stat [B,8,2] are saved for backward;
+ *   drop_v/drop_a: optional injected multipliers [B,8,N] (NULL -> in-kernel Philox with (p_drop, seed), p_drop = 0: none).
+ *   Workspaces, with chunks = combo_bifuse_chunks(B,N): part_ws [B,chunks,8,2], pooled_part [B,chunks,8,C],
+ *   spa_part [B,chunks,8] (the caller sums the *_part buffers over `chunks`).
+ *   backward1 -> dp [B,8,N], r_part [B,chunks,8], dz_part [B,chunks,8,C], dgb_part [B,chunks,2,C] (d gamma_v, d b_ov)
+ *   backward2 (needs rtot[B,8] = sum_chunks r_part) -> dx [B,N,C], du_part [B,chunks,8,C], dc_part [B,chunks,8],
+ *   dln_part [B,chunks,2,C] (d ln_weight, d ln_bias).
+ * ---------------------------------------------------------------------------------------------- */
+int combo_bifuse_chunks(int B, int N);
+int combo_bifuse_forward_f32(const float* x, const float* ln_w, const float* ln_b, float eps, const float* pos,
+                             const float* u, const float* c, const float* z, const float* b_ov, const float* gamma_v,
+                             const float* drop_v, const float* drop_a, float p_drop, unsigned long long seed,
+                             int B, int N, int C, int heads, float* y, float* scores, float* stat, float* part_ws,
+                             float* pooled_part, float* spa_part, combo_stream_t stream);
+int combo_bifuse_backward1_f32(const float* x, const float* ln_w, const float* ln_b, float eps, const float* scores,
+                               const float* stat, const float* z, const float* b_ov, const float* gamma_v,
+                               const float* drop_v, const float* drop_a, float p_drop, unsigned long long seed,
+                               const float* dy, const float* dpooled, const float* dspa, int B, int N, int C, int heads,
+                               float* dp, float* r_part, float* dz_part, float* dgb_part, combo_stream_t stream);
+int combo_bifuse_backward2_f32(const float* x, const float* ln_w, const float* ln_b, float eps, const float* pos,
+                               const float* scores, const float* stat, const float* u, const float* drop_a,
+                               float p_drop, unsigned long long seed, const float* dy, const float* dpooled,
+                               const float* dp, const float* rtot, int B, int N, int C, int heads, float* dx,
+                               float* du_part, float* dc_part, float* dln_part, combo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * a13 (tail)  next-layer attention mask
  *   replaces F.interpolate(outputs_mask, size, bilinear, align_corners=False).sigmoid() < 0.5 and the
  *   "fully blocked row" reset (models/modeling/transformer_decoder/transformer_decoder.py:502-507, :458).

@@ -45,8 +45,7 @@ def _worker(rank, world, port, ret):
     for it in range(4):
         x, y = torch.randn(8, 12, generator=g), torch.randn(8, 4, generator=g)
         xs, ys = x[rank::world], y[rank::world]  # clip i -> rank i mod world
-        opt.zero_grad()
-        _loss(m, xs, ys).backward()
+        opt.backward(_loss(m, xs, ys))
         opt.all_reduce_grads()
         opt.step()
     # num_masks: sum over ranks / world, clamped at 1 (criterion.py:261-265)

@@ -55,8 +55,7 @@ def test_fused_adamw_matches_torch_optimizer():
     opt = FlatAdamW(a, base_lr=1e-3, weight_decay=0.05, backbone_multiplier=0.1, clip_value=0.01)
     for it in range(5):
         x = torch.randn(6, 33, device="cuda")
-        opt.zero_grad()
-        loss_fn(a, x).backward()
+        opt.backward(loss_fn(a, x))
         opt.all_reduce_grads()
         opt.step()
         ref.zero_grad()
