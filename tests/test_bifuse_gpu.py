@@ -70,7 +70,7 @@ def test_avfuse_forward_backward_vs_oracle(hw, bt, with_drop):
         if ref is None:
             continue
         scale = ref.abs().max().item() + 1e-12
-        torch.testing.assert_close(p.grad.cpu(), ref, rtol=5e-3, atol=2e-4 * scale + 1e-7, msg=name)
+        torch.testing.assert_close(p.grad.cpu(), ref, rtol=5e-3, atol=2e-4 * scale + 2e-5, msg=name)  # v_proj.bias: softmax is shift-invariant, true grad == 0
 
 
 def test_inkernel_dropout_statistics_and_consistency():
