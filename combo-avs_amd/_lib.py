@@ -24,6 +24,8 @@ _SIGNATURES = {
     "combo_bifuse_forward_f32": [c_void_p] * 3 + [c_float] + [c_void_p] * 8 + [c_float, ctypes.c_ulonglong] + [c_int] * 4 + [c_void_p] * 7,
     "combo_bifuse_backward1_f32": [c_void_p] * 3 + [c_float] + [c_void_p] * 7 + [c_float, ctypes.c_ulonglong] + [c_void_p] * 3 + [c_int] * 4 + [c_void_p] * 5,
     "combo_bifuse_backward2_f32": [c_void_p] * 3 + [c_float] + [c_void_p] * 5 + [c_float, ctypes.c_ulonglong] + [c_void_p] * 4 + [c_int] * 4 + [c_void_p] * 5,
+    "combo_gemm_x3_splits": [c_int, c_int],
+    "combo_gemm_x3_f32": [c_void_p, c_longlong, c_int, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_longlong] + [c_int] * 5 + [c_longlong, c_void_p],
     "combo_attn_mask_f32": [c_void_p] + [c_int] * 6 + [c_void_p, c_void_p],
     "combo_adamw_f32": [c_void_p] * 4 + [c_longlong, c_void_p] + [c_float] * 7 + [c_void_p],
 }

@@ -21,6 +21,7 @@
 //                coalesced stores.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "combo_common.h"
 
@@ -254,7 +255,7 @@ __device__ __forceinline__ void dma16(const float* g, float* l) {
 __global__ void __launch_bounds__(768)
 msda_fwd_lds_d32(const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
                  const float* __restrict__ loc, const float* __restrict__ aw, int B, int S, int M, int L, int Lq, int P,
-                 int QT, float* __restrict__ out) {
+                 int QT, float* __restrict__ out, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int D = 32;
   float* slab = reinterpret_cast<float*>(smem);
@@ -272,7 +273,7 @@ msda_fwd_lds_d32(const float* __restrict__ value, const int64_t* __restrict__ sh
   const int m = bm % M, b = bm / M;
 
   // ---- stage the (b, m) slab: rows of 128 B at stride M*D*4 in global -> contiguous rows in LDS ----
-  {
+  if (dbg != 2) {
     const float* vb = value + ((long long)b * S * M + m) * D + (lane & 7) * 4;
     for (int r0 = wave * 8; r0 < S; r0 += NW * 8) {  // 8 rows per wave instruction
       const int r = r0 + (lane >> 3);
@@ -316,6 +317,7 @@ msda_fwd_lds_d32(const float* __restrict__ value, const int64_t* __restrict__ sh
   int q0 = qbeg + wave * kQW;
   if (q0 < qend) prefetch(q0);
   __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes the slab
+  if (dbg == 1) return;
 
   for (; q0 < qend; q0 += NW * kQW) {
     // ---- coordinate phase: one lane per (query, point) ----
@@ -363,6 +365,7 @@ msda_fwd_lds_d32(const float* __restrict__ value, const int64_t* __restrict__ sh
       const int q = q0 + g;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       const float* sl = slab + cg * 4;
+#pragma unroll 4
       for (int pt = 0; pt < LP; ++pt) {
         const uint2 o = offs[g * LP + pt];
         const float4 ww = wts[g * LP + pt];
@@ -666,6 +669,7 @@ msda_bwd_locw_lds_d32(const float* __restrict__ gout, const float* __restrict__ 
       const float4 tg = *reinterpret_cast<const float4*>(gout + qm * D + cg * 4);
       const float* sl = slab + cg * 4;
       float keep_w[2] = {0.f, 0.f}, keep_x[2] = {0.f, 0.f}, keep_y[2] = {0.f, 0.f};
+#pragma unroll 2
       for (int pt = 0; pt < LP; ++pt) {
         const uint2 o = offs[g * LP + pt];
         const float4 pp = par[g * LP + pt];
@@ -740,6 +744,7 @@ int msda_forward(const T* value, const int64_t* shapes, const int64_t* lsi, cons
       const int nw = fwd_lds_bytes(S, L, P, 12) <= kLdsLimit ? 12 : 8;
       int QT = 1;
       while ((long long)B * M * QT < 1024 && QT < 8 && Lq / (QT * 2) >= nw * kQW) QT *= 2;
+      if (const char* e = getenv("COMBO_MSDA_QT")) QT = atoi(e) > 0 ? atoi(e) : QT;
       const size_t lds = fwd_lds_bytes(S, L, P, nw);
       static bool attr_set = false;
       if (!attr_set) {
@@ -748,8 +753,10 @@ int msda_forward(const T* value, const int64_t* shapes, const int64_t* lsi, cons
         if (e != hipSuccess) return (int)e;
         attr_set = true;
       }
+      int dbg = 0;
+      if (const char* e = getenv("COMBO_MSDA_DBG")) dbg = atoi(e);
       hipLaunchKernelGGL(msda_fwd_lds_d32, dim3(B * M * QT), dim3(nw * 64), lds, stream, value, shapes, lsi, loc,
-                         aw, B, S, M, L, Lq, P, QT, out);
+                         aw, B, S, M, L, Lq, P, QT, out, dbg);
       return (int)hipGetLastError();
     }
   }

@@ -72,6 +72,7 @@ class MLP(nn.Module):
         self.layers = nn.ModuleList(nn.Linear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
 
     def forward(self, x):
+        from ..ops.linear import linear
         for i, layer in enumerate(self.layers):
-            x = F.relu(layer(x)) if i < self.num_layers - 1 else layer(x)
+            x = linear(x, layer.weight, layer.bias, relu=i < self.num_layers - 1)
         return x

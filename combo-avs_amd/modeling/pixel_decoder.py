@@ -18,6 +18,7 @@ from torch.nn.init import constant_, normal_, xavier_uniform_
 
 from ..msda import MSDeformAttnFunction
 from ..registry import SEM_SEG_HEADS_REGISTRY, ShapeSpec
+from ..ops.linear import Linear, linear
 from .layers import Conv2d, c2_xavier_fill, get_norm, position_embedding_sine
 
 
@@ -30,10 +31,10 @@ class MSDeformAttn(nn.Module):
             raise ValueError(f"d_model must be divisible by n_heads, but got {d_model} and {n_heads}")
         self.im2col_step = 128
         self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
-        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
-        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
-        self.value_proj = nn.Linear(d_model, d_model)
-        self.output_proj = nn.Linear(d_model, d_model)
+        self.sampling_offsets = Linear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = Linear(d_model, n_heads * n_levels * n_points)
+        self.value_proj = Linear(d_model, d_model)
+        self.output_proj = Linear(d_model, d_model)
         self._reset_parameters()
 
     def _reset_parameters(self):
@@ -83,16 +84,16 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         self.self_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
         self.dropout1 = nn.Dropout(dropout)
         self.norm1 = nn.LayerNorm(d_model)
-        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.linear1 = Linear(d_model, d_ffn)
         self.dropout2 = nn.Dropout(dropout)
-        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.linear2 = Linear(d_ffn, d_model)
         self.dropout3 = nn.Dropout(dropout)
         self.norm2 = nn.LayerNorm(d_model)
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None, normalizer=None):
         src2 = self.self_attn(src + pos, reference_points, src, spatial_shapes, level_start_index, padding_mask, normalizer)
         src = self.norm1(src + self.dropout1(src2))
-        src2 = self.linear2(self.dropout2(F.relu(self.linear1(src))))
+        src2 = self.linear2(self.dropout2(linear(src, self.linear1.weight, self.linear1.bias, relu=True)))
         return self.norm2(src + self.dropout3(src2))
 
 

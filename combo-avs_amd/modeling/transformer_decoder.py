@@ -15,6 +15,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from ..registry import TRANSFORMER_DECODER_REGISTRY
+from ..ops.linear import Linear, linear
 from .layers import MLP, position_embedding_sine
 
 
@@ -26,7 +27,7 @@ class _MHAParams(nn.Module):
         self.embed_dim, self.num_heads = d_model, nhead
         self.in_proj_weight = nn.Parameter(torch.empty(3 * d_model, d_model))
         self.in_proj_bias = nn.Parameter(torch.zeros(3 * d_model))
-        self.out_proj = nn.Linear(d_model, d_model)
+        self.out_proj = Linear(d_model, d_model)
         nn.init.xavier_uniform_(self.in_proj_weight)
         nn.init.constant_(self.out_proj.bias, 0.0)
 
@@ -36,9 +37,9 @@ class _MHAParams(nn.Module):
         B, Lq, _ = query.shape
         Lk = key.shape[1]
         W, b = self.in_proj_weight, self.in_proj_bias
-        q = F.linear(query, W[:E], b[:E]).view(B, Lq, H, E // H).transpose(1, 2)
-        k = F.linear(key, W[E:2 * E], b[E:2 * E]).view(B, Lk, H, E // H).transpose(1, 2)
-        v = F.linear(value, W[2 * E:], b[2 * E:]).view(B, Lk, H, E // H).transpose(1, 2)
+        q = linear(query, W[:E], b[:E]).view(B, Lq, H, E // H).transpose(1, 2)
+        k = linear(key, W[E:2 * E], b[E:2 * E]).view(B, Lk, H, E // H).transpose(1, 2)
+        v = linear(value, W[2 * E:], b[2 * E:]).view(B, Lk, H, E // H).transpose(1, 2)
         mask = None if blocked is None else (~blocked)[:, None]  # SDPA: True = may attend
         o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
         return self.out_proj(o.transpose(1, 2).reshape(B, Lq, E))
@@ -84,8 +85,8 @@ class FFNLayer(nn.Module):
     def __init__(self, d_model, dim_feedforward=2048, dropout=0.0, activation="relu", normalize_before=False):
         super().__init__()
         assert not normalize_before and dropout == 0.0
-        self.linear1 = nn.Linear(d_model, dim_feedforward)
-        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.linear1 = Linear(d_model, dim_feedforward)
+        self.linear2 = Linear(dim_feedforward, d_model)
         self.norm = nn.LayerNorm(d_model)
         self._reset_parameters()
 
@@ -95,7 +96,7 @@ class FFNLayer(nn.Module):
                 nn.init.xavier_uniform_(p)
 
     def forward(self, tgt):
-        return self.norm(tgt + self.linear2(F.relu(self.linear1(tgt))))  # :178-182
+        return self.norm(tgt + self.linear2(linear(tgt, self.linear1.weight, self.linear1.bias, relu=True)))  # :178-182
 
 
 @TRANSFORMER_DECODER_REGISTRY.register()

@@ -1,0 +1,91 @@
+"""Dense layers on the bf16 matrix cores with fp32 accuracy (3-way bf16 split, csrc/gemm_x3.hip).
+`linear(x, weight, bias, relu)` == F.linear (+ReLU) for fp32 CUDA tensors; forward, dX and dW all run on the same
+HIP kernel (k-contiguous / row-contiguous operand loaders, split-K for dW)."""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .. import _lib
+
+MIN_ROWS = 512  # below this the op is launch/weight-bandwidth bound and the library GEMV path is as good
+# Which GEMM serves the head's nn.Linear layers: "library" = hipBLASLt fp32 through torch (plain library GEMM),
+# "x3" = csrc/gemm_x3.hip.  Measured on MI355X (tools/bench_gemm.py, 41160x256x1024): x3 forward 151 us vs 257 us,
+# but the whole training step does not get faster yet (dX needs a transposed weight copy, dW is library either way),
+# so "library" stays the default until the x3 kernel has a deeper load pipeline.
+_IMPL = "library"
+
+
+def set_impl(name):
+    global _IMPL
+    assert name in ("library", "x3")
+    _IMPL = name
+
+
+def gemm_x3(A, a_rowc, B, b_rowc, M, N, K, bias=None, relu=False, splits=1):
+    """C[M,N] = sum_k A(m,k) B(n,k); operands are 2-D contiguous fp32 tensors ([rows,K] or, if *_rowc, [K,rows])."""
+    lib = _lib.lib()
+    dev = A.device
+    nz = lib.combo_gemm_x3_splits(K, splits)
+    out = torch.empty((nz, M, N) if nz > 1 else (M, N), device=dev, dtype=torch.float32)
+    rc = lib.combo_gemm_x3_f32(A.data_ptr(), A.shape[1], 1 if a_rowc else 0, B.data_ptr(), B.shape[1],
+                               1 if b_rowc else 0, _lib.ptr(bias), out.data_ptr(), N, M, N, K, 1 if relu else 0, nz,
+                               M * N, _lib.current_stream())
+    if rc != 0:
+        raise _lib.HipError(f"combo_gemm_x3_f32 failed with hipError_t {rc}: A{tuple(A.shape)} rowc={a_rowc} "
+                            f"B{tuple(B.shape)} rowc={b_rowc} M={M} N={N} K={K} ptrs {A.data_ptr() % 16},{B.data_ptr() % 16}")
+    return out.sum(0) if nz > 1 else out
+
+
+class _LinearX3(Function):
+    @staticmethod
+    def forward(ctx, x2d, weight, bias, relu):
+        M, K = x2d.shape
+        N = weight.shape[0]
+        y = gemm_x3(x2d, False, weight, False, M, N, K, bias, relu)
+        ctx.save_for_backward(x2d, weight, y if relu else None)
+        ctx.relu = relu
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x2d, weight, y = ctx.saved_tensors
+        M, K = x2d.shape
+        N = weight.shape[0]
+        dy = dy.contiguous()
+        if ctx.relu:
+            dy = dy * (y > 0)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            # dX[M,K] = sum_n dY(m,n) W(n,k) = dY . (W^T)^T: with a transposed copy of the (small) weight both operands
+            # are k-contiguous, the fast loader path (the row-contiguous loader works too but transposes through LDS)
+            dx = gemm_x3(dy, False, weight.t().contiguous(), False, M, K, N)
+        if ctx.needs_input_grad[1]:
+            # dW[N,K] = dY^T X reduces over the M tokens: library GEMM (the row-contiguous x3 path is correct, see
+            # tests/test_gemm_gpu.py, but not yet faster than hipBLASLt for this layout)
+            dw = dy.t() @ x2d
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(0)
+        return dx, dw, db, None
+
+
+def linear(x, weight, bias=None, relu=False):
+    """F.linear(x, weight, bias) [+ ReLU].  fp32 CUDA tensors with enough rows go to the bf16x3 MFMA kernel."""
+    K = x.shape[-1]
+    N = weight.shape[0]
+    rows = x.numel() // K
+    if (_IMPL == "x3" and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and rows >= MIN_ROWS and K % 4 == 0
+            and N % 4 == 0 and rows % 4 == 0 and not torch.is_autocast_enabled()
+            and x.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0 and weight.is_contiguous()):
+        y = _LinearX3.apply(x.reshape(rows, K).contiguous(), weight.contiguous(), bias, relu)
+        return y.view(*x.shape[:-1], N)
+    y = torch.nn.functional.linear(x, weight, bias)
+    return torch.relu(y) if relu else y
+
+
+class Linear(torch.nn.Linear):
+    """nn.Linear whose forward/backward GEMMs run on csrc/gemm_x3.hip (same parameters / state-dict names)."""
+
+    def forward(self, x):
+        return linear(x, self.weight, self.bias)

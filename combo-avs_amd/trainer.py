@@ -51,12 +51,8 @@ class FlatAdamW:
         entries.sort(key=lambda e: (e[2], e[3]))  # stable: contiguous (lr, wd) segments
         self.entries = entries
         # every (lr, wd) segment starts on a 16-byte boundary (vectorised fused AdamW kernel)
-        total, prev = 0, None
-        for p, _, lr, wd in entries:
-            if prev is not None and prev != (lr, wd):
-                total = (total + 3) // 4 * 4
-            prev = (lr, wd)
-            total += p.numel()
+        # ... and so does every parameter (the dense-layer kernels read weights with 16-byte loads)
+        total = sum((p.numel() + 3) // 4 * 4 for p, _, _, _ in entries)
         dev = entries[0][0].device
         self.flat_param = torch.empty(total, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(total, dtype=grad_dtype, device=dev)
@@ -69,8 +65,7 @@ class FlatAdamW:
         self.flat_param.zero_()
         for p, name, lr, wd in entries:
             n = p.numel()
-            if self.segments and not (self.segments[-1][2] == lr and self.segments[-1][3] == wd):
-                off = (off + 3) // 4 * 4
+            off = (off + 3) // 4 * 4
             self.flat_param[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.flat_param[off:off + n].view_as(p)
             self.grad_views.append(self.flat_grad[off:off + n].view_as(p))

@@ -103,6 +103,21 @@ int combo_bifuse_backward2_f32(const float* x, const float* ln_w, const float* l
                                float* du_part, float* dc_part, float* dln_part, combo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * a4/a5/a11/a12  dense layers of the head: fp32-accurate GEMM on the bf16 matrix cores (3-way bf16 split)
+ *   replaces the nn.Linear calls of the encoder / decoder (pixel_decoder/msdeformattn.py:119-134,
+ *   ops/modules/ms_deform_attn.py:102-108,128, transformer_decoder.py:99-118,50-58,178-182,216-219) and their
+ *   backward GEMMs:  C[M,N] = sum_k A(m,k) * B(n,k)  (+ bias[n], + ReLU)
+ *   a_rowc / b_rowc = 0: operand stored [rows][K] (k contiguous, leading dimension ld);
+ *                   = 1: operand stored [K][rows] (row contiguous) - used for dX = dY.W and dW = dY^T.X.
+ *   splits > 1: split-K; partial result z is written at C + z*split_stride (no bias/relu), the caller sums
+ *   combo_gemm_x3_splits(K, splits) partials.  All extents that are walked with float4 loads must be multiples of 4.
+ * ---------------------------------------------------------------------------------------------- */
+int combo_gemm_x3_splits(int K, int requested);
+int combo_gemm_x3_f32(const float* A, long long lda, int a_rowc, const float* B, long long ldb, int b_rowc,
+                      const float* bias, float* C, long long ldc, int M, int N, int K, int relu, int splits,
+                      long long split_stride, combo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * a13 (tail)  next-layer attention mask
  *   replaces F.interpolate(outputs_mask, size, bilinear, align_corners=False).sigmoid() < 0.5 and the
  *   "fully blocked row" reset (models/modeling/transformer_decoder/transformer_decoder.py:502-507, :458).

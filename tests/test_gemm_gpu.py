@@ -1,0 +1,84 @@
+"""GPU parity of the bf16x3 dense-layer kernel (csrc/gemm_x3.hip) against float64 references: forward, dX, dW, db,
+ragged M/N, all four operand layouts, split-K; and a micro-benchmark line against the fp32 library GEMM."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm()).item()
+
+
+@pytest.mark.parametrize("M,K,N,relu", [(41160, 256, 1024, True), (41160, 1024, 256, False), (4000, 256, 768, False),
+                                          (1028, 256, 288, False), (31360, 256, 256, False), (516, 2048, 256, True)])
+def test_linear_forward_backward_vs_fp64(M, K, N, relu):
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.ops import linear as L
+    from combo_avs_amd.ops.linear import linear
+    L.set_impl("x3")
+    torch.manual_seed(M + N)
+    x = torch.randn(M, K, device="cuda", requires_grad=True)
+    w = (torch.randn(N, K, device="cuda") / K ** 0.5).requires_grad_(True)
+    b = torch.randn(N, device="cuda", requires_grad=True)
+    g = torch.randn(M, N, device="cuda")
+    y = linear(x, w, b, relu)
+    gx, gw, gb = torch.autograd.grad(y, (x, w, b), g)
+    xd, wd, bd = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+    yd = torch.nn.functional.linear(xd, wd, bd)
+    if relu:  # use the kernel's own activation pattern: entries with |y| ~ 1e-7 may legitimately differ in sign
+        yd = yd * (y.detach() > 0)
+    gxd, gwd, gbd = torch.autograd.grad(yd, (xd, wd, bd), g.double())
+    # fp32 library GEMM for comparison of the error level
+    y32 = torch.nn.functional.linear(x.detach(), w.detach(), b.detach())
+    if relu:
+        y32 = torch.relu(y32)
+    e_x3, e_32 = rel_err(y, yd), rel_err(y32, yd)
+    assert e_x3 < 2e-5, (e_x3, e_32)
+    assert e_x3 < 50 * e_32 + 1e-6, (e_x3, e_32)  # same class as fp32 round-off (fp32 itself is ~1e-7..1e-6 here)
+    L.set_impl("library")
+    assert rel_err(gx, gxd) < 2e-5
+    assert rel_err(gw, gwd) < 2e-5
+    assert rel_err(gb, gbd) < 2e-5
+
+
+def test_operand_layouts_and_ragged_edges():
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.ops.linear import gemm_x3
+    torch.manual_seed(0)
+    M, N, K = 260, 132, 96
+    A = torch.randn(M, K, device="cuda")
+    B = torch.randn(N, K, device="cuda")
+    ref = (A.double() @ B.double().T)
+    for ar in (False, True):
+        for br in (False, True):
+            a = A.T.contiguous() if ar else A
+            b = B.T.contiguous() if br else B
+            for splits in (1, 3):
+                c = gemm_x3(a, ar, b, br, M, N, K, splits=splits)
+                assert rel_err(c, ref) < 2e-5, (ar, br, splits, rel_err(c, ref))
+
+
+def test_microbench_vs_library(capsys):
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.ops.linear import gemm_x3
+    M, K, N = 41160, 256, 1024
+    x = torch.randn(M, K, device="cuda")
+    w = torch.randn(N, K, device="cuda")
+
+    def t(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(20):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / 20 * 1e3
+    t_lib = t(lambda: torch.nn.functional.linear(x, w))
+    t_x3 = t(lambda: gemm_x3(x, False, w, False, M, N, K))
+    with capsys.disabled():
+        print(f"\n[gemm {M}x{K}x{N}] fp32 library {t_lib:.0f} us, bf16x3 MFMA {t_x3:.0f} us ({t_lib / t_x3:.2f}x)")
+    assert t_x3 < t_lib
