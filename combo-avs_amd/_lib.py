@@ -26,6 +26,7 @@ _SIGNATURES = {
     "combo_bifuse_backward2_f32": [c_void_p] * 3 + [c_float] + [c_void_p] * 5 + [c_float, ctypes.c_ulonglong] + [c_void_p] * 4 + [c_int] * 4 + [c_void_p] * 5,
     "combo_gemm_x3_splits": [c_int, c_int],
     "combo_gemm_x3_f32": [c_void_p, c_longlong, c_int, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_longlong] + [c_int] * 5 + [c_longlong, c_void_p],
+    "combo_matcher_cost_f32": [c_void_p] * 5 + [c_int] * 9 + [c_float] * 3 + [c_void_p] * 3,
     "combo_attn_mask_f32": [c_void_p] + [c_int] * 6 + [c_void_p, c_void_p],
     "combo_adamw_f32": [c_void_p] * 4 + [c_longlong, c_void_p] + [c_float] * 7 + [c_void_p],
 }

@@ -54,20 +54,22 @@ class HungarianMatcher(nn.Module):
 
     @torch.no_grad()
     def batched_cost(self, logits, masks, labels, gt, points):
-        """Cost tensors of N = (outputs x frames) assignment problems at once.
-        logits [N,Q,K+1], masks [N,Q,h,w], labels [N,Gmax] (padded), gt [N,Gmax,H,W] (zero padded), points [N,P,2]
-        -> [N,Q,Gmax] (columns beyond a frame's real G are garbage and are sliced away by the caller)."""
-        prob = logits.softmax(-1)
-        cost_class = -torch.gather(prob, 2, labels[:, None, :].expand(-1, prob.shape[1], -1))
-        o = point_sample(masks, points)  # [N,Q,P]
-        t = point_sample(gt, points)  # [N,Gmax,P]
-        hw = o.shape[-1]
-        pos, neg = F.softplus(-o), F.softplus(o)
-        tT = t.transpose(1, 2)
-        cost_mask = (torch.bmm(pos, tT) + torch.bmm(neg, 1 - tT)) / hw
-        s = o.sigmoid()
-        cost_dice = 1 - (2 * torch.bmm(s, tT) + 1) / (s.sum(-1)[:, :, None] + t.sum(-1)[:, None, :] + 1)
-        return self.cost_mask * cost_mask + self.cost_class * cost_class + self.cost_dice * cost_dice
+        """Cost tensors of N = (outputs x frames) assignment problems at once, one fused HIP launch
+        (csrc/matcher.hip).  logits [N,Q,K+1], masks [N,Q,h,w], labels [N,Gmax] (padded), gt [N,Gmax,H,W] (zero
+        padded), points [N,P,2] -> [N,Q,Gmax] (columns beyond a frame's real G are sliced away by the caller)."""
+        from .. import _lib
+        logits, masks, gt, points = (t.contiguous().float() for t in (logits, masks, gt, points))
+        labels = labels.contiguous()
+        _lib.require_cuda(logits, masks, labels, gt, points)
+        N, Q, K1 = logits.shape
+        G, (h, w), (H, W), P = gt.shape[1], masks.shape[-2:], gt.shape[-2:], points.shape[1]
+        cost = torch.empty(N, Q, G, device=logits.device, dtype=torch.float32)
+        t_ws = torch.empty(N, G, P, device=logits.device, dtype=torch.float32)
+        _lib.check(_lib.lib().combo_matcher_cost_f32(
+            logits.data_ptr(), masks.data_ptr(), labels.data_ptr(), gt.data_ptr(), points.data_ptr(), N, Q, K1, G, h, w, H, W,
+            P, self.cost_class, self.cost_mask, self.cost_dice, t_ws.data_ptr(), cost.data_ptr(), _lib.current_stream()),
+            "combo_matcher_cost_f32")
+        return cost
 
     @staticmethod
     def solve(costs_host):

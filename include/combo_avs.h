@@ -128,6 +128,18 @@ int combo_attn_mask_f32(const float* logits, int N, int H, int W, int h, int w, 
                         unsigned char* blocked, combo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * a14  Hungarian-matcher cost matrices, all (decoder output x frame) problems at once
+ *   replaces HungarianMatcher.memory_efficient_forward's cost computation (models/modeling/matcher.py:93-131:
+ *   point_sample of predictions and targets at P shared random points, batch_sigmoid_ce_loss :34-52,
+ *   batch_dice_loss :13-28, class cost :97) - everything up to, not including, the LSAP solve.
+ *   logits [N,Q,K1], masks [N,Q,h,w] (mask logits), labels [N,G] int64, gt [N,G,H,W] fp32 0/1, points [N,P,2] in [0,1],
+ *   t_ws [N,G,P] workspace (sampled targets), cost [N,Q,G].  G <= 8.
+ * ---------------------------------------------------------------------------------------------- */
+int combo_matcher_cost_f32(const float* logits, const float* masks, const long long* labels, const float* gt,
+                           const float* points, int N, int Q, int K1, int G, int h, int w, int H, int W, int P,
+                           float w_class, float w_mask, float w_dice, float* t_ws, float* cost, combo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * (f)1  optimiser: fused gradient clip + AdamW on a flat fp32 segment
  *   replaces FullModelGradientClippingOptimizer.step (train_net.py:205-221): p *= 1-lr*wd; m,v EMAs of
  *   clip_coef*g; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps).  clip_coef: device scalar (NULL = 1).
