@@ -27,6 +27,8 @@ _SIGNATURES = {
     "combo_gemm_x3_splits": [c_int, c_int],
     "combo_gemm_x3_f32": [c_void_p, c_longlong, c_int, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_longlong] + [c_int] * 5 + [c_longlong, c_void_p],
     "combo_matcher_cost_f32": [c_void_p] * 5 + [c_int] * 9 + [c_float] * 3 + [c_void_p] * 3,
+    "combo_sem_mix": [c_int, c_int] + [c_void_p] * 4 + [c_int] * 3 + [c_void_p] * 3,
+    "combo_semantic_inference_f32": [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p, c_void_p],
     "combo_attn_mask_f32": [c_void_p] + [c_int] * 6 + [c_void_p, c_void_p],
     "combo_adamw_f32": [c_void_p] * 4 + [c_longlong, c_void_p] + [c_float] * 7 + [c_void_p],
 }
@@ -74,9 +76,15 @@ def current_stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def require_cuda(*tensors):
+def require_cuda(*tensors, channels_last=False):
     for t in tensors:
         if t is not None and not t.is_cuda:
             raise RuntimeError("combo_avs_amd ops run on the GPU only (got a CPU tensor); there is no CPU fallback")
-        if t is not None and not t.is_contiguous():
+        if t is not None and not (t.is_contiguous(memory_format=torch_channels_last()) if channels_last and t.dim() == 4
+                                  else t.is_contiguous()):
             raise RuntimeError("combo_avs_amd ops need contiguous tensors")
+
+
+def torch_channels_last():
+    import torch
+    return torch.channels_last

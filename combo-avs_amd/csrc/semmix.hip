@@ -1,0 +1,143 @@
+// Siam-Encoder-Module mix (reference: models/utils/misc.py:112-131 channel_weighted_block and the per-level mix
+// `features[key] + scale * pre_sam_features[key]`, models/maskformer_model.py:345-352).
+//
+// Activations are channels-last ([B, HW, C] in memory), bf16 under the backbone autocast or fp32.
+//   sem_gap      : sum_i p[b,i,c]            (the gate's global average pool; float atomics onto a zeroed [B,C])
+//   sem_mix      : out[b,i,c] = f[b,i,c] + s[b,c] * p[b,i,c]      (fp32 out: the pixel decoder wants fp32)
+//   sem_mix_bwd  : df = dout, dp = dout * s + dgap[b,c]            (dgap already divided by HW by the caller)
+//   sem_dot      : ds[b,c] = sum_i dout[b,i,c] * p[b,i,c]
+// Pure bandwidth (AI 0.3 flop/B): each kernel touches every element once with 16-byte accesses.
+#include <hip/hip_bf16.h>
+
+#include "combo_common.h"
+
+namespace {
+
+template <typename T> struct Ld8;
+template <> struct Ld8<float> {
+  static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
+    const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[8]) {
+    reinterpret_cast<float4*>(p)[0] = make_float4(v[0], v[1], v[2], v[3]);
+    reinterpret_cast<float4*>(p)[1] = make_float4(v[4], v[5], v[6], v[7]);
+  }
+};
+template <> struct Ld8<__hip_bfloat16> {
+  static __device__ __forceinline__ void load(const __hip_bfloat16* p, float (&v)[8]) {
+    const uint4 r = *reinterpret_cast<const uint4*>(p);
+    const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[2 * k] = __uint_as_float(w[k] << 16);
+      v[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
+    }
+  }
+  static __device__ __forceinline__ void store(__hip_bfloat16* p, const float (&v)[8]) {
+    unsigned w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      unsigned r;
+      asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(v[2 * k]), "v"(v[2 * k + 1]));
+      w[k] = r;
+    }
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+
+// grid (C/8/64.., chunks, B): thread = 8 channels; loops over the pixels of its chunk; atomics onto acc[B,C]
+template <typename T, bool DOT>
+__global__ void __launch_bounds__(256)
+sem_reduce(const T* __restrict__ p, const float* __restrict__ dout, int HW, int C, int chunk, float* __restrict__ acc) {
+  const int c8 = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (c8 >= C) return;
+  const int b = blockIdx.z;
+  const int i0 = blockIdx.y * chunk, i1 = min(HW, i0 + chunk);
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = i0; i < i1; ++i) {
+    const long long o = ((long long)b * HW + i) * C + c8;
+    float v[8];
+    Ld8<T>::load(p + o, v);
+    if (DOT) {
+      float d[8];
+      Ld8<float>::load(dout + o, d);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s[k] += v[k] * d[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s[k] += v[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) __hip_atomic_fetch_add(acc + (long long)b * C + c8 + k, s[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+sem_mix_fwd(const T* __restrict__ f, const T* __restrict__ p, const float* __restrict__ s, long long n8, int HW, int C,
+            float* __restrict__ out) {
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n8; t += (long long)gridDim.x * blockDim.x) {
+    const long long o = t * 8;
+    const int c = (int)(o % C);
+    const long long b = o / ((long long)HW * C);
+    float fv[8], pv[8], sv[8], r[8];
+    Ld8<T>::load(f + o, fv);
+    Ld8<T>::load(p + o, pv);
+    Ld8<float>::load(s + b * C + c, sv);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = fv[k] + sv[k] * pv[k];
+    Ld8<float>::store(out + o, r);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+sem_mix_bwd(const float* __restrict__ dout, const float* __restrict__ s, const float* __restrict__ dgap, long long n8, int HW,
+            int C, T* __restrict__ df, T* __restrict__ dp) {
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n8; t += (long long)gridDim.x * blockDim.x) {
+    const long long o = t * 8;
+    const int c = (int)(o % C);
+    const long long b = o / ((long long)HW * C);
+    float d[8], sv[8], gv[8], r[8];
+    Ld8<float>::load(dout + o, d);
+    Ld8<float>::load(s + b * C + c, sv);
+    Ld8<float>::load(dgap + b * C + c, gv);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = d[k] * sv[k] + gv[k];
+    Ld8<T>::store(df + o, d);
+    Ld8<T>::store(dp + o, r);
+  }
+}
+
+inline int ew_grid(long long n) {
+  long long g = (n + 255) / 256;
+  return (int)(g > 256 * 16 ? 256 * 16 : (g < 1 ? 1 : g));
+}
+
+template <typename T>
+int run(int op, const void* a, const void* b, const float* s, const float* g, int B, int HW, int C, void* o1, void* o2,
+        hipStream_t st) {
+  const long long n8 = (long long)B * HW * C / 8;
+  const int chunk = (HW + 15) / 16;
+  const dim3 rgrid((C / 8 + 255) / 256, (HW + chunk - 1) / chunk, B);
+  switch (op) {
+    case 0: hipLaunchKernelGGL((sem_reduce<T, false>), rgrid, dim3(256), 0, st, (const T*)a, nullptr, HW, C, chunk, (float*)o1); break;
+    case 1: hipLaunchKernelGGL((sem_mix_fwd<T>), dim3(ew_grid(n8)), dim3(256), 0, st, (const T*)a, (const T*)b, s, n8, HW, C, (float*)o1); break;
+    case 2: hipLaunchKernelGGL((sem_reduce<T, true>), rgrid, dim3(256), 0, st, (const T*)a, (const float*)b, HW, C, chunk, (float*)o1); break;
+    case 3: hipLaunchKernelGGL((sem_mix_bwd<T>), dim3(ew_grid(n8)), dim3(256), 0, st, (const float*)a, s, g, n8, HW, C, (T*)o1, (T*)o2); break;
+    default: return COMBO_EINVAL;
+  }
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// op: 0 = gap sum (a = p, o1 = acc[B,C] zeroed), 1 = mix fwd (a = f, b = p, s -> o1 = out fp32),
+//     2 = dot (a = p, b = dout -> o1 = ds[B,C] zeroed), 3 = mix bwd (a = dout, s, g = dgap -> o1 = df, o2 = dp)
+extern "C" int combo_sem_mix(int op, int is_bf16, const void* a, const void* b, const float* s, const float* g, int B, int HW,
+                             int C, void* o1, void* o2, combo_stream_t stream) {
+  if (!a || !o1 || B <= 0 || HW <= 0 || C <= 0 || (C & 7)) return COMBO_EINVAL;
+  return is_bf16 ? run<__hip_bfloat16>(op, a, b, s, g, B, HW, C, o1, o2, (hipStream_t)stream)
+                 : run<float>(op, a, b, s, g, B, HW, C, o1, o2, (hipStream_t)stream);
+}

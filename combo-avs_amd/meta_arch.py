@@ -167,6 +167,16 @@ class MaskFormer(nn.Module):
                     losses.pop(k)
                     raise ValueError(f"Found useless Loss! {k}")
             return losses
+        if self.semantic_on and not self.sem_seg_postprocess_before_inference and not self.is_avss_data:
+            # fused tail (csrc/infer.hip): upsample + sigmoid + class-weighted sum without the [BT,Q,H,W] intermediate
+            from .ops.infer import semantic_inference
+            sem = semantic_inference(outputs["pred_logits"], outputs["pred_masks"], tuple(images.shape[-2:]))
+            res = []
+            for num_img in range(sem.shape[0]):
+                inp = batched_inputs[num_img // 5]
+                height, width = inp.get("height", image_size[0]), inp.get("width", image_size[1])
+                res.append({"sem_seg": sem_seg_postprocess(sem[num_img], image_size, height, width)})
+            return res
         mask_cls_results = outputs["pred_logits"]
         mask_pred_results = F.interpolate(outputs["pred_masks"].float(), size=tuple(images.shape[-2:]), mode="bilinear",
                                           align_corners=False)

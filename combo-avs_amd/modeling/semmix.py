@@ -1,7 +1,10 @@
 """Siam-Encoder-Module mix: `channel_weighted_block` (models/utils/misc.py:112-131) and the
-per-level mix `f <- f + gate(p) * p` (models/maskformer_model.py:345-352).  HIP kernel: csrc/semmix.hip (planned)."""
+per-level mix `f <- f + gate(p) * p` (models/maskformer_model.py:345-352).  The global average pool and the mix run on
+csrc/semmix.hip (channels-last, bf16 or fp32 in, fp32 out); the two tiny gate GEMVs stay library calls."""
 import torch
 from torch import nn
+
+from ..ops import semmix as K
 
 
 class channel_weighted_block(nn.Module):
@@ -12,7 +15,7 @@ class channel_weighted_block(nn.Module):
 
     def forward(self, x):
         b, c, _, _ = x.size()
-        y = x.float().mean(dim=(2, 3))
+        y = K.global_avg_pool(x)  # [B,C] fp32
         y = torch.sigmoid(self.fc2(torch.relu(self.fc1(y))))
         return y.view(b, c, 1, 1)
 
@@ -21,5 +24,5 @@ def sem_mix(features, pre_sam_features, scale_factor_modules):
     out = {}
     for (key, blk) in zip(features.keys(), scale_factor_modules):
         p = pre_sam_features[key]
-        out[key] = features[key] + blk(p).to(p.dtype) * p
+        out[key] = K.mix(features[key], p, blk(p).view(p.shape[0], p.shape[1]))
     return out

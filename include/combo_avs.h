@@ -140,6 +140,27 @@ int combo_matcher_cost_f32(const float* logits, const float* masks, const long l
                            float w_class, float w_mask, float w_dice, float* t_ws, float* cost, combo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * a1  Siam-Encoder-Module mix on channels-last activations (bf16 or fp32 in, fp32 out)
+ *   replaces channel_weighted_block's global average pool (models/utils/misc.py:125) and the mix
+ *   `features[key] + scale * pre_sam_features[key]` (models/maskformer_model.py:352) and their backward.
+ *   op 0: acc[B,C] += sum_i p[b,i,c]                 (a = p; o1 = acc, zero-filled by the caller)
+ *   op 1: out[b,i,c] = f[b,i,c] + s[b,c]*p[b,i,c]    (a = f, b = p; o1 = out fp32)
+ *   op 2: ds[B,C] += sum_i dout[b,i,c]*p[b,i,c]      (a = p, b = dout fp32; o1 = ds, zero-filled)
+ *   op 3: df = dout, dp = dout*s + dgap[b,c]         (a = dout fp32, g = dgap (already / HW); o1 = df, o2 = dp)
+ *   C % 8 == 0; f, p, df, dp are bf16 when is_bf16 != 0, else fp32.
+ * ---------------------------------------------------------------------------------------------- */
+int combo_sem_mix(int op, int is_bf16, const void* a, const void* b, const float* s, const float* g, int B, int HW, int C,
+                  void* o1, void* o2, combo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a17  inference tail: out[f,k,Y,X] = sum_q cls_prob[f,q,k] * sigmoid(bilinear_up(masks[f,q])[Y,X])
+ *   replaces F.interpolate(pred_masks, (H,W), bilinear, align_corners=False) + semantic_inference
+ *   (models/maskformer_model.py:397-402, 460-464).  cls_prob [F,Q,K] = softmax(logits)[..., :-1]; K <= 8 per call.
+ * ---------------------------------------------------------------------------------------------- */
+int combo_semantic_inference_f32(const float* cls_prob, const float* masks, int F, int Q, int K, int h, int w, int H,
+                                 int W, float* out, combo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * (f)1  optimiser: fused gradient clip + AdamW on a flat fp32 segment
  *   replaces FullModelGradientClippingOptimizer.step (train_net.py:205-221): p *= 1-lr*wd; m,v EMAs of
  *   clip_coef*g; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps).  clip_coef: device scalar (NULL = 1).

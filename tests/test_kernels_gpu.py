@@ -84,3 +84,52 @@ def test_fused_matcher_cost_vs_oracle():
     for n in range(N):
         ref = O.matcher_cost(logits[n], masks[n], labels[n], gt[n], pts[n:n + 1])
         torch.testing.assert_close(got[n], ref, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_sem_mix_forward_backward(dtype):
+    """Row a1: channel_weighted_block + mix on csrc/semmix.hip vs the oracle (fp64 torch), channels-last bf16/fp32."""
+    import json, os
+    import numpy as np
+    import synth
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.modeling.semmix import channel_weighted_block, sem_mix
+    from oracle import combo_oracle as O
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "sem_mix.npz"))
+    spec = json.loads(str(z["sem256/spec"]))
+    blk = channel_weighted_block(256)
+    blk.load_state_dict({k: synth.synth_param("sem256." + k, s) for k, s in spec})
+    blk = blk.cuda()
+    f = synth.synth_tensor("sem256.f", (3, 256, 6, 5), 0)
+    p = synth.synth_tensor("sem256.p", (3, 256, 6, 5), 0)
+    if dtype == torch.float32:  # golden fixture produced by the reference's own module
+        out = sem_mix({"res2": f.cuda()}, {"res2": p.cuda()}, [blk])["res2"]
+        np.testing.assert_allclose(out.detach().cpu().numpy(), z["sem256/mixed"], rtol=1e-5, atol=1e-5)
+    fq, pq = f.to(dtype).float(), p.to(dtype).float()  # the values the kernel actually sees
+    P = {"m.0." + k: v.detach().cpu().double() for k, v in blk.state_dict().items()}
+    fr, pr = fq.double().requires_grad_(True), pq.double().requires_grad_(True)
+    ref = O.sem_mix(P, "m.", {"res2": fr}, {"res2": pr})["res2"]
+    g = synth.synth_tensor("sem256.g", tuple(ref.shape), 0)
+    rf, rp = torch.autograd.grad(ref, (fr, pr), g.double())
+    fg = f.cuda().to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    pg = p.cuda().to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    out = sem_mix({"res2": fg}, {"res2": pg}, [blk])["res2"]
+    assert out.dtype == torch.float32
+    torch.testing.assert_close(out.cpu().double(), ref.detach(), rtol=1e-5, atol=1e-5)
+    gf, gp = torch.autograd.grad(out, (fg, pg), g.cuda())
+    tol = dict(rtol=1e-2, atol=2e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(gf.cpu().double(), rf, **tol)
+    torch.testing.assert_close(gp.cpu().double(), rp, **tol)
+
+
+def test_fused_inference_tail_vs_oracle():
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.ops.infer import semantic_inference
+    from oracle import combo_oracle as O
+    torch.manual_seed(0)
+    for K in (2, 11):
+        logits = torch.randn(3, 100, K + 1)
+        masks = torch.randn(3, 100, 56, 56) * 3
+        ref = O.semantic_inference(logits, masks, (224, 224))
+        got = semantic_inference(logits.cuda(), masks.cuda(), (224, 224)).cpu()
+        torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
