@@ -12,13 +12,78 @@ MIN_ROWS = 512  # below this the op is launch/weight-bandwidth bound and the lib
 # "x3" = csrc/gemm_x3.hip.  Measured on MI355X (tools/bench_gemm.py, 41160x256x1024): x3 forward 151 us vs 257 us,
 # but the whole training step does not get faster yet (dX needs a transposed weight copy, dW is library either way),
 # so "library" stays the default until the x3 kernel has a deeper load pipeline.
-_IMPL = "library"
+#   "library3x" = hipBLASLt with torch's allow_tf32 switch: gfx950 has no TF32/xf32 matrix instruction, and
+#   hipBLASLt serves that mode with a 3-way bf16 split as well (measured error 4.4e-6 vs 2.9e-7 for plain fp32, i.e.
+#   the same class as csrc/gemm_x3.hip; tools/blas_test.py).  Forward and dX run 2.2x faster in that mode, the
+#   TN-layout dW GEMM is slower (809 vs 491 us), so dW stays in plain fp32 mode.
+_IMPL = "library3x"
 
 
 def set_impl(name):
     global _IMPL
-    assert name in ("library", "x3")
+    assert name in ("library", "library3x", "x3")
     _IMPL = name
+
+
+def gemm_tn_x3(dy, x):
+    """dW[N,K] = dy[M,N]^T @ x[M,K] on csrc/gemm_tn.hip (fp32-accurate bf16x3 MFMA, split-K over the tokens)."""
+    lib = _lib.lib()
+    M, N = dy.shape
+    K = x.shape[1]
+    splits = lib.combo_gemm_tn_splits(M, N, K)
+    mchunk = (-(-M // splits) + 15) // 16 * 16
+    splits = -(-M // mchunk)
+    part = torch.empty(splits, N, K, device=dy.device, dtype=torch.float32)
+    _lib.check(lib.combo_gemm_tn_x3_f32(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), part.data_ptr(), M, N, K, splits,
+                                        _lib.current_stream()), "combo_gemm_tn_x3_f32")
+    return part.sum(0) if splits > 1 else part[0]
+
+
+class _split3:
+    """context: route library GEMMs through hipBLASLt's bf16x3 path (torch spells the switch `allow_tf32`)."""
+
+    def __init__(self, on):
+        self.on = on
+
+    def __enter__(self):
+        self.prev = torch.backends.cuda.matmul.allow_tf32
+        torch.backends.cuda.matmul.allow_tf32 = self.on
+
+    def __exit__(self, *a):
+        torch.backends.cuda.matmul.allow_tf32 = self.prev
+
+
+class _LinearLib3x(Function):
+    @staticmethod
+    def forward(ctx, x2d, weight, bias, relu):
+        with _split3(True):
+            y = torch.nn.functional.linear(x2d, weight, bias)
+        if relu:
+            y = torch.relu_(y)
+        ctx.save_for_backward(x2d, weight, y if relu else None)
+        ctx.relu = relu
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x2d, weight, y = ctx.saved_tensors
+        if ctx.relu:
+            dy = dy * (y > 0)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            with _split3(True):
+                dx = dy @ weight
+        if ctx.needs_input_grad[1]:
+            if dy.is_contiguous() and x2d.is_contiguous() and dy.shape[0] >= 2048:
+                dw = gemm_tn_x3(dy, x2d)  # long-reduction / tiny-output shape: 3-7x faster than the library GEMM
+            else:
+                with _split3(False):
+                    dw = dy.t() @ x2d
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(0)
+        return dx, dw, db, None
 
 
 def gemm_x3(A, a_rowc, B, b_rowc, M, N, K, bias=None, relu=False, splits=1):
@@ -75,6 +140,10 @@ def linear(x, weight, bias=None, relu=False):
     K = x.shape[-1]
     N = weight.shape[0]
     rows = x.numel() // K
+    if (_IMPL == "library3x" and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32
+            and rows >= MIN_ROWS and not torch.is_autocast_enabled()):
+        y = _LinearLib3x.apply(x.reshape(rows, K), weight, bias, relu)
+        return y.view(*x.shape[:-1], N)
     if (_IMPL == "x3" and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and rows >= MIN_ROWS and K % 4 == 0
             and N % 4 == 0 and rows % 4 == 0 and not torch.is_autocast_enabled()
             and x.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0 and weight.is_contiguous()):

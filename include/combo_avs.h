@@ -117,6 +117,14 @@ int combo_gemm_x3_f32(const float* A, long long lda, int a_rowc, const float* B,
                       const float* bias, float* C, long long ldc, int M, int N, int K, int relu, int splits,
                       long long split_stride, combo_stream_t stream);
 
+/*   Weight gradient dW[N,K] = dY[M,N]^T . X[M,K] (reduction over the M tokens), same 3-way bf16 split, fragments loaded
+ *   straight from global memory (no LDS), split-K over M: partial z is written at out_partials + z*N*K and the caller
+ *   sums the partials.  `splits` must be a value for which ceil(M / roundup16(ceil(M/splits))) == splits
+ *   (combo_gemm_tn_splits returns a suitable first guess; the Python binding fixes the rounding). */
+int combo_gemm_tn_splits(int M, int N, int K);
+int combo_gemm_tn_x3_f32(const float* dY, long long ldy, const float* X, long long ldx, float* out_partials, int M, int N,
+                         int K, int splits, combo_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * a13 (tail)  next-layer attention mask
  *   replaces F.interpolate(outputs_mask, size, bilinear, align_corners=False).sigmoid() < 0.5 and the

@@ -82,3 +82,29 @@ def test_microbench_vs_library(capsys):
     with capsys.disabled():
         print(f"\n[gemm {M}x{K}x{N}] fp32 library {t_lib:.0f} us, bf16x3 MFMA {t_x3:.0f} us ({t_lib / t_x3:.2f}x)")
     assert t_x3 < t_lib
+
+
+@pytest.mark.parametrize("M,N,K", [(41160, 1024, 256), (41160, 256, 1024), (31360, 256, 256), (41160, 96, 256), (4001, 192, 128)])
+def test_weight_gradient_gemm_tn(M, N, K, capsys):
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.ops.linear import gemm_tn_x3
+    torch.manual_seed(M + N + K)
+    dy = torch.randn(M, N, device="cuda")
+    x = torch.randn(M, K, device="cuda")
+    got = gemm_tn_x3(dy, x)
+    ref = dy.double().t() @ x.double()
+    assert rel_err(got, ref) < 2e-5, rel_err(got, ref)
+
+    def t(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(10):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / 10 * 1e3
+    with capsys.disabled():
+        print(f"\n[dW {M}x{N}x{K}] library {t(lambda: dy.t() @ x):.0f} us, gemm_tn_x3 {t(lambda: gemm_tn_x3(dy, x)):.0f} us")
