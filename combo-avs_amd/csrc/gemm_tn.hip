@@ -55,7 +55,7 @@ __device__ __forceinline__ void load8(const float* __restrict__ base, long long 
 // grid: (K/128 tiles, N/128 tiles, splits); block: 256 threads = 4 waves (2 along n x 2 along k), 64x64 per wave
 __global__ void __launch_bounds__(256)
 gemm_tn_x3_kernel(const float* __restrict__ dY, long long ldy, const float* __restrict__ X, long long ldx,
-                  float* __restrict__ out, int M, int N, int K, int mchunk) {
+                  float* __restrict__ out, float* __restrict__ db_part, int M, int N, int K, int mchunk) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wn = wave >> 1, wk = wave & 1;
   const int n0 = blockIdx.y * 128 + wn * 64, k0 = blockIdx.x * 128 + wk * 64;
@@ -72,6 +72,9 @@ gemm_tn_x3_kernel(const float* __restrict__ dY, long long ldy, const float* __re
   const float* pa[2] = {dY + min(n0 + col, N - 1), dY + min(n0 + 32 + col, N - 1)};
   const float* pb[2] = {X + min(k0 + col, K - 1), X + min(k0 + 32 + col, K - 1)};
   float va[2][8], vb[2][8];
+  // bias gradient db[n] = sum_m dY[m,n] rides along: the waves of the first K tile already hold every dY element
+  const bool do_db = db_part != nullptr && blockIdx.x == 0 && wk == 0;
+  float colsum[2] = {0.f, 0.f};
   int m = mbeg + kg * 8;
 #pragma unroll
   for (int i = 0; i < 2; ++i) { load8(pa[i], ldy, m, mend, M - 1, va[i]); load8(pb[i], ldx, m, mend, M - 1, vb[i]); }
@@ -79,6 +82,11 @@ gemm_tn_x3_kernel(const float* __restrict__ dY, long long ldy, const float* __re
     Frag fa[2], fb[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) { fa[i] = make_frag(va[i]); fb[i] = make_frag(vb[i]); }
+    if (do_db) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        colsum[i] += ((va[i][0] + va[i][1]) + (va[i][2] + va[i][3])) + ((va[i][4] + va[i][5]) + (va[i][6] + va[i][7]));
+    }
     if (m - kg * 8 + 16 < mend) {  // next 16 reduction rows, in flight during the MFMAs
 #pragma unroll
       for (int i = 0; i < 2; ++i) { load8(pa[i], ldy, m + 16, mend, M - 1, va[i]); load8(pb[i], ldx, m + 16, mend, M - 1, vb[i]); }
@@ -95,6 +103,14 @@ gemm_tn_x3_kernel(const float* __restrict__ dY, long long ldy, const float* __re
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i].hi, fb[j].hi, acc[i][j], 0, 0, 0);
+  }
+  if (do_db) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float t = colsum[i] + __shfl_xor(colsum[i], 32);
+      const int nr = n0 + i * 32 + col;
+      if (kg == 0 && nr < N) db_part[(long long)blockIdx.z * N + nr] = t;
+    }
   }
   float* o = out + (long long)blockIdx.z * N * K;
 #pragma unroll
@@ -124,15 +140,15 @@ int combo_gemm_tn_splits(int M, int N, int K) {
   return (int)s;
 }
 
-int combo_gemm_tn_x3_f32(const float* dY, long long ldy, const float* X, long long ldx, float* out_partials, int M, int N,
-                         int K, int splits, combo_stream_t stream) {
+int combo_gemm_tn_x3_f32(const float* dY, long long ldy, const float* X, long long ldx, float* out_partials,
+                         float* db_partials, int M, int N, int K, int splits, combo_stream_t stream) {
   if (!dY || !X || !out_partials || M <= 0 || N <= 0 || K <= 0 || splits <= 0) return COMBO_EINVAL;
   int mchunk = (M + splits - 1) / splits;
   mchunk = (mchunk + 15) / 16 * 16;
   const int nz = (M + mchunk - 1) / mchunk;
   if (nz != splits) return COMBO_EINVAL;  // caller sizes `out_partials` with combo_gemm_tn_splits / this rounding
   hipLaunchKernelGGL(gemm_tn_x3_kernel, dim3((K + 127) / 128, (N + 127) / 128, nz), dim3(256), 0, (hipStream_t)stream, dY,
-                     ldy, X, ldx, out_partials, M, N, K, mchunk);
+                     ldy, X, ldx, out_partials, db_partials, M, N, K, mchunk);
   return (int)hipGetLastError();
 }
 

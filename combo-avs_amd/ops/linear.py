@@ -25,8 +25,9 @@ def set_impl(name):
     _IMPL = name
 
 
-def gemm_tn_x3(dy, x):
-    """dW[N,K] = dy[M,N]^T @ x[M,K] on csrc/gemm_tn.hip (fp32-accurate bf16x3 MFMA, split-K over the tokens)."""
+def gemm_tn_x3(dy, x, with_bias_grad=False):
+    """dW[N,K] = dy[M,N]^T @ x[M,K] on csrc/gemm_tn.hip (fp32-accurate bf16x3 MFMA, split-K over the tokens);
+    with_bias_grad: also return db[N] = dy.sum(0), accumulated in the same pass."""
     lib = _lib.lib()
     M, N = dy.shape
     K = x.shape[1]
@@ -34,9 +35,13 @@ def gemm_tn_x3(dy, x):
     mchunk = (-(-M // splits) + 15) // 16 * 16
     splits = -(-M // mchunk)
     part = torch.empty(splits, N, K, device=dy.device, dtype=torch.float32)
-    _lib.check(lib.combo_gemm_tn_x3_f32(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), part.data_ptr(), M, N, K, splits,
-                                        _lib.current_stream()), "combo_gemm_tn_x3_f32")
-    return part.sum(0) if splits > 1 else part[0]
+    dbp = torch.empty(splits, N, device=dy.device, dtype=torch.float32) if with_bias_grad else None
+    _lib.check(lib.combo_gemm_tn_x3_f32(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), part.data_ptr(), _lib.ptr(dbp),
+                                        M, N, K, splits, _lib.current_stream()), "combo_gemm_tn_x3_f32")
+    dw = part.sum(0) if splits > 1 else part[0]
+    if with_bias_grad:
+        return dw, dbp.sum(0)
+    return dw
 
 
 class _split3:
@@ -75,13 +80,16 @@ class _LinearLib3x(Function):
         if ctx.needs_input_grad[0]:
             with _split3(True):
                 dx = dy @ weight
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             if dy.is_contiguous() and x2d.is_contiguous() and dy.shape[0] >= 2048:
-                dw = gemm_tn_x3(dy, x2d)  # long-reduction / tiny-output shape: 3-7x faster than the library GEMM
+                # long-reduction / tiny-output shape: 3x faster than the library GEMM; db rides along
+                r = gemm_tn_x3(dy, x2d, with_bias_grad=want_db)
+                dw, db = r if want_db else (r, None)
             else:
                 with _split3(False):
                     dw = dy.t() @ x2d
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if want_db and db is None:
             db = dy.sum(0)
         return dx, dw, db, None
 

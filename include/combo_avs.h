@@ -122,8 +122,9 @@ int combo_gemm_x3_f32(const float* A, long long lda, int a_rowc, const float* B,
  *   sums the partials.  `splits` must be a value for which ceil(M / roundup16(ceil(M/splits))) == splits
  *   (combo_gemm_tn_splits returns a suitable first guess; the Python binding fixes the rounding). */
 int combo_gemm_tn_splits(int M, int N, int K);
-int combo_gemm_tn_x3_f32(const float* dY, long long ldy, const float* X, long long ldx, float* out_partials, int M, int N,
-                         int K, int splits, combo_stream_t stream);
+/*   db_partials (optional, [splits,N]): per-split column sums of dY = the bias gradient, fused into the same pass. */
+int combo_gemm_tn_x3_f32(const float* dY, long long ldy, const float* X, long long ldx, float* out_partials,
+                         float* db_partials, int M, int N, int K, int splits, combo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a13 (tail)  next-layer attention mask

@@ -91,9 +91,10 @@ def test_weight_gradient_gemm_tn(M, N, K, capsys):
     torch.manual_seed(M + N + K)
     dy = torch.randn(M, N, device="cuda")
     x = torch.randn(M, K, device="cuda")
-    got = gemm_tn_x3(dy, x)
+    got, db = gemm_tn_x3(dy, x, with_bias_grad=True)
     ref = dy.double().t() @ x.double()
     assert rel_err(got, ref) < 2e-5, rel_err(got, ref)
+    assert rel_err(db, dy.double().sum(0)) < 1e-5
 
     def t(fn):
         for _ in range(3):
