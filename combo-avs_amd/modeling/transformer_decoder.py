@@ -199,36 +199,43 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
             output = torch.cat([output, self.scramble_audio(audio_features, bt)], dim=-1)
         elif self.queries_fuse_type == "all":
             output = self.scramble_audio(audio_features, bt)
-        predictions_class, predictions_mask, middles = [], [], []
-        outputs_class, outputs_mask, blocked = self.forward_prediction_heads(output, mf_tok, (h_m, w_m), size_list[0])
+        from ..ops import masklogit
+        nheads_pred = self.num_layers + 1
+        # one buffer for the mask logits of all prediction heads; head i fills slice i (values, no grad) ...
+        logit_buf = torch.empty(nheads_pred, bt, self.num_queries, h_m * w_m, device=mf_tok.device, dtype=torch.float32)
+        predictions_class, mask_embeds = [], []
+        outputs_class, mask_embed, blocked = self.forward_prediction_heads(output, mf_tok, (h_m, w_m), size_list[0], logit_buf[0])
         predictions_class.append(outputs_class)
-        predictions_mask.append(outputs_mask)
-        if self.use_cosine_loss:
-            middles.append(outputs_mask.reshape(bt, self.num_queries, -1))
+        mask_embeds.append(mask_embed)
         for i in range(self.num_layers):
             lvl = i % self.num_feature_levels
             # `blocked` already has the fully-blocked-row reset of :458 applied (fused in the mask kernel)
             output = self.transformer_cross_attention_layers[i](output, src[lvl], blocked, pos[lvl], query_embed)
             output = self.transformer_self_attention_layers[i](output, query_embed)
             output = self.transformer_ffn_layers[i](output)
-            outputs_class, outputs_mask, blocked = self.forward_prediction_heads(
-                output, mf_tok, (h_m, w_m), size_list[(i + 1) % self.num_feature_levels])
+            outputs_class, mask_embed, blocked = self.forward_prediction_heads(
+                output, mf_tok, (h_m, w_m), size_list[(i + 1) % self.num_feature_levels], logit_buf[i + 1])
             predictions_class.append(outputs_class)
-            predictions_mask.append(outputs_mask)
-            if self.use_cosine_loss and i != self.num_layers - 1:
-                middles.append(outputs_mask.reshape(bt, self.num_queries, -1))
+            mask_embeds.append(mask_embed)
         assert len(predictions_class) == self.num_layers + 1
+        # ... and ONE autograd node carries the gradient of all heads back to mask_features / the mask embeddings
+        logits_all = masklogit.attach_mask_logit_grads(mf_tok, logit_buf, mask_embeds)
+        parts = logits_all.unbind(0)  # ONE backward node (a stack of the 10 head gradients), not 19 zero-padded slices
+        predictions_mask = [p.view(bt, self.num_queries, h_m, w_m) for p in parts]
+        middles = list(parts[:-1]) if self.use_cosine_loss else []
         return {
             "pred_logits": predictions_class[-1], "pred_masks": predictions_mask[-1],
             "aux_outputs": [{"pred_logits": a, "pred_masks": b} for a, b in zip(predictions_class[:-1], predictions_mask[:-1])],
             "middles_attn_mask": middles,
         }
 
-    def forward_prediction_heads(self, output, mf_tok, hw, attn_mask_target_size):
-        """:493-509 -> (class logits [BT,Q,K+1], mask logits [BT,Q,H,W], blocked bool [BT,Q,h*w])"""
+    def forward_prediction_heads(self, output, mf_tok, hw, attn_mask_target_size, logits_out):
+        """:493-509 -> (class logits [BT,Q,K+1], mask embedding [BT,Q,C], blocked bool [BT,Q,h*w]); the mask logits
+        [BT,Q,H*W] are written into `logits_out` (their gradient is attached later by one node for all heads)."""
         from ..ops import masklogit
         dec = self.decoder_norm(output)
         outputs_class = self.class_embed(dec)
         mask_embed = self.mask_embed(dec)
-        outputs_mask, blocked = masklogit.mask_logits_and_attn_mask(mask_embed, mf_tok, hw, attn_mask_target_size)
-        return outputs_class, outputs_mask, blocked
+        masklogit.mask_logits_into(mask_embed, mf_tok, logits_out)
+        blocked = masklogit.attn_mask(logits_out.view(output.shape[0], self.num_queries, hw[0], hw[1]), attn_mask_target_size, True)
+        return outputs_class, mask_embed, blocked

@@ -109,10 +109,22 @@ if os.environ.get("BWD_STAGES"):
             g_out = torch.autograd.grad(total, leaves_d, allow_unused=True)
         g_out = [g if g is not None else torch.zeros_like(l) for g, l in zip(g_out, leaves_d)]
         with tm.section("decoder bwd"):
-            g = torch.autograd.grad(leaves, ms_d + [a256_d, fv_d] + P(head.predictor), g_out, allow_unused=True)
+            g = torch.autograd.grad(leaves, ms_d + [a256_d, fv_d] + P(head.predictor), g_out, allow_unused=True, retain_graph=bool(os.environ.get("PROF_STAGE")))
         g_ms, g_a256, g_fv = g[:3], g[3], g[4]
         with tm.section("fusion+mlp bwd"):
             g2 = torch.autograd.grad([fused["visual"]["res2"], a256], [mf_d] + P(head.fusion_module) + P(head.audio_transformation), [g_fv, g_a256], allow_unused=True)
+        if os.environ.get("PROF_STAGE") == "pd" and it == 3:
+            from torch.profiler import profile, ProfilerActivity
+            with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+                g3 = torch.autograd.grad([mf] + list(ms), list(feats_d.values()) + P(head.pixel_decoder), [g2[0]] + list(g_ms), allow_unused=True, retain_graph=True)
+                torch.cuda.synchronize()
+            print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=28, max_name_column_width=60))
+        if os.environ.get("PROF_STAGE") == "dec" and it == 3:
+            from torch.profiler import profile, ProfilerActivity
+            with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+                g = torch.autograd.grad(leaves, ms_d + [a256_d, fv_d] + P(head.predictor), g_out, allow_unused=True, retain_graph=True)
+                torch.cuda.synchronize()
+            print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=28, max_name_column_width=60))
         with tm.section("pixel decoder bwd"):
             g3 = torch.autograd.grad([mf] + list(ms), list(feats_d.values()) + P(head.pixel_decoder), [g2[0]] + list(g_ms), allow_unused=True)
         with tm.section("semmix+backbones bwd"):
