@@ -58,8 +58,9 @@ int combo_msda_forward_f64(const double* value, const int64_t* spatial_shapes, c
 
 /*   grad_out [B,Lq,M*D];  grad_value [B,S,M,D], grad_sampling_loc [B,Lq,M,L,P,2], grad_attn_weight [B,Lq,M,L,P].
  *   All three gradient buffers MUST be zero-filled by the caller (as the reference does,
- *   ms_deform_attn_cuda.cu:126-128).  Accumulation order is not deterministic (float atomics), as in
- *   the reference. */
+ *   ms_deform_attn_cuda.cu:126-128).  LDS path (D == 32, slab fits): grad_value is accumulated in 32-bit fixed point
+ *   (bitwise deterministic, ~1e-7 relative to max|grad_out|), no floating-point atomics anywhere.  Generic path:
+ *   global float atomics, accumulation order not deterministic, as in the reference. */
 int combo_msda_backward_f32(const float* grad_out, const float* value, const int64_t* spatial_shapes,
                             const int64_t* level_start_index, const float* sampling_loc, const float* attn_weight,
                             int B, int S, int M, int D, int L, int Lq, int P,
