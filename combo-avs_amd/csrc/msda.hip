@@ -296,19 +296,37 @@ msda_fwd_lds_d32(const float* __restrict__ value, const int64_t* __restrict__ sh
   const int qbeg = (int)(((long long)Lq * qt) / QT), qend = (int)(((long long)Lq * (qt + 1)) / QT);
   const int npairs = kQW * LP;
 
+  // Per-lane constants of the coordinate phase.  A lane always serves the same (query slot, point) pairs
+  // i = lane + 64*j, so the decomposition i -> (slot, point, level) and the level geometry are loop invariant:
+  // computing them here keeps three runtime integer divisions (~40 VALU instructions each) out of the hot loop.
+  int c_ql[kFwdPre], c_H[kFwdPre], c_W[kFwdPre], c_st[kFwdPre];
+  long long c_eoff[kFwdPre];  // element offset of (slot, point) relative to the first query of the iteration
+  bool c_on[kFwdPre];
+#pragma unroll
+  for (int j = 0; j < kFwdPre; ++j) {
+    const int i = lane + j * 64;
+    const int ql = i / LP, pt = i - ql * LP;
+    const int l = pt / P;
+    c_on[j] = i < npairs;
+    c_ql[j] = ql;
+    c_eoff[j] = (long long)ql * M * LP + pt;
+    int H = lvH[0], W = lvW[0], st = lvS[0];
+#pragma unroll
+    for (int k = 1; k < kMaxLevels; ++k)
+      if (l == k) { H = lvH[k]; W = lvW[k]; st = lvS[k]; }
+    c_H[j] = H; c_W[j] = W; c_st[j] = st;
+  }
   // software prefetch of the sampling locations / weights of the next wave iteration
   float2 pxy[kFwdPre];
   float pa[kFwdPre];
   auto prefetch = [&](int q0) {
+    const long long base = (((long long)b * Lq + q0) * M + m) * LP;
 #pragma unroll
     for (int j = 0; j < kFwdPre; ++j) {
-      const int i = lane + j * 64;
-      const int ql = i / LP, pt = i - ql * LP;
-      const int q = q0 + ql;
       pxy[j] = make_float2(-8.f, -8.f);
       pa[j] = 0.f;
-      if (i < npairs && q < qend) {
-        const long long e = (((long long)b * Lq + q) * M + m) * LP + pt;
+      if (c_on[j] && q0 + c_ql[j] < qend) {
+        const long long e = base + c_eoff[j];
         pxy[j] = *reinterpret_cast<const float2*>(loc + e * 2);
         pa[j] = aw[e];
       }
@@ -324,17 +342,12 @@ msda_fwd_lds_d32(const float* __restrict__ value, const int64_t* __restrict__ sh
 #pragma unroll
     for (int j = 0; j < kFwdPre; ++j) {
       const int i = lane + j * 64;
-      if (i < npairs) {
-        const int ql = i / LP, pt = i - ql * LP;
+      if (c_on[j] && dbg != 3) {
         float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
         unsigned r01 = (unsigned)S | ((unsigned)S << 16), r23 = r01;
         const float2 xy = pxy[j];
         const float a = pa[j];
-        const int l = pt / P;
-        int H = lvH[0], W = lvW[0], st = lvS[0];
-#pragma unroll
-        for (int k = 1; k < kMaxLevels; ++k)
-          if (l == k) { H = lvH[k]; W = lvW[k]; st = lvS[k]; }
+        const int H = c_H[j], W = c_W[j], st = c_st[j];
         const float h_im = xy.y * H - 0.5f, w_im = xy.x * W - 0.5f;
         if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
           const float hf = floorf(h_im), wf = floorf(w_im);
@@ -360,7 +373,7 @@ msda_fwd_lds_d32(const float* __restrict__ value, const int64_t* __restrict__ sh
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     // ---- gather phase: 8 lanes x 4 channels per query, 8 queries per wave ----
-    {
+    if (dbg != 4) {
       const int g = lane >> 3, cg = lane & 7;
       const int q = q0 + g;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
