@@ -106,6 +106,10 @@ def main():
     from combo_avs_amd.meta_arch import build_model
     from combo_avs_amd.trainer import FlatAdamW, train_step
 
+    if os.environ.get("COMBO_MIOPEN_BENCHMARK", "1") == "1":
+        # MIOpen exhaustive find for the host-PyTorch backbone convolutions (+8 % frames/s; costs ~2 min of search in
+        # the first warm-up step on a box with an empty MIOpen user db; COMBO_MIOPEN_BENCHMARK=0 skips it)
+        torch.backends.cudnn.benchmark = True
     cfg = combo_cfg(os.path.join(ROOT, "configs/avs_s4/COMBO_R50_bs8_90k.yaml"))
     torch.manual_seed(0)  # identical random-init weights on every rank (DDP broadcast equivalent)
     model = build_model(cfg).to(dev).train()
