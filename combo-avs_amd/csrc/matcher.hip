@@ -50,38 +50,37 @@ gt_sample_kernel(const float* __restrict__ gt, const float* __restrict__ points,
   t[i] = bilinear(gt + ng * H * W, H, W, xy.x, xy.y);
 }
 
+// One workgroup (8 waves) per (n, q): the mask sits once in LDS (12.5 KB -> 4 workgroups = 32 waves per CU) and the
+// 8 waves split the P points; partial sums meet in a small LDS array.
 __global__ void __launch_bounds__(WAVES * 64)
 matcher_cost_kernel(const float* __restrict__ logits, const float* __restrict__ masks, const long long* __restrict__ labels,
                     const float* __restrict__ t, const float* __restrict__ points, int N, int Q, int K1, int G, int h, int w,
                     int P, float w_class, float w_mask, float w_dice, float* __restrict__ cost) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int qblocks = (Q + WAVES - 1) / WAVES;
-  const int n = blockIdx.x / qblocks;
-  const int q = (blockIdx.x % qblocks) * WAVES + wave;
-  if (q >= Q) return;  // whole wave
-  float* img = smem + wave * h * w;
+  __shared__ float part[WAVES][3 * GMAX + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = blockIdx.x / Q, q = blockIdx.x % Q;
+  float* img = smem;
   const float* src = masks + ((long long)n * Q + q) * h * w;
-  for (int i = lane; i < h * w; i += 64) img[i] = src[i];
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (int i = tid; i < h * w; i += WAVES * 64) img[i] = src[i];
+  __syncthreads();
   float a[GMAX], d[GMAX], tt[GMAX], s_sum = 0.f;
 #pragma unroll
   for (int g = 0; g < GMAX; ++g) { a[g] = 0.f; d[g] = 0.f; tt[g] = 0.f; }
   const float* pts = points + (long long)n * P * 2;
   const float* tn = t + (long long)n * G * P;
-  for (int p = lane; p < P; p += 64) {
+  for (int p = tid; p < P; p += WAVES * 64) {
     const float2 xy = *reinterpret_cast<const float2*>(pts + p * 2);
     const float x = bilinear(img, h, w, xy.x, xy.y);
-    // F.softplus (beta 1, threshold 20) of +x and -x, sigmoid
+    // F.softplus (beta 1, threshold 20) of +x and -x and sigmoid(x) from ONE exp, ONE log and ONE rcp:
+    //   e = exp(-|x|);  softplus(+-x) = max(+-x, 0) + log(1 + e);  sigmoid(x) = (x >= 0 ? 1 : e) / (1 + e)
     const float e = __expf(-fabsf(x));
-    const float l1p = log1pf(e);
+    const float l1p = __logf(1.f + e);
     float sp_pos = fmaxf(x, 0.f) + l1p;   // softplus(x)
     float sp_neg = fmaxf(-x, 0.f) + l1p;  // softplus(-x)
     if (x > 20.f) sp_pos = x;
     if (x < -20.f) sp_neg = -x;
-    const float s = 1.f / (1.f + __expf(-x));
+    const float s = (x >= 0.f ? 1.f : e) * __frcp_rn(1.f + e);
     s_sum += s;
 #pragma unroll
     for (int g = 0; g < GMAX; ++g) {
@@ -94,23 +93,30 @@ matcher_cost_kernel(const float* __restrict__ logits, const float* __restrict__ 
     }
   }
   s_sum = wave_sum(s_sum);
-  // softmax over the K1 class logits of (n, q): tiny, done redundantly per lane
-  const float* lg = logits + ((long long)n * Q + q) * K1;
-  float mx = -3.0e38f;
-  for (int k = 0; k < K1; ++k) mx = fmaxf(mx, lg[k]);
-  float z = 0.f;
-  for (int k = 0; k < K1; ++k) z += expf(lg[k] - mx);
+  if (lane == 0) part[wave][3 * GMAX] = s_sum;
 #pragma unroll
   for (int g = 0; g < GMAX; ++g) {
     if (g < G) {
       const float A = wave_sum(a[g]), D = wave_sum(d[g]), T = wave_sum(tt[g]);
-      if (lane == 0) {
-        const int lab = (int)labels[(long long)n * G + g];
-        const float prob = expf(lg[lab] - mx) / z;
-        cost[((long long)n * Q + q) * G + g] =
-            w_mask * (A / (float)P) + w_class * (-prob) + w_dice * (1.f - (2.f * D + 1.f) / (s_sum + T + 1.f));
-      }
+      if (lane == 0) { part[wave][g] = A; part[wave][GMAX + g] = D; part[wave][2 * GMAX + g] = T; }
     }
+  }
+  __syncthreads();
+  if (tid < G) {
+    const int g = tid;
+    float A = 0.f, D = 0.f, T = 0.f, S = 0.f;
+    for (int wv = 0; wv < WAVES; ++wv) {
+      A += part[wv][g]; D += part[wv][GMAX + g]; T += part[wv][2 * GMAX + g]; S += part[wv][3 * GMAX];
+    }
+    const float* lg = logits + ((long long)n * Q + q) * K1;
+    float mx = -3.0e38f;
+    for (int k = 0; k < K1; ++k) mx = fmaxf(mx, lg[k]);
+    float z = 0.f;
+    for (int k = 0; k < K1; ++k) z += expf(lg[k] - mx);
+    const int lab = (int)labels[(long long)n * G + g];
+    const float prob = expf(lg[lab] - mx) / z;
+    cost[((long long)n * Q + q) * G + g] =
+        w_mask * (A / (float)P) + w_class * (-prob) + w_dice * (1.f - (2.f * D + 1.f) / (S + T + 1.f));
   }
 }
 
@@ -121,12 +127,12 @@ extern "C" int combo_matcher_cost_f32(const float* logits, const float* masks, c
                                       int P, float w_class, float w_mask, float w_dice, float* t_ws, float* cost,
                                       combo_stream_t stream) {
   if (!logits || !masks || !labels || !gt || !points || !t_ws || !cost || N <= 0 || Q <= 0 || K1 <= 0 || G <= 0 ||
-      G > GMAX || h <= 0 || w <= 0 || P <= 0 || (size_t)WAVES * h * w * 4 > 160 * 1024)
+      G > GMAX || h <= 0 || w <= 0 || P <= 0 || (size_t)h * w * 4 > 150 * 1024)
     return COMBO_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const long long tot = (long long)N * G * P;
   hipLaunchKernelGGL(gt_sample_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, gt, points, N, G, H, W, P, t_ws);
-  const size_t lds = (size_t)WAVES * h * w * 4;
+  const size_t lds = (size_t)h * w * 4;
   static bool attr = false;
   if (!attr && lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(matcher_cost_kernel),
@@ -134,8 +140,7 @@ extern "C" int combo_matcher_cost_f32(const float* logits, const float* masks, c
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  const int qblocks = (Q + WAVES - 1) / WAVES;
-  hipLaunchKernelGGL(matcher_cost_kernel, dim3(N * qblocks), dim3(WAVES * 64), lds, st, logits, masks, labels, t_ws,
+  hipLaunchKernelGGL(matcher_cost_kernel, dim3(N * Q), dim3(WAVES * 64), lds, st, logits, masks, labels, t_ws,
                      points, N, Q, K1, G, h, w, P, w_class, w_mask, w_dice, cost);
   return (int)hipGetLastError();
 }
