@@ -187,20 +187,15 @@ class SetCriterion(nn.Module):
         nll = F.cross_entropy(logits.view(L * F_ * Q, -1), target_classes.view(-1), reduction="none").view(L, -1)
         wgt = self.empty_weight[target_classes].view(L, -1)
         loss_ce = (nll * wgt).sum(1) / wgt.sum(1)
-        # ---- mask losses (criterion.py:137-186), all outputs at once ----------------------------------------------
-        src = masks[lidx, frame[None].expand(L, Nm), src_q].reshape(L * Nm, 1, *masks.shape[-2:])
-        tgt = gt[frame[None].expand(L, Nm), tgt_g].reshape(L * Nm, 1, H, W)
-        with torch.no_grad():
-            unc = -point_sample(src.float(), over).abs()[:, 0]  # calculate_uncertainty
-            idx = torch.topk(unc, k=n_unc, dim=1)[1]
-            coords = torch.gather(over, 1, idx[..., None].expand(-1, -1, 2))
-            if extra is not None:
-                coords = torch.cat([coords, extra], dim=1)
-            point_labels = point_sample(tgt, coords).squeeze(1)
-        point_logits = point_sample(src, coords).squeeze(1).float()
-        bce = F.binary_cross_entropy_with_logits(point_logits, point_labels, reduction="none").mean(1).view(L, Nm)
-        sg = point_logits.sigmoid()
-        dice = (1 - (2 * (sg * point_labels).sum(-1) + 1) / (sg.sum(-1) + point_labels.sum(-1) + 1)).view(L, Nm)
+        # ---- mask losses (criterion.py:137-186), all outputs at once: three fused launches (csrc/maskloss.hip) ----------
+        from ..ops import maskloss
+        masks32 = masks.float().contiguous()  # [L,F,Q,h,w]; pairs address their maps by flat index, no gather copies
+        frame_b = frame[None].expand(L, Nm)
+        mask_index = ((lidx * F_ + frame_b) * Q + src_q).reshape(-1).contiguous()
+        gt_index = (frame_b * Gmax + tgt_g).reshape(-1).contiguous()
+        coords = maskloss.uncertain_points(masks32, mask_index, over, extra, n_unc)  # importance sampling, no sort
+        bce, dice = maskloss.mask_losses(masks32, mask_index, gt, gt_index, coords)
+        bce, dice = bce.view(L, Nm), dice.view(L, Nm)
         loss_mask = bce.sum(1) / num_masks
         loss_dice = dice.sum(1) / num_masks
         losses = {}

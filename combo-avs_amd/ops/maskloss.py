@@ -1,0 +1,58 @@
+"""Fused mask losses of the criterion (csrc/maskloss.hip): importance point selection, BCE + dice, backward."""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .. import _lib
+
+
+@torch.no_grad()
+def uncertain_points(masks, mask_index, over_points, extra_points, k):
+    """masks [*, h, w] stacked logits (fp32, contiguous), mask_index [NM] int64, over_points [NM,NS,2],
+    extra_points [NM,NR,2] or None -> coords [NM, k+NR, 2]"""
+    masks = masks.detach()
+    _lib.require_cuda(masks, mask_index, over_points, extra_points)
+    NM, NS = over_points.shape[:2]
+    NR = 0 if extra_points is None else extra_points.shape[1]
+    h, w = masks.shape[-2:]
+    out = torch.empty(NM, k + NR, 2, device=masks.device, dtype=torch.float32)
+    _lib.check(_lib.lib().combo_uncertain_points_f32(masks.data_ptr(), mask_index.data_ptr(), NM, h, w, over_points.data_ptr(), NS,
+                                                     _lib.ptr(extra_points), NR, k, out.data_ptr(), _lib.current_stream()),
+               "combo_uncertain_points_f32")
+    return out
+
+
+class _MaskLoss(Function):
+    @staticmethod
+    def forward(ctx, masks, mask_index, gt, gt_index, coords):
+        _lib.require_cuda(masks, mask_index, gt, gt_index, coords)
+        NM, P = coords.shape[:2]
+        h, w = masks.shape[-2:]
+        H, W = gt.shape[-2:]
+        stats = torch.empty(NM, 4, device=masks.device, dtype=torch.float32)
+        _lib.check(_lib.lib().combo_mask_loss_forward_f32(masks.data_ptr(), mask_index.data_ptr(), NM, h, w, gt.data_ptr(),
+                                                          gt_index.data_ptr(), H, W, coords.data_ptr(), P, stats.data_ptr(),
+                                                          _lib.current_stream()), "combo_mask_loss_forward_f32")
+        ctx.save_for_backward(masks, mask_index, gt, gt_index, coords, stats)
+        bce = stats[:, 0] / P
+        dice = 1 - (2 * stats[:, 1] + 1) / (stats[:, 2] + stats[:, 3] + 1)
+        return bce, dice
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_bce, g_dice):
+        masks, mask_index, gt, gt_index, coords, stats = ctx.saved_tensors
+        NM, P = coords.shape[:2]
+        h, w = masks.shape[-2:]
+        H, W = gt.shape[-2:]
+        grad = torch.zeros_like(masks)
+        _lib.check(_lib.lib().combo_mask_loss_backward_f32(
+            masks.data_ptr(), mask_index.data_ptr(), NM, h, w, gt.data_ptr(), gt_index.data_ptr(), H, W, coords.data_ptr(), P,
+            stats.data_ptr(), g_bce.contiguous().float().data_ptr(), g_dice.contiguous().float().data_ptr(), grad.data_ptr(),
+            _lib.current_stream()), "combo_mask_loss_backward_f32")
+        return grad, None, None, None, None
+
+
+def mask_losses(masks, mask_index, gt, gt_index, coords):
+    """-> (mean-over-points BCE [NM], dice [NM]) of the matched pairs; differentiable w.r.t. `masks`."""
+    return _MaskLoss.apply(masks.contiguous().float(), mask_index, gt.contiguous().float(), gt_index, coords.contiguous())

@@ -171,6 +171,27 @@ int combo_semantic_inference_f32(const float* cls_prob, const float* masks, int 
                                  int W, float* out, combo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * a15  mask losses of the criterion (models/modeling/criterion.py:137-186, :19-62, :70-84)
+ *   Pair n (n < NM) addresses its prediction map masks + mask_index[n]*h*w (stacked [L*F*Q,h,w] logits) and its target
+ *   gt + gt_index[n]*H*W (padded [F*Gmax,H,W] fp32 0/1).
+ *   combo_uncertain_points_f32 : get_uncertain_point_coords_with_randomness with uncertainty -|logit|:
+ *       coords_out[n,0:k] = the k of the NS `over_points[n]` with the smallest |bilinear logit| (radix select, index
+ *       order, ties by index), coords_out[n,k:k+NR] = extra_points[n].
+ *   combo_mask_loss_forward_f32: stats[n] = (sum_p BCEwithlogits(x_p,t_p), sum_p s_p t_p, sum_p s_p, sum_p t_p) over the
+ *       P points coords[n] (x = point_sample(prediction), t = point_sample(target), s = sigmoid(x)).
+ *   combo_mask_loss_backward_f32: grad_masks[mask_index[n]] = d/dlogits (g_bce[n]*mean_p BCE + g_dice[n]*dice);
+ *       grad_masks must be zero-filled (only matched maps are written).
+ * ---------------------------------------------------------------------------------------------- */
+int combo_uncertain_points_f32(const float* masks, const long long* mask_index, int NM, int h, int w, const float* over_points,
+                               int NS, const float* extra_points, int NR, int k, float* coords_out, combo_stream_t stream);
+int combo_mask_loss_forward_f32(const float* masks, const long long* mask_index, int NM, int h, int w, const float* gt,
+                                const long long* gt_index, int H, int W, const float* coords, int P, float* stats,
+                                combo_stream_t stream);
+int combo_mask_loss_backward_f32(const float* masks, const long long* mask_index, int NM, int h, int w, const float* gt,
+                                 const long long* gt_index, int H, int W, const float* coords, int P, const float* stats,
+                                 const float* g_bce, const float* g_dice, float* grad_masks, combo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * (f)1  optimiser: fused gradient clip + AdamW on a flat fp32 segment
  *   replaces FullModelGradientClippingOptimizer.step (train_net.py:205-221): p *= 1-lr*wd; m,v EMAs of
  *   clip_coef*g; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps).  clip_coef: device scalar (NULL = 1).

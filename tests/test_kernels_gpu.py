@@ -133,3 +133,50 @@ def test_fused_inference_tail_vs_oracle():
         ref = O.semantic_inference(logits, masks, (224, 224))
         got = semantic_inference(logits.cuda(), masks.cuda(), (224, 224)).cpu()
         torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
+
+
+def test_fused_mask_loss_vs_oracle():
+    """csrc/maskloss.hip: radix-select importance sampling picks exactly the k most uncertain points (as a set),
+    BCE / dice and their gradient match the oracle's loss_masks on the same points."""
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.ops import maskloss
+    from oracle import combo_oracle as O
+    torch.manual_seed(0)
+    nmaps, NM, h, w, H, W = 30, 7, 56, 56, 224, 224
+    NS, NR, k = 37632, 3136, 9408
+    masks = (torch.randn(nmaps, h, w) * 3)
+    masks[3] = 0.0  # massive ties: every |logit| equal -> ties must be resolved deterministically by index
+    gt = (torch.rand(5, H, W) > 0.5).float()
+    midx = torch.tensor([4, 0, 29, 3, 17, 8, 11])
+    gidx = torch.tensor([0, 4, 2, 2, 1, 3, 0])
+    over = torch.rand(NM, NS, 2)
+    extra = torch.rand(NM, NR, 2)
+    coords = maskloss.uncertain_points(masks.cuda(), midx.cuda(), over.cuda(), extra.cuda(), k).cpu()
+    assert coords.shape == (NM, k + NR, 2)
+    torch.testing.assert_close(coords[:, k:], extra)
+    for n in range(NM):
+        x = O.point_sample(masks[midx[n]][None, None], over[n:n + 1])[0, 0].abs()
+        ref_idx = torch.topk(-x, k)[1]
+        thr = x[ref_idx].max()
+        got = coords[n, :k]
+        # every selected point has |x| <= threshold, and the multiset of selected |x| equals the k smallest
+        gx = O.point_sample(masks[midx[n]][None, None], got[None])[0, 0].abs()
+        assert gx.max() <= thr + 1e-6
+        torch.testing.assert_close(gx.sort()[0], x[ref_idx].sort()[0], rtol=1e-5, atol=1e-6)
+    # losses + gradient on the selected points
+    mg = masks.cuda().requires_grad_(True)
+    bce, dice = maskloss.mask_losses(mg, midx.cuda(), gt.cuda(), gidx.cuda(), coords.cuda())
+    gb, gd = torch.rand(NM), torch.rand(NM)
+    (bce * gb.cuda()).sum().add((dice * gd.cuda()).sum()).backward()
+    mr = masks.clone().requires_grad_(True)
+    src = mr[midx][:, None]
+    tgt = gt[gidx][:, None]
+    logits = O.point_sample(src, coords).squeeze(1)
+    labels = O.point_sample(tgt, coords).squeeze(1)
+    rb = torch.nn.functional.binary_cross_entropy_with_logits(logits, labels, reduction="none").mean(1)
+    sg = logits.sigmoid()
+    rd = 1 - (2 * (sg * labels).sum(-1) + 1) / (sg.sum(-1) + labels.sum(-1) + 1)
+    (rb * gb).sum().add((rd * gd).sum()).backward()
+    torch.testing.assert_close(bce.detach().cpu(), rb.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(dice.detach().cpu(), rd.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(mg.grad.cpu(), mr.grad, rtol=1e-3, atol=1e-6)
