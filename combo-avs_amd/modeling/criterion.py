@@ -209,9 +209,11 @@ class SetCriterion(nn.Module):
             mid = torch.stack(outputs["middles_attn_mask"])  # [9,BT,Q,HW]
             n9, bt = mid.shape[0], mid.shape[1]
             nf = self.n_frame
-            m = mid.reshape(n9, bt // nf, nf, -1).float()
-            x1, x2 = m[:, :, :-1], m[:, :, 1:]
-            cos = (x1 * x2).sum(-1) / torch.sqrt(((x1 * x1).sum(-1) + 1e-12) * ((x2 * x2).sum(-1) + 1e-12))
+            # two fused launches (csrc/cosine.hip): |x_t|^2 and x_t . x_{t+1}; the scalar math below is differentiated
+            # by autograd and the kernels' backward turns d/d(dot), d/d(nrm) into d/dx in one pass
+            dot, nrm = maskloss.cosine_stats(mid.reshape(n9 * bt, -1), nf)
+            dot, nrm = dot.view(n9, bt // nf, nf), nrm.view(n9, bt // nf, nf)
+            cos = dot[..., :-1] / torch.sqrt((nrm[..., :-1] + 1e-12) * (nrm[..., 1:] + 1e-12))
             c = 1 - cos
             lc = (c * torch.exp(-c)).sum((1, 2)) / (bt // nf) / (nf - 1)
             for i in range(n9):

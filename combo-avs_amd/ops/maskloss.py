@@ -56,3 +56,34 @@ class _MaskLoss(Function):
 def mask_losses(masks, mask_index, gt, gt_index, coords):
     """-> (mean-over-points BCE [NM], dice [NM]) of the matched pairs; differentiable w.r.t. `masks`."""
     return _MaskLoss.apply(masks.contiguous().float(), mask_index, gt.contiguous().float(), gt_index, coords.contiguous())
+
+
+class _CosineStats(Function):
+    """x [rows, E] -> (dot[r] = x_r . x_{r+1} within a clip, nrm[r] = |x_r|^2); csrc/cosine.hip"""
+
+    @staticmethod
+    def forward(ctx, x, n_frame):
+        _lib.require_cuda(x)
+        rows, E = x.shape
+        dot = torch.zeros(rows, device=x.device, dtype=torch.float32)
+        nrm = torch.zeros(rows, device=x.device, dtype=torch.float32)
+        _lib.check(_lib.lib().combo_cosine_stats_f32(x.data_ptr(), rows, E, n_frame, dot.data_ptr(), nrm.data_ptr(),
+                                                     _lib.current_stream()), "combo_cosine_stats_f32")
+        ctx.save_for_backward(x)
+        ctx.n_frame = n_frame
+        return dot, nrm
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gdot, gnrm):
+        x, = ctx.saved_tensors
+        rows, E = x.shape
+        grad = torch.empty_like(x)
+        _lib.check(_lib.lib().combo_cosine_grad_f32(x.data_ptr(), rows, E, ctx.n_frame, gdot.contiguous().float().data_ptr(),
+                                                    gnrm.contiguous().float().data_ptr(), grad.data_ptr(), _lib.current_stream()),
+                   "combo_cosine_grad_f32")
+        return grad, None
+
+
+def cosine_stats(x, n_frame):
+    return _CosineStats.apply(x.contiguous().float(), n_frame)

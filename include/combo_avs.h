@@ -191,6 +191,13 @@ int combo_mask_loss_backward_f32(const float* masks, const long long* mask_index
                                  const long long* gt_index, int H, int W, const float* coords, int P, const float* stats,
                                  const float* g_bce, const float* g_dice, float* grad_masks, combo_stream_t stream);
 
+/*   Frame-to-frame cosine loss (criterion.py:208-231): x [rows,E], rows = heads*BT, clips = n_frame consecutive rows.
+ *   stats: nrm[r] += |x_r|^2, dot[r] += x_r . x_{r+1} (same clip; both zero-filled by the caller);
+ *   grad : grad[r] = 2 gnrm[r] x_r + gdot[r] x_{r+1} + gdot[r-1] x_{r-1} (neighbours inside the clip). */
+int combo_cosine_stats_f32(const float* x, long long rows, long long E, int n_frame, float* dot, float* nrm, combo_stream_t stream);
+int combo_cosine_grad_f32(const float* x, long long rows, long long E, int n_frame, const float* gdot, const float* gnrm,
+                          float* grad, combo_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * (f)1  optimiser: fused gradient clip + AdamW on a flat fp32 segment
  *   replaces FullModelGradientClippingOptimizer.step (train_net.py:205-221): p *= 1-lr*wd; m,v EMAs of

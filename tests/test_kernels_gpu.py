@@ -180,3 +180,27 @@ def test_fused_mask_loss_vs_oracle():
     torch.testing.assert_close(bce.detach().cpu(), rb.detach(), rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(dice.detach().cpu(), rd.detach(), rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(mg.grad.cpu(), mr.grad, rtol=1e-3, atol=1e-6)
+
+
+def test_fused_cosine_loss_vs_oracle():
+    """csrc/cosine.hip (stats + gradient) against the oracle's similarity_loss (criterion.py:208-231)."""
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.ops import maskloss
+    from oracle import combo_oracle as O
+    torch.manual_seed(0)
+    n9, bt, Q, HW, nf = 3, 10, 100, 3136, 5
+    mid = torch.randn(n9, bt, Q, HW)
+    mid[:, 1] = mid[:, 0] * 0.9 + 0.1 * torch.randn(n9, Q, HW)  # a nearly parallel pair
+    xr = mid.clone().requires_grad_(True)
+    ref = torch.stack([O.similarity_loss(xr[i], nf) for i in range(n9)])
+    w = torch.tensor([1.0, 2.0, 3.0])
+    (ref * w).sum().backward()
+    xg = mid.cuda().requires_grad_(True)
+    dot, nrm = maskloss.cosine_stats(xg.reshape(n9 * bt, -1), nf)
+    dot, nrm = dot.view(n9, bt // nf, nf), nrm.view(n9, bt // nf, nf)
+    cos = dot[..., :-1] / torch.sqrt((nrm[..., :-1] + 1e-12) * (nrm[..., 1:] + 1e-12))
+    c = 1 - cos
+    got = (c * torch.exp(-c)).sum((1, 2)) / (bt // nf) / (nf - 1)
+    (got * w.cuda()).sum().backward()
+    torch.testing.assert_close(got.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(xg.grad.cpu(), xr.grad, rtol=1e-3, atol=1e-9)
