@@ -36,6 +36,7 @@ _SIGNATURES = {
     "combo_mask_loss_backward_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int] + [c_void_p] * 5,
     "combo_cosine_stats_f32": [c_void_p, c_longlong, c_longlong, c_int, c_void_p, c_void_p, c_void_p],
     "combo_cosine_grad_f32": [c_void_p, c_longlong, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "combo_lsap_small_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "combo_attn_mask_f32": [c_void_p] + [c_int] * 6 + [c_void_p, c_void_p],
     "combo_adamw_f32": [c_void_p] * 4 + [c_longlong, c_void_p] + [c_float] * 7 + [c_void_p],
 }

@@ -61,6 +61,9 @@ class SetCriterion(nn.Module):
         self.importance_sample_ratio = importance_sample_ratio
         self.n_frame = n_frame  # hard-coded 5 in the reference (criterion.py:243,284)
         self.point_source = None  # test hook
+        # True: SciPy on the host like the reference (always used when a frame has > 6 instances)
+        import os
+        self.host_lsap = os.environ.get("COMBO_HOST_LSAP", "0") == "1"
 
     # ---- individual losses -----------------------------------------------------------------------------
     def loss_labels(self, outputs, targets, indices, num_masks):
@@ -119,6 +122,17 @@ class SetCriterion(nn.Module):
             sel["middles_attn_mask"] = outputs["middles_attn_mask"]  # NOT sub-selected (criterion.py:241-254)
         return sel
 
+    def _static_match_index(self, G, L, Gmax, dev):
+        """Small index tensors that depend only on the per-frame instance counts: cached on the device."""
+        key = (G, L, Gmax, str(dev))
+        cache = self.__dict__.setdefault("_match_index_cache", {})
+        if key not in cache:
+            gcount = torch.tensor(list(G) * L, dtype=torch.int32, device=dev)
+            valid = torch.tensor([f * Gmax + g for f in range(len(G)) for g in range(G[f])], dtype=torch.int64, device=dev)
+            frame = torch.cat([torch.full((g,), f, dtype=torch.int64) for f, g in enumerate(G)]).to(dev)
+            cache[key] = (gcount, valid, frame)
+        return cache[key]
+
     def _num_masks(self, targets, device):
         num_masks = torch.as_tensor([sum(len(t["labels"]) for t in targets)], dtype=torch.float, device=device)
         world = 1
@@ -166,19 +180,31 @@ class SetCriterion(nn.Module):
         with torch.no_grad():
             C = self.matcher.batched_cost(logits.view(L * F_, Q, -1), masks.view(L * F_, Q, *masks.shape[-2:]).float(),
                                           lab.repeat(L, 1), gt.repeat(L, 1, 1, 1), mpts)  # [L*F,Q,Gmax]
-            C_host = C.cpu().numpy()  # the only device->host sync of the criterion
-        src_q = torch.empty(L, Nm, dtype=torch.int64)
-        tgt_g = torch.empty(L, Nm, dtype=torch.int64)
         frame = torch.cat([torch.full((g,), f, dtype=torch.int64) for f, g in enumerate(G)])
-        for l in range(L):
-            off = 0
-            for f in range(F_):
-                i, j = self.matcher.solve([C_host[l * F_ + f, :, : G[f]]])[0]
-                src_q[l, off:off + G[f]] = i
-                tgt_g[l, off:off + G[f]] = j
-                off += G[f]
-        self.last_indices = (src_q, tgt_g, frame)
-        src_q, tgt_g, frame = src_q.to(dev), tgt_g.to(dev), frame.to(dev)
+        if Gmax <= self.matcher.LSAP_DEVICE_MAX_G and self.host_lsap is False:
+            # exact assignment on the device: the step has no device->host synchronisation
+            gcount, valid, frame = self._static_match_index(tuple(G), L, Gmax, dev)
+            rfc = self.matcher.solve_device(C, gcount).view(L, F_, Gmax)  # query matched to (frame, target)
+            # scipy returns the pairs of a frame sorted by query index; keep that order so that an injected random-point
+            # stream lands on the same masks as in the reference
+            big = torch.where(rfc < 0, torch.full_like(rfc, 1 << 40), rfc)
+            rows, order = torch.sort(big, dim=2)
+            src_q = rows.view(L, F_ * Gmax).index_select(1, valid)  # [L,Nm]
+            tgt_g = order.view(L, F_ * Gmax).index_select(1, valid)
+            self.last_indices = (src_q, tgt_g, frame)
+        else:
+            C_host = C.cpu().numpy()  # the only device->host sync of the criterion (SciPy LSAP, as in the reference)
+            src_q = torch.empty(L, Nm, dtype=torch.int64)
+            tgt_g = torch.empty(L, Nm, dtype=torch.int64)
+            for l in range(L):
+                off = 0
+                for f in range(F_):
+                    i, j = self.matcher.solve([C_host[l * F_ + f, :, : G[f]]])[0]
+                    src_q[l, off:off + G[f]] = i
+                    tgt_g[l, off:off + G[f]] = j
+                    off += G[f]
+            self.last_indices = (src_q, tgt_g, frame)
+            src_q, tgt_g, frame = src_q.to(dev), tgt_g.to(dev), frame.to(dev)
         num_masks = self._num_masks(targets, dev)
         # ---- classification loss (criterion.py:121-135), per output ---------------------------------------------
         target_classes = torch.full((L, F_, Q), self.num_classes, dtype=torch.int64, device=dev)

@@ -71,6 +71,21 @@ class HungarianMatcher(nn.Module):
             "combo_matcher_cost_f32")
         return cost
 
+    LSAP_DEVICE_MAX_G = 6
+
+    @torch.no_grad()
+    def solve_device(self, cost, gcount):
+        """Exact assignment on the device (csrc/lsap.hip), no host sync.  cost [N,Q,Gpad] fp32, gcount [N] int32
+        -> row_for_col [N,Gpad] int64 (query matched to target g; -1 for padded targets)."""
+        from .. import _lib
+        cost = cost.contiguous().float()
+        _lib.require_cuda(cost, gcount)
+        N, Q, Gpad = cost.shape
+        out = torch.empty(N, Gpad, device=cost.device, dtype=torch.int64)
+        _lib.check(_lib.lib().combo_lsap_small_f32(cost.data_ptr(), gcount.data_ptr(), N, Q, Gpad, out.data_ptr(),
+                                                   _lib.current_stream()), "combo_lsap_small_f32")
+        return out
+
     @staticmethod
     def solve(costs_host):
         out = []

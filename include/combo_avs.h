@@ -170,6 +170,12 @@ int combo_sem_mix(int op, int is_bf16, const void* a, const void* b, const float
 int combo_semantic_inference_f32(const float* cls_prob, const float* masks, int F, int Q, int K, int h, int w, int H,
                                  int W, float* out, combo_stream_t stream);
 
+/*   Exact linear sum assignment on the device for G <= 6 targets per problem (replaces the per-frame
+ *   scipy.optimize.linear_sum_assignment host call + .cpu() sync, matcher.py:132-134).
+ *   cost [N,Q,Gpad], gcount [N] int32 (real number of targets, <= Gpad <= 6) -> row_for_col [N,Gpad] int64 (-1 = padding). */
+int combo_lsap_small_f32(const float* cost, const int* gcount, int N, int Q, int Gpad, long long* row_for_col,
+                         combo_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * a15  mask losses of the criterion (models/modeling/criterion.py:137-186, :19-62, :70-84)
  *   Pair n (n < NM) addresses its prediction map masks + mask_index[n]*h*w (stacked [L*F*Q,h,w] logits) and its target

@@ -204,3 +204,29 @@ def test_fused_cosine_loss_vs_oracle():
     (got * w.cuda()).sum().backward()
     torch.testing.assert_close(got.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(xg.grad.cpu(), xr.grad, rtol=1e-3, atol=1e-9)
+
+
+@pytest.mark.parametrize("G", [1, 2, 3, 5, 6])
+def test_device_lsap_equals_scipy(G):
+    """csrc/lsap.hip: exact optimum == scipy.optimize.linear_sum_assignment (total cost and, without ties, the pairs)."""
+    import numpy as np
+    from scipy.optimize import linear_sum_assignment
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.modeling.matcher import HungarianMatcher
+    m = HungarianMatcher(1, 1, 1, 16)
+    rng = np.random.default_rng(G)
+    N, Q, Gpad = 40, 100, max(G, 2)
+    cost = rng.standard_normal((N, Q, Gpad)).astype(np.float32)
+    cost[0, :, :] = np.round(cost[0] * 2) / 2  # many exact ties
+    gcount = np.full(N, G, dtype=np.int32)
+    gcount[1] = max(1, G - 1)  # ragged
+    got = m.solve_device(torch.from_numpy(cost).cuda(), torch.from_numpy(gcount).cuda()).cpu().numpy()
+    for n in range(N):
+        g = gcount[n]
+        r, c = linear_sum_assignment(cost[n, :, :g])
+        rows = got[n, :g]
+        assert len(set(rows.tolist())) == g and (got[n, g:] == -1).all()
+        tot = cost[n, rows, np.arange(g)].sum()
+        assert abs(tot - cost[n, r, c].sum()) <= 1e-5
+        if n > 1:  # continuous costs: unique optimum -> identical pairs
+            assert dict(zip(c.tolist(), r.tolist())) == dict(zip(range(g), rows.tolist()))
