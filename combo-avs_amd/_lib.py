@@ -20,10 +20,14 @@ _SIGNATURES = {
     "combo_msda_forward_f64": [c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_int, c_void_p],
     "combo_msda_backward_f32": [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 3 + [c_int, c_void_p],
     "combo_msda_backward_f64": [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 3 + [c_int, c_void_p],
+    "combo_event_create": [c_void_p],
+    "combo_event_record": [c_void_p, c_void_p, c_int],
+    "combo_event_elapsed_us": [c_void_p, c_void_p, c_void_p],
+    "combo_event_destroy": [c_void_p],
     "combo_bifuse_chunks": [c_int, c_int],
-    "combo_bifuse_forward_f32": [c_void_p] * 3 + [c_float] + [c_void_p] * 8 + [c_float, ctypes.c_ulonglong] + [c_int] * 4 + [c_void_p] * 7,
-    "combo_bifuse_backward1_f32": [c_void_p] * 3 + [c_float] + [c_void_p] * 7 + [c_float, ctypes.c_ulonglong] + [c_void_p] * 3 + [c_int] * 4 + [c_void_p] * 5,
-    "combo_bifuse_backward2_f32": [c_void_p] * 3 + [c_float] + [c_void_p] * 5 + [c_float, ctypes.c_ulonglong] + [c_void_p] * 4 + [c_int] * 4 + [c_void_p] * 5,
+    "combo_bifuse_forward_f32": [c_void_p] * 3 + [c_float] + [c_void_p] * 8 + [c_float, ctypes.c_ulonglong, c_void_p] + [c_int] * 4 + [c_void_p] * 7,
+    "combo_bifuse_backward1_f32": [c_void_p] * 3 + [c_float] + [c_void_p] * 7 + [c_float, ctypes.c_ulonglong, c_void_p] + [c_void_p] * 3 + [c_int] * 4 + [c_void_p] * 5,
+    "combo_bifuse_backward2_f32": [c_void_p] * 3 + [c_float] + [c_void_p] * 5 + [c_float, ctypes.c_ulonglong, c_void_p] + [c_void_p] * 4 + [c_int] * 4 + [c_void_p] * 5,
     "combo_gemm_x3_splits": [c_int, c_int],
     "combo_gemm_x3_f32": [c_void_p, c_longlong, c_int, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_longlong] + [c_int] * 5 + [c_longlong, c_void_p],
     "combo_matcher_cost_f32": [c_void_p] * 5 + [c_int] * 9 + [c_float] * 3 + [c_void_p] * 3,

@@ -213,12 +213,13 @@ __global__ void __launch_bounds__(THREADS)
 bifuse_apply(const float* __restrict__ x, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps,
              const float* __restrict__ s, const float* __restrict__ stat, const float* __restrict__ z,
              const float* __restrict__ b_ov, const float* __restrict__ gamma_v, const float* __restrict__ drop_v,
-             const float* __restrict__ drop_a, float p_drop, unsigned long long seed, int B, int N, int chunks,
+             const float* __restrict__ drop_a, float p_drop, unsigned long long seed, const unsigned long long* seed_step, int B, int N, int chunks,
              float* __restrict__ y, float* __restrict__ pooled_part /* [B,chunks,NH,C] */,
              float* __restrict__ spa_part /* [B,chunks,NH] */) {
   __shared__ float4 red[WAVES][4][64];
   __shared__ float reds[WAVES][NH];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (seed_step) seed += *seed_step * 0xD1B54A32D192ED03ull;  // device-side step counter: fresh masks per hipGraph replay
   const int b = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
   const int tpc = (N + chunks - 1) / chunks;
   const int i0 = chunk * tpc, i1 = min(N, i0 + tpc);
@@ -273,13 +274,14 @@ __global__ void __launch_bounds__(THREADS)
 bifuse_bwd1(const float* __restrict__ x, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps,
             const float* __restrict__ s, const float* __restrict__ stat, const float* __restrict__ z,
             const float* __restrict__ b_ov, const float* __restrict__ gamma_v, const float* __restrict__ drop_v,
-            const float* __restrict__ drop_a, float p_drop, unsigned long long seed, const float* __restrict__ dy,
+            const float* __restrict__ drop_a, float p_drop, unsigned long long seed, const unsigned long long* seed_step, const float* __restrict__ dy,
             const float* __restrict__ dpooled, const float* __restrict__ dspa, int B, int N, int chunks,
             float* __restrict__ dp /* [B,NH,N] */, float* __restrict__ r_part /* [B,chunks,NH] */,
             float* __restrict__ dz_part /* [B,chunks,NH,C] */, float* __restrict__ dgb_part /* [B,chunks,2,C] */) {
   __shared__ float4 red[WAVES][4][64];
   __shared__ float reds[WAVES][NH];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (seed_step) seed += *seed_step * 0xD1B54A32D192ED03ull;  // device-side step counter: fresh masks per hipGraph replay
   const int b = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
   const int tpc = (N + chunks - 1) / chunks;
   const int i0 = chunk * tpc, i1 = min(N, i0 + tpc);
@@ -361,7 +363,7 @@ bifuse_bwd1(const float* __restrict__ x, const float* __restrict__ ln_w, const f
 __global__ void __launch_bounds__(THREADS)
 bifuse_bwd2(const float* __restrict__ x, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps,
             const float* __restrict__ pos, const float* __restrict__ s, const float* __restrict__ stat,
-            const float* __restrict__ u, const float* __restrict__ drop_a, float p_drop, unsigned long long seed,
+            const float* __restrict__ u, const float* __restrict__ drop_a, float p_drop, unsigned long long seed, const unsigned long long* seed_step,
             const float* __restrict__ dy, const float* __restrict__ dpooled, const float* __restrict__ dp,
             const float* __restrict__ rtot /* [B,NH] */, int B, int N, int chunks, float* __restrict__ dx,
             float* __restrict__ du_part /* [B,chunks,NH,C] */, float* __restrict__ dc_part /* [B,chunks,NH] */,
@@ -369,6 +371,7 @@ bifuse_bwd2(const float* __restrict__ x, const float* __restrict__ ln_w, const f
   __shared__ float4 red[WAVES][4][64];
   __shared__ float reds[WAVES][NH];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (seed_step) seed += *seed_step * 0xD1B54A32D192ED03ull;  // device-side step counter: fresh masks per hipGraph replay
   const int b = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
   const int tpc = (N + chunks - 1) / chunks;
   const int i0 = chunk * tpc, i1 = min(N, i0 + tpc);
@@ -458,7 +461,7 @@ int combo_bifuse_chunks(int B, int N) {
 
 int combo_bifuse_forward_f32(const float* x, const float* ln_w, const float* ln_b, float eps, const float* pos,
                              const float* u, const float* c, const float* z, const float* b_ov, const float* gamma_v,
-                             const float* drop_v, const float* drop_a, float p_drop, unsigned long long seed, int B,
+                             const float* drop_v, const float* drop_a, float p_drop, unsigned long long seed, const unsigned long long* seed_step, int B,
                              int N, int Cch, int heads, float* y, float* scores, float* stat, float* part_ws,
                              float* pooled_part, float* spa_part, combo_stream_t stream) {
   if (!x || !ln_w || !ln_b || !pos || !u || !c || !z || !b_ov || !gamma_v || !y || !scores || !stat || !part_ws ||
@@ -470,13 +473,13 @@ int combo_bifuse_forward_f32(const float* x, const float* ln_w, const float* ln_
                      scores, part_ws);
   hipLaunchKernelGGL(bifuse_softmax_stats, dim3((B * NH + 63) / 64), dim3(64), 0, st, part_ws, B, chunks, stat);
   hipLaunchKernelGGL(bifuse_apply, dim3(B * chunks), dim3(THREADS), 0, st, x, ln_w, ln_b, eps, scores, stat, z, b_ov,
-                     gamma_v, drop_v, drop_a, p_drop, seed, B, N, chunks, y, pooled_part, spa_part);
+                     gamma_v, drop_v, drop_a, p_drop, seed, seed_step, B, N, chunks, y, pooled_part, spa_part);
   return (int)hipGetLastError();
 }
 
 int combo_bifuse_backward1_f32(const float* x, const float* ln_w, const float* ln_b, float eps, const float* scores,
                                const float* stat, const float* z, const float* b_ov, const float* gamma_v,
-                               const float* drop_v, const float* drop_a, float p_drop, unsigned long long seed,
+                               const float* drop_v, const float* drop_a, float p_drop, unsigned long long seed, const unsigned long long* seed_step,
                                const float* dy, const float* dpooled, const float* dspa, int B, int N, int Cch,
                                int heads, float* dp, float* r_part, float* dz_part, float* dgb_part,
                                combo_stream_t stream) {
@@ -485,14 +488,14 @@ int combo_bifuse_backward1_f32(const float* x, const float* ln_w, const float* l
     return COMBO_EINVAL;
   const int chunks = combo_bifuse_chunks(B, N);
   hipLaunchKernelGGL(bifuse_bwd1, dim3(B * chunks), dim3(THREADS), 0, (hipStream_t)stream, x, ln_w, ln_b, eps, scores,
-                     stat, z, b_ov, gamma_v, drop_v, drop_a, p_drop, seed, dy, dpooled, dspa, B, N, chunks, dp, r_part,
+                     stat, z, b_ov, gamma_v, drop_v, drop_a, p_drop, seed, seed_step, dy, dpooled, dspa, B, N, chunks, dp, r_part,
                      dz_part, dgb_part);
   return (int)hipGetLastError();
 }
 
 int combo_bifuse_backward2_f32(const float* x, const float* ln_w, const float* ln_b, float eps, const float* pos,
                                const float* scores, const float* stat, const float* u, const float* drop_a,
-                               float p_drop, unsigned long long seed, const float* dy, const float* dpooled,
+                               float p_drop, unsigned long long seed, const unsigned long long* seed_step, const float* dy, const float* dpooled,
                                const float* dp, const float* rtot, int B, int N, int Cch, int heads, float* dx,
                                float* du_part, float* dc_part, float* dln_part, combo_stream_t stream) {
   if (!x || !pos || !scores || !stat || !u || !dy || !dpooled || !dp || !rtot || !dx || !du_part || !dc_part ||
@@ -500,7 +503,7 @@ int combo_bifuse_backward2_f32(const float* x, const float* ln_w, const float* l
     return COMBO_EINVAL;
   const int chunks = combo_bifuse_chunks(B, N);
   hipLaunchKernelGGL(bifuse_bwd2, dim3(B * chunks), dim3(THREADS), 0, (hipStream_t)stream, x, ln_w, ln_b, eps, pos,
-                     scores, stat, u, drop_a, p_drop, seed, dy, dpooled, dp, rtot, B, N, chunks, dx, du_part, dc_part,
+                     scores, stat, u, drop_a, p_drop, seed, seed_step, dy, dpooled, dp, rtot, B, N, chunks, dx, du_part, dc_part,
                      dln_part);
   return (int)hipGetLastError();
 }

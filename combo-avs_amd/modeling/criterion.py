@@ -134,6 +134,10 @@ class SetCriterion(nn.Module):
         return cache[key]
 
     def _num_masks(self, targets, device):
+        if getattr(self, "num_masks_override", None) is not None:
+            # trainer.GraphedTrainStep: the (all-reduced, clamped) value lives in a static device tensor that is refreshed
+            # outside the captured hipGraph (a host->device copy / collective cannot be part of the graph)
+            return self.num_masks_override
         num_masks = torch.as_tensor([sum(len(t["labels"]) for t in targets)], dtype=torch.float, device=device)
         world = 1
         if dist.is_available() and dist.is_initialized():

@@ -19,33 +19,64 @@ _algo = ALGO_AUTO
 _timing = None  # {"fwd": [(start_event, end_event)], "bwd": [...]} while bench.py measures kernel durations
 
 
-def start_timing():
-    """Record HIP events (on the launch stream) around every core-op launch until stop_timing()."""
-    global _timing
+_graph_only = False
+
+
+def start_timing(graph=False):
+    """Record HIP events (on the launch stream) around every core-op launch until stop_timing().
+    graph=True: only launches issued while the stream is being captured into a hipGraph are bracketed, with
+    *external* event-record nodes (hipEventRecordExternal); after any replay the events hold that replay's
+    timestamps, so stop_timing() returns the per-launch durations of the most recent replay."""
+    global _timing, _graph_only
     _timing = {"fwd": [], "bwd": []}
+    _graph_only = bool(graph)
 
 
 def stop_timing():
     """-> {"fwd_us": [...], "bwd_us": [...]} per-launch durations in microseconds (synchronises)."""
+    import ctypes
     global _timing
     t, _timing = _timing, None
     torch.cuda.synchronize()
-    return {k + "_us": [s.elapsed_time(e) * 1e3 for s, e in v] for k, v in (t or {"fwd": [], "bwd": []}).items()}
+    lib = _lib.lib()
+    out = {}
+    for k, v in (t or {"fwd": [], "bwd": []}).items():
+        out[k + "_us"] = []
+        for s, e in v:
+            us = ctypes.c_float(0.0)
+            _lib.check(lib.combo_event_elapsed_us(s, e, ctypes.byref(us)), "combo_event_elapsed_us")
+            out[k + "_us"].append(float(us.value))
+            lib.combo_event_destroy(s)
+            lib.combo_event_destroy(e)
+    return out
+
+
+def _new_event():
+    import ctypes
+    ev = ctypes.c_void_p()
+    _lib.check(_lib.lib().combo_event_create(ctypes.byref(ev)), "combo_event_create")
+    return ev
 
 
 class _Timed:
+    """HIP events straight from the C ABI (torch refuses external event records on ROCm)."""
+
     def __init__(self, kind):
         self.kind = kind
 
     def __enter__(self):
-        if _timing is not None:
-            self.s = torch.cuda.Event(enable_timing=True)
-            self.e = torch.cuda.Event(enable_timing=True)
-            self.s.record()
+        self.on = _timing is not None
+        if self.on:
+            self.capturing = torch.cuda.is_current_stream_capturing()
+            if _graph_only and not self.capturing:
+                self.on = False
+                return
+            self.s, self.e = _new_event(), _new_event()
+            _lib.check(_lib.lib().combo_event_record(self.s, _lib.current_stream(), int(self.capturing)), "combo_event_record")
 
     def __exit__(self, *a):
-        if _timing is not None:
-            self.e.record()
+        if self.on and _timing is not None:
+            _lib.check(_lib.lib().combo_event_record(self.e, _lib.current_stream(), int(self.capturing)), "combo_event_record")
             _timing[self.kind].append((self.s, self.e))
 
 

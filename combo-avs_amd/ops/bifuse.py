@@ -8,6 +8,17 @@ from torch.autograd.function import once_differentiable
 from .. import _lib
 
 _seed_counter = [0]
+_step_counters = {}
+
+
+def step_counter(device):
+    """Device-resident 64-bit step counter that the kernels mix into the Philox key (`seed_step` of the C ABI).  A
+    captured training step (trainer.GraphedTrainStep) increments it inside the hipGraph, so every replay draws fresh
+    dropout masks although the kernel arguments are frozen."""
+    key = str(device)
+    if key not in _step_counters:
+        _step_counters[key] = torch.zeros(1, dtype=torch.int64, device=device)
+    return _step_counters[key]
 
 
 class _BifuseTokenOp(Function):
@@ -27,7 +38,7 @@ class _BifuseTokenOp(Function):
         spa_part = torch.empty(B, chunks, H, device=dev, dtype=f32)
         _lib.check(lib.combo_bifuse_forward_f32(
             x.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), eps, pos.data_ptr(), u.data_ptr(), c.data_ptr(), z.data_ptr(),
-            b_ov.data_ptr(), gamma_v.data_ptr(), _lib.ptr(drop_v), _lib.ptr(drop_a), p_drop, seed, B, N, C, H,
+            b_ov.data_ptr(), gamma_v.data_ptr(), _lib.ptr(drop_v), _lib.ptr(drop_a), p_drop, seed, step_counter(x.device).data_ptr(), B, N, C, H,
             y.data_ptr(), scores.data_ptr(), stat.data_ptr(), part_ws.data_ptr(), pooled_part.data_ptr(),
             spa_part.data_ptr(), _lib.current_stream()), "combo_bifuse_forward_f32")
         ctx.save_for_backward(x, ln_w, ln_b, pos, u, z, b_ov, gamma_v, scores, stat, drop_v, drop_a)
@@ -51,7 +62,7 @@ class _BifuseTokenOp(Function):
         st = _lib.current_stream()
         _lib.check(lib.combo_bifuse_backward1_f32(
             x.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), eps, scores.data_ptr(), stat.data_ptr(), z.data_ptr(),
-            b_ov.data_ptr(), gamma_v.data_ptr(), _lib.ptr(drop_v), _lib.ptr(drop_a), p_drop, seed, dy.data_ptr(),
+            b_ov.data_ptr(), gamma_v.data_ptr(), _lib.ptr(drop_v), _lib.ptr(drop_a), p_drop, seed, step_counter(x.device).data_ptr(), dy.data_ptr(),
             dpooled.data_ptr(), dspa.data_ptr(), B, N, C, H, dp.data_ptr(), r_part.data_ptr(), dz_part.data_ptr(),
             dgb_part.data_ptr(), st), "combo_bifuse_backward1_f32")
         rtot = r_part.sum(1)
@@ -61,7 +72,8 @@ class _BifuseTokenOp(Function):
         dln_part = torch.empty(B, chunks, 2, C, device=dev, dtype=f32)
         _lib.check(lib.combo_bifuse_backward2_f32(
             x.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), eps, pos.data_ptr(), scores.data_ptr(), stat.data_ptr(),
-            u.data_ptr(), _lib.ptr(drop_a), p_drop, seed, dy.data_ptr(), dpooled.data_ptr(), dp.data_ptr(),
+            u.data_ptr(), _lib.ptr(drop_a), p_drop, seed, step_counter(x.device).data_ptr(), dy.data_ptr(), dpooled.data_ptr(),
+            dp.data_ptr(),
             rtot.data_ptr(), B, N, C, H, dx.data_ptr(), du_part.data_ptr(), dc_part.data_ptr(), dln_part.data_ptr(), st),
             "combo_bifuse_backward2_f32")
         dgb = dgb_part.sum((0, 1))

@@ -131,4 +131,131 @@ def train_step(model, optimizer, batched_inputs):
     optimizer.backward(total)
     optimizer.all_reduce_grads()
     optimizer.step()
-    return loss_dict
+    # detached: a caller holding the losses must not keep this step's autograd graph (and the parameters'
+    # AccumulateGrad nodes, which remember the stream they were created on) alive into the next step
+    return {k: v.detach() for k, v in loss_dict.items()}
+
+
+def _input_leaves(batched_inputs):
+    """Tensors of a batch in a fixed order + the hashable rest (heights, widths, flags given as python values)."""
+    tensors, rest = [], []
+    for b in batched_inputs:
+        for k in sorted(b.keys()):
+            v = b[k]
+            if torch.is_tensor(v):
+                tensors.append(v)
+            elif k == "instances":
+                for inst in v:
+                    for name in ("gt_classes", "gt_masks"):
+                        t = inst[name] if isinstance(inst, dict) else getattr(inst, name)
+                        tensors.append(getattr(t, "tensor", t))
+            else:
+                rest.append((k, v))
+    return tensors, tuple(rest)
+
+
+def _clone_batch(batched_inputs):
+    out = []
+    for b in batched_inputs:
+        nb = {}
+        for k, v in b.items():
+            if torch.is_tensor(v):
+                nb[k] = v.clone()
+            elif k == "instances":
+                nb[k] = []
+                for inst in v:
+                    get = (lambda n, i=inst: i[n]) if isinstance(inst, dict) else (lambda n, i=inst: getattr(i, n))
+                    nb[k].append({n: getattr(get(n), "tensor", get(n)).clone() for n in ("gt_classes", "gt_masks")})
+            else:
+                nb[k] = v
+        out.append(nb)
+    return out
+
+
+class GraphedTrainStep:
+    """`train_step` with forward + loss + backward replayed from ONE captured hipGraph.
+
+    The eager step issues ~5 400 kernel launches (two ResNet-50s, 6+9 transformer layers, 39 losses) for ~70 ms of
+    GPU work: the host is as busy as the GPU.  The device-side LSAP (csrc/lsap.hip) removed the step's last
+    device->host dependency, so the whole forward/backward is a static launch sequence for a given input signature
+    (tensor shapes + instances per frame) and is captured once per signature (`torch.cuda.CUDAGraph` = hipGraph on
+    ROCm).  Per step the host then does: copy the batch into the static input buffers, one graph launch, the RCCL
+    gradient all-reduce and the clip + AdamW launches (those stay eager: lr, bias corrections and the collective
+    change per step / are not graph material).  Randomness stays fresh per replay: torch's Philox generator is
+    graph-aware and the bilateral-fusion kernels mix a device-side step counter into their key
+    (ops/bifuse.step_counter, incremented inside the graph).
+    The returned loss dict holds STATIC tensors that the next call overwrites.
+    Signatures beyond `max_graphs` fall back to the eager step."""
+
+    def __init__(self, model, optimizer, warmup_iters=2, max_graphs=4):
+        self.model, self.opt = model, optimizer
+        self.warmup_iters, self.max_graphs = warmup_iters, max_graphs
+        self.graphs = {}
+
+    def _num_masks(self, batched_inputs, dev):
+        n = 0
+        for b in batched_inputs:
+            for inst in b["instances"]:
+                t = inst["gt_classes"] if isinstance(inst, dict) else inst.gt_classes
+                n += int(t.shape[0])
+        if self.model.is_avss_data:
+            return None  # frame selection depends on flag VALUES: AVSS batches run eagerly
+        num = torch.tensor([float(n)], device=dev)
+        world = 1
+        if dist.is_available() and dist.is_initialized():
+            dist.all_reduce(num)
+            world = dist.get_world_size()
+        return torch.clamp(num / world, min=1)
+
+    def _fwd_bwd(self, batch):
+        loss_dict = self.model(batch)
+        total = torch.stack(list(loss_dict.values())).sum()
+        self.opt.backward(total)
+        return {k: v.detach() for k, v in loss_dict.items()}
+
+    def _capture(self, batched_inputs, num_masks):
+        from .ops import bifuse
+        dev = num_masks.device
+        static_batch = _clone_batch(batched_inputs)
+        static_num = num_masks.clone()
+        crit = self.model.criterion
+        crit.num_masks_override = static_num
+        counter = bifuse.step_counter(dev)
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(self.warmup_iters):  # autotuning / lazy initialisation outside the capture
+                    self._fwd_bwd(static_batch)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                counter.add_(1)
+                static_losses = self._fwd_bwd(static_batch)
+        finally:
+            crit.num_masks_override = None
+        return graph, static_batch, static_num, static_losses
+
+    def __call__(self, batched_inputs):
+        tensors, rest = _input_leaves(batched_inputs)
+        dev = self.model.device
+        num_masks = self._num_masks(batched_inputs, dev)
+        if num_masks is None or not all(t.is_cuda for t in tensors):
+            return train_step(self.model, self.opt, batched_inputs)
+        key = (tuple((tuple(t.shape), t.dtype) for t in tensors), rest, self.model.training)
+        if key not in self.graphs:
+            if len(self.graphs) >= self.max_graphs:
+                return train_step(self.model, self.opt, batched_inputs)
+            self.graphs[key] = self._capture(batched_inputs, num_masks)
+        graph, static_batch, static_num, static_losses = self.graphs[key]
+        static_tensors, _ = _input_leaves(static_batch)
+        src = [t for t, s in zip(tensors, static_tensors) if t.data_ptr() != s.data_ptr()]
+        dst = [s for t, s in zip(tensors, static_tensors) if t.data_ptr() != s.data_ptr()]
+        if src:
+            torch._foreach_copy_(dst, src)
+        static_num.copy_(num_masks)
+        graph.replay()
+        self.opt.all_reduce_grads()
+        self.opt.step()
+        return static_losses

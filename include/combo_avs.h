@@ -37,6 +37,14 @@ typedef void* combo_stream_t;
 int combo_abi_version(void);
 const char* combo_build_arch(void); /* "gfx950" */
 
+/* Timing events on the launch stream (measurement plumbing for bench.py; the reference has no counterpart - it times
+ * whole iterations with detectron2's IterationTimer).  external != 0 records an event-record NODE when `stream` is being
+ * captured into a hipGraph, so the pair can be read after any replay.  elapsed_us needs both events completed. */
+int combo_event_create(void** event);
+int combo_event_record(void* event, combo_stream_t stream, int external);
+int combo_event_elapsed_us(void* start, void* stop, float* us);
+int combo_event_destroy(void* event);
+
 /* ------------------------------------------------------------------------------------------------
  * a6  MSDeformAttn core op
  *   replaces ms_deform_attn_cuda_forward / _backward (ops/src/cuda/ms_deform_attn_cuda.cu:25-85, 88-157)
@@ -80,6 +88,8 @@ int combo_msda_backward_f64(const double* grad_out, const double* value, const i
  *     y_i = xn_i + gamma_v*(sum_h p[h,i]*dropv[h,i]*z[b,h] + b_ov); pooled[b,h] = sum_i p[h,i]*dropa[h,i]*xn_i; spa = sum_i p*dropa
  *   x,y [B,N,C] token-major; pos [N,C]; u,z [B,8,C]; c [B,8]; scores [B,8,N] and stat [B,8,2] are saved for backward;
  *   drop_v/drop_a: optional injected multipliers [B,8,N] (NULL -> in-kernel Philox with (p_drop, seed), p_drop = 0: none).
+ *   seed_step: optional DEVICE pointer to a 64-bit step counter mixed into the Philox key inside the kernels, so that a
+ *   captured hipGraph (kernel arguments frozen) still draws fresh dropout masks on every replay; NULL -> key = seed.
  *   Workspaces, with chunks = combo_bifuse_chunks(B,N): part_ws [B,chunks,8,2], pooled_part [B,chunks,8,C],
  *   spa_part [B,chunks,8] (the caller sums the *_part buffers over `chunks`).
  *   backward1 -> dp [B,8,N], r_part [B,chunks,8], dz_part [B,chunks,8,C], dgb_part [B,chunks,2,C] (d gamma_v, d b_ov)
@@ -89,17 +99,17 @@ int combo_msda_backward_f64(const double* grad_out, const double* value, const i
 int combo_bifuse_chunks(int B, int N);
 int combo_bifuse_forward_f32(const float* x, const float* ln_w, const float* ln_b, float eps, const float* pos,
                              const float* u, const float* c, const float* z, const float* b_ov, const float* gamma_v,
-                             const float* drop_v, const float* drop_a, float p_drop, unsigned long long seed,
+                             const float* drop_v, const float* drop_a, float p_drop, unsigned long long seed, const unsigned long long* seed_step,
                              int B, int N, int C, int heads, float* y, float* scores, float* stat, float* part_ws,
                              float* pooled_part, float* spa_part, combo_stream_t stream);
 int combo_bifuse_backward1_f32(const float* x, const float* ln_w, const float* ln_b, float eps, const float* scores,
                                const float* stat, const float* z, const float* b_ov, const float* gamma_v,
-                               const float* drop_v, const float* drop_a, float p_drop, unsigned long long seed,
+                               const float* drop_v, const float* drop_a, float p_drop, unsigned long long seed, const unsigned long long* seed_step,
                                const float* dy, const float* dpooled, const float* dspa, int B, int N, int C, int heads,
                                float* dp, float* r_part, float* dz_part, float* dgb_part, combo_stream_t stream);
 int combo_bifuse_backward2_f32(const float* x, const float* ln_w, const float* ln_b, float eps, const float* pos,
                                const float* scores, const float* stat, const float* u, const float* drop_a,
-                               float p_drop, unsigned long long seed, const float* dy, const float* dpooled,
+                               float p_drop, unsigned long long seed, const unsigned long long* seed_step, const float* dy, const float* dpooled,
                                const float* dp, const float* rtot, int B, int N, int C, int heads, float* dx,
                                float* du_part, float* dc_part, float* dln_part, combo_stream_t stream);
 

@@ -1,0 +1,118 @@
+"""The captured-hipGraph training step (trainer.GraphedTrainStep) against the eager step on the same state and inputs:
+same 39 losses, same gradients, same parameters after the update; a second batch goes through the static input
+buffers; fused-fusion dropout masks change from replay to replay (device-side step counter)."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _to_gpu(batch):
+    return [{k: (v.cuda() if torch.is_tensor(v) else [{kk: vv.cuda() for kk, vv in i.items()} for i in v])
+             for k, v in b.items()} for b in batch]
+
+
+@pytest.fixture(scope="module")
+def rig():
+    sys.path.insert(0, ROOT)
+    import combo_avs_amd  # noqa: F401
+    from bench import synth_batch
+    from combo_avs_amd import combo_cfg
+    from combo_avs_amd.meta_arch import build_model
+    from combo_avs_amd.trainer import FlatAdamW
+    cfg = combo_cfg(os.path.join(ROOT, "configs/avs_s4/COMBO_R50_bs8_90k.yaml"))
+    torch.manual_seed(0)
+    model = build_model(cfg).cuda().train()
+    for m in model.modules():  # no dropout: eager and replayed steps must agree number for number
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if isinstance(m, torch.nn.MultiheadAttention):
+            m.dropout = 0.0
+    for a in model.sem_seg_head.fusion_module.b_attn.attn_list:
+        a.dropout = 0.0
+    bank = torch.rand(40_000_000, generator=torch.Generator().manual_seed(5)).cuda()
+    state = {"off": 0}
+
+    def point_source(n, p):
+        o = state["off"]
+        state["off"] = o + n * p * 2
+        return bank[o:o + n * p * 2].view(n, p, 2)
+
+    model.criterion.point_source = point_source
+    # every forward (eager, the capture's warm-up iterations, the capture itself) reads the bank from offset 0
+    model.register_forward_pre_hook(lambda m, a: state.__setitem__("off", 0))
+    opt = FlatAdamW(model, base_lr=1e-4, weight_decay=0.05, backbone_multiplier=0.1, clip_value=0.01)
+    batches = [_to_gpu(synth_batch(2, 5, 224, 224, "cpu", seed=s)) for s in (11, 12)]
+    return model, opt, batches, state
+
+
+def _reset(opt, snap):
+    opt.flat_param.copy_(snap)
+    opt.exp_avg.zero_()
+    opt.exp_avg_sq.zero_()
+    opt.step_count = 0
+
+
+def test_graphed_step_equals_eager_step(rig):
+    from combo_avs_amd.trainer import GraphedTrainStep, train_step
+    model, opt, batches, state = rig
+    snap = opt.flat_param.clone()
+    eager = []
+    for b in batches:
+        _reset(opt, snap)
+        losses = train_step(model, opt, b)
+        eager.append(({k: float(v) for k, v in losses.items()}, opt.flat_grad.clone(), opt.flat_param.clone()))
+    graphed = GraphedTrainStep(model, opt)
+    for i, b in enumerate(batches):
+        _reset(opt, snap)
+        losses = graphed(b)
+        ref_l, ref_g, ref_p = eager[i]
+        assert len(losses) == 39
+        for k, v in losses.items():
+            assert abs(float(v) - ref_l[k]) <= 2e-4 * abs(ref_l[k]) + 1e-5, (i, k, float(v), ref_l[k])
+        # boolean attention masks / top-k point selection flip on round-off (atomics in the eager torch ops are not
+        # bitwise reproducible), which moves a few gradient entries: bound the fraction, as the golden grad digests do
+        g = opt.flat_grad
+        bad = ((g - ref_g).abs() > 2e-3 * ref_g.abs().max()).float().mean()
+        assert float(bad) < 0.01, (i, float(bad), float((g - ref_g).abs().max()), float(ref_g.abs().max()))
+        # AdamW step 1 moves every parameter by lr * g / (|g| + eps): parameters whose gradient is ~eps (1e-8) amplify
+        # round-off differences, up to 2 * lr for a sign flip; everything else must agree
+        d = (opt.flat_param - ref_p).abs()
+        assert d.max() <= 2.1e-4 and float((d > 1e-5).float().mean()) < 1e-3, (float(d.max()), float((d > 1e-5).float().mean()))
+    assert len(graphed.graphs) == 1  # both batches share one signature -> one capture, second batch via static buffers
+    l1 = {k: float(v) for k, v in losses.items()}
+    assert any(abs(l1[k] - eager[0][0][k]) > 1e-4 for k in l1)  # the second batch really went through
+
+
+def test_fusion_dropout_is_fresh_on_every_replay():
+    from combo_avs_amd.ops import bifuse
+    torch.manual_seed(0)
+    B, N, C, H = 2, 784, 256, 8
+    dev = "cuda"
+    x = torch.randn(B, N, C, device=dev)
+    args = (torch.ones(C, device=dev), torch.zeros(C, device=dev), 1e-5, torch.randn(N, C, device=dev) * 0.1,
+            torch.randn(B, H, C, device=dev) * 0.05, torch.zeros(B, H, device=dev), torch.randn(B, H, C, device=dev),
+            torch.zeros(C, device=dev), torch.full((C,), 0.5, device=dev))
+    counter = bifuse.step_counter(torch.device("cuda", torch.cuda.current_device()))
+    bifuse.token_op(x, *args, 0.1, seed=77)  # lazy init outside the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        counter.add_(1)
+        y, pooled, spa = bifuse.token_op(x, *args, 0.1, seed=77)
+    outs = []
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        outs.append(y.clone())
+    assert not torch.equal(outs[0], outs[1]) and not torch.equal(outs[1], outs[2])
+    # same counter value + same seed -> same masks (the backward regenerates them from exactly this pair)
+    c = counter.clone()
+    y1, _, _ = bifuse.token_op(x, *args, 0.1, seed=77)
+    counter.copy_(c)
+    y2, _, _ = bifuse.token_op(x, *args, 0.1, seed=77)
+    assert torch.equal(y1, y2)
