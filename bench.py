@@ -126,8 +126,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("COMBO_FORCE_PG") == "1":  # COMBO_FORCE_PG: exercise the RCCL path on one GPU
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     import combo_avs_amd  # noqa: F401
@@ -152,7 +155,7 @@ def main():
     batch = synth_batch(args.clips, T, H, W, dev, seed=100 + rank)
 
     def sync():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -166,9 +169,18 @@ def main():
     else:
         # forward + loss + backward replayed from one hipGraph (captured during the first warm-up step, after MIOpen's
         # find pass); the MSDeformAttn launches are bracketed by external event-record nodes inside the graph
-        step = GraphedTrainStep(model, opt)
+        graphed = GraphedTrainStep(model, opt)
         train_step(model, opt, batch)  # eager: MIOpen find / hipBLASLt heuristics / lazy init
-        for _ in range(max(args.warmup, 1)):
+        try:
+            graphed(batch)  # captures
+            step = graphed
+        except Exception as exc:  # noqa: BLE001 - a failed capture must not cost the run: fall back to eager launches
+            print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eager", file=sys.stderr, flush=True)
+            args.no_graph = True
+
+            def step(b):
+                return train_step(model, opt, b)
+        for _ in range(max(args.warmup - 1, 0)):
             step(batch)
         sync()
     t0 = time.perf_counter()
@@ -183,7 +195,7 @@ def main():
         for _ in range(2):
             train_step(model, opt, batch)
     kt = msda.stop_timing()
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -227,7 +239,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -230,7 +230,9 @@ class GraphedTrainStep:
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # thread_local: RCCL's watchdog thread may poll events while this thread captures; that must not
+            # invalidate the capture (the default "global" mode would)
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 counter.add_(1)
                 static_losses = self._fwd_bwd(static_batch)
         finally:

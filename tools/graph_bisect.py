@@ -106,6 +106,23 @@ def run():
     raise SystemExit("unknown stage " + stage)
 
 
+if os.environ.get("PROFILE"):
+    # kernel inventory of one stage (eager): launches, GPU time, top kernels
+    from torch.profiler import profile, ProfilerActivity
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        run()
+        torch.cuda.synchronize()
+    ev = [e for e in prof.key_averages() if e.device_type.name != "CPU" or e.self_device_time_total > 0]
+    n = sum(e.count for e in ev)
+    t = sum(e.self_device_time_total for e in ev)
+    print(f"[{stage}] PROFILE launches={n} gpu_ms={t / 1e3:.2f}")
+    for e in sorted(ev, key=lambda e: -e.self_device_time_total)[:int(os.environ.get("TOP", "14"))]:
+        print(f"    {e.self_device_time_total / 1e3:7.3f} ms {e.count:5d}x  {e.key[:110]}")
+    raise SystemExit(0)
+
 side = torch.cuda.Stream()
 side.wait_stream(torch.cuda.current_stream())
 with torch.cuda.stream(side):
