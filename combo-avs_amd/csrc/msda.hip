@@ -732,11 +732,194 @@ inline int grid_for(long long total, int block) {
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
+// -------------------------------------------------------------------------------------------------
+// LDS-staged forward v2 ("tap-parallel, persistent"), D == 32, fp32, L*P == LPc.
+//
+// Two changes against msda_fwd_lds_d32, both from measurements of that kernel (gather phase LDS-bound with 29 %
+// bank-conflict cycles; slab staged QT = 4 times per (frame, head), 26 us of the 72 us):
+//  * persistent workgroups: grid = #CUs, each owns a CONTIGUOUS range of (frame, head, query-tile) tiles and
+//    re-stages the slab only when (frame, head) changes: 2 stagings per CU instead of 5 at bs = 8.
+//  * conflict-free gather: a ds_read_b128 is served in four fixed 16-lane groups ({0-3,12-15,20-27}, {4-11,16-19,
+//    28-31} and the same +32); a 128-B value row covers half of the 64 banks, selected by the row's parity.  v1 gave
+//    each 8-lane group its own random row, so two rows of equal parity collided in 3 of 4 accesses.  Here the 16 lanes
+//    of a hardware group read the two HORIZONTALLY ADJACENT rows of one bilinear tap pair (r, r+1: opposite parity,
+//    both 64-B halves) = all 64 banks exactly once.  32 lanes serve one (query, point): 4 taps x 2 halves x 4 lanes
+//    x 16 B; a lane accumulates ITS tap over the L*P points and the four taps meet at the end in two DPP row
+//    rotations.  Per-(query, point, tap) {row byte offset, weight} pairs come from a per-wave LDS scratch that a
+//    coordinate phase (one lane per (query, point)) fills, as in v1.
+// -------------------------------------------------------------------------------------------------
+constexpr int kTapQW = 4;  // queries per wave iteration (2 gather steps of 2 queries); small -> 16 waves fit beside the slab
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+
+template <int LPc>
+__global__ void __launch_bounds__(1024)
+msda_fwd_tap_d32(const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+                 const float* __restrict__ loc, const float* __restrict__ aw, int B, int S, int M, int L, int Lq, int P,
+                 int QT, float* __restrict__ out, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int D = 32, QW = kTapQW, PRE = (QW * LPc + 63) / 64;
+  float* slab = reinterpret_cast<float*>(smem);
+  const int NW = blockDim.x >> 6;
+  const unsigned slab_bytes = (unsigned)(S + 1) * D * 4;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* ent = smem + slab_bytes + wave * (QW * LPc * 32);  // [QW][LPc][4 taps] x {u32 row byte offset, f32 weight}
+
+  // gather roles (see the header comment): lane -> (query of the pair, 64-B half, tap, 16-B piece)
+  const int qsel = lane >> 5, half = (lane >> 4) & 1, kq = (lane >> 2) & 3, c4 = lane & 3;
+  const int tap = ((half ? 0x3102 : 0x1320) >> (kq * 4)) & 3;
+  const unsigned lane_off = (unsigned)(half * 64 + c4 * 16);
+  const unsigned ent_lane = (unsigned)(qsel * LPc * 32 + tap * 16);
+
+  int lvH[kMaxLevels], lvW[kMaxLevels], lvS[kMaxLevels];
+#pragma unroll
+  for (int l = 0; l < kMaxLevels; ++l) {
+    lvH[l] = l < L ? (int)shapes[2 * l] : 1;
+    lvW[l] = l < L ? (int)shapes[2 * l + 1] : 1;
+    lvS[l] = l < L ? (int)lsi[l] : 0;
+  }
+  // coordinate-phase constants: lane serves pairs i = lane + 64 j -> (query slot, point, level geometry)
+  int c_ql[PRE], c_H[PRE], c_W[PRE], c_st[PRE];
+  long long c_eoff[PRE];
+  bool c_on[PRE];
+#pragma unroll
+  for (int j = 0; j < PRE; ++j) {
+    const int i = lane + j * 64;
+    const int ql = i / LPc, pt = i - ql * LPc;
+    const int l = pt / P;
+    c_on[j] = i < QW * LPc;
+    c_ql[j] = ql;
+    c_eoff[j] = (long long)ql * M * LPc + pt;
+    int H = lvH[0], W = lvW[0], st = lvS[0];
+#pragma unroll
+    for (int k = 1; k < kMaxLevels; ++k)
+      if (l == k) { H = lvH[k]; W = lvW[k]; st = lvS[k]; }
+    c_H[j] = H; c_W[j] = W; c_st[j] = st;
+  }
+
+  const int T = B * M * QT, G = gridDim.x;
+  const int wg = xcd_remap(blockIdx.x, G);
+  const int t_beg = (int)(((long long)T * wg) / G), t_end = (int)(((long long)T * (wg + 1)) / G);
+  int cur_bm = -1;
+  for (int t = t_beg; t < t_end; ++t) {
+    const int bm = t / QT, qt = t - bm * QT;
+    const int m = bm % M, b = bm / M;
+    const int qbeg = (int)(((long long)Lq * qt) / QT), qend = (int)(((long long)Lq * (qt + 1)) / QT);
+    float2 pxy[PRE];
+    float pa[PRE];
+    auto prefetch = [&](int q0) {
+      const long long base = (((long long)b * Lq + q0) * M + m) * LPc;
+#pragma unroll
+      for (int j = 0; j < PRE; ++j) {
+        pxy[j] = make_float2(-8.f, -8.f);
+        pa[j] = 0.f;
+        if (c_on[j] && q0 + c_ql[j] < qend) {
+          const long long e = base + c_eoff[j];
+          pxy[j] = *reinterpret_cast<const float2*>(loc + e * 2);
+          pa[j] = aw[e];
+        }
+      }
+    };
+    int q0 = qbeg + wave * QW;
+    if (bm != cur_bm) {  // (uniform over the workgroup)
+      if (cur_bm >= 0) __syncthreads();  // every wave is done gathering from the previous slab
+      const float* vb = value + ((long long)b * S * M + m) * D + (lane & 7) * 4;
+      for (int r0 = wave * 8; r0 < S; r0 += NW * 8) {  // LDS-DMA, 8 rows (1 KiB) per wave instruction
+        const int r = r0 + (lane >> 3);
+        if (r < S) dma16(vb + (long long)r * M * D, slab + r0 * D);
+      }
+      if (tid < 8) *reinterpret_cast<float4*>(slab + S * D + tid * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q0 < qend) prefetch(q0);
+      __syncthreads();  // drains the DMA and publishes the slab
+      cur_bm = bm;
+    } else if (q0 < qend) {
+      prefetch(q0);
+    }
+
+    if (dbg == 1) continue;  // ablation: staging only
+    for (; q0 < qend; q0 += NW * QW) {
+      // ---- coordinate phase ----
+#pragma unroll
+      for (int j = 0; j < PRE; ++j) {
+        if (c_on[j] && dbg != 3) {
+          const unsigned zrow = (unsigned)S * 128u;
+          unsigned a0 = zrow, a1 = zrow, a2 = zrow, a3 = zrow;
+          float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
+          const float2 xy = pxy[j];
+          const float a = pa[j];
+          const int H = c_H[j], W = c_W[j], st = c_st[j];
+          const float h_im = xy.y * H - 0.5f, w_im = xy.x * W - 0.5f;
+          if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+            const float hf = floorf(h_im), wf = floorf(w_im);
+            const int h0 = (int)hf, w0i = (int)wf;
+            const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+            const bool t_ok = h0 >= 0, b_ok = h0 + 1 <= H - 1, l_ok = w0i >= 0, r_ok = w0i + 1 <= W - 1;
+            const unsigned base = (unsigned)(st + h0 * W + w0i) * 128u;
+            if (t_ok && l_ok) a0 = base;
+            if (t_ok && r_ok) a1 = base + 128u;
+            if (b_ok && l_ok) a2 = base + (unsigned)W * 128u;
+            if (b_ok && r_ok) a3 = base + (unsigned)W * 128u + 128u;
+            w0 = hh * hw * a; w1 = hh * lw * a; w2 = lh * hw * a; w3 = lh * lw * a;
+          }
+          // layout [query][point pair][tap][point parity] x 8 B: a gather lane fetches two points of ITS tap per b128
+          const int i = lane + j * 64, ql = c_ql[j], pt = i - ql * LPc;
+          uint2* e = reinterpret_cast<uint2*>(ent + ((ql * (LPc / 2) + (pt >> 1)) * 4) * 16 + (pt & 1) * 8);
+          e[0] = make_uint2(a0, __float_as_uint(w0));
+          e[2] = make_uint2(a1, __float_as_uint(w1));
+          e[4] = make_uint2(a2, __float_as_uint(w2));
+          e[6] = make_uint2(a3, __float_as_uint(w3));
+        }
+      }
+      if (q0 + NW * QW < qend) prefetch(q0 + NW * QW);  // in flight during the gather phase
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+      // ---- gather phase: 2 queries per wave instruction ----
+      if (dbg != 4)
+#pragma unroll 2
+      for (int s = 0; s < QW / 2; ++s) {
+        const char* e = ent + ent_lane + s * (2 * LPc * 32);
+        uint4 en[LPc / 2];
+#pragma unroll
+        for (int pp = 0; pp < LPc / 2; ++pp) en[pp] = *reinterpret_cast<const uint4*>(e + pp * 64);
+        v2f acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
+#pragma unroll
+        for (int pp = 0; pp < LPc / 2; ++pp) {
+          const float4 va = *reinterpret_cast<const float4*>(smem + en[pp].x + lane_off);
+          const float4 vb = *reinterpret_cast<const float4*>(smem + en[pp].z + lane_off);
+          const float wa = __uint_as_float(en[pp].y), wb = __uint_as_float(en[pp].w);
+          acc01 = __builtin_elementwise_fma((v2f){wa, wa}, (v2f){va.x, va.y}, acc01);
+          acc23 = __builtin_elementwise_fma((v2f){wa, wa}, (v2f){va.z, va.w}, acc23);
+          acc01 = __builtin_elementwise_fma((v2f){wb, wb}, (v2f){vb.x, vb.y}, acc01);
+          acc23 = __builtin_elementwise_fma((v2f){wb, wb}, (v2f){vb.z, vb.w}, acc23);
+        }
+        float4 acc = make_float4(acc01.x, acc01.y, acc23.x, acc23.y);
+        // the four taps of a (query, half, piece) sit in the four quads of a 16-lane row
+        acc.x += dpp_f<0x128>(acc.x); acc.y += dpp_f<0x128>(acc.y); acc.z += dpp_f<0x128>(acc.z); acc.w += dpp_f<0x128>(acc.w);
+        acc.x += dpp_f<0x124>(acc.x); acc.y += dpp_f<0x124>(acc.y); acc.z += dpp_f<0x124>(acc.z); acc.w += dpp_f<0x124>(acc.w);
+        const int q = q0 + 2 * s + qsel;
+        if (kq == 0 && q < qend)
+          *reinterpret_cast<float4*>(out + (((long long)b * Lq + q) * M + m) * D + half * 16 + c4 * 4) = acc;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
 inline bool check_common(int B, int S, int M, int D, int L, int Lq, int P) {
   return B > 0 && S > 0 && M > 0 && D > 0 && L > 0 && L <= kMaxLevels && Lq > 0 && P > 0;
 }
 
 size_t fwd_lds_bytes(int S, int L, int P, int nw) { return (size_t)(S + 1) * 128 + (size_t)nw * kQW * L * P * 24; }
+size_t fwd_tap_lds_bytes(int S, int LP, int nw) { return (size_t)(S + 1) * 128 + (size_t)nw * kTapQW * LP * 32; }
 size_t bwd_value_lds_bytes(int S) {
   return (size_t)(S + 1) * 64 + (size_t)((S + 1 + 3) & ~3) * 4 + (size_t)(kBwdVThreads / 64) * 20 * 4;
 }
@@ -751,7 +934,58 @@ int msda_forward(const T* value, const int64_t* shapes, const int64_t* lsi, cons
   if constexpr (sizeof(T) == 4)
     lds_ok = (D == 32) && S < 65535 && L * P <= kMaxLP && fwd_lds_bytes(S, L, P, 8) <= kLdsLimit;
   if (algo == 2 && !lds_ok) return COMBO_EINVAL;
+  bool tap_ok = false;
+  if constexpr (sizeof(T) == 4)
+    tap_ok = (D == 32) && S < 65535 && (L * P == 12 || L * P == 16) && fwd_tap_lds_bytes(S, L * P, 4) <= kLdsLimit;
+  if (algo == 3 && !tap_ok) return COMBO_EINVAL;
+  if (const char* e = getenv("COMBO_MSDA_FWD")) {  // A/B switch: "v1" keeps the one-tile-per-workgroup kernel
+    if (e[0] == 'v' && e[1] == '1') tap_ok = tap_ok && algo == 3;
+  }
   if constexpr (sizeof(T) == 4) {
+    if (tap_ok && (algo == 0 || algo == 3)) {
+      int nw = 16;
+      if (const char* e = getenv("COMBO_MSDA_NW")) nw = atoi(e) >= 4 && atoi(e) <= 16 ? atoi(e) : nw;
+      while (nw > 4 && fwd_tap_lds_bytes(S, L * P, nw) > kLdsLimit) --nw;
+      static int n_cu = 0;
+      if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return COMBO_EINVAL;
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+      }
+      // >= 4 tiles per workgroup so that the contiguous ranges balance to within one tile
+      int QT = (int)((4LL * n_cu + (long long)B * M - 1) / ((long long)B * M));
+      const int qt_max = Lq / (nw * kTapQW) > 0 ? Lq / (nw * kTapQW) : 1;
+      if (QT > qt_max) QT = qt_max;
+      if (QT < 1) QT = 1;
+      if (const char* e = getenv("COMBO_MSDA_QT")) QT = atoi(e) > 0 ? atoi(e) : QT;
+      const long long tiles = (long long)B * M * QT;
+      const int grid = (int)(tiles < n_cu ? tiles : n_cu);
+      const size_t lds = fwd_tap_lds_bytes(S, L * P, nw);
+      int dbg = 0;  // ablation switch for tools/bench_msda.py (1: staging only, 3: no coordinate phase, 4: no gather)
+      if (const char* e = getenv("COMBO_MSDA_DBG")) dbg = atoi(e);
+      static bool attr12 = false, attr16 = false;
+      if (L * P == 12) {
+        if (!attr12) {
+          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_fwd_tap_d32<12>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
+          if (e != hipSuccess) return (int)e;
+          attr12 = true;
+        }
+        hipLaunchKernelGGL(msda_fwd_tap_d32<12>, dim3(grid), dim3(nw * 64), lds, stream, value, shapes, lsi, loc, aw, B,
+                           S, M, L, Lq, P, QT, out, dbg);
+      } else {
+        if (!attr16) {
+          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_fwd_tap_d32<16>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
+          if (e != hipSuccess) return (int)e;
+          attr16 = true;
+        }
+        hipLaunchKernelGGL(msda_fwd_tap_d32<16>, dim3(grid), dim3(nw * 64), lds, stream, value, shapes, lsi, loc, aw, B,
+                           S, M, L, Lq, P, QT, out, dbg);
+      }
+      return (int)hipGetLastError();
+    }
     if (lds_ok && algo != 1) {
       // enough workgroups to fill 256 CUs a few times; each re-stages the slab from L2 (cheap)
       const int nw = fwd_lds_bytes(S, L, P, 12) <= kLdsLimit ? 12 : 8;

@@ -14,7 +14,7 @@ from torch.autograd.function import once_differentiable
 
 from . import _lib
 
-ALGO_AUTO, ALGO_GENERIC, ALGO_LDS = 0, 1, 2
+ALGO_AUTO, ALGO_GENERIC, ALGO_LDS, ALGO_TAP = 0, 1, 2, 3  # 2: one tile per workgroup (v1), 3: persistent tap-parallel forward
 _algo = ALGO_AUTO
 _timing = None  # {"fwd": [(start_event, end_event)], "bwd": [...]} while bench.py measures kernel durations
 

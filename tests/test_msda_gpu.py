@@ -64,7 +64,7 @@ def prod_inputs(B=2, shapes=((7, 7), (14, 14), (28, 28)), M=8, D=32, P=4, seed_t
     return v, list(shapes), loc, w
 
 
-@pytest.mark.parametrize("algo", [1, 2])
+@pytest.mark.parametrize("algo", [1, 2, 3])
 def test_production_shape_vs_reference_digests(algo):
     """R50-S4 @224 shape (S=Lq=1029, M=8, D=32, L=3, P=4): both kernel families against the reference's
     grid_sample core (digests in msda_core.npz) to fp32 round-off."""
@@ -76,7 +76,7 @@ def test_production_shape_vs_reference_digests(algo):
         synth.check_digest(t, synth.unpack(f"prod/{nm}", z), f"prod/{nm}", rtol=1e-4, atol=5e-5)
 
 
-@pytest.mark.parametrize("algo", [1, 2])
+@pytest.mark.parametrize("algo", [1, 2, 3])
 def test_production_shape_vs_oracle_full_tensor(algo):
     v, shapes, loc, w = prod_inputs(B=3, seed_tag="prod3")
     go = synth.synth_tensor("prod3.grad_out", (3, 1029, 256), 0)
@@ -117,6 +117,8 @@ def test_lds_and_generic_agree_bitwise_forward():
     a = run_hip(v, shapes, loc, w, algo=1)[0]
     b = run_hip(v, shapes, loc, w, algo=2)[0]
     assert (a - b).abs().max().item() <= 1e-6
+    c = run_hip(v, shapes, loc, w, algo=3)[0]  # tap-parallel kernel: per-tap partial sums, then combined
+    assert (a - c).abs().max().item() <= 2e-5 * a.abs().max().item()
 
 
 def test_full_size_properties_bs8():

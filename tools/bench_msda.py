@@ -43,7 +43,7 @@ def timeit(fn, iters):
     return s.elapsed_time(e) / iters * 1e3  # us
 
 
-for algo, name in ((1, "generic"), (2, "lds")):
+for algo, name in ((1, "generic"), (2, "lds"), (3, "tap")):
     msda.set_algo(algo)
     t = timeit(lambda: msda.ms_deform_attn_forward(value, sh, lsi, loc, w), a.iters)
     print(f"fwd {name:8s}: {t:8.1f} us   {fwd_bytes / t / 1e3:8.1f} GB/s algorithmic ({fwd_bytes/1e6:.1f} MB)")
