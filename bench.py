@@ -217,10 +217,10 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "r01_msda_pmc.json")
         if os.path.exists(pmc):
             with open(pmc) as f:
-                rec = json.load(f).get("msda_fwd_lds_d32", {})
+                rec = json.load(f).get("msda_fwd_tap_d32", {})
             if rec.get("frames_per_launch") == bt:
                 traffic = rec.get("hbm_bytes_per_launch")
-        roof = {"kernel": "msda_fwd_lds_d32", "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+        roof = {"kernel": "msda_fwd_tap_d32", "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 4), "traffic": traffic, "avg_launch_us": round(avg_us, 2),
                 "launches": len(kt["fwd_us"]), "algorithmic_bytes_per_launch": fwd_bytes}
     if rank == 0:

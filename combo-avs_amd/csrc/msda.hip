@@ -775,7 +775,7 @@ msda_fwd_tap_d32(const float* __restrict__ value, const int64_t* __restrict__ sh
   const int qsel = lane >> 5, half = (lane >> 4) & 1, kq = (lane >> 2) & 3, c4 = lane & 3;
   const int tap = ((half ? 0x3102 : 0x1320) >> (kq * 4)) & 3;
   const unsigned lane_off = (unsigned)(half * 64 + c4 * 16);
-  const unsigned ent_lane = (unsigned)(qsel * LPc * 32 + tap * 16);
+  const unsigned ent_lane = (unsigned)(tap * (QW * LPc * 8) + qsel * LPc * 8);
 
   int lvH[kMaxLevels], lvW[kMaxLevels], lvS[kMaxLevels];
 #pragma unroll
@@ -803,14 +803,29 @@ msda_fwd_tap_d32(const float* __restrict__ value, const int64_t* __restrict__ sh
     c_H[j] = H; c_W[j] = W; c_st[j] = st;
   }
 
-  const int T = B * M * QT, G = gridDim.x;
+  // Work list of this workgroup (NS = B*M slabs, G workgroups):
+  //   phase 1: n_full = NS / G whole slabs (all Lq queries), slab = it*G + wg: the 8 heads of a frame run on
+  //            neighbouring CUs of one XCD at the same time (one HBM fetch per value row);
+  //   phase 2: the R = NS mod G left-over slabs are cut into QT query tiles each and the R*QT tiles are dealt out
+  //            contiguously, so the (G / R) workgroups sharing a slab stage it at the same time from the same L2.
+  const int NS = B * M, G = gridDim.x;
   const int wg = xcd_remap(blockIdx.x, G);
-  const int t_beg = (int)(((long long)T * wg) / G), t_end = (int)(((long long)T * (wg + 1)) / G);
+  const int n_full = NS / G, R = NS - n_full * G;
+  const int p_beg = (int)(((long long)R * QT * wg) / G), p_end = (int)(((long long)R * QT * (wg + 1)) / G);
+  const int n_items = n_full + (p_end - p_beg);
   int cur_bm = -1;
-  for (int t = t_beg; t < t_end; ++t) {
-    const int bm = t / QT, qt = t - bm * QT;
+  for (int it = 0; it < n_items; ++it) {
+    int bm, qbeg = 0, qend = Lq;
+    if (it < n_full) {
+      bm = it * G + wg;
+    } else {
+      const int p = p_beg + (it - n_full);
+      const int qt = p % QT;
+      bm = n_full * G + p / QT;
+      qbeg = (int)(((long long)Lq * qt) / QT);
+      qend = (int)(((long long)Lq * (qt + 1)) / QT);
+    }
     const int m = bm % M, b = bm / M;
-    const int qbeg = (int)(((long long)Lq * qt) / QT), qend = (int)(((long long)Lq * (qt + 1)) / QT);
     float2 pxy[PRE];
     float pa[PRE];
     auto prefetch = [&](int q0) {
@@ -867,13 +882,13 @@ msda_fwd_tap_d32(const float* __restrict__ value, const int64_t* __restrict__ sh
             if (b_ok && r_ok) a3 = base + (unsigned)W * 128u + 128u;
             w0 = hh * hw * a; w1 = hh * lw * a; w2 = lh * hw * a; w3 = lh * lw * a;
           }
-          // layout [query][point pair][tap][point parity] x 8 B: a gather lane fetches two points of ITS tap per b128
-          const int i = lane + j * 64, ql = c_ql[j], pt = i - ql * LPc;
-          uint2* e = reinterpret_cast<uint2*>(ent + ((ql * (LPc / 2) + (pt >> 1)) * 4) * 16 + (pt & 1) * 8);
+          // layout [tap][query][point] x 8 B: consecutive lanes write consecutive 8-B entries (conflict-free
+          // ds_write_b64); a gather lane reads two points of ITS tap per ds_read_b128
+          uint2* e = reinterpret_cast<uint2*>(ent + (lane + j * 64) * 8);
           e[0] = make_uint2(a0, __float_as_uint(w0));
-          e[2] = make_uint2(a1, __float_as_uint(w1));
-          e[4] = make_uint2(a2, __float_as_uint(w2));
-          e[6] = make_uint2(a3, __float_as_uint(w3));
+          e[QW * LPc] = make_uint2(a1, __float_as_uint(w1));
+          e[2 * QW * LPc] = make_uint2(a2, __float_as_uint(w2));
+          e[3 * QW * LPc] = make_uint2(a3, __float_as_uint(w3));
         }
       }
       if (q0 + NW * QW < qend) prefetch(q0 + NW * QW);  // in flight during the gather phase
@@ -885,10 +900,10 @@ msda_fwd_tap_d32(const float* __restrict__ value, const int64_t* __restrict__ sh
       if (dbg != 4)
 #pragma unroll 2
       for (int s = 0; s < QW / 2; ++s) {
-        const char* e = ent + ent_lane + s * (2 * LPc * 32);
+        const char* e = ent + ent_lane + s * (2 * LPc * 8);
         uint4 en[LPc / 2];
 #pragma unroll
-        for (int pp = 0; pp < LPc / 2; ++pp) en[pp] = *reinterpret_cast<const uint4*>(e + pp * 64);
+        for (int pp = 0; pp < LPc / 2; ++pp) en[pp] = *reinterpret_cast<const uint4*>(e + pp * 16);
         v2f acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
 #pragma unroll
         for (int pp = 0; pp < LPc / 2; ++pp) {
@@ -953,14 +968,14 @@ int msda_forward(const T* value, const int64_t* shapes, const int64_t* lsi, cons
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return COMBO_EINVAL;
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
       }
-      // >= 4 tiles per workgroup so that the contiguous ranges balance to within one tile
-      int QT = (int)((4LL * n_cu + (long long)B * M - 1) / ((long long)B * M));
+      // left-over slabs (B*M mod #CUs) are cut into QT tiles so that their tiles divide evenly over the CUs
+      const int NS = B * M, rem = NS % n_cu;
+      auto gcd = [](int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; };
+      int QT = rem ? n_cu / gcd(rem, n_cu) : 1;
       const int qt_max = Lq / (nw * kTapQW) > 0 ? Lq / (nw * kTapQW) : 1;
       if (QT > qt_max) QT = qt_max;
-      if (QT < 1) QT = 1;
       if (const char* e = getenv("COMBO_MSDA_QT")) QT = atoi(e) > 0 ? atoi(e) : QT;
-      const long long tiles = (long long)B * M * QT;
-      const int grid = (int)(tiles < n_cu ? tiles : n_cu);
+      const int grid = NS >= n_cu ? n_cu : (NS * QT < n_cu ? NS * QT : n_cu);
       const size_t lds = fwd_tap_lds_bytes(S, L * P, nw);
       int dbg = 0;  // ablation switch for tools/bench_msda.py (1: staging only, 3: no coordinate phase, 4: no gather)
       if (const char* e = getenv("COMBO_MSDA_DBG")) dbg = atoi(e);

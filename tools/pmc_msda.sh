@@ -11,7 +11,7 @@ f=glob.glob("/tmp/pmc/*counter_collection.csv")[0]
 agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
     m=re.search(r"msda_\w+", r["Kernel_Name"])
-    if m and "lds" in m.group(0): agg[m.group(0)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    if m and ("lds" in m.group(0) or "tap" in m.group(0)): agg[m.group(0)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k,v in sorted(agg.items()):
     print(k, {c: round(sum(x)/len(x),1) for c,x in v.items()}, "n=%d" % len(next(iter(v.values()))))
 PY

@@ -11,7 +11,7 @@ import sys
 from collections import defaultdict
 
 path, steps = sys.argv[1], int(sys.argv[2])
-marker = sys.argv[3] if len(sys.argv) > 3 else "msda_fwd_lds_d32"
+marker = sys.argv[3] if len(sys.argv) > 3 else "msda_fwd_tap_d32"
 per_step = int(sys.argv[4]) if len(sys.argv) > 4 else 6
 rows = []
 with open(path) as f:
