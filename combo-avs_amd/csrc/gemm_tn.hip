@@ -127,11 +127,265 @@ gemm_tn_x3_kernel(const float* __restrict__ dY, long long ldy, const float* __re
     }
 }
 
+
+// -------------------------------------------------------------------------------------------------------------------
+// v2: LDS-DMA ring + interleaved wave tiles (for N % 4 == 0, K % 4 == 0, 16-byte aligned operands).
+//
+// The direct-from-global kernel above is bound by vector-memory ISSUE: 32 dword loads per wave for 12 MFMAs, one
+// k-step of prefetch.  Here a workgroup streams [16 tokens] x [BN + BK columns] stages through a 3-deep LDS ring with
+// global_load_lds_dwordx4 (no VGPR round trip, two stages in flight across a raw s_barrier, counted s_waitcnt vmcnt),
+// and every wave owns a 128(n) x 64(k) tile whose n/k indices are INTERLEAVED: MFMA tile i of the A side holds
+// n = n0 + 4*row + i, so ONE ds_read_b128 of four consecutive n for a token feeds the fragments of four MFMA tiles (and
+// one ds_read_b64 two B tiles): 16 conflict-free LDS reads for 24 MFMAs per k-step, and the token-major operands never
+// need a transpose.  WN = waves along n: block tile 256 x 128 (WN = 2) or 128 x 256 (WN = 1).
+// -------------------------------------------------------------------------------------------------------------------
+constexpr int kTS = 16;      // tokens (reduction rows) per stage
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+// LDS reads as inline asm: hipcc drains every outstanding LDS-DMA (s_waitcnt vmcnt(0)) in front of a ds_read it can
+// see, which would serialise the ring; ordering is done by hand (counted vmcnt -> s_barrier -> these reads).
+__device__ __forceinline__ f4v lds_read128(unsigned addr) {
+  f4v r;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr));
+  return r;
+}
+__device__ __forceinline__ f2v lds_read64(unsigned addr) {
+  f2v r;
+  asm volatile("ds_read_b64 %0, %1" : "=v"(r) : "v"(addr));
+  return r;
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ void glds16(const float* g, char* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <int WN, int kStages>
+__global__ void __launch_bounds__(256, kStages <= 3 ? 2 : 1)
+gemm_tn_glds_kernel(const float* __restrict__ dY, long long ldy, const float* __restrict__ X, long long ldx,
+                    float* __restrict__ out, float* __restrict__ db_part, int M, int N, int K, int mchunk) {
+  constexpr int WK = 4 / WN, BN = 128 * WN, BK = 64 * WK;
+  constexpr int A_BYTES = kTS * BN * 4, B_BYTES = kTS * BK * 4, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_PIECES = A_BYTES / 1024, B_PIECES = B_BYTES / 1024, PIECES = A_PIECES + B_PIECES;  // 1-KiB DMA pieces
+  constexpr int PPW = PIECES / 4;  // pieces per wave per stage (24 KiB / 4 waves = 6)
+  static_assert(PIECES % 4 == 0, "pieces must divide over the 4 waves");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wn = wave / WK, wk = wave % WK;
+  const int n_blk = blockIdx.y * BN, k_blk = blockIdx.x * BK;
+  const int mbeg = blockIdx.z * mchunk, mend = min(M, mbeg + mchunk);
+  const int nst = (mend - mbeg + kTS - 1) / kTS;
+  const int col = lane & 31, kg = lane >> 5;
+
+  // ---- per-lane DMA source columns (constant over the stages), clamped inside the matrix ----
+  // piece q of a stage (1 KiB = one wave instruction): q < A_PIECES -> dY rows, else X rows
+  auto issue = [&](int s) {
+    char* st = smem + (s % kStages) * STAGE;
+    const int m0 = mbeg + s * kTS;
+#pragma unroll
+    for (int u = 0; u < PPW; ++u) {
+      const int q = wave + 4 * u;  // wave-uniform
+      if (q < A_PIECES) {
+        int t, c;
+        if (BN == 256) { t = q; c = n_blk + lane * 4; }                          // one 1-KiB row per piece
+        else { t = q * 2 + (lane >> 5); c = n_blk + (lane & 31) * 4; }           // two 512-B rows per piece
+        c = min(c, N - 4);
+        const int m = min(m0 + t, M - 1);
+        glds16(dY + (long long)m * ldy + c, st + q * 1024);
+      } else {
+        const int qb = q - A_PIECES;
+        int t, c;
+        if (BK == 128) { t = qb * 2 + (lane >> 5); c = k_blk + (lane & 31) * 4; }
+        else { t = qb; c = k_blk + lane * 4; }
+        c = min(c, K - 4);
+        const int m = min(m0 + t, M - 1);
+        glds16(X + (long long)m * ldx + c, st + A_BYTES + qb * 1024);
+      }
+    }
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const bool do_db = db_part != nullptr && blockIdx.x == 0 && wk == 0;
+  float4 colsum = make_float4(0.f, 0.f, 0.f, 0.f);
+
+#pragma unroll
+  for (int p = 0; p < kStages - 1; ++p)
+    if (p < nst) issue(p);
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned a_off = lds0 + (unsigned)((kg * 8 * BN + wn * 128 + col * 4) * 4);
+  const unsigned b_off = lds0 + (unsigned)(A_BYTES + (kg * 8 * BK + wk * 64 + col * 2) * 4);
+  for (int s = 0; s < nst; ++s) {
+    // stage s has landed once MY pieces of it are done (counted: up to kStages-2 younger stages stay in flight) and
+    // everybody passed the barrier; the barrier also says everybody finished reading stage s-1, whose slot the stage
+    // issued below reuses
+    const int younger = min(kStages - 2, nst - 1 - s);
+    if (younger >= 3) wait_vm<3 * PPW>();
+    else if (younger == 2) wait_vm<2 * PPW>();
+    else if (younger == 1) wait_vm<PPW>();
+    else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    if (s + kStages - 1 < nst) issue(s + kStages - 1);
+    const unsigned so = (unsigned)((s % kStages) * STAGE);
+    f4v ra[8];
+    f2v rb[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      ra[t] = lds_read128(a_off + so + t * (BN * 4));
+      rb[t] = lds_read64(b_off + so + t * (BK * 4));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(ra[6]), "+v"(ra[7]),
+                   "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(rb[4]), "+v"(rb[5]), "+v"(rb[6]), "+v"(rb[7])
+                 :
+                 : "memory");
+    float4 va[8];
+    float2 vb[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      va[t] = make_float4(ra[t].x, ra[t].y, ra[t].z, ra[t].w);
+      vb[t] = make_float2(rb[t].x, rb[t].y);
+    }
+    if (mbeg + (s + 1) * kTS > mend) {  // ragged last stage: rows beyond mend contribute nothing (zero the A side)
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        if (mbeg + s * kTS + kg * 8 + t >= mend) va[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (do_db) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) { colsum.x += va[t].x; colsum.y += va[t].y; colsum.z += va[t].z; colsum.w += va[t].w; }
+    }
+    Frag fa[4], fb[2];
+    {
+      float v[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] = va[t].x;
+      fa[0] = make_frag(v);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] = va[t].y;
+      fa[1] = make_frag(v);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] = va[t].z;
+      fa[2] = make_frag(v);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] = va[t].w;
+      fa[3] = make_frag(v);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] = vb[t].x;
+      fb[0] = make_frag(v);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[t] = vb[t].y;
+      fb[1] = make_frag(v);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i].lo, fb[j].hi, acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i].hi, fb[j].lo, acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i].hi, fb[j].hi, acc[i][j], 0, 0, 0);
+  }
+  const int n0 = n_blk + wn * 128, k0 = k_blk + wk * 64;
+  if (do_db) {
+    colsum.x += __shfl_xor(colsum.x, 32); colsum.y += __shfl_xor(colsum.y, 32);
+    colsum.z += __shfl_xor(colsum.z, 32); colsum.w += __shfl_xor(colsum.w, 32);
+    const int nr = n0 + col * 4;
+    if (kg == 0 && nr < N) *reinterpret_cast<float4*>(db_part + (long long)blockIdx.z * N + nr) = colsum;
+  }
+  float* o = out + (long long)blockIdx.z * N * K;
+  const int kc = k0 + col * 2;
+  if (kc < K) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int nr = n0 + 4 * ((e & 3) + 8 * (e >> 2) + 4 * kg) + i;
+        if (nr < N) *reinterpret_cast<float2*>(o + (long long)nr * K + kc) = make_float2(acc[i][0][e], acc[i][1][e]);
+      }
+  }
+}
+
+inline bool glds_ok(const float* dY, long long ldy, const float* X, long long ldx, int M, int N, int K) {
+  return N % 4 == 0 && K % 4 == 0 && N >= 64 && K >= 64 && ldy % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)dY & 15) == 0 &&
+         ((uintptr_t)X & 15) == 0 && M >= 256;
+}
+
+// out[i] = sum_z part[z*n + i] (i < n) and db[j] = sum_z db_part[z*nb + j] (j < nb): ONE launch finishes the split-K
+// weight gradient and the fused bias gradient, in a fixed summation order (deterministic), straight into the caller's
+// destination (e.g. a row block of a packed in_proj gradient).
+__global__ void __launch_bounds__(256)
+splitk_reduce_kernel(const float* __restrict__ part, int splits, long long n, float* __restrict__ out,
+                     const float* __restrict__ db_part, int nb, float* __restrict__ db) {
+  const long long n4 = n >> 2;
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i < n4) {
+    float4 a = reinterpret_cast<const float4*>(part)[i];
+    for (int z = 1; z < splits; ++z) {
+      const float4 b = reinterpret_cast<const float4*>(part + (long long)z * n)[i];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = a;
+  } else if (i - n4 < nb) {
+    const int j = (int)(i - n4);
+    float a = db_part[j];
+    for (int z = 1; z < splits; ++z) a += db_part[(long long)z * nb + j];
+    db[j] = a;
+  }
+}
+
 }  // namespace
 
 extern "C" {
 
+int combo_splitk_reduce_f32(const float* partials, int splits, long long n, float* out, const float* db_partials, int nb,
+                            float* db, combo_stream_t stream) {
+  if (!partials || !out || splits <= 0 || n <= 0 || (n & 3) || ((uintptr_t)partials & 15) || ((uintptr_t)out & 15) ||
+      (nb > 0 && (!db_partials || !db)))
+    return COMBO_EINVAL;
+  const long long threads = (n >> 2) + (nb > 0 ? nb : 0);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     partials, splits, n, out, db_partials, nb > 0 ? nb : 0, db);
+  return (int)hipGetLastError();
+}
+
+static int tn_variant(int N, int K) {  // 2: 256(n) x 128(k) block tiles, 1: 128 x 256
+  const long long t2 = (long long)((N + 255) / 256) * ((K + 127) / 128) * 256 * 128;
+  const long long t1 = (long long)((N + 127) / 128) * ((K + 255) / 256) * 128 * 256;
+  return t2 <= t1 ? 2 : 1;  // less padded area wins
+}
+
 int combo_gemm_tn_splits(int M, int N, int K) {
+  if (const char* e = getenv("COMBO_GEMM_TN_SPLITS")) {  // tuning override
+    const int v = atoi(e);
+    if (v > 0) return v < (M + 127) / 128 ? v : (M + 127) / 128;
+  }
+  if (N % 4 == 0 && K % 4 == 0 && N >= 64 && K >= 64 && M >= 256) {
+    const int v = tn_variant(N, K);
+    const long long tiles = v == 2 ? (long long)((N + 255) / 256) * ((K + 127) / 128)
+                                   : (long long)((N + 127) / 128) * ((K + 255) / 256);
+    // measured (tools/bench_dw.py, COMBO_GEMM_TN_SPLITS sweep): one workgroup per CU for outputs of <= 4 tiles (every
+    // extra split costs a 128-KiB partial tile written and re-read), two per CU for larger outputs
+    long long s = ((tiles <= 4 ? 256 : 512) + tiles - 1) / tiles;
+    const long long maxs = (M + 127) / 128;   // at least 8 stages per split
+    if (s > maxs) s = maxs;
+    if (s < 1) s = 1;
+    return (int)s;
+  }
   const long long tiles = (long long)((N + 127) / 128) * ((K + 127) / 128);
   long long s = (2048 + tiles - 1) / tiles;           // ~8 workgroups per CU
   const long long maxs = (M + 255) / 256;             // at least 256 reduction rows per split
@@ -147,6 +401,34 @@ int combo_gemm_tn_x3_f32(const float* dY, long long ldy, const float* X, long lo
   mchunk = (mchunk + 15) / 16 * 16;
   const int nz = (M + mchunk - 1) / mchunk;
   if (nz != splits) return COMBO_EINVAL;  // caller sizes `out_partials` with combo_gemm_tn_splits / this rounding
+  const char* force = getenv("COMBO_GEMM_TN");  // "v1": direct-from-global kernel everywhere (A/B measurements)
+  if (glds_ok(dY, ldy, X, ldx, M, N, K) && !(force && force[0] == 'v' && force[1] == '1')) {
+    constexpr int stage_bytes = kTS * 256 * 4 + kTS * 128 * 4;  // both variants: 24 KiB
+    int stages = 3;  // 3 stages x 2 workgroups/CU, or 5-6 stages x 1 workgroup/CU
+    if (const char* e = getenv("COMBO_GEMM_TN_STAGES")) stages = atoi(e) == 5 ? 5 : 3;
+    static bool attr = false;
+    if (!attr) {
+      const void* fns[4] = {reinterpret_cast<const void*>(gemm_tn_glds_kernel<2, 3>), reinterpret_cast<const void*>(gemm_tn_glds_kernel<1, 3>),
+                            reinterpret_cast<const void*>(gemm_tn_glds_kernel<2, 5>), reinterpret_cast<const void*>(gemm_tn_glds_kernel<1, 5>)};
+      for (int i = 0; i < 4; ++i) {
+        hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (i < 2 ? 3 : 5) * stage_bytes);
+        if (e != hipSuccess) return (int)e;
+      }
+      attr = true;
+    }
+    const int lds = stages * stage_bytes;
+    const bool v2 = tn_variant(N, K) == 2;
+    const dim3 grid = v2 ? dim3((K + 127) / 128, (N + 255) / 256, nz) : dim3((K + 255) / 256, (N + 127) / 128, nz);
+    if (v2 && stages == 3)
+      hipLaunchKernelGGL((gemm_tn_glds_kernel<2, 3>), grid, dim3(256), lds, (hipStream_t)stream, dY, ldy, X, ldx, out_partials, db_partials, M, N, K, mchunk);
+    else if (v2)
+      hipLaunchKernelGGL((gemm_tn_glds_kernel<2, 5>), grid, dim3(256), lds, (hipStream_t)stream, dY, ldy, X, ldx, out_partials, db_partials, M, N, K, mchunk);
+    else if (stages == 3)
+      hipLaunchKernelGGL((gemm_tn_glds_kernel<1, 3>), grid, dim3(256), lds, (hipStream_t)stream, dY, ldy, X, ldx, out_partials, db_partials, M, N, K, mchunk);
+    else
+      hipLaunchKernelGGL((gemm_tn_glds_kernel<1, 5>), grid, dim3(256), lds, (hipStream_t)stream, dY, ldy, X, ldx, out_partials, db_partials, M, N, K, mchunk);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(gemm_tn_x3_kernel, dim3((K + 127) / 128, (N + 127) / 128, nz), dim3(256), 0, (hipStream_t)stream, dY,
                      ldy, X, ldx, out_partials, db_partials, M, N, K, mchunk);
   return (int)hipGetLastError();

@@ -15,7 +15,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from ..registry import TRANSFORMER_DECODER_REGISTRY
-from ..ops.linear import Linear, linear
+from ..ops.linear import Linear, in_proj, linear
 from .layers import MLP, position_embedding_sine
 
 
@@ -36,10 +36,10 @@ class _MHAParams(nn.Module):
         E, H = self.embed_dim, self.num_heads
         B, Lq, _ = query.shape
         Lk = key.shape[1]
-        W, b = self.in_proj_weight, self.in_proj_bias
-        q = linear(query, W[:E], b[:E]).view(B, Lq, H, E // H).transpose(1, 2)
-        k = linear(key, W[E:2 * E], b[E:2 * E]).view(B, Lk, H, E // H).transpose(1, 2)
-        v = linear(value, W[2 * E:], b[2 * E:]).view(B, Lk, H, E // H).transpose(1, 2)
+        q, k, v = in_proj(query, key, value, self.in_proj_weight, self.in_proj_bias, same_qk=query is key)
+        q = q.view(B, Lq, H, E // H).transpose(1, 2)
+        k = k.view(B, Lk, H, E // H).transpose(1, 2)
+        v = v.view(B, Lk, H, E // H).transpose(1, 2)
         mask = None if blocked is None else (~blocked)[:, None]  # SDPA: True = may attend
         o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
         return self.out_proj(o.transpose(1, 2).reshape(B, Lq, E))

@@ -25,23 +25,37 @@ def set_impl(name):
     _IMPL = name
 
 
-def gemm_tn_x3(dy, x, with_bias_grad=False):
+def gemm_tn_x3(dy, x, with_bias_grad=False, out=None, db_out=None):
     """dW[N,K] = dy[M,N]^T @ x[M,K] on csrc/gemm_tn.hip (fp32-accurate bf16x3 MFMA, split-K over the tokens);
-    with_bias_grad: also return db[N] = dy.sum(0), accumulated in the same pass."""
+    with_bias_grad: also return db[N] = dy.sum(0), accumulated in the same pass.  The split-K partials (and the
+    bias partials) are finished by ONE reduce launch that writes straight into `out` / `db_out` when given
+    (contiguous row blocks of a packed gradient, e.g. nn.MultiheadAttention's in_proj)."""
     lib = _lib.lib()
     M, N = dy.shape
     K = x.shape[1]
     splits = lib.combo_gemm_tn_splits(M, N, K)
     mchunk = (-(-M // splits) + 15) // 16 * 16
     splits = -(-M // mchunk)
-    part = torch.empty(splits, N, K, device=dy.device, dtype=torch.float32)
-    dbp = torch.empty(splits, N, device=dy.device, dtype=torch.float32) if with_bias_grad else None
+    dev = dy.device
+    part = torch.empty(splits, N, K, device=dev, dtype=torch.float32)
+    dbp = torch.empty(splits, N, device=dev, dtype=torch.float32) if with_bias_grad else None
+    st = _lib.current_stream()
     _lib.check(lib.combo_gemm_tn_x3_f32(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), part.data_ptr(), _lib.ptr(dbp),
-                                        M, N, K, splits, _lib.current_stream()), "combo_gemm_tn_x3_f32")
-    dw = part.sum(0) if splits > 1 else part[0]
+                                        M, N, K, splits, st), "combo_gemm_tn_x3_f32")
+    if out is None and splits == 1 and (db_out is None):
+        return (part[0], dbp[0]) if with_bias_grad else part[0]
+    dw = out if out is not None else torch.empty(N, K, device=dev, dtype=torch.float32)
+    db = None
     if with_bias_grad:
-        return dw, dbp.sum(0)
-    return dw
+        db = db_out if db_out is not None else torch.empty(N, device=dev, dtype=torch.float32)
+    if (N * K) % 4 == 0 and dw.is_contiguous() and dw.data_ptr() % 16 == 0 and (db is None or db.is_contiguous()):
+        _lib.check(lib.combo_splitk_reduce_f32(part.data_ptr(), splits, N * K, dw.data_ptr(), _lib.ptr(dbp),
+                                               N if with_bias_grad else 0, _lib.ptr(db), st), "combo_splitk_reduce_f32")
+    else:
+        torch.sum(part, 0, out=dw)
+        if with_bias_grad:
+            torch.sum(dbp, 0, out=db)
+    return (dw, db) if with_bias_grad else dw
 
 
 class _split3:
@@ -82,7 +96,7 @@ class _LinearLib3x(Function):
                 dx = dy @ weight
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            if dy.is_contiguous() and x2d.is_contiguous() and dy.shape[0] >= 2048:
+            if dy.stride(1) == 1 and x2d.stride(1) == 1 and dy.shape[0] >= 512:
                 # long-reduction / tiny-output shape: 3x faster than the library GEMM; db rides along
                 r = gemm_tn_x3(dy, x2d, with_bias_grad=want_db)
                 dw, db = r if want_db else (r, None)
@@ -92,6 +106,70 @@ class _LinearLib3x(Function):
         if want_db and db is None:
             db = dy.sum(0)
         return dx, dw, db, None
+
+
+def _dw_into(dy, x2d, dw_out, db_out):
+    """dW (+ db) of one projection, written into row blocks of a packed gradient."""
+    if dy.stride(1) == 1 and x2d.stride(1) == 1 and dy.shape[0] >= 512:
+        gemm_tn_x3(dy, x2d, with_bias_grad=db_out is not None, out=dw_out, db_out=db_out)
+    else:
+        with _split3(False):
+            torch.mm(dy.t(), x2d, out=dw_out)
+        if db_out is not None:
+            torch.sum(dy, 0, out=db_out)
+
+
+class _InProj(Function):
+    """q, k, v = nn.MultiheadAttention's packed input projection.  The packed [3E,E] weight is sliced INSIDE the node:
+    sliced leaves would cost, per attention layer and step, 6 zero-filled [3E,E]/[3E] gradients + 6 slice copies +
+    4 accumulation adds in autograd; here the three weight gradients land in row blocks of one [3E,E] tensor."""
+
+    @staticmethod
+    def forward(ctx, xq, xk, xv, W, b, same_qk):
+        E = W.shape[1]
+        with _split3(True):
+            q = torch.nn.functional.linear(xq, W[:E], b[:E])
+            k = torch.nn.functional.linear(xk, W[E:2 * E], b[E:2 * E])
+            v = torch.nn.functional.linear(xv, W[2 * E:], b[2 * E:])
+        ctx.save_for_backward(xq, xk, xv, W)
+        ctx.same_qk = same_qk
+        return q, k, v
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dq, dk, dv):
+        xq, xk, xv, W = ctx.saved_tensors
+        E = W.shape[1]
+        dq, dk, dv = dq.contiguous(), dk.contiguous(), dv.contiguous()
+        dxq = dxk = dxv = None
+        with _split3(True):
+            if ctx.needs_input_grad[0]:
+                dxq = dq @ W[:E]
+                if ctx.same_qk:  # q and k read the same tensor: accumulate in the GEMM epilogue, not in autograd
+                    dxq = torch.addmm(dxq, dk, W[E:2 * E])
+            if ctx.needs_input_grad[1] and not ctx.same_qk:
+                dxk = dk @ W[E:2 * E]
+            if ctx.needs_input_grad[2]:
+                dxv = dv @ W[2 * E:]
+        dW = db = None
+        if ctx.needs_input_grad[3]:
+            dW = torch.empty_like(W)
+            db = torch.empty(3 * E, device=W.device, dtype=W.dtype)
+            for i, (dy, x) in enumerate(((dq, xq), (dk, xk), (dv, xv))):
+                _dw_into(dy, x, dW[i * E:(i + 1) * E], db[i * E:(i + 1) * E])
+        return dxq, dxk, dxv, dW, db, None
+
+
+def in_proj(xq, xk, xv, weight, bias, same_qk=False):
+    """Packed q/k/v projection of nn.MultiheadAttention ([..., E] inputs -> three [..., E] outputs).  same_qk: xq and
+    xk are the same tensor (self-attention); pass xk=None-equivalent semantics by giving the tensor twice."""
+    E = weight.shape[1]
+    if torch.is_autocast_enabled() or not xq.is_cuda or xq.dtype != torch.float32:
+        return (linear(xq, weight[:E], bias[:E]), linear(xk, weight[E:2 * E], bias[E:2 * E]),
+                linear(xv, weight[2 * E:], bias[2 * E:]))
+    shp = (xq.shape[:-1], xk.shape[:-1], xv.shape[:-1])
+    q, k, v = _InProj.apply(xq.reshape(-1, E), xk.reshape(-1, E), xv.reshape(-1, E), weight, bias, same_qk)
+    return q.view(*shp[0], E), k.view(*shp[1], E), v.view(*shp[2], E)
 
 
 def gemm_x3(A, a_rowc, B, b_rowc, M, N, K, bias=None, relu=False, splits=1):

@@ -136,6 +136,11 @@ int combo_gemm_tn_splits(int M, int N, int K);
 /*   db_partials (optional, [splits,N]): per-split column sums of dY = the bias gradient, fused into the same pass. */
 int combo_gemm_tn_x3_f32(const float* dY, long long ldy, const float* X, long long ldx, float* out_partials,
                          float* db_partials, int M, int N, int K, int splits, combo_stream_t stream);
+/*   Finishes a split-K result in ONE launch: out[i] = sum_z partials[z*n + i] (n % 4 == 0, 16-byte aligned) and, when
+ *   nb > 0, db[j] = sum_z db_partials[z*nb + j]; fixed summation order.  `out` may be a row block of a larger matrix
+ *   (nn.MultiheadAttention's packed in_proj_weight gradient). */
+int combo_splitk_reduce_f32(const float* partials, int splits, long long n, float* out, const float* db_partials, int nb,
+                            float* db, combo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a13 (tail)  next-layer attention mask

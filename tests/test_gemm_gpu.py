@@ -84,7 +84,9 @@ def test_microbench_vs_library(capsys):
     assert t_x3 < t_lib
 
 
-@pytest.mark.parametrize("M,N,K", [(41160, 1024, 256), (41160, 256, 1024), (31360, 256, 256), (41160, 96, 256), (4001, 192, 128)])
+@pytest.mark.parametrize("M,N,K", [(41160, 1024, 256), (41160, 256, 1024), (31360, 256, 256), (41160, 96, 256), (4001, 192, 128),
+                                   (4000, 256, 2048), (4000, 2048, 256), (1960, 256, 256), (300, 68, 260), (5000, 3, 256),
+                                   (257, 64, 64), (41160, 288, 256)])
 def test_weight_gradient_gemm_tn(M, N, K, capsys):
     import combo_avs_amd  # noqa: F401
     from combo_avs_amd.ops.linear import gemm_tn_x3
@@ -109,3 +111,22 @@ def test_weight_gradient_gemm_tn(M, N, K, capsys):
         return s.elapsed_time(e) / 10 * 1e3
     with capsys.disabled():
         print(f"\n[dW {M}x{N}x{K}] library {t(lambda: dy.t() @ x):.0f} us, gemm_tn_x3 {t(lambda: gemm_tn_x3(dy, x)):.0f} us")
+
+
+def test_weight_gradient_gemm_tn_strided_views_and_packed_output():
+    """Row-strided operands (column blocks of wider tensors) and the reduce writing into a row block of a packed
+    gradient (nn.MultiheadAttention's in_proj layout)."""
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.ops.linear import gemm_tn_x3
+    torch.manual_seed(3)
+    M, N, K = 7840, 256, 256
+    big_dy = torch.randn(M, 3 * N, device="cuda")
+    big_x = torch.randn(M, K + 64, device="cuda")
+    dy, x = big_dy[:, N:2 * N], big_x[:, 64:]
+    dW = torch.full((3 * N, K), 7.0, device="cuda")
+    db = torch.full((3 * N,), 7.0, device="cuda")
+    gemm_tn_x3(dy, x, with_bias_grad=True, out=dW[N:2 * N], db_out=db[N:2 * N])
+    ref = dy.double().t() @ x.double()
+    assert rel_err(dW[N:2 * N], ref) < 2e-5
+    assert rel_err(db[N:2 * N], dy.double().sum(0)) < 1e-5
+    assert (dW[:N] == 7).all() and (dW[2 * N:] == 7).all() and (db[:N] == 7).all() and (db[2 * N:] == 7).all()
