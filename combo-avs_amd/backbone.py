@@ -5,7 +5,10 @@ Parameter / buffer names follow detectron2 (`stem.conv1.weight`, `res2.0.conv1.n
 torchvggish (`features.N`, `embeddings.N`) so reference checkpoints load 1:1.
 
 MI355X notes: FrozenBN is an affine map with constant statistics, so it is folded into the preceding conv's
-weights each step (w' = w * scale, b' = shift) and the conv runs with bias; activations are channels_last."""
+weights each step (w' = w * scale, b' = shift) and the conv runs with bias; activations are channels_last.
+The fold of ALL convolutions of a ResNet (+ the cast to the compute dtype, + the way back for the gradients) is ONE
+autograd node built on multi-tensor (`torch._foreach_*`) kernels: ~4 launches per backbone and direction instead of
+~10 tiny launches per convolution (53 convolutions x 2 backbones); scale/shift are cached (the statistics are frozen)."""
 import torch
 from torch import nn
 from torch.nn import functional as F
@@ -31,6 +34,32 @@ class FrozenBatchNorm2d(nn.Module):
         return x * scale.to(x.dtype)[None, :, None, None] + shift.to(x.dtype)[None, :, None, None]
 
 
+class _FoldAll(torch.autograd.Function):
+    """folded_i = (weight_i * scale_i).to(dtype) for every convolution of a backbone, as one node."""
+
+    @staticmethod
+    def forward(ctx, dtype, scales, *weights):
+        folded = torch._foreach_mul(weights, scales)
+        if dtype != torch.float32:
+            out = [torch.empty_like(w, dtype=dtype) for w in weights]
+            torch._foreach_copy_(out, folded)
+        else:
+            out = folded
+        ctx.scales = scales
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        idx = [i for i, g in enumerate(grads) if g is not None]
+        g32 = [torch.empty_like(grads[i], dtype=torch.float32) for i in idx]
+        torch._foreach_copy_(g32, [grads[i] for i in idx])
+        torch._foreach_mul_(g32, [ctx.scales[i] for i in idx])
+        out = [None] * len(grads)
+        for i, g in zip(idx, g32):
+            out[i] = g
+        return (None, None) + tuple(out)
+
+
 class ConvBN(nn.Conv2d):
     """conv (no bias) + FrozenBN, folded: conv(x, w*scale) + shift."""
 
@@ -39,7 +68,9 @@ class ConvBN(nn.Conv2d):
         self.norm = FrozenBatchNorm2d(cout)
         nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")
 
-    def forward(self, x):
+    def forward(self, x, folded=None):
+        if folded is not None:  # (w * scale, shift) prepared for the whole backbone by ResNet.forward
+            return F.conv2d(x, folded[0], folded[1], self.stride, self.padding)
         scale, shift = self.norm.scale_shift()
         w = self.weight * scale[:, None, None, None]
         return F.conv2d(x, w, shift, self.stride, self.padding)  # autocast (if enabled) picks the compute dtype
@@ -53,11 +84,16 @@ class Bottleneck(nn.Module):
         self.conv2 = ConvBN(mid, mid, 3, stride=stride, padding=1)  # STRIDE_IN_1X1: False
         self.conv3 = ConvBN(mid, cout, 1)
 
-    def forward(self, x):
-        out = F.relu_(self.conv1(x))
-        out = F.relu_(self.conv2(out))
-        out = self.conv3(out)
-        sc = self.shortcut(x) if self.shortcut is not None else x
+    def convs(self):
+        """the order `forward` consumes the folded weights in"""
+        return [self.conv1, self.conv2, self.conv3] + ([self.shortcut] if self.shortcut is not None else [])
+
+    def forward(self, x, folded=None):
+        nxt = (lambda: next(folded)) if folded is not None else (lambda: None)
+        out = F.relu_(self.conv1(x, nxt()))
+        out = F.relu_(self.conv2(out, nxt()))
+        out = self.conv3(out, nxt())
+        sc = self.shortcut(x, nxt()) if self.shortcut is not None else x
         return F.relu_(out + sc)
 
 
@@ -66,8 +102,9 @@ class BasicStem(nn.Module):
         super().__init__()
         self.conv1 = ConvBN(cin, cout, 7, stride=2, padding=3)
 
-    def forward(self, x):
-        return F.max_pool2d(F.relu_(self.conv1(x)), kernel_size=3, stride=2, padding=1)
+    def forward(self, x, folded=None):
+        return F.max_pool2d(F.relu_(self.conv1(x, next(folded) if folded is not None else None)), kernel_size=3, stride=2,
+                            padding=1)
 
 
 class ResNet(nn.Module):
@@ -86,14 +123,45 @@ class ResNet(nn.Module):
             setattr(self, name, nn.Sequential(*layers))
             self._strides[name], self._channels[name] = 4 * 2 ** i, cout
         self.size_divisibility = 0
+        self._bn_cache = {}
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._bn_cache.clear())
+
+    def _apply(self, fn, *args, **kwargs):
+        self._bn_cache.clear()  # .to() / .cuda() moved the frozen statistics
+        return super()._apply(fn, *args, **kwargs)
+
+    def _conv_list(self):
+        convs = [self.stem.conv1]
+        for name in ("res2", "res3", "res4", "res5"):
+            for blk in getattr(self, name):
+                convs += blk.convs()
+        return convs
+
+    def _frozen_affine(self, convs, dtype):
+        """(scale [C,1,1,1] fp32, shift [C] compute-dtype) of every FrozenBN: constants, computed once."""
+        key = (dtype, str(convs[0].weight.device))
+        if key not in self._bn_cache:
+            with torch.no_grad():
+                ss = [c.norm.scale_shift() for c in convs]
+                self._bn_cache[key] = ([sc[:, None, None, None].contiguous() for sc, _ in ss], [sh.to(dtype) for _, sh in ss])
+        return self._bn_cache[key]
 
     def forward(self, x):
-        x = self.stem(x.contiguous(memory_format=torch.channels_last))
-        out = {}
-        for name in ("res2", "res3", "res4", "res5"):
-            x = getattr(self, name)(x)
-            if name in self._out_features:
-                out[name] = x
+        # compute dtype: the caller's autocast dtype, made explicit (weights are folded + cast by one node for the whole
+        # backbone, activations are cast once at the input)
+        dtype = torch.get_autocast_dtype("cuda") if (x.is_cuda and torch.is_autocast_enabled("cuda")) else x.dtype
+        convs = self._conv_list()
+        scales, shifts = self._frozen_affine(convs, dtype)
+        folded_w = _FoldAll.apply(dtype, scales, *[c.weight for c in convs])
+        folded = iter(zip(folded_w, shifts))
+        with torch.autocast("cuda", enabled=False):
+            x = self.stem(x.to(dtype).contiguous(memory_format=torch.channels_last), folded)
+            out = {}
+            for name in ("res2", "res3", "res4", "res5"):
+                for blk in getattr(self, name):
+                    x = blk(x, folded)
+                if name in self._out_features:
+                    out[name] = x
         return out
 
     def output_shape(self):

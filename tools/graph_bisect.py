@@ -112,6 +112,14 @@ if os.environ.get("PROFILE"):
     for _ in range(3):
         run()
     torch.cuda.synchronize()
+    if os.environ.get("OPS"):  # aten-op level table (which framework ops own the small kernels)
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+            run()
+            torch.cuda.synchronize()
+        print(prof.key_averages(group_by_input_shape=bool(os.environ.get("SHAPES"))).table(
+            sort_by="self_cuda_time_total", row_limit=int(os.environ.get("TOP", "40")), max_name_column_width=48,
+            max_shapes_column_width=60))
+        raise SystemExit(0)
     with profile(activities=[ProfilerActivity.CUDA]) as prof:
         run()
         torch.cuda.synchronize()
