@@ -58,6 +58,32 @@ def gemm_tn_x3(dy, x, with_bias_grad=False, out=None, db_out=None):
     return (dw, db) if with_bias_grad else dw
 
 
+import os as _os
+NT_MIN_ROWS = 16384 if _os.environ.get('COMBO_GEMM_NT', '1') == '1' else 1 << 60  # csrc/gemm_nt.hip needs enough 256-token tiles to fill the chip; below: hipBLASLt's 3xbf16 mode
+
+
+def gemm_nt_x3(a, b, bias=None, relu=False):
+    """C[M,N] = a[M,K] @ b[N,K]^T (+ bias) (+ ReLU) on csrc/gemm_nt.hip (fp32-accurate bf16x3 MFMA, LDS-DMA ring)."""
+    M, K = a.shape
+    N = b.shape[0]
+    out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    _lib.check(_lib.lib().combo_gemm_nt_x3_f32(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), _lib.ptr(bias),
+                                               out.data_ptr(), N, M, N, K, 1 if relu else 0, _lib.current_stream()),
+               "combo_gemm_nt_x3_f32")
+    return out
+
+
+def _nt_ok(a, n_out, b=None):
+    """csrc/gemm_nt.hip wins over hipBLASLt's 3xbf16 path once its 256 x 128 tiles fill the chip (measured in
+    tests/test_gemm_gpu.py: 143 vs 258 us at 41160x256->1024, but 38 vs 23 us at ->96 and 139 vs 90 us at 16384x2048->256)."""
+    tiles = -(-a.shape[0] // 256) * -(-n_out // 128)
+    ok = (a.shape[0] >= NT_MIN_ROWS and tiles >= 256 and n_out >= 128 and a.shape[1] % 16 == 0 and a.stride(1) == 1 and
+          a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0)
+    if b is not None:
+        ok = ok and b.stride(1) == 1 and b.stride(0) % 4 == 0 and b.data_ptr() % 16 == 0
+    return ok
+
+
 class _split3:
     """context: route library GEMMs through hipBLASLt's bf16x3 path (torch spells the switch `allow_tf32`)."""
 
@@ -75,10 +101,13 @@ class _split3:
 class _LinearLib3x(Function):
     @staticmethod
     def forward(ctx, x2d, weight, bias, relu):
-        with _split3(True):
-            y = torch.nn.functional.linear(x2d, weight, bias)
-        if relu:
-            y = torch.relu_(y)
+        if _nt_ok(x2d, weight.shape[0], weight) and (bias is None or bias.is_contiguous()):
+            y = gemm_nt_x3(x2d, weight, bias, relu)  # bias + ReLU in the epilogue
+        else:
+            with _split3(True):
+                y = torch.nn.functional.linear(x2d, weight, bias)
+            if relu:
+                y = torch.relu_(y)
         ctx.save_for_backward(x2d, weight, y if relu else None)
         ctx.relu = relu
         ctx.has_bias = bias is not None
@@ -92,8 +121,13 @@ class _LinearLib3x(Function):
             dy = dy * (y > 0)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            with _split3(True):
-                dx = dy @ weight
+            dyc = dy if dy.stride(1) == 1 else dy.contiguous()
+            if _nt_ok(dyc, weight.shape[1]):  # (the transposed weight below is contiguous and freshly allocated)
+                # [K,N]: a weight-sized transpose so that dX = dY . W is the same K-contiguous NT kernel
+                dx = gemm_nt_x3(dyc, weight.t().contiguous())
+            else:
+                with _split3(True):
+                    dx = dy @ weight
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             if dy.stride(1) == 1 and x2d.stride(1) == 1 and dy.shape[0] >= 512:

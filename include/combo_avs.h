@@ -128,6 +128,12 @@ int combo_gemm_x3_f32(const float* A, long long lda, int a_rowc, const float* B,
                       const float* bias, float* C, long long ldc, int M, int N, int K, int relu, int splits,
                       long long split_stride, combo_stream_t stream);
 
+/*   Forward / input-gradient GEMM C[M,N] = A[M,K] . B[N,K]^T (+ bias[N]) (+ ReLU) with the same 3-way bf16 split, both
+ *   operands K-contiguous (A = tokens, B = an nn.Linear weight; for dX = dY . W pass B = W^T).  LDS-DMA ring with a
+ *   source-side chunk swizzle (csrc/gemm_nt.hip).  K % 16 == 0, lda/ldb % 4 == 0, A and B 16-byte aligned. */
+int combo_gemm_nt_x3_f32(const float* A, long long lda, const float* B, long long ldb, const float* bias, float* C,
+                         long long ldc, int M, int N, int K, int relu, combo_stream_t stream);
+
 /*   Weight gradient dW[N,K] = dY[M,N]^T . X[M,K] (reduction over the M tokens), same 3-way bf16 split, fragments loaded
  *   straight from global memory (no LDS), split-K over M: partial z is written at out_partials + z*N*K and the caller
  *   sums the partials.  `splits` must be a value for which ceil(M / roundup16(ceil(M/splits))) == splits

@@ -130,3 +130,54 @@ def test_weight_gradient_gemm_tn_strided_views_and_packed_output():
     assert rel_err(dW[N:2 * N], ref) < 2e-5
     assert rel_err(db[N:2 * N], dy.double().sum(0)) < 1e-5
     assert (dW[:N] == 7).all() and (dW[2 * N:] == 7).all() and (db[:N] == 7).all() and (db[2 * N:] == 7).all()
+
+
+@pytest.mark.parametrize("M,K,N,bias,relu", [(41160, 256, 1024, True, True), (41160, 1024, 256, True, False),
+                                             (41160, 256, 192, True, False), (41160, 256, 96, False, False),
+                                             (20001, 64, 288, True, True), (16384, 2048, 256, False, False),
+                                             (300, 16, 40, True, False)])
+def test_gemm_nt_x3(M, K, N, bias, relu, capsys):
+    """C = A B^T (+bias, +ReLU) on csrc/gemm_nt.hip vs fp64; ragged M / N tiles, K a multiple of 16."""
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.ops.linear import gemm_nt_x3
+    torch.manual_seed(M + K + N)
+    a = torch.randn(M, K, device="cuda")
+    w = torch.randn(N, K, device="cuda") * 0.1
+    b = torch.randn(N, device="cuda") if bias else None
+    got = gemm_nt_x3(a, w, b, relu)
+    ref = a.double() @ w.double().t()
+    if bias:
+        ref = ref + b.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    assert rel_err(got, ref) < 2e-5, rel_err(got, ref)
+
+    def t(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(10):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / 10 * 1e3
+
+    def lib3():
+        torch.backends.cuda.matmul.allow_tf32 = True
+        y = torch.nn.functional.linear(a, w, b)
+        torch.backends.cuda.matmul.allow_tf32 = False
+        return y
+    with capsys.disabled():
+        print(f"\n[NT {M}x{K}->{N}] hipBLASLt 3xbf16 {t(lib3):.0f} us, gemm_nt_x3 {t(lambda: gemm_nt_x3(a, w, b, relu)):.0f} us")
+
+
+def test_gemm_nt_x3_strided_token_operand():
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.ops.linear import gemm_nt_x3
+    torch.manual_seed(5)
+    big = torch.randn(20000, 512, device="cuda")
+    a = big[:, 128:384]  # row stride 512, 16-byte aligned start
+    w = torch.randn(200, 256, device="cuda")
+    assert rel_err(gemm_nt_x3(a, w), a.double() @ w.double().t()) < 2e-5
