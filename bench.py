@@ -105,6 +105,52 @@ def cpu_baseline(timeout_s=300):
                 "sample": f"one oracle step did not finish within {timeout_s} s on this host"}
 
 
+def infer_bench(args, model, batch, world, rank, dev):
+    """Eval-mode throughput: dual backbones + VGGish + SEM mix + head + fused upsample/sigmoid/class-mix tail
+    (csrc/infer.hip), the whole forward replayed from one hipGraph.  Prints one JSON line (not the BASELINE metric)."""
+    model.eval()
+    eval_batch = [{k: v for k, v in b.items() if k != "instances"} for b in batch]
+
+    def fwd():
+        with torch.no_grad():
+            return model(eval_batch)
+    for _ in range(2):
+        fwd()
+    torch.cuda.synchronize()
+    step = fwd
+    if not args.no_graph:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            static_out = fwd()
+        step = g.replay
+    for _ in range(args.warmup):
+        step()
+    if dist.is_initialized():
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if dist.is_initialized():
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist.is_initialized():
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        frames = args.clips * 5 * world * args.steps
+        print(json.dumps({
+            "metric": "inference frames/sec (224x224, 5-frame clips)", "value": round(frames / elapsed, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": f"COMBO-R50 S4 eval forward, bs={args.clips} clips x 5 frames x 224x224 per GPU -> "
+                                   "[K,224,224] semantic maps per frame", "launch": "eager" if args.no_graph else "hipGraph",
+                       "parallelism": f"dp{world}"}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,6 +161,9 @@ def main():
     ap.add_argument("--head-dtype", default="fp32", choices=["bf16", "fp32"], help="dense layers of the head")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of the captured hipGraph step")
+    ap.add_argument("--mode", default="train", choices=["train", "infer"],
+                    help="train = the BASELINE metric (default); infer = eval-mode forward + fused semantic-inference tail "
+                         "(SURVEY 8(f) rank 4: what pred.py times)")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_child:
@@ -153,6 +202,11 @@ def main():
                     backbone_multiplier=cfg.SOLVER.BACKBONE_MULTIPLIER, clip_value=cfg.SOLVER.CLIP_GRADIENTS.CLIP_VALUE)
     T, H, W = 5, 224, 224
     batch = synth_batch(args.clips, T, H, W, dev, seed=100 + rank)
+    if args.mode == "infer":
+        infer_bench(args, model, batch, world, rank, dev)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
 
     def sync():
         if dist.is_initialized():
@@ -223,6 +277,24 @@ def main():
         roof = {"kernel": "msda_fwd_tap_d32", "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 4), "traffic": traffic, "avg_launch_us": round(avg_us, 2),
                 "launches": len(kt["fwd_us"]), "algorithmic_bytes_per_launch": fwd_bytes}
+    # secondary rooflines (same HIP-event pass): the two hand-written 3xbf16 GEMM kernels against the dense bf16 MFMA
+    # peak (2.5 PFLOP/s); MFMA flops = 3 products x 2*M*N*K.  Only the large launches (>= 1 GFLOP) are counted.
+    kernels = {}
+    for kind in ("gemm_nt_x3", "gemm_tn_x3"):
+        evs = [(us, meta) for us, meta in kt.get("kernels", {}).get(kind, []) if meta and 2.0 * meta[0] * meta[1] * meta[2] >= 1e9]
+        if evs:
+            flops = sum(3 * 2.0 * m[0] * m[1] * m[2] for _, m in evs)
+            tsum = sum(us for us, _ in evs) * 1e-6
+            kernels[kind] = {"bound": "mfma", "launches_timed": len(evs), "avg_launch_us": round(tsum / len(evs) * 1e6, 1),
+                             "achieved": round(flops / tsum / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s (bf16 MFMA, 3 products per fp32 MAC)",
+                             "frac": round(flops / tsum / 2.5e15, 4), "fp32_equivalent_tflops": round(flops / 3 / tsum / 1e12, 1)}
+    bwd = kt.get("bwd_us") or []
+    if bwd:
+        bwd_bytes = bt * 5.53e6  # SURVEY 8(d)-style count: value grad 1.05 + loc/w in 1.19 + grads out 1.19 + grad_out 1.05 + value 1.05 MB
+        kernels["msda_bwd (value + loc/w kernels)"] = {"bound": "hbm", "avg_launch_us": round(sum(bwd) / len(bwd), 1),
+                                                       "achieved": round(bwd_bytes / (sum(bwd) / len(bwd) * 1e-6) / 1e9, 1),
+                                                       "peak": 8000.0, "unit": "GB/s",
+                                                       "frac": round(bwd_bytes / (sum(bwd) / len(bwd) * 1e-6) / 8e12, 4)}
     if rank == 0:
         out = {
             "metric": "train frames/sec (224x224, 5-frame clips)", "value": round(value, 2), "unit": "frames/s",
@@ -235,6 +307,7 @@ def main():
                        "global_batch_clips": args.clips * world, "frames_per_clip": T, "parallelism": f"dp{world}",
                        "precision": "bf16 backbones (host PyTorch), fp32 head + HIP kernels" if args.dtype == "bf16" else "fp32"},
             "roofline": roof,
+            "other_kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

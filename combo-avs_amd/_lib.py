@@ -16,6 +16,7 @@ c_void_p, c_int, c_float, c_longlong = ctypes.c_void_p, ctypes.c_int, ctypes.c_f
 _SIGNATURES = {
     "combo_abi_version": [],
     "combo_build_arch": [],
+    "combo_msda_backward_needs_zero": [c_int] * 6,
     "combo_msda_forward_f32": [c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_int, c_void_p],
     "combo_msda_forward_f64": [c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_int, c_void_p],
     "combo_msda_backward_f32": [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 3 + [c_int, c_void_p],
@@ -102,3 +103,52 @@ def require_cuda(*tensors, channels_last=False):
 def torch_channels_last():
     import torch
     return torch.channels_last
+
+
+# ---- kernel timing (bench.py): HIP events from the C ABI around selected launches -------------------------------
+_timing = None  # {kind: [(start_event, stop_event, meta)]} while a measurement is running
+
+
+def start_timing():
+    """Bracket every instrumented launch (ops wrapped in `timed(kind)`) with HIP events on the launch stream until
+    stop_timing().  Launches issued while the stream is being captured into a hipGraph are skipped (HIP rejects event
+    records inside a capture on ROCm 7)."""
+    global _timing
+    _timing = {}
+
+
+def stop_timing():
+    """-> {kind: [(microseconds, meta), ...]} (synchronises)."""
+    import torch
+    global _timing
+    t, _timing = _timing, None
+    torch.cuda.synchronize()
+    out = {}
+    for kind, evs in (t or {}).items():
+        out[kind] = []
+        for s, e, meta in evs:
+            us = ctypes.c_float(0.0)
+            check(lib().combo_event_elapsed_us(s, e, ctypes.byref(us)), "combo_event_elapsed_us")
+            out[kind].append((float(us.value), meta))
+            lib().combo_event_destroy(s)
+            lib().combo_event_destroy(e)
+    return out
+
+
+class timed:
+    def __init__(self, kind, meta=None):
+        self.kind, self.meta = kind, meta
+
+    def __enter__(self):
+        import torch
+        self.on = _timing is not None and not torch.cuda.is_current_stream_capturing()
+        if self.on:
+            self.s, self.e = ctypes.c_void_p(), ctypes.c_void_p()
+            check(lib().combo_event_create(ctypes.byref(self.s)), "combo_event_create")
+            check(lib().combo_event_create(ctypes.byref(self.e)), "combo_event_create")
+            check(lib().combo_event_record(self.s, current_stream(), 0), "combo_event_record")
+
+    def __exit__(self, *a):
+        if self.on and _timing is not None:
+            check(lib().combo_event_record(self.e, current_stream(), 0), "combo_event_record")
+            _timing.setdefault(self.kind, []).append((self.s, self.e, self.meta))

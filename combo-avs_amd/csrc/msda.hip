@@ -1104,6 +1104,14 @@ int msda_backward(const T* gout, const T* value, const int64_t* shapes, const in
 
 extern "C" {
 
+// 0 when combo_msda_backward_* will take the LDS kernels, which write every element of the three gradients; 1 when the
+// generic global-atomics kernels run and the caller has to zero-fill the outputs (mirrors the dispatch in msda_backward)
+int combo_msda_backward_needs_zero(int S, int D, int L, int P, int elem_bytes, int algo) {
+  const bool lds_ok = elem_bytes == 4 && D == 32 && S < 65535 && L * P <= kMaxLP && fwd_lds_bytes(S, L, P, 8) <= kLdsLimit &&
+                      bwd_value_lds_bytes(S) <= kLdsLimit;
+  return (lds_ok && algo != 1) ? 0 : 1;
+}
+
 int combo_msda_forward_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
                            const float* sampling_loc, const float* attn_weight, int B, int S, int M, int D, int L,
                            int Lq, int P, float* out, int algo, combo_stream_t stream) {

@@ -16,68 +16,21 @@ from . import _lib
 
 ALGO_AUTO, ALGO_GENERIC, ALGO_LDS, ALGO_TAP = 0, 1, 2, 3  # 2: one tile per workgroup (v1), 3: persistent tap-parallel forward
 _algo = ALGO_AUTO
-_timing = None  # {"fwd": [(start_event, end_event)], "bwd": [...]} while bench.py measures kernel durations
-
-
-_graph_only = False
 
 
 def start_timing(graph=False):
-    """Record HIP events (on the launch stream) around every core-op launch until stop_timing().
-    graph=True: only launches issued while the stream is being captured into a hipGraph are bracketed, with
-    *external* event-record nodes (hipEventRecordExternal); after any replay the events hold that replay's
-    timestamps, so stop_timing() returns the per-launch durations of the most recent replay."""
-    global _timing, _graph_only
-    _timing = {"fwd": [], "bwd": []}
-    _graph_only = bool(graph)
+    """Record HIP events around every instrumented launch (MSDeformAttn core, dense-layer GEMMs) until stop_timing()."""
+    _lib.start_timing()
 
 
 def stop_timing():
-    """-> {"fwd_us": [...], "bwd_us": [...]} per-launch durations in microseconds (synchronises)."""
-    import ctypes
-    global _timing
-    t, _timing = _timing, None
-    torch.cuda.synchronize()
-    lib = _lib.lib()
-    out = {}
-    for k, v in (t or {"fwd": [], "bwd": []}).items():
-        out[k + "_us"] = []
-        for s, e in v:
-            us = ctypes.c_float(0.0)
-            _lib.check(lib.combo_event_elapsed_us(s, e, ctypes.byref(us)), "combo_event_elapsed_us")
-            out[k + "_us"].append(float(us.value))
-            lib.combo_event_destroy(s)
-            lib.combo_event_destroy(e)
-    return out
+    """-> {"fwd_us": [...], "bwd_us": [...], "kernels": {kind: [(us, meta)]}} per-launch durations (synchronises)."""
+    t = _lib.stop_timing()
+    return {"fwd_us": [u for u, _ in t.get("msda_fwd", [])], "bwd_us": [u for u, _ in t.get("msda_bwd", [])], "kernels": t}
 
 
-def _new_event():
-    import ctypes
-    ev = ctypes.c_void_p()
-    _lib.check(_lib.lib().combo_event_create(ctypes.byref(ev)), "combo_event_create")
-    return ev
-
-
-class _Timed:
-    """HIP events straight from the C ABI (torch refuses external event records on ROCm)."""
-
-    def __init__(self, kind):
-        self.kind = kind
-
-    def __enter__(self):
-        self.on = _timing is not None
-        if self.on:
-            self.capturing = torch.cuda.is_current_stream_capturing()
-            if _graph_only and not self.capturing:
-                self.on = False
-                return
-            self.s, self.e = _new_event(), _new_event()
-            _lib.check(_lib.lib().combo_event_record(self.s, _lib.current_stream(), int(self.capturing)), "combo_event_record")
-
-    def __exit__(self, *a):
-        if self.on and _timing is not None:
-            _lib.check(_lib.lib().combo_event_record(self.e, _lib.current_stream(), int(self.capturing)), "combo_event_record")
-            _timing[self.kind].append((self.s, self.e))
+def _Timed(kind):
+    return _lib.timed("msda_" + kind)
 
 
 def set_algo(algo: int):
@@ -129,9 +82,10 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     B, S, M, D, L, Lq, P = _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
     if tuple(grad_output.shape) != (B, Lq, M * D):
         raise RuntimeError("ms_deform_attn_backward: grad_output [B,Lq,M*D] expected")
-    grad_value = torch.zeros_like(value)
-    grad_loc = torch.zeros_like(sampling_loc)
-    grad_w = torch.zeros_like(attn_weight)
+    # the LDS kernels write every output element; only the generic (global-atomics) path accumulates into zeros
+    need_zero = _lib.lib().combo_msda_backward_needs_zero(S, D, L, P, value.element_size(), _algo)
+    alloc = torch.zeros_like if need_zero else torch.empty_like
+    grad_value, grad_loc, grad_w = alloc(value), alloc(sampling_loc), alloc(attn_weight)
     fn = getattr(_lib.lib(), "combo_msda_backward_" + _suffix(value.dtype))
     with _Timed("bwd"):
         rc = fn(grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),

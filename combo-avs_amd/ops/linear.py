@@ -40,8 +40,10 @@ def gemm_tn_x3(dy, x, with_bias_grad=False, out=None, db_out=None):
     part = torch.empty(splits, N, K, device=dev, dtype=torch.float32)
     dbp = torch.empty(splits, N, device=dev, dtype=torch.float32) if with_bias_grad else None
     st = _lib.current_stream()
-    _lib.check(lib.combo_gemm_tn_x3_f32(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), part.data_ptr(), _lib.ptr(dbp),
-                                        M, N, K, splits, st), "combo_gemm_tn_x3_f32")
+    with _lib.timed("gemm_tn_x3", (M, N, K)):
+        rc = lib.combo_gemm_tn_x3_f32(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), part.data_ptr(), _lib.ptr(dbp),
+                                      M, N, K, splits, st)
+    _lib.check(rc, "combo_gemm_tn_x3_f32")
     if out is None and splits == 1 and (db_out is None):
         return (part[0], dbp[0]) if with_bias_grad else part[0]
     dw = out if out is not None else torch.empty(N, K, device=dev, dtype=torch.float32)
@@ -67,9 +69,10 @@ def gemm_nt_x3(a, b, bias=None, relu=False):
     M, K = a.shape
     N = b.shape[0]
     out = torch.empty(M, N, device=a.device, dtype=torch.float32)
-    _lib.check(_lib.lib().combo_gemm_nt_x3_f32(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), _lib.ptr(bias),
-                                               out.data_ptr(), N, M, N, K, 1 if relu else 0, _lib.current_stream()),
-               "combo_gemm_nt_x3_f32")
+    with _lib.timed("gemm_nt_x3", (M, N, K)):
+        rc = _lib.lib().combo_gemm_nt_x3_f32(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), _lib.ptr(bias),
+                                             out.data_ptr(), N, M, N, K, 1 if relu else 0, _lib.current_stream())
+    _lib.check(rc, "combo_gemm_nt_x3_f32")
     return out
 
 

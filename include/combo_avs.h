@@ -55,6 +55,9 @@ int combo_event_destroy(void* event);
  *   algo: 0 = auto, 1 = generic (gather from L2), 2 = LDS-staged value slab (D==32, slab must fit LDS)
  *   im2col_step of the reference has no meaning here (the batch is never chunked) and is not a parameter.
  * ---------------------------------------------------------------------------------------------- */
+/* 1: the gradients must be zero-filled by the caller (generic path accumulates with atomics, like the reference's
+ * at::zeros at ms_deform_attn_cuda.cu:126-128); 0: the LDS kernels overwrite every element. */
+int combo_msda_backward_needs_zero(int S, int D, int L, int P, int elem_bytes, int algo);
 int combo_msda_forward_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
                            const float* sampling_loc, const float* attn_weight,
                            int B, int S, int M, int D, int L, int Lq, int P,
