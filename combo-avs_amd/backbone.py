@@ -68,9 +68,9 @@ class ConvBN(nn.Conv2d):
         self.norm = FrozenBatchNorm2d(cout)
         nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")
 
-    def forward(self, x, folded=None):
+    def forward(self, x, folded=None, bias=True):
         if folded is not None:  # (w * scale, shift) prepared for the whole backbone by ResNet.forward
-            return F.conv2d(x, folded[0], folded[1], self.stride, self.padding)
+            return F.conv2d(x, folded[0], folded[1] if bias else None, self.stride, self.padding)
         scale, shift = self.norm.scale_shift()
         w = self.weight * scale[:, None, None, None]
         return F.conv2d(x, w, shift, self.stride, self.padding)  # autocast (if enabled) picks the compute dtype
@@ -89,12 +89,22 @@ class Bottleneck(nn.Module):
         return [self.conv1, self.conv2, self.conv3] + ([self.shortcut] if self.shortcut is not None else [])
 
     def forward(self, x, folded=None):
-        nxt = (lambda: next(folded)) if folded is not None else (lambda: None)
-        out = F.relu_(self.conv1(x, nxt()))
-        out = F.relu_(self.conv2(out, nxt()))
-        out = self.conv3(out, nxt())
-        sc = self.shortcut(x, nxt()) if self.shortcut is not None else x
-        return F.relu_(out + sc)
+        if folded is None:
+            out = F.relu_(self.conv1(x))
+            out = F.relu_(self.conv2(out))
+            out = self.conv3(out)
+            sc = self.shortcut(x) if self.shortcut is not None else x
+            return F.relu_(out + sc)
+        # folded path: convolutions run WITHOUT bias, bias (+ residual) + ReLU is one fused pass (csrc/biasact.hip)
+        from .ops.biasact import bias_act
+        f1, f2, f3 = next(folded), next(folded), next(folded)
+        out = bias_act(self.conv1(x, f1, bias=False), f1[2])
+        out = bias_act(self.conv2(out, f2, bias=False), f2[2])
+        out = self.conv3(out, f3, bias=False)
+        if self.shortcut is not None:
+            fs = next(folded)
+            return bias_act(out, f3[2] + fs[2], self.shortcut(x, fs, bias=False))
+        return bias_act(out, f3[2], x)
 
 
 class BasicStem(nn.Module):
@@ -103,8 +113,11 @@ class BasicStem(nn.Module):
         self.conv1 = ConvBN(cin, cout, 7, stride=2, padding=3)
 
     def forward(self, x, folded=None):
-        return F.max_pool2d(F.relu_(self.conv1(x, next(folded) if folded is not None else None)), kernel_size=3, stride=2,
-                            padding=1)
+        if folded is None:
+            return F.max_pool2d(F.relu_(self.conv1(x)), kernel_size=3, stride=2, padding=1)
+        from .ops.biasact import bias_act
+        f = next(folded)
+        return F.max_pool2d(bias_act(self.conv1(x, f, bias=False), f[2]), kernel_size=3, stride=2, padding=1)
 
 
 class ResNet(nn.Module):
@@ -143,7 +156,8 @@ class ResNet(nn.Module):
         if key not in self._bn_cache:
             with torch.no_grad():
                 ss = [c.norm.scale_shift() for c in convs]
-                self._bn_cache[key] = ([sc[:, None, None, None].contiguous() for sc, _ in ss], [sh.to(dtype) for _, sh in ss])
+                self._bn_cache[key] = ([sc[:, None, None, None].contiguous() for sc, _ in ss], [sh.to(dtype) for _, sh in ss],
+                                       [sh.float().contiguous() for _, sh in ss])
         return self._bn_cache[key]
 
     def forward(self, x):
@@ -151,9 +165,9 @@ class ResNet(nn.Module):
         # backbone, activations are cast once at the input)
         dtype = torch.get_autocast_dtype("cuda") if (x.is_cuda and torch.is_autocast_enabled("cuda")) else x.dtype
         convs = self._conv_list()
-        scales, shifts = self._frozen_affine(convs, dtype)
+        scales, shifts, shifts32 = self._frozen_affine(convs, dtype)
         folded_w = _FoldAll.apply(dtype, scales, *[c.weight for c in convs])
-        folded = iter(zip(folded_w, shifts))
+        folded = iter(zip(folded_w, shifts, shifts32))
         with torch.autocast("cuda", enabled=False):
             x = self.stem(x.to(dtype).contiguous(memory_format=torch.channels_last), folded)
             out = {}

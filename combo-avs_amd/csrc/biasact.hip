@@ -1,0 +1,85 @@
+// Epilogue of the host-PyTorch backbone convolutions (bf16, NHWC): y = relu(y + bias[c] (+ residual)) in ONE pass, and its
+// backward dx = dy * (y > 0).  MIOpen runs conv, bias add and ReLU as three kernels (three passes over the activation);
+// FrozenBN is folded into (weight, bias) (backbone.py), so this is all that is left between two convolutions.
+// Reference semantics: detectron2 BottleneckBlock.forward (conv -> FrozenBN -> relu; out += shortcut; relu) [d2, not in
+// /root/reference; parity unpinned, see DESIGN.md section 2].
+#include "combo_common.h"
+
+namespace {
+
+typedef unsigned short u16;
+
+__device__ __forceinline__ float bf2f(u16 v) { return __uint_as_float((unsigned)v << 16); }
+__device__ __forceinline__ u16 f2bf(float f) {  // round to nearest even
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u16)((u >> 16) | 0x40);  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (u16)(u >> 16);
+}
+
+// 8 channels (16 bytes) per thread; C % 8 == 0
+__global__ void __launch_bounds__(256)
+bias_act_kernel(u16* __restrict__ y, const float* __restrict__ bias, const u16* __restrict__ res, long long n8, int C8,
+                int relu) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const int c8 = (int)(i % C8);
+  uint4 v = reinterpret_cast<const uint4*>(y)[i];
+  uint4 r = make_uint4(0, 0, 0, 0);
+  if (res) r = reinterpret_cast<const uint4*>(res)[i];
+  const float4 b0 = reinterpret_cast<const float4*>(bias)[c8 * 2], b1 = reinterpret_cast<const float4*>(bias)[c8 * 2 + 1];
+  const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+  unsigned vin[4] = {v.x, v.y, v.z, v.w}, rin[4] = {r.x, r.y, r.z, r.w}, out[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float lo = bf2f((u16)(vin[k] & 0xffffu)) + bb[2 * k], hi = bf2f((u16)(vin[k] >> 16)) + bb[2 * k + 1];
+    if (res) { lo += bf2f((u16)(rin[k] & 0xffffu)); hi += bf2f((u16)(rin[k] >> 16)); }
+    if (relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+    out[k] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+  }
+  reinterpret_cast<uint4*>(y)[i] = make_uint4(out[0], out[1], out[2], out[3]);
+}
+
+__global__ void __launch_bounds__(256)
+relu_grad_kernel(const u16* __restrict__ dy, const u16* __restrict__ y, long long n8, u16* __restrict__ dx) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const uint4 g = reinterpret_cast<const uint4*>(dy)[i];
+  const uint4 v = reinterpret_cast<const uint4*>(y)[i];
+  const unsigned gin[4] = {g.x, g.y, g.z, g.w}, vin[4] = {v.x, v.y, v.z, v.w};
+  unsigned out[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    // y is a ReLU output: positive <=> sign bit clear and magnitude non-zero
+    const unsigned lo_on = ((vin[k] & 0x7fffu) != 0 && (vin[k] & 0x8000u) == 0) ? 0xffffu : 0u;
+    const unsigned hi_on = ((vin[k] & 0x7fff0000u) != 0 && (vin[k] & 0x80000000u) == 0) ? 0xffff0000u : 0u;
+    out[k] = gin[k] & (lo_on | hi_on);
+  }
+  reinterpret_cast<uint4*>(dx)[i] = make_uint4(out[0], out[1], out[2], out[3]);
+}
+
+}  // namespace
+
+extern "C" {
+
+int combo_bias_act_bf16(void* y, const float* bias, const void* residual, long long tokens, int C, int relu,
+                        combo_stream_t stream) {
+  if (!y || !bias || tokens <= 0 || C <= 0 || C % 8 != 0 || ((uintptr_t)y & 15) || ((uintptr_t)bias & 15) ||
+      ((uintptr_t)residual & 15))
+    return COMBO_EINVAL;
+  const long long n8 = tokens * (C / 8);
+  hipLaunchKernelGGL(bias_act_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (u16*)y, bias,
+                     (const u16*)residual, n8, C / 8, relu);
+  return (int)hipGetLastError();
+}
+
+int combo_relu_grad_bf16(const void* dy, const void* y, long long n, void* dx, combo_stream_t stream) {
+  if (!dy || !y || !dx || n <= 0 || n % 8 != 0 || ((uintptr_t)dy & 15) || ((uintptr_t)y & 15) || ((uintptr_t)dx & 15))
+    return COMBO_EINVAL;
+  const long long n8 = n / 8;
+  hipLaunchKernelGGL(relu_grad_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const u16*)dy, (const u16*)y, n8, (u16*)dx);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,51 @@
+"""Fused epilogue of the backbone convolutions (csrc/biasact.hip): y <- relu(y + bias[c] (+ residual)), in place on the
+convolution output (bf16, channels_last), one pass; backward dx = dy * (y > 0) for both the convolution branch and the
+residual branch."""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .. import _lib
+
+
+def fusable(y, residual=None):
+    ok = (y.is_cuda and y.dtype == torch.bfloat16 and y.dim() == 4 and y.shape[1] % 8 == 0
+          and y.is_contiguous(memory_format=torch.channels_last))
+    if residual is not None:
+        ok = ok and residual.dtype == y.dtype and residual.shape == y.shape and residual.is_contiguous(memory_format=torch.channels_last)
+    return ok
+
+
+class _BiasAct(Function):
+    @staticmethod
+    def forward(ctx, y, bias, residual, relu):
+        N, C, H, W = y.shape
+        _lib.check(_lib.lib().combo_bias_act_bf16(y.data_ptr(), bias.data_ptr(), _lib.ptr(residual), N * H * W, C, 1 if relu else 0,
+                                                  _lib.current_stream()), "combo_bias_act_bf16")
+        ctx.mark_dirty(y)
+        ctx.relu, ctx.has_res = relu, residual is not None
+        if relu:
+            ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        dx = dy
+        if ctx.relu:
+            (y,) = ctx.saved_tensors
+            dy = dy.contiguous(memory_format=torch.channels_last)
+            dx = torch.empty_like(dy)
+            _lib.check(_lib.lib().combo_relu_grad_bf16(dy.data_ptr(), y.data_ptr(), dy.numel(), dx.data_ptr(), _lib.current_stream()),
+                       "combo_relu_grad_bf16")
+        return dx, None, (dx if ctx.has_res else None), None
+
+
+def bias_act(y, bias, residual=None, relu=True):
+    """y: convolution output WITHOUT bias (modified in place); bias: fp32 [C]; residual: same shape as y or None."""
+    if fusable(y, residual):
+        return _BiasAct.apply(y, bias, residual, relu)
+    out = y + bias.to(y.dtype)[None, :, None, None]
+    if residual is not None:
+        out = out + residual
+    return torch.relu_(out) if relu else out

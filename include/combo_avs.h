@@ -46,6 +46,15 @@ int combo_event_elapsed_us(void* start, void* stop, float* us);
 int combo_event_destroy(void* event);
 
 /* ------------------------------------------------------------------------------------------------
+ * Backbone epilogue (host-PyTorch ResNets, bf16 NHWC): y <- relu(y + bias[c] (+ residual)) in place, one pass (MIOpen
+ * runs conv, bias and ReLU as three kernels); backward dx = dy * (y > 0).  Replaces d2 BottleneckBlock's
+ * FrozenBN-affine + relu + residual add ([d2]; FrozenBN folded as in backbone.py).  y/residual/dy/dx: bf16, C % 8 == 0.
+ * ---------------------------------------------------------------------------------------------- */
+int combo_bias_act_bf16(void* y, const float* bias, const void* residual, long long tokens, int C, int relu,
+                        combo_stream_t stream);
+int combo_relu_grad_bf16(const void* dy, const void* y, long long n, void* dx, combo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * a6  MSDeformAttn core op
  *   replaces ms_deform_attn_cuda_forward / _backward (ops/src/cuda/ms_deform_attn_cuda.cu:25-85, 88-157)
  *   out[b,q,m,:] = sum_{l<L,p<P} w[b,q,m,l,p] * bilinear(value_l[b,:,m,:], loc*(W_l,H_l) - 0.5), zero padding.
