@@ -58,9 +58,27 @@ relu_grad_kernel(const u16* __restrict__ dy, const u16* __restrict__ y, long lon
   reinterpret_cast<uint4*>(dx)[i] = make_uint4(out[0], out[1], out[2], out[3]);
 }
 
+// fp32: dx = dy * (y > 0)  (ReLU backward of the head's fused Linear+ReLU layers; one kernel instead of compare + mul)
+__global__ void __launch_bounds__(256)
+relu_grad_f32_kernel(const float* __restrict__ dy, const float* __restrict__ y, long long n4, float* __restrict__ dx) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4 g = reinterpret_cast<const float4*>(dy)[i];
+  const float4 v = reinterpret_cast<const float4*>(y)[i];
+  reinterpret_cast<float4*>(dx)[i] = make_float4(v.x > 0.f ? g.x : 0.f, v.y > 0.f ? g.y : 0.f, v.z > 0.f ? g.z : 0.f, v.w > 0.f ? g.w : 0.f);
+}
+
 }  // namespace
 
 extern "C" {
+
+int combo_relu_grad_f32(const float* dy, const float* y, long long n, float* dx, combo_stream_t stream) {
+  if (!dy || !y || !dx || n <= 0 || n % 4 != 0 || ((uintptr_t)dy & 15) || ((uintptr_t)y & 15) || ((uintptr_t)dx & 15))
+    return COMBO_EINVAL;
+  const long long n4 = n / 4;
+  hipLaunchKernelGGL(relu_grad_f32_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, y, n4, dx);
+  return (int)hipGetLastError();
+}
 
 int combo_bias_act_bf16(void* y, const float* bias, const void* residual, long long tokens, int C, int relu,
                         combo_stream_t stream) {

@@ -165,15 +165,22 @@ class SetCriterion(nn.Module):
         n_unc = int(self.importance_sample_ratio * P)
         n_rand = P - n_unc
         # ---- random points, reference order -----------------------------------------------------------------
-        mpts, over, extra = [], [], []
-        for _ in range(L):
-            mpts.append(torch.cat([ps(1, P) for _ in range(F_)], 0))  # [F,P,2]
-            over.append(ps(Nm, n_over))
-            if n_rand > 0:
-                extra.append(ps(Nm, n_rand))
-        mpts = torch.stack(mpts).view(L * F_, P, 2)
-        over = torch.stack(over).view(L * Nm, n_over, 2)
-        extra = torch.stack(extra).view(L * Nm, n_rand, 2) if n_rand > 0 else None
+        if self.point_source is None:
+            # default generator: three launches for all outputs (an injected stream is consumed in the reference's call order
+            # below; with torch's own generator there is no stream to stay compatible with)
+            mpts = torch.rand(L * F_, P, 2, device=dev)
+            over = torch.rand(L * Nm, n_over, 2, device=dev)
+            extra = torch.rand(L * Nm, n_rand, 2, device=dev) if n_rand > 0 else None
+        else:
+            mpts, over, extra = [], [], []
+            for _ in range(L):
+                mpts.append(torch.cat([ps(1, P) for _ in range(F_)], 0))  # [F,P,2]
+                over.append(ps(Nm, n_over))
+                if n_rand > 0:
+                    extra.append(ps(Nm, n_rand))
+            mpts = torch.stack(mpts).view(L * F_, P, 2)
+            over = torch.stack(over).view(L * Nm, n_over, 2)
+            extra = torch.stack(extra).view(L * Nm, n_rand, 2) if n_rand > 0 else None
         # ---- Hungarian matching: batched costs, one host sync -------------------------------------------------
         H, W = targets[0]["masks"].shape[-2:]
         gt = torch.zeros(F_, Gmax, H, W, device=dev)

@@ -87,6 +87,17 @@ def _nt_ok(a, n_out, b=None):
     return ok
 
 
+def relu_grad(dy, y):
+    """dy * (y > 0) in one launch (csrc/biasact.hip)."""
+    if dy.is_cuda and dy.dtype == torch.float32 and y.dtype == torch.float32 and dy.is_contiguous() and y.is_contiguous() \
+            and dy.numel() % 4 == 0 and dy.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0:
+        dx = torch.empty_like(dy)
+        _lib.check(_lib.lib().combo_relu_grad_f32(dy.data_ptr(), y.data_ptr(), dy.numel(), dx.data_ptr(), _lib.current_stream()),
+                   "combo_relu_grad_f32")
+        return dx
+    return dy * (y > 0)
+
+
 class _split3:
     """context: route library GEMMs through hipBLASLt's bf16x3 path (torch spells the switch `allow_tf32`)."""
 
@@ -121,7 +132,7 @@ class _LinearLib3x(Function):
     def backward(ctx, dy):
         x2d, weight, y = ctx.saved_tensors
         if ctx.relu:
-            dy = dy * (y > 0)
+            dy = relu_grad(dy, y)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dyc = dy if dy.stride(1) == 1 else dy.contiguous()
@@ -243,7 +254,7 @@ class _LinearX3(Function):
         N = weight.shape[0]
         dy = dy.contiguous()
         if ctx.relu:
-            dy = dy * (y > 0)
+            dy = relu_grad(dy, y)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             # dX[M,K] = sum_n dY(m,n) W(n,k) = dY . (W^T)^T: with a transposed copy of the (small) weight both operands

@@ -53,6 +53,8 @@ int combo_event_destroy(void* event);
 int combo_bias_act_bf16(void* y, const float* bias, const void* residual, long long tokens, int C, int relu,
                         combo_stream_t stream);
 int combo_relu_grad_bf16(const void* dy, const void* y, long long n, void* dx, combo_stream_t stream);
+/* fp32 variant for the head's Linear+ReLU layers (MLP.forward transformer_decoder.py:216-219, FFN :178-182, encoder FFN). */
+int combo_relu_grad_f32(const float* dy, const float* y, long long n, float* dx, combo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a6  MSDeformAttn core op
