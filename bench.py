@@ -160,6 +160,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"], help="host-PyTorch backbone compute dtype")
     ap.add_argument("--head-dtype", default="fp32", choices=["bf16", "fp32"], help="dense layers of the head")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backbone", default="r50", choices=["r50", "pvt"],
+                    help="r50 = BASELINE configs[1] (default, the quoted metric); pvt = COMBO-PVTv2-B5 (configs 4-5 family)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of the captured hipGraph step")
     ap.add_argument("--mode", default="train", choices=["train", "infer"],
                     help="train = the BASELINE metric (default); infer = eval-mode forward + fused semantic-inference tail "
@@ -191,7 +193,8 @@ def main():
         # MIOpen exhaustive find for the host-PyTorch backbone convolutions (+8 % frames/s; costs ~2 min of search in
         # the first warm-up step on a box with an empty MIOpen user db; COMBO_MIOPEN_BENCHMARK=0 skips it)
         torch.backends.cudnn.benchmark = True
-    cfg = combo_cfg(os.path.join(ROOT, "configs/avs_s4/COMBO_R50_bs8_90k.yaml"))
+    cfg_file = "COMBO_R50_bs8_90k.yaml" if args.backbone == "r50" else "COMBO_PVTV2B5_bs8_90k.yaml"
+    cfg = combo_cfg(os.path.join(ROOT, "configs/avs_s4", cfg_file))
     torch.manual_seed(0)  # identical random-init weights on every rank (DDP broadcast equivalent)
     model = build_model(cfg).to(dev).train()
     if args.dtype == "bf16":
@@ -301,7 +304,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": f"COMBO-R50 S4, bs={args.clips} clips x 5 frames x 224x224 per GPU, full train step "
+            "config": {"workload": f"COMBO-{'R50' if args.backbone == 'r50' else 'PVTv2-B5'} S4, bs={args.clips} clips x 5 frames x 224x224 per GPU, full train step "
                                    "(fwd + 39-term loss + bwd + all-reduce + clip + AdamW), random-init weights",
                        "launch": "eager" if args.no_graph else "hipGraph (fwd+loss+bwd captured; all-reduce + AdamW eager)",
                        "global_batch_clips": args.clips * world, "frames_per_clip": T, "parallelism": f"dp{world}",

@@ -13,3 +13,4 @@ from . import _lib  # noqa: F401
 from .config import (CfgNode, add_audio_config, add_fuse_config, add_maskformer2_config, combo_cfg, get_cfg)  # noqa: E402,F401
 from .registry import (BACKBONE_REGISTRY, META_ARCH_REGISTRY, SEM_SEG_HEADS_REGISTRY,  # noqa: E402,F401
                        TRANSFORMER_DECODER_REGISTRY)
+from . import backbone, backbone_pvt  # noqa: E402,F401  (populate BACKBONE_REGISTRY: build_resnet_backbone, build_pvtv2_b5_backbone)

@@ -1,0 +1,211 @@
+"""Host-PyTorch PVTv2-B5 backbone (outside the HIP hot path, BASELINE.json north_star; SURVEY 8(b) registry surface and
+8(f) rank 2): `BACKBONE_REGISTRY["build_pvtv2_b5_backbone"]`, the visual encoder of the reference's headline COMBO-PVT
+configs (models/modeling/backbone/pvtv2.py:236-409).
+
+Written from the published architecture (Pyramid Vision Transformer v2: four stages of overlapping patch embedding +
+transformer blocks with spatial-reduction attention and a depth-wise-conv MLP) with the reference's hyper-parameters
+(pvtv2.py:391-409: dims 64/128/320/512, heads 1/2/5/8, depths 3/6/40/3, sr 8/4/2/1, qkv bias, LayerNorm eps 1e-6,
+stochastic depth 0.1 with the linear decay rule) and its parameter names (`patch_embed{i}.proj|norm`,
+`block{i}.{j}.{norm1,attn.{q,kv,sr,norm,proj},norm2,mlp.{fc1,dwconv.dwconv,fc2}}`, `norm{i}`), so reference
+checkpoints load 1:1.
+
+MI355X notes: tokens stay batch-first [B,N,C]; the spatial-reduction attention goes through
+`F.scaled_dot_product_attention` (no [B,heads,N,N'] score tensor in HBM: at 512x512 stage 1 that tensor alone is
+B x 16384 x 256 floats); the stage output is returned as an NCHW *view* of the token-major tensor (channels_last
+memory), which is what the SEM mix and the pixel decoder consume; stochastic depth draws its per-sample mask on the
+device (graph-capturable)."""
+import math
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from .registry import BACKBONE_REGISTRY, ShapeSpec
+
+
+def drop_path(x, p, training):
+    """Stochastic depth per sample (timm DropPath semantics: keep with prob 1-p, rescale by 1/(1-p))."""
+    if p == 0.0 or not training:
+        return x
+    keep = 1.0 - p
+    mask = (torch.rand(x.shape[0], *([1] * (x.dim() - 1)), device=x.device, dtype=x.dtype) < keep).to(x.dtype)
+    return x * (mask / keep)
+
+
+class DropPath(nn.Module):
+    def __init__(self, p=0.0):
+        super().__init__()
+        self.p = float(p)
+
+    def forward(self, x):
+        return drop_path(x, self.p, self.training)
+
+    def extra_repr(self):
+        return f"p={self.p}"
+
+
+def _init(m):
+    """pvtv2.py:324-337: trunc-normal(0.02) linears, unit LayerNorm, fan-out normal convolutions."""
+    if isinstance(m, nn.Linear):
+        nn.init.trunc_normal_(m.weight, std=0.02)
+        if m.bias is not None:
+            nn.init.zeros_(m.bias)
+    elif isinstance(m, nn.LayerNorm):
+        nn.init.ones_(m.weight)
+        nn.init.zeros_(m.bias)
+    elif isinstance(m, nn.Conv2d):
+        fan_out = m.kernel_size[0] * m.kernel_size[1] * m.out_channels // m.groups
+        nn.init.normal_(m.weight, 0.0, math.sqrt(2.0 / fan_out))
+        if m.bias is not None:
+            nn.init.zeros_(m.bias)
+
+
+class DWConv(nn.Module):
+    """3x3 depth-wise convolution on the token grid (pvtv2.py:377-388)."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.dwconv = nn.Conv2d(dim, dim, 3, 1, 1, bias=True, groups=dim)
+
+    def forward(self, x, H, W):
+        B, N, C = x.shape
+        y = self.dwconv(x.view(B, H, W, C).permute(0, 3, 1, 2))  # NCHW view of token-major memory (channels_last)
+        return y.permute(0, 2, 3, 1).reshape(B, N, C)
+
+
+class Mlp(nn.Module):
+    """fc1 -> depth-wise conv -> GELU -> fc2 (pvtv2.py:17-57, linear=False)."""
+
+    def __init__(self, dim, hidden, drop=0.0):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.dwconv = DWConv(hidden)
+        self.act = nn.GELU()
+        self.fc2 = nn.Linear(hidden, dim)
+        self.drop = nn.Dropout(drop)
+
+    def forward(self, x, H, W):
+        x = self.drop(self.act(self.dwconv(self.fc1(x), H, W)))
+        return self.drop(self.fc2(x))
+
+
+class Attention(nn.Module):
+    """Spatial-reduction attention (pvtv2.py:60-132, linear=False): keys/values come from the token grid reduced by a
+    strided sr x sr convolution + LayerNorm."""
+
+    def __init__(self, dim, num_heads, qkv_bias, attn_drop=0.0, proj_drop=0.0, sr_ratio=1):
+        super().__init__()
+        assert dim % num_heads == 0, f"dim {dim} should be divided by num_heads {num_heads}."
+        self.dim, self.num_heads, self.sr_ratio = dim, num_heads, sr_ratio
+        self.scale = (dim // num_heads) ** -0.5
+        self.q = nn.Linear(dim, dim, bias=qkv_bias)
+        self.kv = nn.Linear(dim, dim * 2, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+        if sr_ratio > 1:
+            self.sr = nn.Conv2d(dim, dim, kernel_size=sr_ratio, stride=sr_ratio)
+            self.norm = nn.LayerNorm(dim)
+
+    def forward(self, x, H, W):
+        B, N, C = x.shape
+        h, d = self.num_heads, C // self.num_heads
+        q = self.q(x).view(B, N, h, d).transpose(1, 2)
+        if self.sr_ratio > 1:
+            x_ = self.sr(x.view(B, H, W, C).permute(0, 3, 1, 2))  # [B,C,H/sr,W/sr]
+            x_ = self.norm(x_.flatten(2).transpose(1, 2))
+        else:
+            x_ = x
+        kv = self.kv(x_).view(B, -1, 2, h, d)
+        k, v = kv[:, :, 0].transpose(1, 2), kv[:, :, 1].transpose(1, 2)
+        o = F.scaled_dot_product_attention(q, k, v, dropout_p=self.attn_drop.p if self.training else 0.0, scale=self.scale)
+        return self.proj_drop(self.proj(o.transpose(1, 2).reshape(B, N, C)))
+
+
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio, qkv_bias, drop, attn_drop, drop_path_p, norm_eps, sr_ratio):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=norm_eps)
+        self.attn = Attention(dim, num_heads, qkv_bias, attn_drop, drop, sr_ratio)
+        self.drop_path = DropPath(drop_path_p) if drop_path_p > 0.0 else nn.Identity()
+        self.norm2 = nn.LayerNorm(dim, eps=norm_eps)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio), drop)
+
+    def forward(self, x, H, W):
+        x = x + self.drop_path(self.attn(self.norm1(x), H, W))
+        return x + self.drop_path(self.mlp(self.norm2(x), H, W))
+
+
+class OverlapPatchEmbed(nn.Module):
+    """Overlapping patch embedding: strided convolution (kernel > stride) + LayerNorm (pvtv2.py:193-233; note the norm
+    here is a default-eps LayerNorm, `:210`)."""
+
+    def __init__(self, patch_size, stride, in_chans, embed_dim):
+        super().__init__()
+        assert patch_size > stride, "Set larger patch_size than stride"
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=stride, padding=patch_size // 2)
+        self.norm = nn.LayerNorm(embed_dim)
+
+    def forward(self, x):
+        x = self.proj(x)
+        H, W = x.shape[-2:]
+        return self.norm(x.flatten(2).transpose(1, 2)), H, W
+
+
+class PyramidVisionTransformerV2(nn.Module):
+    def __init__(self, in_chans=3, embed_dims=(64, 128, 256, 512), num_heads=(1, 2, 4, 8), mlp_ratios=(4, 4, 4, 4),
+                 qkv_bias=False, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.0, norm_eps=1e-5,
+                 depths=(3, 4, 6, 3), sr_ratios=(8, 4, 2, 1), num_stages=4, out_features=None):
+        super().__init__()
+        self.depths, self.num_stages = list(depths), num_stages
+        self._out_features = list(out_features or [f"res{i + 2}" for i in range(num_stages)])
+        total = sum(depths)
+        dpr = [drop_path_rate * i / max(total - 1, 1) for i in range(total)]  # linear stochastic-depth decay (:262)
+        cur = 0
+        self._out_feature_strides, self._out_feature_channels = {}, {}
+        for i in range(num_stages):
+            setattr(self, f"patch_embed{i + 1}", OverlapPatchEmbed(7 if i == 0 else 3, 4 if i == 0 else 2,
+                                                                   in_chans if i == 0 else embed_dims[i - 1], embed_dims[i]))
+            setattr(self, f"block{i + 1}", nn.ModuleList([
+                Block(embed_dims[i], num_heads[i], mlp_ratios[i], qkv_bias, drop_rate, attn_drop_rate, dpr[cur + j], norm_eps,
+                      sr_ratios[i]) for j in range(depths[i])]))
+            setattr(self, f"norm{i + 1}", nn.LayerNorm(embed_dims[i], eps=norm_eps))
+            cur += depths[i]
+            stage = f"res{i + 2}"
+            if stage in self._out_features:
+                self._out_feature_strides[stage] = 4 if i == 0 else 2 ** (i + 2)
+                self._out_feature_channels[stage] = embed_dims[i]
+        self.size_divisibility = 0
+        self.apply(_init)
+
+    def freeze_patch_emb(self):
+        self.patch_embed1.requires_grad_(False)
+
+    def no_weight_decay(self):
+        return {"pos_embed1", "pos_embed2", "pos_embed3", "pos_embed4", "cls_token"}
+
+    def forward(self, x):
+        B = x.shape[0]
+        outs = {}
+        for i in range(self.num_stages):
+            x, H, W = getattr(self, f"patch_embed{i + 1}")(x)
+            for blk in getattr(self, f"block{i + 1}"):
+                x = blk(x, H, W)
+            x = getattr(self, f"norm{i + 1}")(x)
+            x = x.view(B, H, W, -1).permute(0, 3, 1, 2)  # NCHW view, channels_last memory (the reference copies to NCHW, :359)
+            stage = f"res{i + 2}"
+            if stage in self._out_features:
+                outs[stage] = x
+        return outs
+
+    def output_shape(self):
+        return {n: ShapeSpec(channels=self._out_feature_channels[n], stride=self._out_feature_strides[n]) for n in self._out_features}
+
+
+@BACKBONE_REGISTRY.register()
+def build_pvtv2_b5_backbone(cfg, input_shape=None):
+    """PVTv2-B5 (pvtv2.py:391-409)."""
+    return PyramidVisionTransformerV2(
+        embed_dims=(64, 128, 320, 512), num_heads=(1, 2, 5, 8), mlp_ratios=(4, 4, 4, 4), qkv_bias=True, norm_eps=1e-6,
+        depths=(3, 6, 40, 3), sr_ratios=(8, 4, 2, 1), drop_rate=0.0, drop_path_rate=0.1,
+        out_features=cfg.MODEL.PVT.OUT_FEATURES)

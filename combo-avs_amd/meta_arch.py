@@ -10,6 +10,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from . import backbone_pvt  # noqa: F401  (registers build_pvtv2_b5_backbone)
 from .backbone import VGGish
 from .modeling.criterion import SetCriterion, SetCriterion_SS
 from .modeling.head import MaskFormerHead

@@ -77,3 +77,31 @@ def test_one_train_step_updates_parameters(setup):
     delta = (opt.flat_param - before).abs()
     assert delta.max() > 0 and torch.isfinite(opt.flat_param).all()
     assert delta.max() <= 1.2e-4  # |AdamW step| <= lr at step 1 (+ weight decay), lr = 1e-4 / 1e-5
+
+
+def test_pvt_config_trains_eager_and_graphed():
+    """COMBO-PVTv2-B5 (the reference's headline backbone, configs/avs_s4/COMBO_PVTV2B5_bs8_90k.yaml): the same head on
+    the PVT pyramid (64/128/320/512 channels), one eager and two graph-replayed training steps, finite and decreasing
+    nothing-burger checks aside: 39 losses, parameters move, bf16 backbones."""
+    sys.path.insert(0, ROOT)
+    import combo_avs_amd  # noqa: F401
+    from bench import synth_batch
+    from combo_avs_amd import combo_cfg
+    from combo_avs_amd.meta_arch import build_model
+    from combo_avs_amd.trainer import FlatAdamW, GraphedTrainStep, train_step
+    cfg = combo_cfg(os.path.join(ROOT, "configs/avs_s4/COMBO_PVTV2B5_bs8_90k.yaml"))
+    torch.manual_seed(0)
+    model = build_model(cfg).cuda().train()
+    model.backbone_dtype = torch.bfloat16
+    assert type(model.backbone).__name__ == "PyramidVisionTransformerV2"
+    opt = FlatAdamW(model, base_lr=1e-4, weight_decay=0.05, backbone_multiplier=0.1, clip_value=0.01)
+    batch = synth_batch(1, 5, 224, 224, "cuda", seed=4)
+    before = opt.flat_param.clone()
+    losses = train_step(model, opt, batch)
+    assert len(losses) == 39 and all(torch.isfinite(v) for v in losses.values())
+    step = GraphedTrainStep(model, opt)
+    for _ in range(2):
+        losses = step(batch)
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(v) for v in losses.values())
+    assert torch.isfinite(opt.flat_param).all() and (opt.flat_param - before).abs().max() > 0

@@ -112,6 +112,18 @@ if os.environ.get("PROFILE"):
     for _ in range(3):
         run()
     torch.cuda.synchronize()
+    if os.environ.get("STACKS"):  # which call sites own the copies / adds
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+            run()
+            torch.cuda.synchronize()
+        rows = []
+        for e in prof.key_averages(group_by_stack_n=8):
+            if e.key in os.environ["STACKS"].split(",") and e.device_time_total > 0:
+                rows.append(e)
+        for e in sorted(rows, key=lambda e: -e.device_time_total)[:int(os.environ.get("TOP", "25"))]:
+            st = [f for f in e.stack if "combo" in f or "bench" in f or "tools/" in f][:3]
+            print(f"{e.device_time_total / 1e3:7.3f} ms {e.count:4d}x {e.key:18s} | " + " <- ".join(x.split("/")[-1][:60] for x in st))
+        raise SystemExit(0)
     if os.environ.get("OPS"):  # aten-op level table (which framework ops own the small kernels)
         with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
             run()
