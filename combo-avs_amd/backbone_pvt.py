@@ -69,7 +69,12 @@ class DWConv(nn.Module):
 
     def forward(self, x, H, W):
         B, N, C = x.shape
-        y = self.dwconv(x.view(B, H, W, C).permute(0, 3, 1, 2))  # NCHW view of token-major memory (channels_last)
+        from .ops import dwconv
+        xt = x.view(B, H, W, C)
+        w, b = self.dwconv.weight, self.dwconv.bias
+        if dwconv.usable(xt, w):  # bf16 tokens on the GPU: bandwidth-bound HIP kernels (csrc/dwconv.hip), fp32 weights
+            return dwconv.dwconv3x3(xt, w, b).view(B, N, C)
+        y = self.dwconv(xt.permute(0, 3, 1, 2))  # NCHW view of token-major memory (channels_last)
         return y.permute(0, 2, 3, 1).reshape(B, N, C)
 
 

@@ -1,0 +1,137 @@
+// Depth-wise 3x3 convolution on token-major (NHWC) bf16 activations: the DWConv inside every PVTv2 MLP
+// (models/modeling/backbone/pvtv2.py:377-388: Conv2d(dim, dim, 3, 1, 1, groups=dim) on the [B,H,W,C] token grid).
+// MIOpen has no tuned depth-wise bf16 NHWC solver on gfx950: it runs naive_conv_* kernels for forward / backward-data
+// and a grouped CK kernel for the weight gradient (2.4 ms per call at 125 440 x 256: 158 ms of a 232 ms PVTv2-B5
+// forward+backward).  The op is pure bandwidth (9 MACs per element), so: one thread = one token x 8 channels (16-byte
+// bf16 vectors, fp32 accumulate), neighbours come from L1/L2; the weight gradient accumulates 9 taps (+ the bias
+// gradient) x 8 channels in registers over a slice of tokens and writes one partial per slice, which the split-K
+// reduce kernel (gemm_tn.hip) sums.  Weights stay fp32 (tap-major [9][C]): no per-step cast kernels.
+#include "combo_common.h"
+
+namespace {
+
+typedef unsigned short u16;
+
+__device__ __forceinline__ float bf2f(unsigned v16) { return __uint_as_float(v16 << 16); }
+__device__ __forceinline__ unsigned f2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40;
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ __forceinline__ void unpack8(const uint4 v, float (&f)[8]) {
+  f[0] = bf2f(v.x & 0xffffu); f[1] = bf2f(v.x >> 16); f[2] = bf2f(v.y & 0xffffu); f[3] = bf2f(v.y >> 16);
+  f[4] = bf2f(v.z & 0xffffu); f[5] = bf2f(v.z >> 16); f[6] = bf2f(v.w & 0xffffu); f[7] = bf2f(v.w >> 16);
+}
+
+// y[p,c] = bias[c] + sum_tap wT[tap or 8-tap][c] * x[p + off(tap), c]   (zero padding; flip = 1 gives backward-data)
+__global__ void __launch_bounds__(256)
+dwconv3x3_kernel(const u16* __restrict__ x, const float* __restrict__ wT, const float* __restrict__ bias, int B, int H,
+                 int W, int C8, int flip, u16* __restrict__ y) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  const long long total = (long long)B * H * W * C8;
+  if (i >= total) return;
+  const int c8 = (int)(i % C8);
+  const long long p = i / C8;
+  const int w = (int)(p % W), h = (int)((p / W) % H);
+  const int C = C8 * 8;
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = bias ? bias[c8 * 8 + k] : 0.f;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int dy = t / 3 - 1, dx = t % 3 - 1;
+    const int hh = h + dy, ww = w + dx;
+    if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+    const uint4 v = *reinterpret_cast<const uint4*>(x + ((p + dy * W + dx) * C8 + c8) * 8);
+    float xv[8];
+    unpack8(v, xv);
+    const float* wp = wT + (flip ? 8 - t : t) * C + c8 * 8;
+    const float4 w0 = *reinterpret_cast<const float4*>(wp), w1 = *reinterpret_cast<const float4*>(wp + 4);
+    acc[0] += w0.x * xv[0]; acc[1] += w0.y * xv[1]; acc[2] += w0.z * xv[2]; acc[3] += w0.w * xv[3];
+    acc[4] += w1.x * xv[4]; acc[5] += w1.y * xv[5]; acc[6] += w1.z * xv[6]; acc[7] += w1.w * xv[7];
+  }
+  uint4 o;
+  o.x = f2bf(acc[0]) | (f2bf(acc[1]) << 16); o.y = f2bf(acc[2]) | (f2bf(acc[3]) << 16);
+  o.z = f2bf(acc[4]) | (f2bf(acc[5]) << 16); o.w = f2bf(acc[6]) | (f2bf(acc[7]) << 16);
+  *reinterpret_cast<uint4*>(y + i * 8) = o;
+}
+
+// partial[s][tap][c] = sum over the tokens of slice s of dy[p,c] * x[p + off(tap), c];  partial[s][9][c] = sum dy[p,c]
+__global__ void __launch_bounds__(256)
+dwconv3x3_wgrad_kernel(const u16* __restrict__ x, const u16* __restrict__ dy, int B, int H, int W, int C8, int slices,
+                       int tok_per_slice, float* __restrict__ partial) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= (long long)slices * C8) return;
+  const int c8 = (int)(i % C8), s = (int)(i / C8);
+  const long long tokens = (long long)B * H * W;
+  const long long p0 = (long long)s * tok_per_slice, p1 = min(tokens, p0 + tok_per_slice);
+  float acc[10][8];
+#pragma unroll
+  for (int t = 0; t < 10; ++t)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[t][k] = 0.f;
+  int w = (int)(p0 % W), h = (int)((p0 / W) % H);
+  for (long long p = p0; p < p1; ++p) {
+    float g[8];
+    unpack8(*reinterpret_cast<const uint4*>(dy + (p * C8 + c8) * 8), g);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[9][k] += g[k];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int ddy = t / 3 - 1, ddx = t % 3 - 1;
+      const int hh = h + ddy, ww = w + ddx;
+      if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+      float xv[8];
+      unpack8(*reinterpret_cast<const uint4*>(x + ((p + ddy * W + ddx) * C8 + c8) * 8), xv);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[t][k] += g[k] * xv[k];
+    }
+    if (++w == W) { w = 0; if (++h == H) h = 0; }
+  }
+  const int C = C8 * 8;
+  float* o = partial + (long long)s * 10 * C + c8 * 8;
+#pragma unroll
+  for (int t = 0; t < 10; ++t) {
+    *reinterpret_cast<float4*>(o + t * C) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+    *reinterpret_cast<float4*>(o + t * C + 4) = make_float4(acc[t][4], acc[t][5], acc[t][6], acc[t][7]);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int combo_dwconv3x3_bf16(const void* x, const float* w_tap_major, const float* bias, int B, int H, int W, int C, int flip,
+                         void* y, combo_stream_t stream) {
+  if (!x || !w_tap_major || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 != 0 || ((uintptr_t)x & 15) ||
+      ((uintptr_t)y & 15) || ((uintptr_t)w_tap_major & 15) || ((uintptr_t)bias & 15))
+    return COMBO_EINVAL;
+  const long long total = (long long)B * H * W * (C / 8);
+  hipLaunchKernelGGL(dwconv3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const u16*)x, w_tap_major, bias, B, H, W, C / 8, flip, (u16*)y);
+  return (int)hipGetLastError();
+}
+
+int combo_dwconv3x3_wgrad_slices(int B, int H, int W, int C) {
+  const long long tokens = (long long)B * H * W;
+  long long s = (65536LL * 8) / (C > 0 ? C : 8);  // ~64k threads
+  if (s > tokens / 8) s = tokens / 8;             // at least 8 tokens per thread
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+int combo_dwconv3x3_wgrad_bf16(const void* x, const void* dy, int B, int H, int W, int C, int slices, float* partials,
+                               combo_stream_t stream) {
+  if (!x || !dy || !partials || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 != 0 || slices <= 0 || ((uintptr_t)x & 15) ||
+      ((uintptr_t)dy & 15) || ((uintptr_t)partials & 15))
+    return COMBO_EINVAL;
+  const long long tokens = (long long)B * H * W;
+  const int tps = (int)((tokens + slices - 1) / slices);
+  const long long threads = (long long)slices * (C / 8);
+  hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const u16*)x, (const u16*)dy, B, H, W, C / 8, slices, tps, partials);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -57,6 +57,20 @@ int combo_relu_grad_bf16(const void* dy, const void* y, long long n, void* dx, c
 int combo_relu_grad_f32(const float* dy, const float* y, long long n, float* dx, combo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * PVTv2 depth-wise 3x3 convolution on token-major bf16 activations (models/modeling/backbone/pvtv2.py:377-388, DWConv:
+ * Conv2d(dim, dim, 3, 1, 1, groups=dim) on the [B,H,W,C] token grid), fp32 weights in tap-major layout [9][C].
+ *   forward:        y = bias + sum_tap w[tap] * x[. + off(tap)]            (flip = 0)
+ *   backward-data:  dx = sum_tap w[8 - tap] * dy[. + off(tap)]             (flip = 1, bias = NULL)
+ *   weight/bias gradient: partials [slices][10][C] (taps 0..8, row 9 = bias gradient); the caller sums the slices
+ *   (combo_splitk_reduce_f32).  slices from combo_dwconv3x3_wgrad_slices.  C % 8 == 0.
+ * ---------------------------------------------------------------------------------------------- */
+int combo_dwconv3x3_bf16(const void* x, const float* w_tap_major, const float* bias, int B, int H, int W, int C, int flip,
+                         void* y, combo_stream_t stream);
+int combo_dwconv3x3_wgrad_slices(int B, int H, int W, int C);
+int combo_dwconv3x3_wgrad_bf16(const void* x, const void* dy, int B, int H, int W, int C, int slices, float* partials,
+                               combo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * a6  MSDeformAttn core op
  *   replaces ms_deform_attn_cuda_forward / _backward (ops/src/cuda/ms_deform_attn_cuda.cu:25-85, 88-157)
  *   out[b,q,m,:] = sum_{l<L,p<P} w[b,q,m,l,p] * bilinear(value_l[b,:,m,:], loc*(W_l,H_l) - 0.5), zero padding.

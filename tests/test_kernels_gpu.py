@@ -288,3 +288,27 @@ def test_bias_act_kernels_exact():
         want = (g.float() * (ref.float() > 0)).to(torch.bfloat16)
         for gg in grads:
             assert torch.equal(gg, want)
+
+
+@pytest.mark.parametrize("B,H,W,C", [(3, 14, 14, 1280), (2, 7, 9, 64), (4, 56, 56, 256)])
+def test_dwconv3x3_bf16_vs_torch(B, H, W, C):
+    """csrc/dwconv.hip (PVTv2 DWConv) forward / backward-data / weight + bias gradients against F.conv2d in fp32 on the
+    same bf16-rounded inputs."""
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.ops.dwconv import dwconv3x3
+    torch.manual_seed(B * C + H)
+    x = torch.randn(B, H, W, C, device="cuda").to(torch.bfloat16).requires_grad_(True)
+    w = (torch.randn(C, 1, 3, 3, device="cuda") * 0.3).requires_grad_(True)
+    b = torch.randn(C, device="cuda").requires_grad_(True)
+    y = dwconv3x3(x, w, b)
+    g = torch.randn_like(y)
+    dx, dw, db = torch.autograd.grad(y, (x, w, b), g)
+    xr = x.detach().float().permute(0, 3, 1, 2).requires_grad_(True)
+    wr, br = w.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, wr, br, 1, 1, groups=C)
+    dxr, dwr, dbr = torch.autograd.grad(yr, (xr, wr, br), g.float().permute(0, 3, 1, 2))
+    assert y.dtype == torch.bfloat16 and dx.dtype == torch.bfloat16 and dw.dtype == torch.float32
+    assert (y.float() - yr.permute(0, 2, 3, 1)).abs().max() <= 2e-2 * yr.abs().max()          # bf16 output rounding
+    assert (dx.float() - dxr.permute(0, 2, 3, 1)).abs().max() <= 2e-2 * dxr.abs().max()
+    assert (dw - dwr).abs().max() <= 2e-4 * dwr.abs().max() + 1e-3                               # fp32 accumulation
+    assert (db - dbr).abs().max() <= 2e-4 * dbr.abs().max() + 1e-3
