@@ -39,13 +39,17 @@ class _DWConv3x3(Function):
                        "combo_dwconv3x3_bf16")
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             slices = lib.combo_dwconv3x3_wgrad_slices(B, H, W, C)
-            tps = -(-(B * H * W) // slices)
-            slices = -(-(B * H * W) // tps)
+            # two-level sum of the per-slice partials: slice s = s2 * 16 + s1; pass 1 sums over s2 (many threads), pass 2
+            # over the 16 s1 (the split-K reduce kernel walks its split axis serially, so that axis must stay short)
+            slices = -(-slices // 16) * 16
             part = torch.empty(slices, 10, C, device=x.device, dtype=torch.float32)
             _lib.check(lib.combo_dwconv3x3_wgrad_bf16(x.data_ptr(), dy.data_ptr(), B, H, W, C, slices, part.data_ptr(), st),
                        "combo_dwconv3x3_wgrad_bf16")
+            tmp = torch.empty(16, 10, C, device=x.device, dtype=torch.float32)
             tot = torch.empty(10, C, device=x.device, dtype=torch.float32)
-            _lib.check(lib.combo_splitk_reduce_f32(part.data_ptr(), slices, 10 * C, tot.data_ptr(), 0, 0, 0, st),
+            _lib.check(lib.combo_splitk_reduce_f32(part.data_ptr(), slices // 16, 16 * 10 * C, tmp.data_ptr(), 0, 0, 0, st),
+                       "combo_splitk_reduce_f32")
+            _lib.check(lib.combo_splitk_reduce_f32(tmp.data_ptr(), 16, 10 * C, tot.data_ptr(), 0, 0, 0, st),
                        "combo_splitk_reduce_f32")
             dw = tot[:9].t().reshape(C, 1, 3, 3)
             db = tot[9] if ctx.has_bias else None
