@@ -31,6 +31,8 @@ _SIGNATURES = {
     "combo_event_record": [c_void_p, c_void_p, c_int],
     "combo_event_elapsed_us": [c_void_p, c_void_p, c_void_p],
     "combo_event_destroy": [c_void_p],
+    "combo_msda_prep_forward_f32": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "combo_msda_prep_backward_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_void_p],
     "combo_bifuse_chunks": [c_int, c_int],
     "combo_bifuse_forward_f32": [c_void_p] * 3 + [c_float] + [c_void_p] * 8 + [c_float, ctypes.c_ulonglong, c_void_p] + [c_int] * 4 + [c_void_p] * 7,
     "combo_bifuse_backward1_f32": [c_void_p] * 3 + [c_float] + [c_void_p] * 7 + [c_float, ctypes.c_ulonglong, c_void_p] + [c_void_p] * 3 + [c_int] * 4 + [c_void_p] * 5,

@@ -8,6 +8,7 @@ position encodings and reference points are cached per resolution; tokens stay [
 (one 128-B row per head) which is the layout the LDS-staged kernels consume.
 """
 import math
+import os
 from typing import Dict
 
 import numpy as np
@@ -62,15 +63,27 @@ class MSDeformAttn(nn.Module):
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], float(0))
         value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
-        sampling_offsets = self.sampling_offsets(query).view(N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
-        attention_weights = self.attention_weights(query).view(N, Len_q, self.n_heads, self.n_levels * self.n_points)
-        attention_weights = F.softmax(attention_weights, -1).view(N, Len_q, self.n_heads, self.n_levels, self.n_points)
         if reference_points.shape[-1] != 2:
             raise ValueError(f"Last dim of reference_points must be 2, but get {reference_points.shape[-1]} instead.")
         if offset_normalizer is None:
             offset_normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
-        sampling_locations = (reference_points[:, :, None, :, None, :]
-                              + sampling_offsets / offset_normalizer[None, None, None, :, None, :])
+        fused = (query.is_cuda and query.dtype == torch.float32 and not torch.is_autocast_enabled()
+                 and self.n_levels * self.n_points <= 16 and self.sampling_offsets.bias is not None
+                 and os.environ.get("COMBO_MSDA_PREP", "1") == "1")
+        if fused:
+            # row a5 as two launches: ONE GEMM for both projections + the prologue kernel (loc = ref + off / (W,H); softmax)
+            from ..ops.linear import linear_cat
+            from ..ops.msdaprep import msda_prep
+            proj = linear_cat(query, self.sampling_offsets.weight, self.sampling_offsets.bias,
+                              self.attention_weights.weight, self.attention_weights.bias)
+            sampling_locations, attention_weights = msda_prep(proj, reference_points, offset_normalizer, self.n_heads,
+                                                              self.n_levels, self.n_points)
+        else:
+            sampling_offsets = self.sampling_offsets(query).view(N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
+            attention_weights = self.attention_weights(query).view(N, Len_q, self.n_heads, self.n_levels * self.n_points)
+            attention_weights = F.softmax(attention_weights, -1).view(N, Len_q, self.n_heads, self.n_levels, self.n_points)
+            sampling_locations = (reference_points[:, :, None, :, None, :]
+                                  + sampling_offsets / offset_normalizer[None, None, None, :, None, :])
         output = MSDeformAttnFunction.apply(value.float(), input_spatial_shapes, input_level_start_index,
                                             sampling_locations.float(), attention_weights.float(), self.im2col_step)
         return self.output_proj(output.to(query.dtype))

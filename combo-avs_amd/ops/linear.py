@@ -220,6 +220,49 @@ def in_proj(xq, xk, xv, weight, bias, same_qk=False):
     return q.view(*shp[0], E), k.view(*shp[1], E), v.view(*shp[2], E)
 
 
+class _LinearCat(Function):
+    """y = x @ cat(W1, W2)^T + cat(b1, b2): two nn.Linear layers that read the same input as ONE GEMM (forward, dX and dW
+    each once); the weight gradients are returned as row blocks of the merged gradient."""
+
+    @staticmethod
+    def forward(ctx, x2d, w1, b1, w2, b2):
+        W = torch.cat([w1, w2], 0)
+        b = torch.cat([b1, b2], 0)
+        if _nt_ok(x2d, W.shape[0], W):
+            y = gemm_nt_x3(x2d, W, b)
+        else:
+            with _split3(True):
+                y = torch.nn.functional.linear(x2d, W, b)
+        ctx.save_for_backward(x2d, W)
+        ctx.n1 = w1.shape[0]
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x2d, W = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if _nt_ok(dy, W.shape[1]):
+                dx = gemm_nt_x3(dy, W.t().contiguous())
+            else:
+                with _split3(True):
+                    dx = dy @ W
+        dW = torch.empty_like(W)
+        db = torch.empty(W.shape[0], device=W.device, dtype=W.dtype)
+        _dw_into(dy, x2d, dW, db)
+        n1 = ctx.n1
+        return dx, dW[:n1], db[:n1], dW[n1:], db[n1:]
+
+
+def linear_cat(x, w1, b1, w2, b2):
+    """[..., K] -> [..., N1 + N2]; fp32 CUDA tensors."""
+    K = x.shape[-1]
+    y = _LinearCat.apply(x.reshape(-1, K), w1, b1, w2, b2)
+    return y.view(*x.shape[:-1], y.shape[-1])
+
+
 def gemm_x3(A, a_rowc, B, b_rowc, M, N, K, bias=None, relu=False, splits=1):
     """C[M,N] = sum_k A(m,k) B(n,k); operands are 2-D contiguous fp32 tensors ([rows,K] or, if *_rowc, [K,rows])."""
     lib = _lib.lib()

@@ -109,6 +109,18 @@ int combo_msda_backward_f64(const double* grad_out, const double* value, const i
                             int algo, combo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * a5  MSDeformAttn prologue (ops/modules/ms_deform_attn.py:101-118)
+ *   proj [tokens, M*L*P*3] = [sampling offsets (M,L,P,2) | attention logits (M,L*P)] (the two nn.Linear outputs, merged),
+ *   ref [B or 1, Lq, L, 2] reference points (ref_batch_stride = Lq*L*2 or 0), normalizer [L,2] = (W_l, H_l)
+ *   -> sampling_loc [tokens,M,L,P,2] = ref + offset / normalizer, attn_weight [tokens,M,L,P] = softmax over L*P.
+ *   backward: d_proj from (d_loc, d_attn, attn).  tokens = B*Lq, L*P <= 16.
+ * ---------------------------------------------------------------------------------------------- */
+int combo_msda_prep_forward_f32(const float* proj, const float* ref, const float* normalizer, long long tokens, int Lq,
+                                int M, int L, int P, int ref_batch_stride, float* loc, float* attn, combo_stream_t stream);
+int combo_msda_prep_backward_f32(const float* dloc, const float* dattn, const float* attn, const float* normalizer,
+                                 long long tokens, int M, int L, int P, float* dproj, combo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * a8-a9  bilateral audio-visual fusion, token stage (C == 256 channels, 8 heads)
  *   replaces, for one fused level, LayerNorm_v + BiMultiHeadAttention's visual-side chain + the layer-scale residual
  *   (fusion_module/utils/fuse_helper.py:155-237 and :320-332) in its algebraically collapsed form:

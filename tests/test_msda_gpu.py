@@ -170,3 +170,31 @@ def test_error_behaviour():
         msda.ms_deform_attn_forward(v.cuda().half(), sh, lsi, loc.cuda().half(), w.cuda().half())
     with pytest.raises(RuntimeError):  # int32 shapes
         msda.ms_deform_attn_forward(v.cuda(), sh.int(), lsi, loc.cuda(), w.cuda())
+
+
+def test_prologue_kernel_and_merged_projection_match_torch():
+    """Row a5: linear_cat + msda_prep (one GEMM + one kernel) against the reference formulation (two Linear layers, view,
+    division, broadcast add, softmax; ms_deform_attn.py:101-118), forward and all gradients."""
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.ops.linear import linear_cat
+    from combo_avs_amd.ops.msdaprep import msda_prep
+    torch.manual_seed(0)
+    B, Lq, C, M, L, P = 3, 1029, 256, 8, 3, 4
+    q = torch.randn(B, Lq, C, device="cuda", requires_grad=True)
+    w1 = (torch.randn(M * L * P * 2, C, device="cuda") * 0.05).requires_grad_(True)
+    b1 = torch.randn(M * L * P * 2, device="cuda").requires_grad_(True)
+    w2 = (torch.randn(M * L * P, C, device="cuda") * 0.05).requires_grad_(True)
+    b2 = torch.randn(M * L * P, device="cuda").requires_grad_(True)
+    ref = torch.rand(1, Lq, L, 2, device="cuda").expand(B, -1, -1, -1)
+    norm = torch.tensor([[7.0, 7.0], [14.0, 14.0], [28.0, 28.0]], device="cuda")
+    loc, attn = msda_prep(linear_cat(q, w1, b1, w2, b2), ref, norm, M, L, P)
+    off = torch.nn.functional.linear(q, w1, b1).view(B, Lq, M, L, P, 2)
+    lg = torch.nn.functional.linear(q, w2, b2).view(B, Lq, M, L * P)
+    attn_r = lg.softmax(-1).view(B, Lq, M, L, P)
+    loc_r = ref[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    assert (loc - loc_r).abs().max() < 2e-5 and (attn - attn_r).abs().max() < 2e-6
+    g1, g2 = torch.randn_like(loc), torch.randn_like(attn)
+    got = torch.autograd.grad([loc, attn], [q, w1, b1, w2, b2], [g1, g2])
+    want = torch.autograd.grad([loc_r, attn_r], [q, w1, b1, w2, b2], [g1, g2])
+    for a, b in zip(got, want):
+        assert (a - b).abs().max() <= 2e-4 * b.abs().max() + 1e-6, float((a - b).abs().max() / b.abs().max())
