@@ -32,6 +32,14 @@ def drop_path(x, p, training):
     return x * (mask / keep)
 
 
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 class DropPath(nn.Module):
     def __init__(self, p=0.0):
         super().__init__()
@@ -42,6 +50,51 @@ class DropPath(nn.Module):
 
     def extra_repr(self):
         return f"p={self.p}"
+
+
+class _CastAll(torch.autograd.Function):
+    """bf16 copies of ALL linear / convolution parameters of the backbone as one autograd node (two multi-tensor launches
+    per direction) instead of autocast's one cast kernel per parameter and step (~1 000 forward + ~900 backward launches
+    for PVTv2-B5)."""
+
+    @staticmethod
+    def forward(ctx, dtype, *params):
+        out = [torch.empty_like(p, dtype=dtype) for p in params]
+        torch._foreach_copy_(out, params)
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        idx = [i for i, g in enumerate(grads) if g is not None]
+        g32 = [torch.empty_like(grads[i], dtype=torch.float32) for i in idx]
+        if idx:
+            torch._foreach_copy_(g32, [grads[i] for i in idx])
+        out = [None] * len(grads)
+        for i, g in zip(idx, g32):
+            out[i] = g
+        return (None,) + tuple(out)
+
+
+# Explicit-precision helpers.  `wts` maps id(parameter) -> its compute-dtype copy (from _CastAll) when the backbone runs
+# in reduced precision; None = use the module's own parameters (fp32 / eval / CPU).  The dtype rules are autocast's:
+# linear / convolution / attention in the compute dtype, LayerNorm in fp32, residual sums promote to fp32.
+def _p(param, wts):
+    return param if wts is None else wts.get(id(param), param)
+
+
+def _linear(x, mod, wts):
+    w = _p(mod.weight, wts)
+    return F.linear(x if x.dtype == w.dtype else x.to(w.dtype), w, None if mod.bias is None else _p(mod.bias, wts))
+
+
+def _conv(x, mod, wts):
+    w = _p(mod.weight, wts)
+    return F.conv2d(x if x.dtype == w.dtype else x.to(w.dtype), w, None if mod.bias is None else _p(mod.bias, wts), mod.stride,
+                    mod.padding, mod.dilation, mod.groups)
+
+
+def _ln(x, mod, wts):
+    return F.layer_norm(x if wts is None else x.float(), mod.normalized_shape, mod.weight, mod.bias, mod.eps)
 
 
 def _init(m):
@@ -89,9 +142,9 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden, dim)
         self.drop = nn.Dropout(drop)
 
-    def forward(self, x, H, W):
-        x = self.drop(self.act(self.dwconv(self.fc1(x), H, W)))
-        return self.drop(self.fc2(x))
+    def forward(self, x, H, W, wts=None):
+        x = self.drop(self.act(self.dwconv(_linear(x, self.fc1, wts), H, W)))
+        return self.drop(_linear(x, self.fc2, wts))
 
 
 class Attention(nn.Module):
@@ -112,19 +165,19 @@ class Attention(nn.Module):
             self.sr = nn.Conv2d(dim, dim, kernel_size=sr_ratio, stride=sr_ratio)
             self.norm = nn.LayerNorm(dim)
 
-    def forward(self, x, H, W):
+    def forward(self, x, H, W, wts=None):
         B, N, C = x.shape
         h, d = self.num_heads, C // self.num_heads
-        q = self.q(x).view(B, N, h, d).transpose(1, 2)
+        q = _linear(x, self.q, wts).view(B, N, h, d).transpose(1, 2)
         if self.sr_ratio > 1:
-            x_ = self.sr(x.view(B, H, W, C).permute(0, 3, 1, 2))  # [B,C,H/sr,W/sr]
-            x_ = self.norm(x_.flatten(2).transpose(1, 2))
+            x_ = _conv(x.view(B, H, W, C).permute(0, 3, 1, 2), self.sr, wts)  # [B,C,H/sr,W/sr]
+            x_ = _ln(x_.flatten(2).transpose(1, 2), self.norm, wts)
         else:
             x_ = x
-        kv = self.kv(x_).view(B, -1, 2, h, d)
+        kv = _linear(x_, self.kv, wts).view(B, -1, 2, h, d)
         k, v = kv[:, :, 0].transpose(1, 2), kv[:, :, 1].transpose(1, 2)
         o = F.scaled_dot_product_attention(q, k, v, dropout_p=self.attn_drop.p if self.training else 0.0, scale=self.scale)
-        return self.proj_drop(self.proj(o.transpose(1, 2).reshape(B, N, C)))
+        return self.proj_drop(_linear(o.transpose(1, 2).reshape(B, N, C), self.proj, wts))
 
 
 class Block(nn.Module):
@@ -136,9 +189,9 @@ class Block(nn.Module):
         self.norm2 = nn.LayerNorm(dim, eps=norm_eps)
         self.mlp = Mlp(dim, int(dim * mlp_ratio), drop)
 
-    def forward(self, x, H, W):
-        x = x + self.drop_path(self.attn(self.norm1(x), H, W))
-        return x + self.drop_path(self.mlp(self.norm2(x), H, W))
+    def forward(self, x, H, W, wts=None):
+        x = x + self.drop_path(self.attn(_ln(x, self.norm1, wts), H, W, wts))
+        return x + self.drop_path(self.mlp(_ln(x, self.norm2, wts), H, W, wts))
 
 
 class OverlapPatchEmbed(nn.Module):
@@ -151,10 +204,10 @@ class OverlapPatchEmbed(nn.Module):
         self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=stride, padding=patch_size // 2)
         self.norm = nn.LayerNorm(embed_dim)
 
-    def forward(self, x):
-        x = self.proj(x)
+    def forward(self, x, wts=None):
+        x = _conv(x, self.proj, wts)
         H, W = x.shape[-2:]
-        return self.norm(x.flatten(2).transpose(1, 2)), H, W
+        return _ln(x.flatten(2).transpose(1, 2), self.norm, wts), H, W
 
 
 class PyramidVisionTransformerV2(nn.Module):
@@ -189,14 +242,32 @@ class PyramidVisionTransformerV2(nn.Module):
     def no_weight_decay(self):
         return {"pos_embed1", "pos_embed2", "pos_embed3", "pos_embed4", "cls_token"}
 
+    def _cast_params(self):
+        """every parameter autocast would cast per use: linear / convolution weights and biases, except the depth-wise
+        convolutions (csrc/dwconv.hip reads fp32 weights)"""
+        ps = []
+        for name, mod in self.named_modules():
+            if isinstance(mod, (nn.Linear, nn.Conv2d)) and not name.endswith("dwconv.dwconv"):
+                ps += [p for p in (mod.weight, mod.bias) if p is not None]
+        return ps
+
     def forward(self, x):
+        wts = None
+        if x.is_cuda and torch.is_autocast_enabled("cuda"):
+            dtype = torch.get_autocast_dtype("cuda")
+            params = self._cast_params()
+            wts = {id(p): c for p, c in zip(params, _CastAll.apply(dtype, *params))}
+        with torch.autocast("cuda", enabled=False) if wts is not None else _NullCtx():
+            return self._forward(x, wts)
+
+    def _forward(self, x, wts):
         B = x.shape[0]
         outs = {}
         for i in range(self.num_stages):
-            x, H, W = getattr(self, f"patch_embed{i + 1}")(x)
+            x, H, W = getattr(self, f"patch_embed{i + 1}")(x, wts)
             for blk in getattr(self, f"block{i + 1}"):
-                x = blk(x, H, W)
-            x = getattr(self, f"norm{i + 1}")(x)
+                x = blk(x, H, W, wts)
+            x = _ln(x, getattr(self, f"norm{i + 1}"), wts)
             x = x.view(B, H, W, -1).permute(0, 3, 1, 2)  # NCHW view, channels_last memory (the reference copies to NCHW, :359)
             stage = f"res{i + 2}"
             if stage in self._out_features:
