@@ -149,3 +149,37 @@ def test_fast_matching_path_agrees_with_replay(head_run):
     for la, lb in zip(a, b):
         for (i1, j1), (i2, j2) in zip(la, lb):
             assert torch.equal(i1, i2) and torch.equal(j1, j2)
+
+
+def test_criterion_ragged_instance_counts_vs_oracle(head_run):
+    """Frames with 0 / 1 / 2 / 3 / 6 ground-truth instances in one batch (all-frames mode): the batched HIP criterion
+    (padded cost tensors, device LSAP, flat pair lists) against the CPU oracle's per-frame loop on the same RNG stream."""
+    z, head, feats, audio, out = head_run
+    crit, wd = make_criterion("all")
+    o = {"pred_logits": out["pred_logits"].detach(), "pred_masks": out["pred_masks"].detach(),
+         "aux_outputs": [{k: v.detach() for k, v in a.items()} for a in out["aux_outputs"]],
+         "middles_attn_mask": [m.detach() for m in out["middles_attn_mask"]]}
+    counts = [2, 0, 3, 1, 6]
+    g = torch.Generator().manual_seed(7)
+    targets = []
+    yy, xx = torch.meshgrid(torch.arange(224), torch.arange(224), indexing="ij")
+    for n in counts:
+        masks = []
+        for _ in range(n):
+            cx, cy = (torch.rand(2, generator=g) * 0.6 + 0.2) * 224
+            r = (torch.rand(1, generator=g) * 0.2 + 0.05) * 224
+            masks.append(((xx - cx) ** 2 + (yy - cy) ** 2) < r * r)
+        targets.append({"labels": torch.randint(0, 2, (n,), generator=g, dtype=torch.int64),
+                        "masks": torch.stack(masks) if n else torch.zeros(0, 224, 224, dtype=torch.bool)})
+    torch.manual_seed(23)
+    got = crit(o, [{k: v.cuda() for k, v in t.items()} for t in targets])
+    torch.manual_seed(23)
+    cpu = {"pred_logits": o["pred_logits"].cpu(), "pred_masks": o["pred_masks"].cpu(),
+           "aux_outputs": [{k: v.cpu() for k, v in a.items()} for a in o["aux_outputs"]],
+           "middles_attn_mask": [m.cpu() for m in o["middles_attn_mask"]]}
+    from oracle import combo_oracle as O
+    ref = O.set_criterion(cpu, targets, num_classes=2)
+    assert sorted(got) == sorted(ref) and len(got) == 39
+    for k in sorted(ref):
+        a, b = float(got[k]), float(ref[k])
+        assert abs(a - b) <= 5e-3 * abs(b) + 5e-4, (k, a, b)
