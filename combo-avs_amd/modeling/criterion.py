@@ -145,6 +145,37 @@ class SetCriterion(nn.Module):
             world = dist.get_world_size()
         return torch.clamp(num_masks / world, min=1)  # stays on the device: no .item() sync
 
+    def _losses_no_targets(self, outputs, logits, L, F_, Q, dev):
+        """No ground-truth instance in the whole batch: every query is "no object", the mask losses are empty sums (0, still
+        attached to the graph like the reference's), the cosine term is unchanged."""
+        target_classes = torch.full((L * F_ * Q,), self.num_classes, dtype=torch.int64, device=dev)
+        nll = F.cross_entropy(logits.view(L * F_ * Q, -1), target_classes, reduction="none").view(L, -1)
+        loss_ce = nll.mean(1)  # all weights equal eos_coef: the weighted mean is the plain mean
+        zero = outputs["pred_masks"].sum() * 0.0
+        losses = {}
+        for l in range(L):
+            sfx = "" if l == 0 else f"_{l - 1}"
+            losses["loss_ce" + sfx], losses["loss_mask" + sfx], losses["loss_dice" + sfx] = loss_ce[l], zero, zero
+        losses.update(self._cosine_losses(outputs))
+        return losses
+
+    def _cosine_losses(self, outputs):
+        """frame-to-frame cosine loss on the intermediate mask logits (criterion.py:208-231, 282-286)"""
+        from ..ops import maskloss
+        losses = {}
+        if "middles_attn_mask" in outputs and len(outputs["middles_attn_mask"]):
+            mid = torch.stack(outputs["middles_attn_mask"])  # [9,BT,Q,HW]
+            n9, bt = mid.shape[0], mid.shape[1]
+            nf = self.n_frame
+            dot, nrm = maskloss.cosine_stats(mid.reshape(n9 * bt, -1), nf)
+            dot, nrm = dot.view(n9, bt // nf, nf), nrm.view(n9, bt // nf, nf)
+            cos = dot[..., :-1] / torch.sqrt((nrm[..., :-1] + 1e-12) * (nrm[..., 1:] + 1e-12))
+            c = 1 - cos
+            lc = (c * torch.exp(-c)).sum((1, 2)) / (bt // nf) / (nf - 1)
+            for i in range(n9):
+                losses[f"loss_cosine_{i}"] = lc[i]
+        return losses
+
     def _losses(self, outputs, targets):
         """All decoder outputs (final + aux) are processed TOGETHER: one batched cost computation + one D2H copy for
         the 10 x F assignment problems, one batched importance-sampling / point-sampling / loss evaluation for the
@@ -160,6 +191,8 @@ class SetCriterion(nn.Module):
         Q = logits.shape[2]
         G = [int(t["labels"].shape[0]) for t in targets]
         Gmax, Nm = max(G), sum(G)
+        if Nm == 0:
+            return self._losses_no_targets(outputs, logits, L, F_, Q, dev)
         P = self.num_points
         n_over = int(P * self.oversample_ratio)
         n_unc = int(self.importance_sample_ratio * P)
@@ -241,20 +274,7 @@ class SetCriterion(nn.Module):
             losses["loss_ce" + sfx] = loss_ce[l]
             losses["loss_mask" + sfx] = loss_mask[l]
             losses["loss_dice" + sfx] = loss_dice[l]
-        # ---- frame-to-frame cosine loss on the intermediate mask logits (criterion.py:208-231, 282-286) -----------
-        if "middles_attn_mask" in outputs and len(outputs["middles_attn_mask"]):
-            mid = torch.stack(outputs["middles_attn_mask"])  # [9,BT,Q,HW]
-            n9, bt = mid.shape[0], mid.shape[1]
-            nf = self.n_frame
-            # two fused launches (csrc/cosine.hip): |x_t|^2 and x_t . x_{t+1}; the scalar math below is differentiated
-            # by autograd and the kernels' backward turns d/d(dot), d/d(nrm) into d/dx in one pass
-            dot, nrm = maskloss.cosine_stats(mid.reshape(n9 * bt, -1), nf)
-            dot, nrm = dot.view(n9, bt // nf, nf), nrm.view(n9, bt // nf, nf)
-            cos = dot[..., :-1] / torch.sqrt((nrm[..., :-1] + 1e-12) * (nrm[..., 1:] + 1e-12))
-            c = 1 - cos
-            lc = (c * torch.exp(-c)).sum((1, 2)) / (bt // nf) / (nf - 1)
-            for i in range(n9):
-                losses[f"loss_cosine_{i}"] = lc[i]
+        losses.update(self._cosine_losses(outputs))
         return losses
 
     def forward(self, outputs, targets):

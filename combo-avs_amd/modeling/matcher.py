@@ -64,11 +64,19 @@ class HungarianMatcher(nn.Module):
         N, Q, K1 = logits.shape
         G, (h, w), (H, W), P = gt.shape[1], masks.shape[-2:], gt.shape[-2:], points.shape[1]
         cost = torch.empty(N, Q, G, device=logits.device, dtype=torch.float32)
-        t_ws = torch.empty(N, G, P, device=logits.device, dtype=torch.float32)
-        _lib.check(_lib.lib().combo_matcher_cost_f32(
-            logits.data_ptr(), masks.data_ptr(), labels.data_ptr(), gt.data_ptr(), points.data_ptr(), N, Q, K1, G, h, w, H, W,
-            P, self.cost_class, self.cost_mask, self.cost_dice, t_ws.data_ptr(), cost.data_ptr(), _lib.current_stream()),
-            "combo_matcher_cost_f32")
+        GC = 8  # targets per launch (csrc/matcher.hip keeps 3*G+1 running sums in registers); columns are independent
+        for g0 in range(0, G, GC):
+            g1 = min(G, g0 + GC)
+            gsub = gt[:, g0:g1].contiguous() if (g0, g1) != (0, G) else gt
+            lsub = labels[:, g0:g1].contiguous() if (g0, g1) != (0, G) else labels
+            csub = cost if (g0, g1) == (0, G) else torch.empty(N, Q, g1 - g0, device=logits.device, dtype=torch.float32)
+            t_ws = torch.empty(N, g1 - g0, P, device=logits.device, dtype=torch.float32)
+            _lib.check(_lib.lib().combo_matcher_cost_f32(
+                logits.data_ptr(), masks.data_ptr(), lsub.data_ptr(), gsub.data_ptr(), points.data_ptr(), N, Q, K1, g1 - g0, h, w,
+                H, W, P, self.cost_class, self.cost_mask, self.cost_dice, t_ws.data_ptr(), csub.data_ptr(), _lib.current_stream()),
+                "combo_matcher_cost_f32")
+            if csub is not cost:
+                cost[:, :, g0:g1] = csub
         return cost
 
     LSAP_DEVICE_MAX_G = 6

@@ -183,3 +183,37 @@ def test_criterion_ragged_instance_counts_vs_oracle(head_run):
     for k in sorted(ref):
         a, b = float(got[k]), float(ref[k])
         assert abs(a - b) <= 5e-3 * abs(b) + 5e-4, (k, a, b)
+
+
+@pytest.mark.parametrize("counts", [[0, 0, 0, 0, 0], [10, 1, 0, 2, 7]])
+def test_criterion_empty_batch_and_many_instances_vs_oracle(head_run, counts):
+    """No instance at all (empty sums, like the reference), and frames with more than 8 / more than 6 instances (cost kernel
+    in column chunks, SciPy LSAP on the host instead of the small-G device solver)."""
+    from oracle import combo_oracle as O
+    z, head, feats, audio, out = head_run
+    crit, wd = make_criterion("all")
+    o = {"pred_logits": out["pred_logits"].detach(), "pred_masks": out["pred_masks"].detach(),
+         "aux_outputs": [{k: v.detach() for k, v in a.items()} for a in out["aux_outputs"]],
+         "middles_attn_mask": [m.detach() for m in out["middles_attn_mask"]]}
+    g = torch.Generator().manual_seed(9)
+    yy, xx = torch.meshgrid(torch.arange(224), torch.arange(224), indexing="ij")
+    targets = []
+    for n in counts:
+        masks = []
+        for _ in range(n):
+            cx, cy = (torch.rand(2, generator=g) * 0.6 + 0.2) * 224
+            r = (torch.rand(1, generator=g) * 0.2 + 0.05) * 224
+            masks.append(((xx - cx) ** 2 + (yy - cy) ** 2) < r * r)
+        targets.append({"labels": torch.randint(0, 2, (n,), generator=g, dtype=torch.int64),
+                        "masks": torch.stack(masks) if n else torch.zeros(0, 224, 224, dtype=torch.bool)})
+    torch.manual_seed(29)
+    got = crit(o, [{k: v.cuda() for k, v in t.items()} for t in targets])
+    torch.manual_seed(29)
+    cpu = {"pred_logits": o["pred_logits"].cpu(), "pred_masks": o["pred_masks"].cpu(),
+           "aux_outputs": [{k: v.cpu() for k, v in a.items()} for a in o["aux_outputs"]],
+           "middles_attn_mask": [m.cpu() for m in o["middles_attn_mask"]]}
+    ref = O.set_criterion(cpu, targets, num_classes=2)
+    assert sorted(got) == sorted(ref) and len(got) == 39
+    for k in sorted(ref):
+        a, b = float(got[k]), float(ref[k])
+        assert abs(a - b) <= 5e-3 * abs(b) + 5e-4, (k, a, b)
