@@ -4,6 +4,7 @@
 
 `instances` may be detectron2 `Instances` (anything with .gt_classes/.gt_masks) or plain dicts with those keys.
 """
+import os
 from typing import Tuple
 
 import torch
@@ -117,6 +118,17 @@ class MaskFormer(nn.Module):
     def device(self):
         return self.pixel_mean.device
 
+    # measured (bs = 8, hipGraph step, A/B in one session): 67.4 ms with the two encoders on two streams vs 66.7 ms on one -
+    # the replayed graph does not overlap the branches and the fork/join costs a little; kept as an opt-in experiment
+    parallel_backbones = os.environ.get("COMBO_PARALLEL_BACKBONES", "0") == "1"
+
+    def _side_stream(self, device):
+        streams = self.__dict__.setdefault("_side_streams", {})
+        key = str(device)
+        if key not in streams:
+            streams[key] = torch.cuda.Stream(device=device)
+        return streams[key]
+
     def _pad(self, x):
         """ImageList.from_tensors: zero-pad H, W up to a multiple of size_divisibility (all frames share a size)."""
         d = self.size_divisibility
@@ -142,14 +154,32 @@ class MaskFormer(nn.Module):
         audio_feature = audio_feature.unsqueeze(1)
         if self.is_avss_data:
             audio_feature = audio_feature[vid_flag.bool()]
-        with amp:
-            features = self.backbone(images)
         if self.use_pre_sam:
             pre = torch.cat([b["pre_masks"].to(dev, non_blocking=True) for b in batched_inputs], dim=0)
             pre = self._pad((pre.float() - self.pixel_mean) / self.pixel_std)
-            with amp:
-                pre_sam_features = self.pre_sam_backbone(pre)
+            if images.is_cuda and self.parallel_backbones:
+                # the Siam pair is independent until the SEM mix: run the second encoder on its own HIP stream (fork/join
+                # with events, also inside a captured hipGraph).  Autograd replays each backward on its forward stream, so
+                # the two backward passes overlap as well; the late stages (14x14, 7x7 maps) do not fill 256 CUs alone.
+                cur, side = torch.cuda.current_stream(), self._side_stream(images.device)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    pre.record_stream(side)
+                    with amp:
+                        pre_sam_features = self.pre_sam_backbone(pre)
+                with amp:
+                    features = self.backbone(images)
+                cur.wait_stream(side)
+                for v in pre_sam_features.values():
+                    v.record_stream(cur)
+            else:
+                with amp:
+                    features = self.backbone(images)
+                    pre_sam_features = self.pre_sam_backbone(pre)
             features = sem_mix(features, pre_sam_features, self.scale_factor_module)  # :345-352
+        else:
+            with amp:
+                features = self.backbone(images)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.head_dtype == torch.bfloat16):
             outputs = self.sem_seg_head(features, audio_feature)
         if self.training:
