@@ -159,6 +159,8 @@ def main():
     ap.add_argument("--clips", type=int, default=8, help="clips per GPU (BASELINE config 2: 8)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"], help="host-PyTorch backbone compute dtype")
     ap.add_argument("--head-dtype", default="fp32", choices=["bf16", "fp32"], help="dense layers of the head")
+    ap.add_argument("--grad-comm", default="fp32", choices=["fp32", "bf16"],
+                    help="dtype of the gradient all-reduce (fp32 = the reference's DDP semantics; bf16 halves the xGMI bytes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backbone", default="r50", choices=["r50", "pvt"],
                     help="r50 = BASELINE configs[1] (default, the quoted metric); pvt = COMBO-PVTv2-B5 (configs 4-5 family)")
@@ -208,7 +210,8 @@ def main():
     if args.head_dtype == "bf16":
         model.head_dtype = torch.bfloat16
     opt = FlatAdamW(model, base_lr=cfg.SOLVER.BASE_LR, weight_decay=cfg.SOLVER.WEIGHT_DECAY,
-                    backbone_multiplier=cfg.SOLVER.BACKBONE_MULTIPLIER, clip_value=cfg.SOLVER.CLIP_GRADIENTS.CLIP_VALUE)
+                    backbone_multiplier=cfg.SOLVER.BACKBONE_MULTIPLIER, clip_value=cfg.SOLVER.CLIP_GRADIENTS.CLIP_VALUE,
+                    grad_comm_dtype=torch.bfloat16 if args.grad_comm == "bf16" else torch.float32)
     T, H, W = 5, 224, 224
     batch = synth_batch(args.clips, T, H, W, dev, seed=100 + rank)
     if args.mode == "infer":
@@ -313,6 +316,7 @@ def main():
             "config": {"workload": f"COMBO-{'R50' if args.backbone == 'r50' else 'PVTv2-B5'} S4, bs={args.clips} clips x 5 frames x 224x224 per GPU, full train step "
                                    "(fwd + 39-term loss + bwd + all-reduce + clip + AdamW), random-init weights",
                        "launch": "eager" if args.no_graph else "hipGraph (fwd+loss+bwd captured; all-reduce + AdamW eager)",
+                       "grad_all_reduce": args.grad_comm,
                        "global_batch_clips": args.clips * world, "frames_per_clip": T, "parallelism": f"dp{world}",
                        "precision": "bf16 backbones (host PyTorch), fp32 head + HIP kernels" if args.dtype == "bf16" else "fp32"},
             "roofline": roof,

@@ -46,7 +46,8 @@ class FlatAdamW:
     """Flat-buffer AdamW with full-model grad-norm clipping and a single gradient all-reduce."""
 
     def __init__(self, model, base_lr=1e-4, weight_decay=0.05, backbone_multiplier=0.1, clip_value=0.01,
-                 betas=(0.9, 0.999), eps=1e-8, weight_decay_norm=0.0, weight_decay_embed=0.0, grad_dtype=torch.float32):
+                 betas=(0.9, 0.999), eps=1e-8, weight_decay_norm=0.0, weight_decay_embed=0.0, grad_dtype=torch.float32,
+                 grad_comm_dtype=torch.float32):
         entries = param_groups(model, base_lr, weight_decay, backbone_multiplier, weight_decay_norm, weight_decay_embed)
         entries.sort(key=lambda e: (e[2], e[3]))  # stable: contiguous (lr, wd) segments
         self.entries = entries
@@ -76,6 +77,8 @@ class FlatAdamW:
             else:
                 self.segments.append([off, off + n, lr, wd])
             off += n
+        # optionally transport the gradient in bf16 (half the xGMI bytes), fp32 master + fp32 optimiser
+        self.grad_comm_dtype = grad_comm_dtype
         self.betas, self.eps, self.clip_value = betas, eps, clip_value
         self.step_count = 0
         self.lr_scale = 1.0  # WarmupPolyLR factor, set by the caller each iteration
@@ -116,8 +119,14 @@ class FlatAdamW:
 
     def all_reduce_grads(self):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat_grad)  # ONE collective (RCCL over xGMI on GPU; gloo in the CPU tests)
-            self.flat_grad.div_(dist.get_world_size())
+            world = dist.get_world_size()
+            if self.grad_comm_dtype != self.flat_grad.dtype:
+                buf = (self.flat_grad / world).to(self.grad_comm_dtype)  # pre-divide: keeps the sum inside bf16's range
+                dist.all_reduce(buf)
+                self.flat_grad.copy_(buf)
+            else:
+                dist.all_reduce(self.flat_grad)  # ONE collective (RCCL over xGMI on GPU; gloo in the CPU tests)
+                self.flat_grad.div_(world)
 
     @torch.no_grad()
     def step(self):

@@ -30,7 +30,7 @@ def _loss(m, x, y):
     return ((out - y) ** 2).mean() * 100
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, comm_dtype=torch.float32):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
@@ -40,7 +40,7 @@ def _worker(rank, world, port, ret):
     from combo_avs_amd.modeling.criterion import SetCriterion
     from combo_avs_amd.trainer import FlatAdamW
     m = _model()
-    opt = FlatAdamW(m, base_lr=1e-2, weight_decay=0.05, backbone_multiplier=0.1, clip_value=0.01)
+    opt = FlatAdamW(m, base_lr=1e-2, weight_decay=0.05, backbone_multiplier=0.1, clip_value=0.01, grad_comm_dtype=comm_dtype)
     g = torch.Generator().manual_seed(7)
     for it in range(4):
         x, y = torch.randn(8, 12, generator=g), torch.randn(8, 4, generator=g)
@@ -80,6 +80,22 @@ def test_two_rank_step_equals_single_process_reference_optimizer():
     for k, v in m.state_dict().items():
         torch.testing.assert_close(ret["params"][k], v, rtol=1e-5, atol=1e-7, msg=k)
     assert ret["num_masks"] == 2.0  # (1 + 3) / 2
+
+
+def test_bf16_gradient_transport_stays_close_to_fp32():
+    """SURVEY 8(f) rank 1 option: the flat gradient is all-reduced in bf16 (fp32 master weights and optimiser state)."""
+    res = []
+    for dt in (torch.float32, torch.bfloat16):
+        port = _free_port()
+        ret = mp.Manager().dict()
+        mp.spawn(_worker, args=(2, port, ret, dt), nprocs=2, join=True)
+        res.append(dict(ret["params"]))
+    moved = 0.0
+    for k in res[0]:
+        d = (res[0][k] - res[1][k]).abs().max()
+        assert d <= 3e-2 * 4 * 1e-2 + 1e-6, (k, float(d))  # 4 AdamW steps of at most lr = 1e-2 each: a few % of the motion
+        moved = max(moved, float(d))
+    assert moved > 0  # the bf16 path really ran
 
 
 def test_param_group_rules():
