@@ -165,9 +165,10 @@ __device__ __forceinline__ void glds16(const float* g, char* l) {
 }
 
 template <int WN, int kStages>
-__global__ void __launch_bounds__(256, kStages <= 3 ? 2 : 1)
-gemm_tn_glds_kernel(const float* __restrict__ dY, long long ldy, const float* __restrict__ X, long long ldx,
-                    float* __restrict__ out, float* __restrict__ db_part, int M, int N, int K, int mchunk) {
+__device__ __forceinline__ void
+gemm_tn_glds_body(const float* __restrict__ dY, long long ldy, const float* __restrict__ X, long long ldx,
+                  float* __restrict__ out, float* __restrict__ db_part, int M, int N, int K, int mchunk, int bx, int by,
+                  int bz) {
   constexpr int WK = 4 / WN, BN = 128 * WN, BK = 64 * WK;
   constexpr int A_BYTES = kTS * BN * 4, B_BYTES = kTS * BK * 4, STAGE = A_BYTES + B_BYTES;
   constexpr int A_PIECES = A_BYTES / 1024, B_PIECES = B_BYTES / 1024, PIECES = A_PIECES + B_PIECES;  // 1-KiB DMA pieces
@@ -177,8 +178,8 @@ gemm_tn_glds_kernel(const float* __restrict__ dY, long long ldy, const float* __
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wn = wave / WK, wk = wave % WK;
-  const int n_blk = blockIdx.y * BN, k_blk = blockIdx.x * BK;
-  const int mbeg = blockIdx.z * mchunk, mend = min(M, mbeg + mchunk);
+  const int n_blk = by * BN, k_blk = bx * BK;
+  const int mbeg = bz * mchunk, mend = min(M, mbeg + mchunk);
   const int nst = (mend - mbeg + kTS - 1) / kTS;
   const int col = lane & 31, kg = lane >> 5;
 
@@ -216,7 +217,7 @@ gemm_tn_glds_kernel(const float* __restrict__ dY, long long ldy, const float* __
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  const bool do_db = db_part != nullptr && blockIdx.x == 0 && wk == 0;
+  const bool do_db = db_part != nullptr && bx == 0 && wk == 0;
   float4 colsum = make_float4(0.f, 0.f, 0.f, 0.f);
 
 #pragma unroll
@@ -305,9 +306,9 @@ gemm_tn_glds_kernel(const float* __restrict__ dY, long long ldy, const float* __
     colsum.x += __shfl_xor(colsum.x, 32); colsum.y += __shfl_xor(colsum.y, 32);
     colsum.z += __shfl_xor(colsum.z, 32); colsum.w += __shfl_xor(colsum.w, 32);
     const int nr = n0 + col * 4;
-    if (kg == 0 && nr < N) *reinterpret_cast<float4*>(db_part + (long long)blockIdx.z * N + nr) = colsum;
+    if (kg == 0 && nr < N) *reinterpret_cast<float4*>(db_part + (long long)bz * N + nr) = colsum;
   }
-  float* o = out + (long long)blockIdx.z * N * K;
+  float* o = out + (long long)bz * N * K;
   const int kc = k0 + col * 2;
   if (kc < K) {
 #pragma unroll
@@ -317,6 +318,47 @@ gemm_tn_glds_kernel(const float* __restrict__ dY, long long ldy, const float* __
         const int nr = n0 + 4 * ((e & 3) + 8 * (e >> 2) + 4 * kg) + i;
         if (nr < N) *reinterpret_cast<float2*>(o + (long long)nr * K + kc) = make_float2(acc[i][0][e], acc[i][1][e]);
       }
+  }
+}
+
+template <int WN, int kStages>
+__global__ void __launch_bounds__(256, kStages <= 3 ? 2 : 1)
+gemm_tn_glds_kernel(const float* __restrict__ dY, long long ldy, const float* __restrict__ X, long long ldx,
+                    float* __restrict__ out, float* __restrict__ db_part, int M, int N, int K, int mchunk) {
+  gemm_tn_glds_body<WN, kStages>(dY, ldy, X, ldx, out, db_part, M, N, K, mchunk, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Grouped launch: many independent weight-gradient problems in ONE kernel.  The decoder's dW GEMMs (M = BT*100 tokens)
+// are latency-bound (~25 us each for 0.5 GFLOP, 114 of them per step) and not on the backward critical path, so
+// ops/linear.py defers them and runs them together at the end of the backward pass.  The problem table travels in the
+// kernel arguments (so it is frozen into a captured hipGraph together with the pointers).
+constexpr int kMaxGroup = 40;
+struct TnGroupArgs {
+  int count;
+  int block_start[kMaxGroup + 1];
+  combo_gemm_tn_problem p[kMaxGroup];
+};
+
+__global__ void __launch_bounds__(256, 2)
+gemm_tn_grouped_kernel(const TnGroupArgs args) {
+  const int b = blockIdx.x;
+  int pi = 0;
+  for (int i = 1; i < args.count; ++i)
+    if (b >= args.block_start[i]) pi = i;
+  const combo_gemm_tn_problem& pr = args.p[pi];
+  const int local = b - args.block_start[pi];
+  int mchunk = (pr.M + pr.splits - 1) / pr.splits;
+  mchunk = (mchunk + 15) / 16 * 16;
+  const long long t2 = (long long)((pr.N + 255) / 256) * ((pr.K + 127) / 128) * 256 * 128;
+  const long long t1 = (long long)((pr.N + 127) / 128) * ((pr.K + 255) / 256) * 128 * 256;
+  if (t2 <= t1) {
+    const int tk = (pr.K + 127) / 128, tn = (pr.N + 255) / 256;
+    gemm_tn_glds_body<2, 3>(pr.dY, pr.ldy, pr.X, pr.ldx, pr.partials, pr.db_partials, pr.M, pr.N, pr.K, mchunk, local % tk,
+                            (local / tk) % tn, local / (tk * tn));
+  } else {
+    const int tk = (pr.K + 255) / 256, tn = (pr.N + 127) / 128;
+    gemm_tn_glds_body<1, 3>(pr.dY, pr.ldy, pr.X, pr.ldx, pr.partials, pr.db_partials, pr.M, pr.N, pr.K, mchunk, local % tk,
+                            (local / tk) % tn, local / (tk * tn));
   }
 }
 
@@ -345,6 +387,37 @@ splitk_reduce_kernel(const float* __restrict__ part, int splits, long long n, fl
     float a = db_part[j];
     for (int z = 1; z < splits; ++z) a += db_part[(long long)z * nb + j];
     db[j] = a;
+  }
+}
+
+struct ReduceGroupArgs {
+  int count;
+  long long thread_start[kMaxGroup + 1];
+  combo_reduce_problem p[kMaxGroup];
+};
+
+__global__ void __launch_bounds__(256)
+splitk_reduce_grouped_kernel(const ReduceGroupArgs args) {
+  const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (t >= args.thread_start[args.count]) return;
+  int pi = 0;
+  for (int i = 1; i < args.count; ++i)
+    if (t >= args.thread_start[i]) pi = i;
+  const combo_reduce_problem& pr = args.p[pi];
+  const long long i = t - args.thread_start[pi];
+  const long long n4 = pr.n >> 2;
+  if (i < n4) {
+    float4 a = reinterpret_cast<const float4*>(pr.partials)[i];
+    for (int z = 1; z < pr.splits; ++z) {
+      const float4 b = reinterpret_cast<const float4*>(pr.partials + (long long)z * pr.n)[i];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    reinterpret_cast<float4*>(pr.out)[i] = a;
+  } else if (i - n4 < pr.nb) {
+    const int j = (int)(i - n4);
+    float a = pr.db_partials[j];
+    for (int z = 1; z < pr.splits; ++z) a += pr.db_partials[(long long)z * pr.nb + j];
+    pr.db[j] = a;
   }
 }
 
@@ -431,6 +504,60 @@ int combo_gemm_tn_x3_f32(const float* dY, long long ldy, const float* X, long lo
   }
   hipLaunchKernelGGL(gemm_tn_x3_kernel, dim3((K + 127) / 128, (N + 127) / 128, nz), dim3(256), 0, (hipStream_t)stream, dY,
                      ldy, X, ldx, out_partials, db_partials, M, N, K, mchunk);
+  return (int)hipGetLastError();
+}
+
+int combo_gemm_tn_x3_grouped_f32(const combo_gemm_tn_problem* problems, int count, combo_stream_t stream) {
+  if (!problems || count <= 0) return COMBO_EINVAL;
+  constexpr int lds = 3 * (kTS * 256 * 4 + kTS * 128 * 4);
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_grouped_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  for (int base = 0; base < count; base += kMaxGroup) {
+    TnGroupArgs a;
+    a.count = count - base < kMaxGroup ? count - base : kMaxGroup;
+    int blocks = 0;
+    for (int i = 0; i < a.count; ++i) {
+      const combo_gemm_tn_problem& pr = problems[base + i];
+      if (!glds_ok(pr.dY, pr.ldy, pr.X, pr.ldx, pr.M, pr.N, pr.K) || !pr.partials || pr.splits <= 0) return COMBO_EINVAL;
+      int mchunk = (pr.M + pr.splits - 1) / pr.splits;
+      mchunk = (mchunk + 15) / 16 * 16;
+      if ((pr.M + mchunk - 1) / mchunk != pr.splits) return COMBO_EINVAL;
+      const long long tiles = tn_variant(pr.N, pr.K) == 2 ? (long long)((pr.N + 255) / 256) * ((pr.K + 127) / 128)
+                                                         : (long long)((pr.N + 127) / 128) * ((pr.K + 255) / 256);
+      a.block_start[i] = blocks;
+      a.p[i] = pr;
+      blocks += (int)(tiles * pr.splits);
+    }
+    a.block_start[a.count] = blocks;
+    hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, a);
+  }
+  return (int)hipGetLastError();
+}
+
+int combo_splitk_reduce_grouped_f32(const combo_reduce_problem* problems, int count, combo_stream_t stream) {
+  if (!problems || count <= 0) return COMBO_EINVAL;
+  for (int base = 0; base < count; base += kMaxGroup) {
+    ReduceGroupArgs a;
+    a.count = count - base < kMaxGroup ? count - base : kMaxGroup;
+    long long threads = 0;
+    for (int i = 0; i < a.count; ++i) {
+      const combo_reduce_problem& pr = problems[base + i];
+      if (!pr.partials || !pr.out || pr.splits <= 0 || pr.n <= 0 || (pr.n & 3) || ((uintptr_t)pr.partials & 15) ||
+          ((uintptr_t)pr.out & 15) || (pr.nb > 0 && (!pr.db_partials || !pr.db)))
+        return COMBO_EINVAL;
+      a.thread_start[i] = threads;
+      a.p[i] = pr;
+      threads += (pr.n >> 2) + (pr.nb > 0 ? pr.nb : 0);
+    }
+    a.thread_start[a.count] = threads;
+    hipLaunchKernelGGL(splitk_reduce_grouped_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, a);
+  }
   return (int)hipGetLastError();
 }
 

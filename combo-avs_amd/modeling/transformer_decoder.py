@@ -28,6 +28,7 @@ class _MHAParams(nn.Module):
         self.in_proj_weight = nn.Parameter(torch.empty(3 * d_model, d_model))
         self.in_proj_bias = nn.Parameter(torch.zeros(3 * d_model))
         self.out_proj = Linear(d_model, d_model)
+        self.out_proj.defer_dw = True
         nn.init.xavier_uniform_(self.in_proj_weight)
         nn.init.constant_(self.out_proj.bias, 0.0)
 
@@ -36,7 +37,8 @@ class _MHAParams(nn.Module):
         E, H = self.embed_dim, self.num_heads
         B, Lq, _ = query.shape
         Lk = key.shape[1]
-        q, k, v = in_proj(query, key, value, self.in_proj_weight, self.in_proj_bias, same_qk=query is key)
+        # (these weights are used once per forward: their dW GEMMs may be deferred into the grouped launch, ops/linear.py)
+        q, k, v = in_proj(query, key, value, self.in_proj_weight, self.in_proj_bias, same_qk=query is key, defer=True)
         q = q.view(B, Lq, H, E // H).transpose(1, 2)
         k = k.view(B, Lk, H, E // H).transpose(1, 2)
         v = v.view(B, Lk, H, E // H).transpose(1, 2)
@@ -87,6 +89,7 @@ class FFNLayer(nn.Module):
         assert not normalize_before and dropout == 0.0
         self.linear1 = Linear(d_model, dim_feedforward)
         self.linear2 = Linear(dim_feedforward, d_model)
+        self.linear2.defer_dw = True
         self.norm = nn.LayerNorm(d_model)
         self._reset_parameters()
 
@@ -96,7 +99,7 @@ class FFNLayer(nn.Module):
                 nn.init.xavier_uniform_(p)
 
     def forward(self, tgt):
-        return self.norm(tgt + self.linear2(linear(tgt, self.linear1.weight, self.linear1.bias, relu=True)))  # :178-182
+        return self.norm(tgt + self.linear2(linear(tgt, self.linear1.weight, self.linear1.bias, relu=True, defer=True)))  # :178-182
 
 
 @TRANSFORMER_DECODER_REGISTRY.register()

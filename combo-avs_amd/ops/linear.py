@@ -1,6 +1,8 @@
 """Dense layers on the bf16 matrix cores with fp32 accuracy (3-way bf16 split, csrc/gemm_x3.hip).
 `linear(x, weight, bias, relu)` == F.linear (+ReLU) for fp32 CUDA tensors; forward, dX and dW all run on the same
 HIP kernel (k-contiguous / row-contiguous operand loaders, split-K for dW)."""
+import ctypes
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -114,7 +116,8 @@ class _split3:
 
 class _LinearLib3x(Function):
     @staticmethod
-    def forward(ctx, x2d, weight, bias, relu):
+    def forward(ctx, x2d, weight, bias, relu, defer=False):
+        ctx.defer = defer
         if _nt_ok(x2d, weight.shape[0], weight) and (bias is None or bias.is_contiguous()):
             y = gemm_nt_x3(x2d, weight, bias, relu)  # bias + ReLU in the epilogue
         else:
@@ -144,6 +147,13 @@ class _LinearLib3x(Function):
                     dx = dy @ weight
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
+            if ctx.defer and _dw_queue is not None:
+                dw_t = torch.empty_like(weight)
+                db_t = torch.empty(weight.shape[0], device=weight.device, dtype=weight.dtype) if want_db else None
+                dyc = dy if dy.stride(1) == 1 else dy.contiguous()
+                if _deferrable(dyc, x2d, dw_t):
+                    _dw_queue.append((dyc, x2d, dw_t, db_t))  # computed by the grouped launch when deferred_dw() closes
+                    return dx, dw_t, db_t, None, None
             if dy.stride(1) == 1 and x2d.stride(1) == 1 and dy.shape[0] >= 512:
                 # long-reduction / tiny-output shape: 3x faster than the library GEMM; db rides along
                 r = gemm_tn_x3(dy, x2d, with_bias_grad=want_db)
@@ -153,11 +163,75 @@ class _LinearLib3x(Function):
                     dw = dy.t() @ x2d
         if want_db and db is None:
             db = dy.sum(0)
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
-def _dw_into(dy, x2d, dw_out, db_out):
+class _TnProblem(ctypes.Structure):  # combo_gemm_tn_problem (include/combo_avs.h)
+    _fields_ = [("dY", ctypes.c_void_p), ("X", ctypes.c_void_p), ("partials", ctypes.c_void_p), ("db_partials", ctypes.c_void_p),
+                ("ldy", ctypes.c_longlong), ("ldx", ctypes.c_longlong), ("M", ctypes.c_int), ("N", ctypes.c_int),
+                ("K", ctypes.c_int), ("splits", ctypes.c_int)]
+
+
+class _RedProblem(ctypes.Structure):  # combo_reduce_problem
+    _fields_ = [("partials", ctypes.c_void_p), ("out", ctypes.c_void_p), ("db_partials", ctypes.c_void_p), ("db", ctypes.c_void_p),
+                ("n", ctypes.c_longlong), ("splits", ctypes.c_int), ("nb", ctypes.c_int)]
+
+
+_dw_queue = None  # [(dy, x2d, dw_out, db_out)] while a deferred_dw() context is open
+
+
+class deferred_dw:
+    """Inside this context the weight gradients of layers marked `defer=True` are not computed when autograd reaches them:
+    (dY, X, destination) is queued and ONE grouped launch (+ one grouped reduce) computes them all when the context closes.
+    The decoder's dW GEMMs are ~25 us of latency each for 0.5 GFLOP (114 per step) and nothing on the backward critical
+    path reads them.  Only valid for weights that are used ONCE per forward (autograd would otherwise sum the not yet
+    written tensors) and when the gradients are read after the context closes (trainer.FlatAdamW.backward does that)."""
+
+    def __enter__(self):
+        global _dw_queue
+        self.prev, _dw_queue = _dw_queue, []
+        return self
+
+    def __exit__(self, *exc):
+        global _dw_queue
+        q, _dw_queue = _dw_queue, self.prev
+        if exc[0] is None and q:
+            _flush_dw(q)
+        return False
+
+
+def _deferrable(dy, x2d, dw_out):
+    M, N = dy.shape
+    K = x2d.shape[1]
+    return (_dw_queue is not None and dy.stride(1) == 1 and x2d.stride(1) == 1 and M >= 256 and N % 4 == 0 and K % 4 == 0
+            and N >= 64 and K >= 64 and dy.stride(0) % 4 == 0 and x2d.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0
+            and x2d.data_ptr() % 16 == 0 and dw_out.is_contiguous() and dw_out.data_ptr() % 16 == 0 and (N * K) % 4 == 0)
+
+
+def _flush_dw(q):
+    lib, st = _lib.lib(), _lib.current_stream()
+    n = len(q)
+    tn, red, keep = (_TnProblem * n)(), (_RedProblem * n)(), []
+    for i, (dy, x2d, dw, db) in enumerate(q):
+        M, N = dy.shape
+        K = x2d.shape[1]
+        splits = lib.combo_gemm_tn_splits(M, N, K)
+        mchunk = (-(-M // splits) + 15) // 16 * 16
+        splits = -(-M // mchunk)
+        part = torch.empty(splits, N, K, device=dy.device, dtype=torch.float32)
+        dbp = torch.empty(splits, N, device=dy.device, dtype=torch.float32) if db is not None else None
+        keep.append((part, dbp))
+        tn[i] = _TnProblem(dy.data_ptr(), x2d.data_ptr(), part.data_ptr(), _lib.ptr(dbp), dy.stride(0), x2d.stride(0), M, N, K, splits)
+        red[i] = _RedProblem(part.data_ptr(), dw.data_ptr(), _lib.ptr(dbp), _lib.ptr(db), N * K, splits, N if db is not None else 0)
+    _lib.check(lib.combo_gemm_tn_x3_grouped_f32(ctypes.cast(tn, ctypes.c_void_p), n, st), "combo_gemm_tn_x3_grouped_f32")
+    _lib.check(lib.combo_splitk_reduce_grouped_f32(ctypes.cast(red, ctypes.c_void_p), n, st), "combo_splitk_reduce_grouped_f32")
+
+
+def _dw_into(dy, x2d, dw_out, db_out, defer=False):
     """dW (+ db) of one projection, written into row blocks of a packed gradient."""
+    if defer and _deferrable(dy, x2d, dw_out) and (db_out is None or db_out.is_contiguous()):
+        _dw_queue.append((dy, x2d, dw_out, db_out))
+        return
     if dy.stride(1) == 1 and x2d.stride(1) == 1 and dy.shape[0] >= 512:
         gemm_tn_x3(dy, x2d, with_bias_grad=db_out is not None, out=dw_out, db_out=db_out)
     else:
@@ -173,7 +247,8 @@ class _InProj(Function):
     4 accumulation adds in autograd; here the three weight gradients land in row blocks of one [3E,E] tensor."""
 
     @staticmethod
-    def forward(ctx, xq, xk, xv, W, b, same_qk):
+    def forward(ctx, xq, xk, xv, W, b, same_qk, defer=False):
+        ctx.defer = defer
         E = W.shape[1]
         with _split3(True):
             q = torch.nn.functional.linear(xq, W[:E], b[:E])
@@ -204,11 +279,11 @@ class _InProj(Function):
             dW = torch.empty_like(W)
             db = torch.empty(3 * E, device=W.device, dtype=W.dtype)
             for i, (dy, x) in enumerate(((dq, xq), (dk, xk), (dv, xv))):
-                _dw_into(dy, x, dW[i * E:(i + 1) * E], db[i * E:(i + 1) * E])
-        return dxq, dxk, dxv, dW, db, None
+                _dw_into(dy, x, dW[i * E:(i + 1) * E], db[i * E:(i + 1) * E], defer=ctx.defer)
+        return dxq, dxk, dxv, dW, db, None, None
 
 
-def in_proj(xq, xk, xv, weight, bias, same_qk=False):
+def in_proj(xq, xk, xv, weight, bias, same_qk=False, defer=False):
     """Packed q/k/v projection of nn.MultiheadAttention ([..., E] inputs -> three [..., E] outputs).  same_qk: xq and
     xk are the same tensor (self-attention); pass xk=None-equivalent semantics by giving the tensor twice."""
     E = weight.shape[1]
@@ -216,7 +291,7 @@ def in_proj(xq, xk, xv, weight, bias, same_qk=False):
         return (linear(xq, weight[:E], bias[:E]), linear(xk, weight[E:2 * E], bias[E:2 * E]),
                 linear(xv, weight[2 * E:], bias[2 * E:]))
     shp = (xq.shape[:-1], xk.shape[:-1], xv.shape[:-1])
-    q, k, v = _InProj.apply(xq.reshape(-1, E), xk.reshape(-1, E), xv.reshape(-1, E), weight, bias, same_qk)
+    q, k, v = _InProj.apply(xq.reshape(-1, E), xk.reshape(-1, E), xv.reshape(-1, E), weight, bias, same_qk, defer)
     return q.view(*shp[0], E), k.view(*shp[1], E), v.view(*shp[2], E)
 
 
@@ -312,14 +387,14 @@ class _LinearX3(Function):
         return dx, dw, db, None
 
 
-def linear(x, weight, bias=None, relu=False):
+def linear(x, weight, bias=None, relu=False, defer=False):
     """F.linear(x, weight, bias) [+ ReLU].  fp32 CUDA tensors with enough rows go to the bf16x3 MFMA kernel."""
     K = x.shape[-1]
     N = weight.shape[0]
     rows = x.numel() // K
     if (_IMPL == "library3x" and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32
             and rows >= MIN_ROWS and not torch.is_autocast_enabled()):
-        y = _LinearLib3x.apply(x.reshape(rows, K), weight, bias, relu)
+        y = _LinearLib3x.apply(x.reshape(rows, K), weight, bias, relu, defer)
         return y.view(*x.shape[:-1], N)
     if (_IMPL == "x3" and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and rows >= MIN_ROWS and K % 4 == 0
             and N % 4 == 0 and rows % 4 == 0 and not torch.is_autocast_enabled()
@@ -333,5 +408,7 @@ def linear(x, weight, bias=None, relu=False):
 class Linear(torch.nn.Linear):
     """nn.Linear whose forward/backward GEMMs run on csrc/gemm_x3.hip (same parameters / state-dict names)."""
 
+    defer_dw = False  # set by modules whose weights are used once per forward (see deferred_dw)
+
     def forward(self, x):
-        return linear(x, self.weight, self.bias)
+        return linear(x, self.weight, self.bias, defer=self.defer_dw)

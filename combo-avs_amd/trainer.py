@@ -91,7 +91,9 @@ class FlatAdamW:
         """d loss / d params straight into the flat gradient buffer: `autograd.grad` (no per-parameter AccumulateGrad
         add kernels - 530 launches/step for this model) followed by ONE batched concatenation into the flat buffer
         (`torch.cat(out=)`: ~5 launches; a `_foreach_copy_` decays into one D2D memcpy per parameter here)."""
-        grads = torch.autograd.grad(loss, self.params, allow_unused=True)
+        from .ops.linear import deferred_dw
+        with deferred_dw():  # latency-bound decoder weight gradients: one grouped launch when the context closes
+            grads = torch.autograd.grad(loss, self.params, allow_unused=True)
         if self.flat_grad.dtype != torch.float32 or any(g is not None and g.dtype != torch.float32 for g in grads):
             dst = [v for v, g in zip(self.grad_views, grads) if g is not None]
             src = [g for g in grads if g is not None]

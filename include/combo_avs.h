@@ -182,6 +182,24 @@ int combo_gemm_tn_splits(int M, int N, int K);
 /*   db_partials (optional, [splits,N]): per-split column sums of dY = the bias gradient, fused into the same pass. */
 int combo_gemm_tn_x3_f32(const float* dY, long long ldy, const float* X, long long ldx, float* out_partials,
                          float* db_partials, int M, int N, int K, int splits, combo_stream_t stream);
+/*   Grouped variants: many independent problems in one launch (the problem tables travel in the kernel arguments, in
+ *   chunks of 40).  Used for the decoder's weight gradients, which are latency-bound one by one and off the backward
+ *   critical path (ops/linear.py defers them to the end of the backward pass).  Every problem must satisfy the conditions
+ *   of the LDS-DMA kernel (N, K multiples of 4 and >= 64, M >= 256, 16-byte aligned rows); `splits` as for
+ *   combo_gemm_tn_x3_f32, partials [splits][N][K], db_partials [splits][N] or NULL. */
+typedef struct {
+  const float* dY; const float* X; float* partials; float* db_partials;
+  long long ldy, ldx;
+  int M, N, K, splits;
+} combo_gemm_tn_problem;
+typedef struct {
+  const float* partials; float* out; const float* db_partials; float* db;
+  long long n;
+  int splits, nb;
+} combo_reduce_problem;
+int combo_gemm_tn_x3_grouped_f32(const combo_gemm_tn_problem* problems, int count, combo_stream_t stream);
+int combo_splitk_reduce_grouped_f32(const combo_reduce_problem* problems, int count, combo_stream_t stream);
+
 /*   Finishes a split-K result in ONE launch: out[i] = sum_z partials[z*n + i] (n % 4 == 0, 16-byte aligned) and, when
  *   nb > 0, db[j] = sum_z db_partials[z*nb + j]; fixed summation order.  `out` may be a row block of a larger matrix
  *   (nn.MultiheadAttention's packed in_proj_weight gradient). */

@@ -217,3 +217,26 @@ def test_criterion_empty_batch_and_many_instances_vs_oracle(head_run, counts):
     for k in sorted(ref):
         a, b = float(got[k]), float(ref[k])
         assert abs(a - b) <= 5e-3 * abs(b) + 5e-4, (k, a, b)
+
+
+def test_deferred_grouped_weight_gradients_equal_immediate(head_run):
+    """ops.linear.deferred_dw: the decoder's weight gradients computed by ONE grouped launch at the end of the backward
+    pass against the same gradients computed launch by launch."""
+    from combo_avs_amd.ops.linear import deferred_dw
+    z, head, feats, audio, out = head_run
+    named = [(n, p) for n, p in head.named_parameters() if p.requires_grad and n.startswith("predictor.")]
+    loss = sum(a["pred_masks"].float().pow(2).mean() + a["pred_logits"].float().pow(2).mean() for a in out["aux_outputs"]) \
+        + out["pred_masks"].float().pow(2).mean() + out["pred_logits"].float().pow(2).mean()
+    params = [p for _, p in named]
+    ref = torch.autograd.grad(loss, params, retain_graph=True, allow_unused=True)
+    with deferred_dw():
+        got = torch.autograd.grad(loss, params, retain_graph=True, allow_unused=True)
+    torch.cuda.synchronize()
+    n_checked = 0
+    for (name, _), a, b in zip(named, got, ref):
+        if b is None:
+            assert a is None
+            continue
+        assert (a - b).abs().max() <= 2e-5 * b.abs().max() + 1e-9, (name, float((a - b).abs().max()), float(b.abs().max()))
+        n_checked += 1
+    assert n_checked > 100
