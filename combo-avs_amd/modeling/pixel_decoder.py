@@ -36,6 +36,7 @@ class MSDeformAttn(nn.Module):
         self.attention_weights = Linear(d_model, n_heads * n_levels * n_points)
         self.value_proj = Linear(d_model, d_model)
         self.output_proj = Linear(d_model, d_model)
+        self.value_proj.defer_dw = self.output_proj.defer_dw = True  # used once per forward: dW may join the grouped launch
         self._reset_parameters()
 
     def _reset_parameters(self):
@@ -75,7 +76,7 @@ class MSDeformAttn(nn.Module):
             from ..ops.linear import linear_cat
             from ..ops.msdaprep import msda_prep
             proj = linear_cat(query, self.sampling_offsets.weight, self.sampling_offsets.bias,
-                              self.attention_weights.weight, self.attention_weights.bias)
+                              self.attention_weights.weight, self.attention_weights.bias, defer=True)
             sampling_locations, attention_weights = msda_prep(proj, reference_points, offset_normalizer, self.n_heads,
                                                               self.n_levels, self.n_points)
         else:
@@ -100,13 +101,14 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         self.linear1 = Linear(d_model, d_ffn)
         self.dropout2 = nn.Dropout(dropout)
         self.linear2 = Linear(d_ffn, d_model)
+        self.linear2.defer_dw = True
         self.dropout3 = nn.Dropout(dropout)
         self.norm2 = nn.LayerNorm(d_model)
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None, normalizer=None):
         src2 = self.self_attn(src + pos, reference_points, src, spatial_shapes, level_start_index, padding_mask, normalizer)
         src = self.norm1(src + self.dropout1(src2))
-        src2 = self.linear2(self.dropout2(linear(src, self.linear1.weight, self.linear1.bias, relu=True)))
+        src2 = self.linear2(self.dropout2(linear(src, self.linear1.weight, self.linear1.bias, relu=True, defer=True)))
         return self.norm2(src + self.dropout3(src2))
 
 

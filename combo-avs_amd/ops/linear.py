@@ -300,7 +300,8 @@ class _LinearCat(Function):
     each once); the weight gradients are returned as row blocks of the merged gradient."""
 
     @staticmethod
-    def forward(ctx, x2d, w1, b1, w2, b2):
+    def forward(ctx, x2d, w1, b1, w2, b2, defer=False):
+        ctx.defer = defer
         W = torch.cat([w1, w2], 0)
         b = torch.cat([b1, b2], 0)
         if _nt_ok(x2d, W.shape[0], W):
@@ -326,15 +327,15 @@ class _LinearCat(Function):
                     dx = dy @ W
         dW = torch.empty_like(W)
         db = torch.empty(W.shape[0], device=W.device, dtype=W.dtype)
-        _dw_into(dy, x2d, dW, db)
+        _dw_into(dy, x2d, dW, db, defer=ctx.defer)
         n1 = ctx.n1
-        return dx, dW[:n1], db[:n1], dW[n1:], db[n1:]
+        return dx, dW[:n1], db[:n1], dW[n1:], db[n1:], None
 
 
-def linear_cat(x, w1, b1, w2, b2):
+def linear_cat(x, w1, b1, w2, b2, defer=False):
     """[..., K] -> [..., N1 + N2]; fp32 CUDA tensors."""
     K = x.shape[-1]
-    y = _LinearCat.apply(x.reshape(-1, K), w1, b1, w2, b2)
+    y = _LinearCat.apply(x.reshape(-1, K), w1, b1, w2, b2, defer)
     return y.view(*x.shape[:-1], y.shape[-1])
 
 
