@@ -47,6 +47,7 @@ _SIGNATURES = {
     "combo_gemm_tn_x3_f32": [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "combo_gemm_tn_x3_grouped_f32": [c_void_p, c_int, c_void_p],
     "combo_splitk_reduce_grouped_f32": [c_void_p, c_int, c_void_p],
+    "combo_ln_param_grad_grouped_f32": [c_void_p, c_int, c_void_p],
     "combo_splitk_reduce_f32": [c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "combo_uncertain_points_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p],
     "combo_mask_loss_forward_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p],

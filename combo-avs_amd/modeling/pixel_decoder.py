@@ -23,6 +23,14 @@ from ..ops.linear import Linear, linear
 from .layers import Conv2d, c2_xavier_fill, get_norm, position_embedding_sine
 
 
+def _deferred_layer_norm(dim):
+    """per-layer post-norm: applied once per forward, so its parameter gradients may join the grouped launch"""
+    from ..ops.layernorm import LayerNorm
+    ln = LayerNorm(dim)
+    ln.defer_dw = True
+    return ln
+
+
 class MSDeformAttn(nn.Module):
     """ops/modules/ms_deform_attn.py:32-129"""
 
@@ -97,13 +105,13 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         super().__init__()
         self.self_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
         self.dropout1 = nn.Dropout(dropout)
-        self.norm1 = nn.LayerNorm(d_model)
+        self.norm1 = _deferred_layer_norm(d_model)
         self.linear1 = Linear(d_model, d_ffn)
         self.dropout2 = nn.Dropout(dropout)
         self.linear2 = Linear(d_ffn, d_model)
         self.linear2.defer_dw = True
         self.dropout3 = nn.Dropout(dropout)
-        self.norm2 = nn.LayerNorm(d_model)
+        self.norm2 = _deferred_layer_norm(d_model)
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None, normalizer=None):
         src2 = self.self_attn(src + pos, reference_points, src, spatial_shapes, level_start_index, padding_mask, normalizer)

@@ -19,6 +19,14 @@ from ..ops.linear import Linear, in_proj, linear
 from .layers import MLP, position_embedding_sine
 
 
+def _deferred_layer_norm(dim):
+    """per-layer post-norm: applied once per forward, so its parameter gradients may join the grouped launch"""
+    from ..ops.layernorm import LayerNorm
+    ln = LayerNorm(dim)
+    ln.defer_dw = True
+    return ln
+
+
 class _MHAParams(nn.Module):
     """Parameter container with nn.MultiheadAttention's names (in_proj_weight/in_proj_bias/out_proj.*)."""
 
@@ -52,7 +60,7 @@ class SelfAttentionLayer(nn.Module):
         super().__init__()
         assert not normalize_before and dropout == 0.0, "shipped configs: PRE_NORM False, dropout 0"
         self.self_attn = _MHAParams(d_model, nhead)
-        self.norm = nn.LayerNorm(d_model)
+        self.norm = _deferred_layer_norm(d_model)
         self._reset_parameters()
 
     def _reset_parameters(self):
@@ -70,7 +78,7 @@ class CrossAttentionLayer(nn.Module):
         super().__init__()
         assert not normalize_before and dropout == 0.0
         self.multihead_attn = _MHAParams(d_model, nhead)
-        self.norm = nn.LayerNorm(d_model)
+        self.norm = _deferred_layer_norm(d_model)
         self._reset_parameters()
 
     def _reset_parameters(self):
@@ -90,7 +98,7 @@ class FFNLayer(nn.Module):
         self.linear1 = Linear(d_model, dim_feedforward)
         self.linear2 = Linear(dim_feedforward, d_model)
         self.linear2.defer_dw = True
-        self.norm = nn.LayerNorm(d_model)
+        self.norm = _deferred_layer_norm(d_model)
         self._reset_parameters()
 
     def _reset_parameters(self):

@@ -178,6 +178,28 @@ class _RedProblem(ctypes.Structure):  # combo_reduce_problem
 
 
 _dw_queue = None  # [(dy, x2d, dw_out, db_out)] while a deferred_dw() context is open
+_ln_queue = None  # [(dy, x, mean, rstd, out[2,C])]: LayerNorm parameter gradients, same idea (ops/layernorm.py)
+
+
+class _LnProblem(ctypes.Structure):  # combo_ln_grad_problem
+    _fields_ = [("dy", ctypes.c_void_p), ("x", ctypes.c_void_p), ("mean", ctypes.c_void_p), ("rstd", ctypes.c_void_p),
+                ("partials", ctypes.c_void_p), ("tokens", ctypes.c_longlong), ("C", ctypes.c_int), ("tokens_per_slice", ctypes.c_int)]
+
+
+def _flush_ln(q):
+    lib, st = _lib.lib(), _lib.current_stream()
+    n = len(q)
+    pr, red, keep = (_LnProblem * n)(), (_RedProblem * n)(), []
+    for i, (dy, x, mean, rstd, out) in enumerate(q):
+        T, C = dy.shape
+        tps = 64
+        slices = -(-T // tps)
+        part = torch.empty(slices, 2, C, device=dy.device, dtype=torch.float32)
+        keep.append(part)
+        pr[i] = _LnProblem(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), part.data_ptr(), T, C, tps)
+        red[i] = _RedProblem(part.data_ptr(), out.data_ptr(), 0, 0, 2 * C, slices, 0)
+    _lib.check(lib.combo_ln_param_grad_grouped_f32(ctypes.cast(pr, ctypes.c_void_p), n, st), "combo_ln_param_grad_grouped_f32")
+    _lib.check(lib.combo_splitk_reduce_grouped_f32(ctypes.cast(red, ctypes.c_void_p), n, st), "combo_splitk_reduce_grouped_f32")
 
 
 class deferred_dw:
@@ -188,15 +210,19 @@ class deferred_dw:
     written tensors) and when the gradients are read after the context closes (trainer.FlatAdamW.backward does that)."""
 
     def __enter__(self):
-        global _dw_queue
+        global _dw_queue, _ln_queue
         self.prev, _dw_queue = _dw_queue, []
+        self.prev_ln, _ln_queue = _ln_queue, []
         return self
 
     def __exit__(self, *exc):
-        global _dw_queue
+        global _dw_queue, _ln_queue
         q, _dw_queue = _dw_queue, self.prev
+        ql, _ln_queue = _ln_queue, self.prev_ln
         if exc[0] is None and q:
             _flush_dw(q)
+        if exc[0] is None and ql:
+            _flush_ln(ql)
         return False
 
 

@@ -200,6 +200,18 @@ typedef struct {
 int combo_gemm_tn_x3_grouped_f32(const combo_gemm_tn_problem* problems, int count, combo_stream_t stream);
 int combo_splitk_reduce_grouped_f32(const combo_reduce_problem* problems, int count, combo_stream_t stream);
 
+/*   Grouped LayerNorm parameter gradients (deferred like the weight gradients above): per problem
+ *   partials[slice][0][c] = sum_t dy*(x-mean)*rstd, partials[slice][1][c] = sum_t dy over the tokens of the slice
+ *   (slices = ceil(tokens / tokens_per_slice)); the caller sums the slices (combo_splitk_reduce_grouped_f32, n = 2*C).
+ *   Replaces ATen's per-layer cuComputePartGradGammaBeta + cuComputeGradGammaBeta for nn.LayerNorm
+ *   (transformer_decoder.py / msdeformattn.py post-norm layers). */
+typedef struct {
+  const float* dy; const float* x; const float* mean; const float* rstd; float* partials;
+  long long tokens;
+  int C, tokens_per_slice;
+} combo_ln_grad_problem;
+int combo_ln_param_grad_grouped_f32(const combo_ln_grad_problem* problems, int count, combo_stream_t stream);
+
 /*   Finishes a split-K result in ONE launch: out[i] = sum_z partials[z*n + i] (n % 4 == 0, 16-byte aligned) and, when
  *   nb > 0, db[j] = sum_z db_partials[z*nb + j]; fixed summation order.  `out` may be a row block of a larger matrix
  *   (nn.MultiheadAttention's packed in_proj_weight gradient). */

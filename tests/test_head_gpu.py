@@ -220,11 +220,11 @@ def test_criterion_empty_batch_and_many_instances_vs_oracle(head_run, counts):
 
 
 def test_deferred_grouped_weight_gradients_equal_immediate(head_run):
-    """ops.linear.deferred_dw: the decoder's weight gradients computed by ONE grouped launch at the end of the backward
-    pass against the same gradients computed launch by launch."""
+    """ops.linear.deferred_dw: the decoder's / pixel decoder's weight gradients and LayerNorm parameter gradients computed by
+    grouped launches at the end of the backward pass against the same gradients computed launch by launch."""
     from combo_avs_amd.ops.linear import deferred_dw
     z, head, feats, audio, out = head_run
-    named = [(n, p) for n, p in head.named_parameters() if p.requires_grad and n.startswith("predictor.")]
+    named = [(n, p) for n, p in head.named_parameters() if p.requires_grad and (n.startswith("predictor.") or n.startswith("pixel_decoder."))]
     loss = sum(a["pred_masks"].float().pow(2).mean() + a["pred_logits"].float().pow(2).mean() for a in out["aux_outputs"]) \
         + out["pred_masks"].float().pow(2).mean() + out["pred_logits"].float().pow(2).mean()
     params = [p for _, p in named]
