@@ -74,5 +74,6 @@ class MLP(nn.Module):
     def forward(self, x):
         from ..ops.linear import linear
         for i, layer in enumerate(self.layers):
-            x = linear(x, layer.weight, layer.bias, relu=i < self.num_layers - 1)
+            # defer=True: the weight gradients may join ops.linear.deferred_dw's grouped launch (repeated uses are summed there)
+            x = linear(x, layer.weight, layer.bias, relu=i < self.num_layers - 1, defer=True)
         return x

@@ -141,7 +141,7 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
             self.transformer_self_attention_layers.append(SelfAttentionLayer(hidden_dim, nheads, 0.0, normalize_before=pre_norm))
             self.transformer_cross_attention_layers.append(CrossAttentionLayer(hidden_dim, nheads, 0.0, normalize_before=pre_norm))
             self.transformer_ffn_layers.append(FFNLayer(hidden_dim, dim_feedforward, 0.0, normalize_before=pre_norm))
-        self.decoder_norm = nn.LayerNorm(hidden_dim)
+        self.decoder_norm = _deferred_layer_norm(hidden_dim)  # applied 10x per forward: the deferred queue sums the uses
         self.num_queries = num_queries
         query_feat_dim = hidden_dim - audio_out_dim if queries_fuse_type == "dim" else hidden_dim
         self.query_feat = nn.Embedding(num_queries, query_feat_dim)

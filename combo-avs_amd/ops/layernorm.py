@@ -29,15 +29,23 @@ class _LayerNorm(Function):
         mask = [ctx.needs_input_grad[0], ctx.needs_input_grad[1] and not deferred, ctx.needs_input_grad[2] and not deferred]
         dx, dw, db = torch.ops.aten.native_layer_norm_backward(dy, x, [C], mean, rstd, weight, bias, mask)
         if deferred:
+            use = (dy.view(-1, C), x.view(-1, C), mean.reshape(-1), rstd.reshape(-1))
+            key = ("ln", weight.data_ptr())
+            ent = _linear_mod._dw_index.get(key)
+            if ent is not None:  # another application of the same LayerNorm: joins the entry, autograd gets "no gradient"
+                ent[0].append(use)
+                return dx, None, None, None
             out = torch.empty(2, C, device=x.device, dtype=torch.float32)  # filled when deferred_dw() closes
-            q.append((dy.view(-1, C), x.view(-1, C), mean.reshape(-1), rstd.reshape(-1), out))
+            ent = [[use], out]
+            q.append(ent)
+            _linear_mod._dw_index[key] = ent
             dw, db = out[0], out[1]
         return dx, dw, db, None
 
 
 class LayerNorm(nn.LayerNorm):
-    """Same parameters / state-dict as nn.LayerNorm.  `defer_dw = True` marks an instance that is applied ONCE per forward
-    (its deferred parameter gradients must not be summed by autograd before they are written)."""
+    """Same parameters / state-dict as nn.LayerNorm.  `defer_dw = True`: the parameter gradients may join the grouped launch
+    of ops.linear.deferred_dw (repeated applications of one instance are summed there)."""
     defer_dw = False
 
     def forward(self, x):

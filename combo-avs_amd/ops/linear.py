@@ -148,12 +148,20 @@ class _LinearLib3x(Function):
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             if ctx.defer and _dw_queue is not None:
-                dw_t = torch.empty_like(weight)
-                db_t = torch.empty(weight.shape[0], device=weight.device, dtype=weight.dtype) if want_db else None
                 dyc = dy if dy.stride(1) == 1 else dy.contiguous()
-                if _deferrable(dyc, x2d, dw_t):
-                    _dw_queue.append((dyc, x2d, dw_t, db_t))  # computed by the grouped launch when deferred_dw() closes
-                    return dx, dw_t, db_t, None, None
+                key = ("w", weight.data_ptr())
+                ent = _dw_index.get(key)
+                if ent is not None and _deferrable(dyc, x2d, ent[1]):
+                    ent[0].append((dyc, x2d))  # another use of the same weight: joins the entry, autograd gets "no gradient"
+                    return dx, None, None, None, None
+                if ent is None:
+                    dw_t = torch.empty_like(weight)
+                    db_t = torch.empty(weight.shape[0], device=weight.device, dtype=weight.dtype) if want_db else None
+                    if _deferrable(dyc, x2d, dw_t):
+                        ent = [[(dyc, x2d)], dw_t, db_t]
+                        _dw_queue.append(ent)  # computed by the grouped launch when deferred_dw() closes
+                        _dw_index[key] = ent
+                        return dx, dw_t, db_t, None, None
             if dy.stride(1) == 1 and x2d.stride(1) == 1 and dy.shape[0] >= 512:
                 # long-reduction / tiny-output shape: 3x faster than the library GEMM; db rides along
                 r = gemm_tn_x3(dy, x2d, with_bias_grad=want_db)
@@ -177,7 +185,8 @@ class _RedProblem(ctypes.Structure):  # combo_reduce_problem
                 ("n", ctypes.c_longlong), ("splits", ctypes.c_int), ("nb", ctypes.c_int)]
 
 
-_dw_queue = None  # [(dy, x2d, dw_out, db_out)] while a deferred_dw() context is open
+_dw_queue = None  # [[uses, dw_out, db_out]] while a deferred_dw() context is open (uses = [(dy, x2d), ...])
+_dw_index = {}    # ("w" | "ln", parameter address) -> queue entry: repeated uses of one parameter join its entry
 _ln_queue = None  # [(dy, x, mean, rstd, out[2,C])]: LayerNorm parameter gradients, same idea (ops/layernorm.py)
 
 
@@ -187,19 +196,25 @@ class _LnProblem(ctypes.Structure):  # combo_ln_grad_problem
 
 
 def _flush_ln(q):
+    """q: [[uses, out[2,C]]] with uses = [(dy, x, mean, rstd), ...] (see _flush_dw for repeated uses)."""
     lib, st = _lib.lib(), _lib.current_stream()
-    n = len(q)
-    pr, red, keep = (_LnProblem * n)(), (_RedProblem * n)(), []
-    for i, (dy, x, mean, rstd, out) in enumerate(q):
-        T, C = dy.shape
-        tps = 64
-        slices = -(-T // tps)
-        part = torch.empty(slices, 2, C, device=dy.device, dtype=torch.float32)
+    n_pr = sum(len(e[0]) for e in q)
+    pr, red, keep = (_LnProblem * n_pr)(), (_RedProblem * len(q))(), []
+    t, tps = 0, 64
+    for i, (uses, out) in enumerate(q):
+        C = out.shape[1]
+        plan = [-(-u[0].shape[0] // tps) for u in uses]
+        total = sum(plan)
+        part = torch.empty(total, 2, C, device=out.device, dtype=torch.float32)
         keep.append(part)
-        pr[i] = _LnProblem(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), part.data_ptr(), T, C, tps)
-        red[i] = _RedProblem(part.data_ptr(), out.data_ptr(), 0, 0, 2 * C, slices, 0)
-    _lib.check(lib.combo_ln_param_grad_grouped_f32(ctypes.cast(pr, ctypes.c_void_p), n, st), "combo_ln_param_grad_grouped_f32")
-    _lib.check(lib.combo_splitk_reduce_grouped_f32(ctypes.cast(red, ctypes.c_void_p), n, st), "combo_splitk_reduce_grouped_f32")
+        off = 0
+        for (dy, x, mean, rstd), slices in zip(uses, plan):
+            pr[t] = _LnProblem(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), part[off].data_ptr(), dy.shape[0], C, tps)
+            t += 1
+            off += slices
+        red[i] = _RedProblem(part.data_ptr(), out.data_ptr(), 0, 0, 2 * C, total, 0)
+    _lib.check(lib.combo_ln_param_grad_grouped_f32(ctypes.cast(pr, ctypes.c_void_p), n_pr, st), "combo_ln_param_grad_grouped_f32")
+    _lib.check(lib.combo_splitk_reduce_grouped_f32(ctypes.cast(red, ctypes.c_void_p), len(q), st), "combo_splitk_reduce_grouped_f32")
 
 
 class deferred_dw:
@@ -210,15 +225,17 @@ class deferred_dw:
     written tensors) and when the gradients are read after the context closes (trainer.FlatAdamW.backward does that)."""
 
     def __enter__(self):
-        global _dw_queue, _ln_queue
+        global _dw_queue, _ln_queue, _dw_index
         self.prev, _dw_queue = _dw_queue, []
         self.prev_ln, _ln_queue = _ln_queue, []
+        self.prev_index, _dw_index = _dw_index, {}
         return self
 
     def __exit__(self, *exc):
-        global _dw_queue, _ln_queue
+        global _dw_queue, _ln_queue, _dw_index
         q, _dw_queue = _dw_queue, self.prev
         ql, _ln_queue = _ln_queue, self.prev_ln
+        _dw_index = self.prev_index
         if exc[0] is None and q:
             _flush_dw(q)
         if exc[0] is None and ql:
@@ -235,28 +252,40 @@ def _deferrable(dy, x2d, dw_out):
 
 
 def _flush_dw(q):
+    """q: [[uses, dw_out, db_out]] with uses = [(dy, x2d), ...]: a weight that is applied several times per forward (the
+    prediction heads run 10 times) is ONE entry - every use becomes its own GEMM problem writing its own slice of the
+    entry's split-K partials, and one reduce sums all slices, i.e. the sum over the uses costs nothing extra."""
     lib, st = _lib.lib(), _lib.current_stream()
-    n = len(q)
-    tn, red, keep = (_TnProblem * n)(), (_RedProblem * n)(), []
-    for i, (dy, x2d, dw, db) in enumerate(q):
-        M, N = dy.shape
-        K = x2d.shape[1]
-        splits = lib.combo_gemm_tn_splits(M, N, K)
-        mchunk = (-(-M // splits) + 15) // 16 * 16
-        splits = -(-M // mchunk)
-        part = torch.empty(splits, N, K, device=dy.device, dtype=torch.float32)
-        dbp = torch.empty(splits, N, device=dy.device, dtype=torch.float32) if db is not None else None
+    n_tn = sum(len(e[0]) for e in q)
+    tn, red, keep = (_TnProblem * n_tn)(), (_RedProblem * len(q))(), []
+    t = 0
+    for i, (uses, dw, db) in enumerate(q):
+        N, K = dw.shape
+        plan = []
+        for dy, x2d in uses:
+            M = dy.shape[0]
+            splits = lib.combo_gemm_tn_splits(M, N, K)
+            mchunk = (-(-M // splits) + 15) // 16 * 16
+            plan.append(-(-M // mchunk))
+        total = sum(plan)
+        part = torch.empty(total, N, K, device=dw.device, dtype=torch.float32)
+        dbp = torch.empty(total, N, device=dw.device, dtype=torch.float32) if db is not None else None
         keep.append((part, dbp))
-        tn[i] = _TnProblem(dy.data_ptr(), x2d.data_ptr(), part.data_ptr(), _lib.ptr(dbp), dy.stride(0), x2d.stride(0), M, N, K, splits)
-        red[i] = _RedProblem(part.data_ptr(), dw.data_ptr(), _lib.ptr(dbp), _lib.ptr(db), N * K, splits, N if db is not None else 0)
-    _lib.check(lib.combo_gemm_tn_x3_grouped_f32(ctypes.cast(tn, ctypes.c_void_p), n, st), "combo_gemm_tn_x3_grouped_f32")
-    _lib.check(lib.combo_splitk_reduce_grouped_f32(ctypes.cast(red, ctypes.c_void_p), n, st), "combo_splitk_reduce_grouped_f32")
+        off = 0
+        for (dy, x2d), splits in zip(uses, plan):
+            tn[t] = _TnProblem(dy.data_ptr(), x2d.data_ptr(), part[off].data_ptr(), dbp[off].data_ptr() if dbp is not None else 0,
+                               dy.stride(0), x2d.stride(0), dy.shape[0], N, K, splits)
+            t += 1
+            off += splits
+        red[i] = _RedProblem(part.data_ptr(), dw.data_ptr(), _lib.ptr(dbp), _lib.ptr(db), N * K, total, N if db is not None else 0)
+    _lib.check(lib.combo_gemm_tn_x3_grouped_f32(ctypes.cast(tn, ctypes.c_void_p), n_tn, st), "combo_gemm_tn_x3_grouped_f32")
+    _lib.check(lib.combo_splitk_reduce_grouped_f32(ctypes.cast(red, ctypes.c_void_p), len(q), st), "combo_splitk_reduce_grouped_f32")
 
 
 def _dw_into(dy, x2d, dw_out, db_out, defer=False):
     """dW (+ db) of one projection, written into row blocks of a packed gradient."""
     if defer and _deferrable(dy, x2d, dw_out) and (db_out is None or db_out.is_contiguous()):
-        _dw_queue.append((dy, x2d, dw_out, db_out))
+        _dw_queue.append([[(dy, x2d)], dw_out, db_out])
         return
     if dy.stride(1) == 1 and x2d.stride(1) == 1 and dy.shape[0] >= 512:
         gemm_tn_x3(dy, x2d, with_bias_grad=db_out is not None, out=dw_out, db_out=db_out)
