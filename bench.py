@@ -9,9 +9,16 @@ Workload (BASELINE.json configs[1]): COMBO-R50 S4, bs = 8 clips x 5 frames x 224
 synthetic inputs resident in HBM, random-init weights, one FULL training step = dual-R50 + VGGish forward, SEM mix,
 pixel decoder (HIP MSDeformAttn), bilateral fusion, masked decoder, 39-term loss with Hungarian matching, backward,
 one RCCL gradient all-reduce, grad-norm clip + AdamW.  Metric: train frames/s (whole job).
-Extra objects: `roofline` for the dominant HIP kernel (MSDeformAttn forward core, HBM-bound; duration measured
-live with HIP events on the launch stream during the timed steps) and `cpu_baseline` (the CPU oracle's full training
-step on the host cores, bounded sample, rank 0 at N=1 only).
+Forward + loss + backward are replayed from ONE captured hipGraph (trainer.GraphedTrainStep; `--no-graph` = eager
+launches; a failed capture falls back to eager and says so on stderr).  The first warm-up step is eager (MIOpen's
+exhaustive find for the backbone convolutions, ~2 min on a box with an empty MIOpen user db; COMBO_MIOPEN_BENCHMARK=0
+skips it), the capture happens in the second.
+Extra objects: `roofline` for the MSDeformAttn forward core (HBM-bound; duration by HIP events around its launches in two
+EAGER runs of the same step right after the timed region - HIP cannot record events inside a captured graph on ROCm 7),
+`other_kernels` (the 3xbf16 GEMM kernels against the bf16 MFMA peak, the MSDeformAttn backward against HBM, same event
+pass) and `cpu_baseline` (the CPU oracle's full training step on the host cores, bounded sample, rank 0 at N=1 only).
+Other modes (not the BASELINE metric): `--mode infer` (eval forward + fused inference tail), `--backbone pvt`
+(COMBO-PVTv2-B5), `--grad-comm bf16` (bf16 gradient all-reduce), `--dtype fp32`.
 """
 import argparse
 import json
@@ -300,6 +307,14 @@ def main():
             kernels[kind] = {"bound": "mfma", "launches_timed": len(evs), "avg_launch_us": round(tsum / len(evs) * 1e6, 1),
                              "achieved": round(flops / tsum / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s (bf16 MFMA, 3 products per fp32 MAC)",
                              "frac": round(flops / tsum / 2.5e15, 4), "fp32_equivalent_tflops": round(flops / 3 / tsum / 1e12, 1)}
+    grp = kt.get("kernels", {}).get("gemm_tn_x3_grouped", [])
+    if grp:  # all weight-gradient GEMMs of the head in one grouped launch per step (ops.linear.deferred_dw)
+        tsum = sum(us for us, _ in grp) * 1e-6
+        flops = sum(3 * m[0] for _, m in grp)
+        kernels["gemm_tn_x3 (grouped launch, %d problems)" % grp[0][1][1]] = {
+            "bound": "mfma", "launches_timed": len(grp), "avg_launch_us": round(tsum / len(grp) * 1e6, 1),
+            "achieved": round(flops / tsum / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s (bf16 MFMA, 3 products per fp32 MAC)",
+            "frac": round(flops / tsum / 2.5e15, 4), "fp32_equivalent_tflops": round(flops / 3 / tsum / 1e12, 1)}
     bwd = kt.get("bwd_us") or []
     if bwd:
         bwd_bytes = bt * 5.53e6  # SURVEY 8(d)-style count: value grad 1.05 + loc/w in 1.19 + grads out 1.19 + grad_out 1.05 + value 1.05 MB

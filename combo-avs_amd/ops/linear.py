@@ -278,7 +278,10 @@ def _flush_dw(q):
             t += 1
             off += splits
         red[i] = _RedProblem(part.data_ptr(), dw.data_ptr(), _lib.ptr(dbp), _lib.ptr(db), N * K, total, N if db is not None else 0)
-    _lib.check(lib.combo_gemm_tn_x3_grouped_f32(ctypes.cast(tn, ctypes.c_void_p), n_tn, st), "combo_gemm_tn_x3_grouped_f32")
+    flops = sum(2.0 * dy.shape[0] * e[1].shape[0] * e[1].shape[1] for e in q for dy, _ in e[0])
+    with _lib.timed("gemm_tn_x3_grouped", (flops, n_tn)):
+        rc = lib.combo_gemm_tn_x3_grouped_f32(ctypes.cast(tn, ctypes.c_void_p), n_tn, st)
+    _lib.check(rc, "combo_gemm_tn_x3_grouped_f32")
     _lib.check(lib.combo_splitk_reduce_grouped_f32(ctypes.cast(red, ctypes.c_void_p), len(q), st), "combo_splitk_reduce_grouped_f32")
 
 
