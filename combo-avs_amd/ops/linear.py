@@ -185,6 +185,7 @@ class _RedProblem(ctypes.Structure):  # combo_reduce_problem
                 ("n", ctypes.c_longlong), ("splits", ctypes.c_int), ("nb", ctypes.c_int)]
 
 
+_GROUP_TOKENS_PER_SPLIT = int(_os.environ.get("COMBO_DW_TOKENS_PER_SPLIT", "1024"))
 _dw_queue = None  # [[uses, dw_out, db_out]] while a deferred_dw() context is open (uses = [(dy, x2d), ...])
 _dw_index = {}    # ("w" | "ln", parameter address) -> queue entry: repeated uses of one parameter join its entry
 _ln_queue = None  # [(dy, x, mean, rstd, out[2,C])]: LayerNorm parameter gradients, same idea (ops/layernorm.py)
@@ -264,7 +265,9 @@ def _flush_dw(q):
         plan = []
         for dy, x2d in uses:
             M = dy.shape[0]
-            splits = lib.combo_gemm_tn_splits(M, N, K)
+            # a problem of a grouped launch does not have to fill the chip alone: long token chunks per workgroup keep the
+            # split-K partial traffic (and the reduce) small; the group as a whole still has thousands of workgroups
+            splits = min(lib.combo_gemm_tn_splits(M, N, K), max(1, -(-M // _GROUP_TOKENS_PER_SPLIT)))
             mchunk = (-(-M // splits) + 15) // 16 * 16
             plan.append(-(-M // mchunk))
         total = sum(plan)
