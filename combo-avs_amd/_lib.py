@@ -19,6 +19,7 @@ _SIGNATURES = {
     "combo_dwconv3x3_bf16": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "combo_dwconv3x3_wgrad_slices": [c_int] * 4,
     "combo_dwconv3x3_wgrad_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "combo_fold_cast_grouped": [c_void_p, c_int, c_void_p],
     "combo_bias_act_bf16": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p],
     "combo_relu_grad_bf16": [c_void_p, c_void_p, c_longlong, c_void_p, c_void_p],
     "combo_relu_grad_f32": [c_void_p, c_void_p, c_longlong, c_void_p, c_void_p],

@@ -39,21 +39,30 @@ class _FoldAll(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, dtype, scales, *weights):
+        ctx.scales = scales
+        if weights[0].is_cuda and all(w.is_contiguous() for w in weights):
+            from .ops.foldcast import fold_cast  # ONE launch per 56 tensors (csrc/foldcast.hip)
+            out = [torch.empty_like(w, dtype=dtype) for w in weights]
+            fold_cast([w.detach() for w in weights], out, scales)
+            return tuple(out)
         folded = torch._foreach_mul(weights, scales)
         if dtype != torch.float32:
             out = [torch.empty_like(w, dtype=dtype) for w in weights]
             torch._foreach_copy_(out, folded)
         else:
             out = folded
-        ctx.scales = scales
         return tuple(out)
 
     @staticmethod
     def backward(ctx, *grads):
         idx = [i for i, g in enumerate(grads) if g is not None]
-        g32 = [torch.empty_like(grads[i], dtype=torch.float32) for i in idx]
-        torch._foreach_copy_(g32, [grads[i] for i in idx])
-        torch._foreach_mul_(g32, [ctx.scales[i] for i in idx])
+        g32 = [torch.empty(grads[i].shape, dtype=torch.float32, device=grads[i].device) for i in idx]
+        if idx and grads[idx[0]].is_cuda:
+            from .ops.foldcast import fold_cast
+            fold_cast([grads[i].contiguous() for i in idx], g32, [ctx.scales[i] for i in idx])
+        elif idx:
+            torch._foreach_copy_(g32, [grads[i] for i in idx])
+            torch._foreach_mul_(g32, [ctx.scales[i] for i in idx])
         out = [None] * len(grads)
         for i, g in zip(idx, g32):
             out[i] = g

@@ -60,14 +60,21 @@ class _CastAll(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dtype, *params):
         out = [torch.empty_like(p, dtype=dtype) for p in params]
-        torch._foreach_copy_(out, params)
+        if params[0].is_cuda and all(p.is_contiguous() for p in params):
+            from .ops.foldcast import fold_cast  # csrc/foldcast.hip: tables of 56 tensors per launch
+            fold_cast([p.detach() for p in params], out)
+        else:
+            torch._foreach_copy_(out, params)
         return tuple(out)
 
     @staticmethod
     def backward(ctx, *grads):
         idx = [i for i, g in enumerate(grads) if g is not None]
-        g32 = [torch.empty_like(grads[i], dtype=torch.float32) for i in idx]
-        if idx:
+        g32 = [torch.empty(grads[i].shape, dtype=torch.float32, device=grads[i].device) for i in idx]
+        if idx and grads[idx[0]].is_cuda:
+            from .ops.foldcast import fold_cast
+            fold_cast([grads[i].contiguous() for i in idx], g32)
+        elif idx:
             torch._foreach_copy_(g32, [grads[i] for i in idx])
         out = [None] * len(grads)
         for i, g in zip(idx, g32):

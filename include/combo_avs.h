@@ -46,6 +46,19 @@ int combo_event_elapsed_us(void* start, void* stop, float* us);
 int combo_event_destroy(void* event);
 
 /* ------------------------------------------------------------------------------------------------
+ * Multi-tensor scale-per-output-channel + cast: dst[e] = cast(src[e] * scale[e / inner]) (scale NULL: plain cast) for
+ * many contiguous tensors in one launch (tables of 56 in the kernel arguments).  Folds FrozenBN (d2 FrozenBatchNorm2d
+ * [d2]) into all convolution weights of a ResNet and casts them to bf16, maps the gradients back, and makes the per-step
+ * bf16 parameter copies of PVTv2 - what autocast / torch._foreach_* do with one kernel per tensor.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* src; void* dst; const float* scale;
+  long long numel;
+  int inner, src_bf16, dst_bf16;
+} combo_fold_problem;
+int combo_fold_cast_grouped(const combo_fold_problem* problems, int count, combo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Backbone epilogue (host-PyTorch ResNets, bf16 NHWC): y <- relu(y + bias[c] (+ residual)) in place, one pass (MIOpen
  * runs conv, bias and ReLU as three kernels); backward dx = dy * (y > 0).  Replaces d2 BottleneckBlock's
  * FrozenBN-affine + relu + residual add ([d2]; FrozenBN folded as in backbone.py).  y/residual/dy/dx: bf16, C % 8 == 0.
