@@ -122,6 +122,13 @@ class MaskFormer(nn.Module):
     # the replayed graph does not overlap the branches and the fork/join costs a little; kept as an opt-in experiment
     parallel_backbones = os.environ.get("COMBO_PARALLEL_BACKBONES", "0") == "1"
 
+    def _loss_weights(self, keys, device):
+        cache = self.__dict__.setdefault("_loss_weight_cache", {})
+        ck = (tuple(keys), str(device))
+        if ck not in cache:
+            cache[ck] = torch.tensor([float(self.criterion.weight_dict[k]) for k in keys], dtype=torch.float32, device=device)
+        return cache[ck]
+
     def _side_stream(self, device):
         streams = self.__dict__.setdefault("_side_streams", {})
         key = str(device)
@@ -191,6 +198,21 @@ class MaskFormer(nn.Module):
                 losses = self.criterion(outputs, targets, vid_flag, gt_flag)
             else:
                 losses = self.criterion(outputs, targets)
+            if getattr(losses, "families", None):
+                # family-wise weighting (4 multiplications + 4 sums); same 39 weighted entries, plus `.total`
+                from .modeling.criterion import LossDict
+                weighted, total = LossDict(), None
+                weighted.families = []
+                for keys, vec in losses.families:
+                    for k in keys:
+                        if k not in self.criterion.weight_dict:
+                            raise ValueError(f"Found useless Loss! {k}")
+                    wv = vec * self._loss_weights(keys, vec.device)
+                    weighted.families.append((keys, wv))
+                    weighted.update(zip(keys, wv.unbind(0)))
+                    total = wv.sum() if total is None else total + wv.sum()
+                weighted.total = total
+                return weighted
             for k in list(losses.keys()):
                 if k in self.criterion.weight_dict:
                     losses[k] = losses[k] * self.criterion.weight_dict[k]

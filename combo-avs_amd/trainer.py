@@ -160,7 +160,9 @@ def poly_lr_factor(it, max_iter, power=0.9, constant_ending=0.0):
 def train_step(model, optimizer, batched_inputs):
     """forward -> 39-term loss -> backward -> one all-reduce -> clip + AdamW.  Returns the loss dict (device tensors)."""
     loss_dict = model(batched_inputs)
-    total = torch.stack(list(loss_dict.values())).sum()
+    total = getattr(loss_dict, "total", None)  # family-wise sum from the meta-arch (modeling.criterion.LossDict)
+    if total is None:
+        total = torch.stack(list(loss_dict.values())).sum()
     optimizer.backward(total)
     optimizer.all_reduce_grads()
     optimizer.step()
@@ -242,7 +244,9 @@ class GraphedTrainStep:
 
     def _fwd_bwd(self, batch):
         loss_dict = self.model(batch)
-        total = torch.stack(list(loss_dict.values())).sum()
+        total = getattr(loss_dict, "total", None)
+        if total is None:
+            total = torch.stack(list(loss_dict.values())).sum()
         self.opt.backward(total)
         return {k: v.detach() for k, v in loss_dict.items()}
 
