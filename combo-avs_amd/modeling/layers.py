@@ -30,6 +30,20 @@ def position_embedding_sine(b, h, w, device, num_pos_feats=128, temperature=1000
     return pe.to(dtype)
 
 
+def conv1x1_or_conv(conv, x):
+    """A stride-1 1x1 convolution on a channels_last fp32 tensor IS a token-major GEMM [B*H*W, Cin] x [Cin, Cout]: route it
+    through ops.linear (csrc/gemm_nt.hip forward / dX, deferred grouped weight gradient) - measured 102 + 220 us against
+    MIOpen's fp32 245 + 401 us at 40 x 256 x 56 x 56 (tools/bench_conv1x1.py).  Everything else goes to MIOpen."""
+    if (conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1 and x.is_cuda
+            and x.dtype == torch.float32 and not torch.is_autocast_enabled() and x.dim() == 4
+            and x.is_contiguous(memory_format=torch.channels_last) and x.shape[1] % 16 == 0):
+        from ..ops.linear import linear
+        B, C, H, W = x.shape
+        y = linear(x.permute(0, 2, 3, 1).reshape(B * H * W, C), conv.weight.view(conv.out_channels, C), conv.bias, defer=True)
+        return y.view(B, H, W, conv.out_channels).permute(0, 3, 1, 2)  # NCHW view, channels_last memory
+    return F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, conv.groups)
+
+
 class Conv2d(nn.Conv2d):
     """nn.Conv2d + optional norm + optional activation; parameters are named like detectron2's wrapper
     (`<name>.weight`, `<name>.norm.weight`) so reference checkpoints load 1:1."""
@@ -40,7 +54,7 @@ class Conv2d(nn.Conv2d):
         self.activation = activation
 
     def forward(self, x):
-        x = F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+        x = conv1x1_or_conv(self, x)
         if self.norm is not None:
             x = self.norm(x)
         if self.activation is not None:
