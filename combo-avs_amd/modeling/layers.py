@@ -44,6 +44,20 @@ def conv1x1_or_conv(conv, x):
     return F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
+def norm_act(x, norm, activation=None):
+    """norm -> activation of detectron2's Conv2d wrapper; GroupNorm (+ ReLU) on a channels_last fp32 map is one fused
+    channels_last-in / channels_last-out op (csrc/groupnorm.hip), everything else goes through the modules."""
+    if isinstance(norm, nn.GroupNorm):
+        from ..ops import groupnorm
+        if groupnorm.usable(x, norm) and activation in (None, F.relu):
+            return groupnorm.group_norm(x, norm, relu=activation is F.relu)
+    if norm is not None:
+        x = norm(x)
+    if activation is not None:
+        x = activation(x)
+    return x
+
+
 class Conv2d(nn.Conv2d):
     """nn.Conv2d + optional norm + optional activation; parameters are named like detectron2's wrapper
     (`<name>.weight`, `<name>.norm.weight`) so reference checkpoints load 1:1."""
@@ -55,11 +69,7 @@ class Conv2d(nn.Conv2d):
 
     def forward(self, x):
         x = conv1x1_or_conv(self, x)
-        if self.norm is not None:
-            x = self.norm(x)
-        if self.activation is not None:
-            x = self.activation(x)
-        return x
+        return norm_act(x, self.norm, self.activation)
 
 
 def get_norm(norm, out_channels):

@@ -20,7 +20,7 @@ from torch.nn.init import constant_, normal_, xavier_uniform_
 from ..msda import MSDeformAttnFunction
 from ..registry import SEM_SEG_HEADS_REGISTRY, ShapeSpec
 from ..ops.linear import Linear, linear
-from .layers import conv1x1_or_conv, Conv2d, c2_xavier_fill, get_norm, position_embedding_sine
+from .layers import conv1x1_or_conv, norm_act, Conv2d, c2_xavier_fill, get_norm, position_embedding_sine
 
 
 def _deferred_layer_norm(dim):
@@ -260,7 +260,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
             for idx, f in enumerate(self.transformer_in_features[::-1]):
                 x = features[f].float()
                 proj = self.input_proj[idx]  # Sequential(1x1 conv, GroupNorm): the conv is a token-major GEMM (layers.py)
-                srcs.append(proj[1](conv1x1_or_conv(proj[0], x)))
+                srcs.append(norm_act(conv1x1_or_conv(proj[0], x), proj[1]))
                 pos.append(position_embedding_sine(1, x.shape[2], x.shape[3], x.device, self.conv_dim // 2))
             y, spatial_shapes, level_start_index, shapes_list = self.transformer(srcs, pos)
             bs = y.shape[0]

@@ -122,6 +122,21 @@ int combo_msda_backward_f64(const double* grad_out, const double* value, const i
                             int algo, combo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * a2  GroupNorm (+ ReLU) on channels_last / token-major fp32 maps [B, HW, C] (the norm + activation of detectron2's Conv2d
+ *   wrapper [d2] as used at msdeformattn.py:215-224 (input_proj) and :271-286 (FPN lateral / output convolutions)).
+ *   forward:  y = relu?(GN(x)); mean, rstd [B,G] are saved for backward; part_ws [B*slices*C*2] floats with
+ *             slices = combo_groupnorm_nhwc_slices(HW).
+ *   backward: dx, dgamma, dbeta from dy (masked by y > 0 when relu); part_ws as above, s12_ws [B*G*2 + B*C*2].  C <= 1024.
+ * ---------------------------------------------------------------------------------------------- */
+int combo_groupnorm_nhwc_slices(int HW);
+int combo_groupnorm_nhwc_forward_f32(const float* x, const float* gamma, const float* beta, int B, int HW, int C, int G,
+                                     float eps, int relu, float* part_ws, float* mean, float* rstd, float* y,
+                                     combo_stream_t stream);
+int combo_groupnorm_nhwc_backward_f32(const float* dy, const float* x, const float* y, const float* mean, const float* rstd,
+                                      const float* gamma, int B, int HW, int C, int G, int relu, float* part_ws, float* s12_ws,
+                                      float* dx, float* dgamma, float* dbeta, combo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * a5  MSDeformAttn prologue (ops/modules/ms_deform_attn.py:101-118)
  *   proj [tokens, M*L*P*3] = [sampling offsets (M,L,P,2) | attention logits (M,L*P)] (the two nn.Linear outputs, merged),
  *   ref [B or 1, Lq, L, 2] reference points (ref_batch_stride = Lq*L*2 or 0), normalizer [L,2] = (W_l, H_l)

@@ -347,3 +347,29 @@ def test_pvt_batched_casts_match_autocast():
     assert checked > len(params) // 4  # (at the 0.02-std initialisation about half of the gradients are below bf16 noise)
     fa = torch.cat([g.flatten() for g in ga if g is not None]); fb = torch.cat([g.flatten() for g in gb if g is not None])
     assert float((fa - fb).norm() / fb.norm()) < 0.2
+
+
+@pytest.mark.parametrize("B,C,H,W,relu", [(3, 256, 14, 14, True), (2, 256, 56, 56, False), (4, 64, 7, 9, True)])
+def test_groupnorm_nhwc_vs_torch(B, C, H, W, relu):
+    """csrc/groupnorm.hip (GroupNorm(32) [+ ReLU] on channels_last maps) against nn.GroupNorm (+ relu) in fp64."""
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.ops.groupnorm import group_norm
+    torch.manual_seed(C + H)
+    gn = torch.nn.GroupNorm(32, C).cuda()
+    with torch.no_grad():
+        gn.weight.uniform_(0.5, 1.5); gn.bias.normal_(0, 0.3)
+    x = (torch.randn(B, C, H, W, device="cuda") * 2 + 0.5).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = group_norm(x, gn, relu=relu)
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    g = torch.randn_like(y)
+    dx, dw, db = torch.autograd.grad(y, (x, gn.weight, gn.bias), g)
+    x64 = x.detach().double().contiguous().requires_grad_(True)
+    w64, b64 = gn.weight.detach().double().requires_grad_(True), gn.bias.detach().double().requires_grad_(True)
+    y64 = torch.nn.functional.group_norm(x64, 32, w64, b64, gn.eps)
+    if relu:
+        y64 = y64.relu()
+    dx64, dw64, db64 = torch.autograd.grad(y64, (x64, w64, b64), g.double())
+    assert (y.double() - y64).abs().max() < 2e-5
+    assert (dx.double() - dx64).abs().max() <= 2e-5 * dx64.abs().max() + 1e-6
+    assert (dw.double() - dw64).abs().max() <= 2e-5 * dw64.abs().max() + 1e-5
+    assert (db.double() - db64).abs().max() <= 2e-5 * db64.abs().max() + 1e-5
