@@ -43,7 +43,7 @@ _SIGNATURES = {
     "combo_bifuse_backward2_f32": [c_void_p] * 3 + [c_float] + [c_void_p] * 5 + [c_float, ctypes.c_ulonglong, c_void_p] + [c_void_p] * 4 + [c_int] * 4 + [c_void_p] * 5,
     "combo_gemm_x3_splits": [c_int, c_int],
     "combo_gemm_x3_f32": [c_void_p, c_longlong, c_int, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_longlong] + [c_int] * 5 + [c_longlong, c_void_p],
-    "combo_matcher_cost_f32": [c_void_p] * 5 + [c_int] * 9 + [c_float] * 3 + [c_void_p] * 3,
+    "combo_matcher_cost_f32": [c_void_p] * 6 + [c_int] * 9 + [c_float] * 3 + [c_void_p] * 3,
     "combo_sem_mix": [c_int, c_int] + [c_void_p] * 4 + [c_int] * 3 + [c_void_p] * 3,
     "combo_semantic_inference_f32": [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p, c_void_p],
     "combo_gemm_nt_x3_f32": [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_void_p],
@@ -55,7 +55,7 @@ _SIGNATURES = {
     "combo_splitk_reduce_f32": [c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "combo_uncertain_points_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p],
     "combo_mask_loss_forward_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p],
-    "combo_mask_loss_backward_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int] + [c_void_p] * 5,
+    "combo_mask_loss_backward_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int] + [c_void_p] * 4 + [c_int, c_void_p],
     "combo_cosine_stats_f32": [c_void_p, c_longlong, c_longlong, c_int, c_void_p, c_void_p, c_void_p],
     "combo_cosine_grad_f32": [c_void_p, c_longlong, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "combo_lsap_small_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],

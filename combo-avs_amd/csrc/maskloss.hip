@@ -200,7 +200,8 @@ __global__ void __launch_bounds__(THREADS)
 mask_loss_bwd_kernel(const float* __restrict__ masks, const long long* __restrict__ midx, int h, int w,
                      const float* __restrict__ gt, const long long* __restrict__ gidx, int H, int W,
                      const float* __restrict__ coords, int P, const float* __restrict__ stats,
-                     const float* __restrict__ g_bce, const float* __restrict__ g_dice, float* __restrict__ grad_masks) {
+                     const float* __restrict__ g_bce, const float* __restrict__ g_dice, float* __restrict__ grad_masks,
+                     int accumulate) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* img = smem;
   float* gimg = smem + h * w;
@@ -235,7 +236,10 @@ mask_loss_bwd_kernel(const float* __restrict__ masks, const long long* __restric
   }
   __syncthreads();
   float* dst = grad_masks + midx[n] * h * w;
-  for (int i = tid; i < h * w; i += THREADS) dst[i] = gimg[i];
+  // accumulate: the map already holds another term's gradient (cosine loss written by combo_cosine_grad_f32); a map is
+  // matched at most once per frame and output, so the read-modify-write needs no atomics
+  if (accumulate) { for (int i = tid; i < h * w; i += THREADS) dst[i] += gimg[i]; }
+  else { for (int i = tid; i < h * w; i += THREADS) dst[i] = gimg[i]; }
 }
 
 }  // namespace
@@ -264,12 +268,13 @@ int combo_mask_loss_forward_f32(const float* masks, const long long* mask_index,
 
 int combo_mask_loss_backward_f32(const float* masks, const long long* mask_index, int NM, int h, int w, const float* gt,
                                  const long long* gt_index, int H, int W, const float* coords, int P, const float* stats,
-                                 const float* g_bce, const float* g_dice, float* grad_masks, combo_stream_t stream) {
+                                 const float* g_bce, const float* g_dice, float* grad_masks, int accumulate,
+                                 combo_stream_t stream) {
   if (!masks || !mask_index || !gt || !gt_index || !coords || !stats || !g_bce || !g_dice || !grad_masks || NM <= 0 ||
       P <= 0 || (size_t)h * w * 8 > 60 * 1024)
     return COMBO_EINVAL;
   hipLaunchKernelGGL(mask_loss_bwd_kernel, dim3(NM), dim3(THREADS), (size_t)h * w * 8, (hipStream_t)stream, masks, mask_index,
-                     h, w, gt, gt_index, H, W, coords, P, stats, g_bce, g_dice, grad_masks);
+                     h, w, gt, gt_index, H, W, coords, P, stats, g_bce, g_dice, grad_masks, accumulate);
   return (int)hipGetLastError();
 }
 

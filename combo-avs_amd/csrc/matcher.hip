@@ -53,7 +53,8 @@ gt_sample_kernel(const float* __restrict__ gt, const float* __restrict__ points,
 // One workgroup (8 waves) per (n, q): the mask sits once in LDS (12.5 KB -> 4 workgroups = 32 waves per CU) and the
 // 8 waves split the P points; partial sums meet in a small LDS array.
 __global__ void __launch_bounds__(WAVES * 64)
-matcher_cost_kernel(const float* __restrict__ logits, const float* __restrict__ masks, const long long* __restrict__ labels,
+matcher_cost_kernel(const float* __restrict__ logits, const float* __restrict__ masks, const long long* __restrict__ mask_base,
+                    const long long* __restrict__ labels,
                     const float* __restrict__ t, const float* __restrict__ points, int N, int Q, int K1, int G, int h, int w,
                     int P, float w_class, float w_mask, float w_dice, float* __restrict__ cost) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -61,7 +62,9 @@ matcher_cost_kernel(const float* __restrict__ logits, const float* __restrict__ 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = blockIdx.x / Q, q = blockIdx.x % Q;
   float* img = smem;
-  const float* src = masks + ((long long)n * Q + q) * h * w;
+  // mask_base[n]: index of query 0's map of problem n inside a larger stack of maps (e.g. the [heads, BT, Q] logits
+  // buffer of the decoder: no gathered copy of the ground-truth frames), NULL: maps are packed [N, Q]
+  const float* src = masks + ((mask_base ? mask_base[n] : (long long)n * Q) + q) * h * w;
   for (int i = tid; i < h * w; i += WAVES * 64) img[i] = src[i];
   __syncthreads();
   float a[GMAX], d[GMAX], tt[GMAX], s_sum = 0.f;
@@ -122,7 +125,8 @@ matcher_cost_kernel(const float* __restrict__ logits, const float* __restrict__ 
 
 }  // namespace
 
-extern "C" int combo_matcher_cost_f32(const float* logits, const float* masks, const long long* labels, const float* gt,
+extern "C" int combo_matcher_cost_f32(const float* logits, const float* masks, const long long* mask_base,
+                                      const long long* labels, const float* gt,
                                       const float* points, int N, int Q, int K1, int G, int h, int w, int H, int W,
                                       int P, float w_class, float w_mask, float w_dice, float* t_ws, float* cost,
                                       combo_stream_t stream) {
@@ -140,7 +144,7 @@ extern "C" int combo_matcher_cost_f32(const float* logits, const float* masks, c
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  hipLaunchKernelGGL(matcher_cost_kernel, dim3(N * Q), dim3(WAVES * 64), lds, st, logits, masks, labels, t_ws,
+  hipLaunchKernelGGL(matcher_cost_kernel, dim3(N * Q), dim3(WAVES * 64), lds, st, logits, masks, mask_base, labels, t_ws,
                      points, N, Q, K1, G, h, w, P, w_class, w_mask, w_dice, cost);
   return (int)hipGetLastError();
 }

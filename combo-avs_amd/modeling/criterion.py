@@ -141,6 +141,20 @@ class SetCriterion(nn.Module):
             cache[key] = (gcount, valid, frame)
         return cache[key]
 
+    def _fused_index(self, frame_ids, heads, BT, Q, dev):
+        """Cached index tensors of the fused path: GT-frame selector, head of criterion layer l (l = 0 is the FINAL
+        prediction = last head, l >= 1 is aux output l-1), global frame of GT frame f, and the map index of query 0 of
+        every (layer, GT frame) problem inside the [heads, BT, Q] stack."""
+        key = ("fused", frame_ids, heads, BT, Q, str(dev))
+        cache = self.__dict__.setdefault("_match_index_cache", {})
+        if key not in cache:
+            hol = [heads - 1] + list(range(heads - 1))
+            sel = torch.tensor(list(frame_ids), dtype=torch.int64, device=dev)
+            head_of_layer = torch.tensor(hol, dtype=torch.int64, device=dev)
+            base = torch.tensor([(h * BT + f) * Q for h in hol for f in frame_ids], dtype=torch.int64, device=dev)
+            cache[key] = (sel, head_of_layer, sel, base)
+        return cache[key]
+
     def _num_masks(self, targets, device):
         if getattr(self, "num_masks_override", None) is not None:
             # trainer.GraphedTrainStep: the (all-reduced, clamped) value lives in a static device tensor that is refreshed
@@ -162,7 +176,7 @@ class SetCriterion(nn.Module):
         zero = (outputs["pred_masks"].sum() * 0.0).expand(L)
         return self._assemble(loss_ce, zero, zero, outputs)
 
-    def _assemble(self, loss_ce, loss_mask, loss_dice, outputs):
+    def _assemble(self, loss_ce, loss_mask, loss_dice, outputs, lc="compute"):
         L = loss_ce.shape[0]
         sfx = [""] + [f"_{l - 1}" for l in range(1, L)]
         losses = LossDict()
@@ -171,7 +185,8 @@ class SetCriterion(nn.Module):
             keys = [name + s_ for s_ in sfx]
             losses.families.append((keys, vec))
             losses.update(zip(keys, vec.unbind(0)))
-        lc = self._cosine_vector(outputs)
+        if isinstance(lc, str):
+            lc = self._cosine_vector(outputs)
         if lc is not None:
             keys = [f"loss_cosine_{i}" for i in range(lc.shape[0])]
             losses.families.append((keys, lc))
@@ -192,8 +207,10 @@ class SetCriterion(nn.Module):
             return (c * torch.exp(-c)).sum((1, 2)) / (bt // nf) / (nf - 1)
         return None
 
-    def _losses(self, outputs, targets):
-        """All decoder outputs (final + aux) are processed TOGETHER: one batched cost computation + one D2H copy for
+    def _losses(self, outputs, targets, frame_ids=None):
+        """frame_ids (host list of the frames that carry ground truth) + outputs["_logits_all"]: fused path - the mask
+        logits of all heads are read from the decoder's single buffer and differentiated by one node.
+        All decoder outputs (final + aux) are processed TOGETHER: one batched cost computation + one D2H copy for
         the 10 x F assignment problems, one batched importance-sampling / point-sampling / loss evaluation for the
         10 x (matched masks), one batched cosine loss.  Random points are drawn in the reference's order
         (per output: matcher points frame by frame, then the 3x-oversampled and the extra uniform loss points,
@@ -203,7 +220,16 @@ class SetCriterion(nn.Module):
         ps = self.point_source or default_point_source(dev)
         L, F_ = len(layers), len(targets)
         logits = torch.stack([lo["pred_logits"] for lo in layers]).float()  # [L,F,Q,K+1]
-        masks = torch.stack([lo["pred_masks"] for lo in layers])  # [L,F,Q,h,w]
+        xall = outputs.get("_logits_all") if frame_ids is not None else None
+        fused = (xall is not None and xall.is_cuda and xall.dtype == torch.float32 and xall.is_contiguous()
+                 and xall.shape[0] == L and len(frame_ids) == F_)
+        if fused:
+            heads, BT = xall.shape[0], xall.shape[1]
+            sel, head_of_layer, gframe, mask_base = self._fused_index(tuple(frame_ids), heads, BT, xall.shape[2], dev)
+            logits = logits.index_select(1, sel)  # class logits of the GT frames (small); the maps are addressed in place
+            masks = None
+        else:
+            masks = torch.stack([lo["pred_masks"] for lo in layers])  # [L,F,Q,h,w]
         Q = logits.shape[2]
         G = [int(t["labels"].shape[0]) for t in targets]
         Gmax, Nm = max(G), sum(G)
@@ -238,8 +264,12 @@ class SetCriterion(nn.Module):
             gt[f, : G[f]] = t["masks"].to(gt)
             lab[f, : G[f]] = t["labels"]
         with torch.no_grad():
-            C = self.matcher.batched_cost(logits.view(L * F_, Q, -1), masks.view(L * F_, Q, *masks.shape[-2:]).float(),
-                                          lab.repeat(L, 1), gt.repeat(L, 1, 1, 1), mpts)  # [L*F,Q,Gmax]
+            if fused:
+                C = self.matcher.batched_cost(logits.reshape(L * F_, Q, -1), xall, lab.repeat(L, 1), gt.repeat(L, 1, 1, 1), mpts,
+                                              mask_base=mask_base)
+            else:
+                C = self.matcher.batched_cost(logits.view(L * F_, Q, -1), masks.view(L * F_, Q, *masks.shape[-2:]).float(),
+                                              lab.repeat(L, 1), gt.repeat(L, 1, 1, 1), mpts)  # [L*F,Q,Gmax]
         frame = torch.cat([torch.full((g,), f, dtype=torch.int64) for f, g in enumerate(G)])
         if Gmax <= self.matcher.LSAP_DEVICE_MAX_G and self.host_lsap is False:
             # exact assignment on the device: the step has no device->host synchronisation
@@ -270,15 +300,28 @@ class SetCriterion(nn.Module):
         target_classes = torch.full((L, F_, Q), self.num_classes, dtype=torch.int64, device=dev)
         lidx = torch.arange(L, device=dev)[:, None].expand(L, Nm)
         target_classes[lidx, frame[None].expand(L, Nm), src_q] = lab[frame[None].expand(L, Nm), tgt_g]
-        nll = F.cross_entropy(logits.view(L * F_ * Q, -1), target_classes.view(-1), reduction="none").view(L, -1)
+        nll = F.cross_entropy(logits.reshape(L * F_ * Q, -1), target_classes.view(-1), reduction="none").view(L, -1)
         wgt = self.empty_weight[target_classes].view(L, -1)
         loss_ce = (nll * wgt).sum(1) / wgt.sum(1)
         # ---- mask losses (criterion.py:137-186), all outputs at once: three fused launches (csrc/maskloss.hip) ----------
         from ..ops import maskloss
-        masks32 = masks.float().contiguous()  # [L,F,Q,h,w]; pairs address their maps by flat index, no gather copies
         frame_b = frame[None].expand(L, Nm)
-        mask_index = ((lidx * F_ + frame_b) * Q + src_q).reshape(-1).contiguous()
         gt_index = (frame_b * Gmax + tgt_g).reshape(-1).contiguous()
+        if fused:
+            mask_index = ((head_of_layer[lidx] * BT + gframe[frame_b]) * Q + src_q).reshape(-1).contiguous()
+            coords = maskloss.uncertain_points(xall.view(-1, *xall.shape[-2:]), mask_index, over, extra, n_unc)
+            n_mid = len(outputs.get("middles_attn_mask", []))
+            bce, dice, dot, nrm = maskloss.mask_and_cosine(xall, n_mid, self.n_frame, mask_index, gt, gt_index, coords)
+            bce, dice = bce.view(L, Nm), dice.view(L, Nm)
+            lc = None
+            if n_mid:
+                nf = self.n_frame
+                dot, nrm = dot.view(n_mid, BT // nf, nf), nrm.view(n_mid, BT // nf, nf)
+                c = 1 - dot[..., :-1] / torch.sqrt((nrm[..., :-1] + 1e-12) * (nrm[..., 1:] + 1e-12))
+                lc = (c * torch.exp(-c)).sum((1, 2)) / (BT // nf) / (nf - 1)
+            return self._assemble(loss_ce, bce.sum(1) / num_masks, dice.sum(1) / num_masks, outputs, lc)
+        masks32 = masks.float().contiguous()  # [L,F,Q,h,w]; pairs address their maps by flat index, no gather copies
+        mask_index = ((lidx * F_ + frame_b) * Q + src_q).reshape(-1).contiguous()
         coords = maskloss.uncertain_points(masks32, mask_index, over, extra, n_unc)  # importance sampling, no sort
         bce, dice = maskloss.mask_losses(masks32, mask_index, gt, gt_index, coords)
         bce, dice = bce.view(L, Nm), dice.view(L, Nm)
@@ -287,8 +330,12 @@ class SetCriterion(nn.Module):
         return self._assemble(loss_ce, loss_mask, loss_dice, outputs)
 
     def forward(self, outputs, targets):
-        if len(outputs["pred_logits"]) != len(targets):  # S4 training: GT on the first frame of each clip only
-            index = torch.arange(0, len(outputs["pred_logits"]), 5, device=outputs["pred_logits"].device)
+        bt = len(outputs["pred_logits"])
+        s4 = bt != len(targets)  # S4 training: GT on the first frame of each clip only
+        if "_logits_all" in outputs and outputs["_logits_all"].is_cuda:
+            return self._losses(outputs, targets, frame_ids=list(range(0, bt, 5)) if s4 else list(range(bt)))
+        if s4:
+            index = torch.arange(0, bt, 5, device=outputs["pred_logits"].device)
             outputs = self._select(outputs, index)
         return self._losses(outputs, targets)
 

@@ -53,11 +53,12 @@ class HungarianMatcher(nn.Module):
         return costs
 
     @torch.no_grad()
-    def batched_cost(self, logits, masks, labels, gt, points):
+    def batched_cost(self, logits, masks, labels, gt, points, mask_base=None):
         """Cost tensors of N = (outputs x frames) assignment problems at once, one fused HIP launch
         (csrc/matcher.hip).  logits [N,Q,K+1], masks [N,Q,h,w], labels [N,Gmax] (padded), gt [N,Gmax,H,W] (zero
         padded), points [N,P,2] -> [N,Q,Gmax] (columns beyond a frame's real G are sliced away by the caller)."""
         from .. import _lib
+        # mask_base [N] int64: problem n's maps start at masks.view(-1,h,w)[mask_base[n]] (no gathered copy of the GT frames)
         logits, masks, gt, points = (t.contiguous().float() for t in (logits, masks, gt, points))
         labels = labels.contiguous()
         _lib.require_cuda(logits, masks, labels, gt, points)
@@ -72,7 +73,8 @@ class HungarianMatcher(nn.Module):
             csub = cost if (g0, g1) == (0, G) else torch.empty(N, Q, g1 - g0, device=logits.device, dtype=torch.float32)
             t_ws = torch.empty(N, g1 - g0, P, device=logits.device, dtype=torch.float32)
             _lib.check(_lib.lib().combo_matcher_cost_f32(
-                logits.data_ptr(), masks.data_ptr(), lsub.data_ptr(), gsub.data_ptr(), points.data_ptr(), N, Q, K1, g1 - g0, h, w,
+                logits.data_ptr(), masks.data_ptr(), _lib.ptr(mask_base), lsub.data_ptr(), gsub.data_ptr(), points.data_ptr(), N, Q, K1,
+                g1 - g0, h, w,
                 H, W, P, self.cost_class, self.cost_mask, self.cost_dice, t_ws.data_ptr(), csub.data_ptr(), _lib.current_stream()),
                 "combo_matcher_cost_f32")
             if csub is not cost:

@@ -238,6 +238,9 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
             "pred_logits": predictions_class[-1], "pred_masks": predictions_mask[-1],
             "aux_outputs": [{"pred_logits": a, "pred_masks": b} for a, b in zip(predictions_class[:-1], predictions_mask[:-1])],
             "middles_attn_mask": middles,
+            # the same logits as ONE tensor [heads, BT, Q, h, w] (head i = prediction after layer i-1, last = final): the
+            # criterion's fused path reads and differentiates this buffer directly (ops/maskloss.py::mask_and_cosine)
+            "_logits_all": logits_all.view(nheads_pred, bt, self.num_queries, h_m, w_m),
         }
 
     def forward_prediction_heads(self, output, mf_tok, hw, attn_mask_target_size, logits_out):

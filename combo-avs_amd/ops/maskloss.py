@@ -48,7 +48,7 @@ class _MaskLoss(Function):
         grad = torch.zeros_like(masks)
         _lib.check(_lib.lib().combo_mask_loss_backward_f32(
             masks.data_ptr(), mask_index.data_ptr(), NM, h, w, gt.data_ptr(), gt_index.data_ptr(), H, W, coords.data_ptr(), P,
-            stats.data_ptr(), g_bce.contiguous().float().data_ptr(), g_dice.contiguous().float().data_ptr(), grad.data_ptr(),
+            stats.data_ptr(), g_bce.contiguous().float().data_ptr(), g_dice.contiguous().float().data_ptr(), grad.data_ptr(), 0,
             _lib.current_stream()), "combo_mask_loss_backward_f32")
         return grad, None, None, None, None
 
@@ -56,6 +56,63 @@ class _MaskLoss(Function):
 def mask_losses(masks, mask_index, gt, gt_index, coords):
     """-> (mean-over-points BCE [NM], dice [NM]) of the matched pairs; differentiable w.r.t. `masks`."""
     return _MaskLoss.apply(masks.contiguous().float(), mask_index, gt.contiguous().float(), gt_index, coords.contiguous())
+
+
+class _MaskAndCosine(Function):
+    """Mask losses of the matched pairs AND the frame-to-frame cosine statistics on ONE stack of mask logits
+    `x` [heads, BT, Q, h, w] (the decoder's logits buffer), with ONE gradient buffer: the cosine gradient kernel writes it,
+    the mask-loss backward adds its few matched maps in place.  Separately the two terms cost a gathered stack of the GT
+    frames, its scatter back (index_add into zero-filled tensors), a stack of the 9 intermediate heads and one 50 MB
+    accumulation add per head."""
+
+    @staticmethod
+    def forward(ctx, x, cos_heads, n_frame, mask_index, gt, gt_index, coords):
+        heads, BT, Q, h, w = x.shape
+        lib, st = _lib.lib(), _lib.current_stream()
+        NM, P = coords.shape[:2]
+        H, W = gt.shape[-2:]
+        stats = torch.empty(NM, 4, device=x.device, dtype=torch.float32)
+        _lib.check(lib.combo_mask_loss_forward_f32(x.data_ptr(), mask_index.data_ptr(), NM, h, w, gt.data_ptr(), gt_index.data_ptr(),
+                                                   H, W, coords.data_ptr(), P, stats.data_ptr(), st), "combo_mask_loss_forward_f32")
+        rows, E = cos_heads * BT, Q * h * w
+        dot = torch.zeros(rows, device=x.device, dtype=torch.float32)
+        nrm = torch.zeros(rows, device=x.device, dtype=torch.float32)
+        if rows > 0:
+            _lib.check(lib.combo_cosine_stats_f32(x.data_ptr(), rows, E, n_frame, dot.data_ptr(), nrm.data_ptr(), st),
+                       "combo_cosine_stats_f32")
+        ctx.save_for_backward(x, mask_index, gt, gt_index, coords, stats)
+        ctx.meta = (cos_heads, n_frame)
+        bce = stats[:, 0] / P
+        dice = 1 - (2 * stats[:, 1] + 1) / (stats[:, 2] + stats[:, 3] + 1)
+        return bce, dice, dot, nrm
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_bce, g_dice, gdot, gnrm):
+        x, mask_index, gt, gt_index, coords, stats = ctx.saved_tensors
+        cos_heads, n_frame = ctx.meta
+        heads, BT, Q, h, w = x.shape
+        lib, st = _lib.lib(), _lib.current_stream()
+        NM, P = coords.shape[:2]
+        H, W = gt.shape[-2:]
+        rows, E = cos_heads * BT, Q * h * w
+        grad = torch.empty_like(x)
+        if rows > 0:
+            _lib.check(lib.combo_cosine_grad_f32(x.data_ptr(), rows, E, n_frame, gdot.contiguous().float().data_ptr(),
+                                                 gnrm.contiguous().float().data_ptr(), grad.data_ptr(), st), "combo_cosine_grad_f32")
+        if cos_heads < heads:
+            grad.view(heads, -1)[cos_heads:].zero_()  # heads without a cosine term (the final prediction)
+        _lib.check(lib.combo_mask_loss_backward_f32(
+            x.data_ptr(), mask_index.data_ptr(), NM, h, w, gt.data_ptr(), gt_index.data_ptr(), H, W, coords.data_ptr(), P,
+            stats.data_ptr(), g_bce.contiguous().float().data_ptr(), g_dice.contiguous().float().data_ptr(), grad.data_ptr(), 1, st),
+            "combo_mask_loss_backward_f32")
+        return grad, None, None, None, None, None, None
+
+
+def mask_and_cosine(x, cos_heads, n_frame, mask_index, gt, gt_index, coords):
+    """x [heads, BT, Q, h, w] fp32 contiguous -> (bce [NM], dice [NM], dot [cos_heads*BT], nrm [cos_heads*BT])"""
+    _lib.require_cuda(x, mask_index, gt, gt_index, coords)
+    return _MaskAndCosine.apply(x, cos_heads, n_frame, mask_index, gt.contiguous().float(), gt_index, coords.contiguous())
 
 
 class _CosineStats(Function):

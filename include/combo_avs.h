@@ -264,8 +264,10 @@ int combo_attn_mask_f32(const float* logits, int N, int H, int W, int h, int w, 
  *   logits [N,Q,K1], masks [N,Q,h,w] (mask logits), labels [N,G] int64, gt [N,G,H,W] fp32 0/1, points [N,P,2] in [0,1],
  *   t_ws [N,G,P] workspace (sampled targets), cost [N,Q,G].  G <= 8.
  * ---------------------------------------------------------------------------------------------- */
-int combo_matcher_cost_f32(const float* logits, const float* masks, const long long* labels, const float* gt,
-                           const float* points, int N, int Q, int K1, int G, int h, int w, int H, int W, int P,
+/*   mask_base (optional, [N] int64): index of query 0's map of problem n inside a larger stack of maps (the decoder's
+ *   [heads, BT, Q] logits buffer), so the ground-truth frames need no gathered copy; NULL: maps packed [N, Q]. */
+int combo_matcher_cost_f32(const float* logits, const float* masks, const long long* mask_base, const long long* labels,
+                           const float* gt, const float* points, int N, int Q, int K1, int G, int h, int w, int H, int W, int P,
                            float w_class, float w_mask, float w_dice, float* t_ws, float* cost, combo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -314,7 +316,8 @@ int combo_mask_loss_forward_f32(const float* masks, const long long* mask_index,
                                 combo_stream_t stream);
 int combo_mask_loss_backward_f32(const float* masks, const long long* mask_index, int NM, int h, int w, const float* gt,
                                  const long long* gt_index, int H, int W, const float* coords, int P, const float* stats,
-                                 const float* g_bce, const float* g_dice, float* grad_masks, combo_stream_t stream);
+                                 const float* g_bce, const float* g_dice, float* grad_masks, int accumulate,
+                                 combo_stream_t stream); /* accumulate != 0: grad_masks[...] += (another term is already there) */
 
 /*   Frame-to-frame cosine loss (criterion.py:208-231): x [rows,E], rows = heads*BT, clips = n_frame consecutive rows.
  *   stats: nrm[r] += |x_r|^2, dot[r] += x_r . x_{r+1} (same clip; both zero-filled by the caller);

@@ -240,3 +240,34 @@ def test_deferred_grouped_weight_gradients_equal_immediate(head_run):
         assert (a - b).abs().max() <= 2e-5 * b.abs().max() + 1e-9, (name, float((a - b).abs().max()), float(b.abs().max()))
         n_checked += 1
     assert n_checked > 100
+
+
+@pytest.mark.parametrize("mode", ["s4", "all"])
+def test_fused_criterion_path_equals_unfused(head_run, mode):
+    """The criterion reading the decoder's single logits buffer (`_logits_all`: matcher with map offsets, one node for
+    mask losses + cosine statistics, one gradient buffer) against the path through the per-head outputs: same 39 losses,
+    same gradients (same injected random-point stream)."""
+    z, head, feats, audio, out = head_run
+    assert "_logits_all" in out and out["_logits_all"].shape[0] == 10
+    targets = [{k: v.cuda() for k, v in t.items()} for t in gen_inputs.make_targets(mode)]
+    named = dict(head.named_parameters())
+    probe = [named[n] for n in ("predictor.mask_embed.layers.2.weight", "predictor.query_feat.weight",
+                                "pixel_decoder.mask_features.weight", "predictor.transformer_ffn_layers.4.linear1.weight")]
+    res = []
+    for fused in (True, False):
+        crit, wd = make_criterion(mode)
+        o = {"pred_logits": out["pred_logits"], "pred_masks": out["pred_masks"], "aux_outputs": [dict(a) for a in out["aux_outputs"]],
+             "middles_attn_mask": list(out["middles_attn_mask"])}
+        if fused:
+            o["_logits_all"] = out["_logits_all"]
+        torch.manual_seed(11)
+        losses = crit(o, targets)
+        total = sum(losses[k] * wd[k] for k in losses)
+        grads = torch.autograd.grad(total, probe, retain_graph=True)
+        res.append(({k: float(v) for k, v in losses.items()}, grads))
+    (la, ga), (lb, gb) = res
+    assert sorted(la) == sorted(lb) and len(la) == 39
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 1e-5 * abs(lb[k]) + 1e-6, (k, la[k], lb[k])
+    for a, b in zip(ga, gb):
+        assert (a - b).abs().max() <= 2e-4 * b.abs().max() + 1e-8, float((a - b).abs().max() / b.abs().max())
