@@ -20,6 +20,7 @@ from torch.nn.init import constant_, normal_, xavier_uniform_
 from ..msda import MSDeformAttnFunction
 from ..registry import SEM_SEG_HEADS_REGISTRY, ShapeSpec
 from ..ops.linear import Linear, linear
+from ..ops.upsample import upsample_bilinear
 from .layers import conv1x1_or_conv, norm_act, Conv2d, c2_xavier_fill, get_norm, position_embedding_sine
 
 
@@ -271,7 +272,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
             for idx, f in enumerate(self.in_features[: self.num_fpn_levels][::-1]):
                 x = features[f].float()
                 cur_fpn = self.lateral_convs[idx](x)
-                y = cur_fpn + F.interpolate(out[-1], size=cur_fpn.shape[-2:], mode="bilinear", align_corners=False)
+                y = cur_fpn + upsample_bilinear(out[-1], cur_fpn.shape[-2:])  # :349-350 (HIP kernels for the exact-2x case)
                 out.append(self.output_convs[idx](y))
             multi_scale_features = out[: self.maskformer_num_feature_levels]
             return self.mask_features(out[-1]), out[0], multi_scale_features

@@ -136,6 +136,14 @@ int combo_groupnorm_nhwc_backward_f32(const float* dy, const float* x, const flo
                                       const float* gamma, int B, int HW, int C, int G, int relu, float* part_ws, float* s12_ws,
                                       float* dx, float* dgamma, float* dbeta, combo_stream_t stream);
 
+/* a2  FPN top-down step: bilinear 2x upsampling, align_corners = False, channels_last fp32 [B,H,W,C] -> [B,2H,2W,C]
+ *   (msdeformattn.py:349-350); backward as a gather (H, W are the INPUT sizes in both calls).  C % 4 == 0. */
+/*   x_batch_stride / dx_batch_stride (floats): the small map may be a per-level row block of the encoder memory [B, S, C]. */
+int combo_upsample2x_bilinear_nhwc_f32(const float* x, long long x_batch_stride, int B, int H, int W, int C, float* y,
+                                       combo_stream_t stream);
+int combo_upsample2x_bilinear_nhwc_backward_f32(const float* dy, int B, int H, int W, int C, float* dx,
+                                                long long dx_batch_stride, combo_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * a5  MSDeformAttn prologue (ops/modules/ms_deform_attn.py:101-118)
  *   proj [tokens, M*L*P*3] = [sampling offsets (M,L,P,2) | attention logits (M,L*P)] (the two nn.Linear outputs, merged),

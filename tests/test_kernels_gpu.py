@@ -373,3 +373,19 @@ def test_groupnorm_nhwc_vs_torch(B, C, H, W, relu):
     assert (dx.double() - dx64).abs().max() <= 2e-5 * dx64.abs().max() + 1e-6
     assert (dw.double() - dw64).abs().max() <= 2e-5 * dw64.abs().max() + 1e-5
     assert (db.double() - db64).abs().max() <= 2e-5 * db64.abs().max() + 1e-5
+
+
+@pytest.mark.parametrize("B,C,H,W", [(3, 256, 28, 28), (2, 8, 5, 7), (1, 64, 1, 3)])
+def test_upsample2x_bilinear_nhwc_vs_torch(B, C, H, W):
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.ops.upsample import upsample_bilinear
+    torch.manual_seed(H * W)
+    x = torch.randn(B, C, H, W, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = upsample_bilinear(x, (2 * H, 2 * W))
+    xr = x.detach().clone().requires_grad_(True)
+    yr = torch.nn.functional.interpolate(xr, size=(2 * H, 2 * W), mode="bilinear", align_corners=False)
+    assert (y - yr).abs().max() < 1e-6
+    g = torch.randn_like(yr)
+    dx, = torch.autograd.grad(y, x, g.contiguous(memory_format=torch.channels_last))
+    dxr, = torch.autograd.grad(yr, xr, g)
+    assert (dx - dxr).abs().max() <= 1e-5 * dxr.abs().max() + 1e-6
