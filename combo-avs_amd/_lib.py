@@ -49,6 +49,8 @@ _SIGNATURES = {
     "combo_sem_mix": [c_int, c_int] + [c_void_p] * 4 + [c_int] * 3 + [c_void_p] * 3,
     "combo_semantic_inference_f32": [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p, c_void_p],
     "combo_gemm_nt_x3_f32": [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_void_p],
+    "combo_conv3x3_nhwc_x3_f32": [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_longlong] + [c_int] * 6 + [c_void_p],
+    "combo_conv3x3_wgrad_x3_f32": [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p] + [c_int] * 6 + [c_void_p],
     "combo_gemm_tn_splits": [c_int, c_int, c_int],
     "combo_gemm_tn_x3_f32": [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "combo_gemm_tn_x3_grouped_f32": [c_void_p, c_int, c_void_p],

@@ -2,7 +2,7 @@
 #include "combo_common.h"
 
 extern "C" {
-int combo_abi_version(void) { return 2; }
+int combo_abi_version(void) { return 3; }
 const char* combo_build_arch(void) { return "gfx950"; }
 
 // Timing events that also work inside a captured hipGraph: with external != 0 the record becomes an event-record NODE

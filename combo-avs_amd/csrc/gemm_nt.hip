@@ -13,6 +13,15 @@
 //     of row r at physical chunk c ^ ((r >> 2) & 3) - a swizzle on the SOURCE address, the LDS image stays lane-linear -
 //     which makes every lane group hit 16 distinct bank quads
 //   * operands are split on the fly into bf16 hi/lo (x.w ~ hi.hi + hi.lo + lo.hi, error ~2^-16 relative)
+//
+// CONV = true turns the same kernel into the implicit-GEMM 3x3 / stride 1 / pad 1 convolution of the pixel decoder's FPN
+// output layer (pixel_decoder/msdeformattn.py:281-286 in the reference; MIOpen's fp32 kernels were the largest library
+// item of the head): A = the NHWC map as [B*H*W tokens, Cin], K = 9*Cin ordered (tap, cin), B = the weight as
+// [Cout, 3, 3, Cin].  A BK = 16 stage lies inside one tap, so the only change is the DMA source row of the A pieces:
+// token + dy*W + dx, or a row of zeros when the tap falls outside the map (pad).  dX is the same kernel on dY with the
+// taps flipped and the weight transposed ([Cin, 3', 3', Cout]); the caller prepares both weight images once per step.
+#include <cstdlib>
+
 #include "combo_common.h"
 
 namespace {
@@ -62,30 +71,71 @@ constexpr int kBM = 256, kBN = 128, kBK = 16, kStages = 3;
 constexpr int kABytes = kBM * kBK * 4, kBBytes = kBN * kBK * 4, kStage = kABytes + kBBytes;  // 16 + 8 = 24 KiB
 constexpr int kPieces = kStage / 1024, kPPW = kPieces / 4;                                    // 24 pieces, 6 per wave
 
+// DBG (ablation builds, env COMBO_NT_DBG, tools/bench_nt.py): 1 no epilogue stores, 2 no MFMA, 4 no bf16 split,
+// 8 no LDS reads, 16 no DMA.  The product launches DBG = 0.
+__device__ __attribute__((aligned(64))) float g_zero_row[16];  // zero-initialised: the source of padded taps
+
+struct ConvGeom {
+  int H, W, Cin;
+};
+
+template <int DBG, bool CONV>
 __global__ void __launch_bounds__(256, 2)
 gemm_nt_glds_kernel(const float* __restrict__ A, long long lda, const float* __restrict__ B, long long ldb,
-                    const float* __restrict__ bias, float* __restrict__ C, long long ldc, int M, int N, int K, int relu) {
+                    const float* __restrict__ bias, float* __restrict__ C, long long ldc, int M, int N, int K, int relu,
+                    int remap, ConvGeom cg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  // consecutive workgroups walk the n tiles of one token tile: the A rows are shared through L2
+  // consecutive LOGICAL workgroups walk the n tiles of one token tile.  Hardware deals blockIdx round-robin over the 8
+  // XCDs (private L2s), so the logical index gives every XCD a contiguous range: the n tiles that share the A rows of a
+  // token tile run on ONE XCD at the same time and the rows come out of HBM once, not once per n tile.
   const int n_tiles = (N + kBN - 1) / kBN;
-  const int m_blk = (blockIdx.x / n_tiles) * kBM, n_blk = (blockIdx.x % n_tiles) * kBN;
+  const int logical = remap ? xcd_contiguous(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int m_blk = (logical / n_tiles) * kBM, n_blk = (logical % n_tiles) * kBN;
   const int nst = K / kBK;
 
   // DMA: piece q (1 KiB = 16 rows x 64 B) of a stage; lane -> (row, physical chunk); source = logical chunk (swizzle)
   const int p_row = lane >> 2, p_chunk = lane & 3;
+  // CONV: this lane's four A rows (pieces wave, wave+4, wave+8, wave+12) -> 9-bit masks of the taps that stay inside the map
+  unsigned tap_ok[4] = {0u, 0u, 0u, 0u};
+  if (CONV) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = min(m_blk + (wave + 4 * u) * 16 + p_row, M - 1);
+      const int x = t % cg.W, y = (t / cg.W) % cg.H;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+        if (yy >= 0 && yy < cg.H && xx >= 0 && xx < cg.W) tap_ok[u] |= 1u << tap;
+      }
+    }
+  }
   auto issue = [&](int s) {
+    if (DBG & 16) return;
     char* st = smem + (s % kStages) * kStage;
     const int k0 = s * kBK;
+    int tap = 0, cin0 = k0, shift = 0;  // CONV: the stage's tap (wave-uniform), first input channel and token shift
+    if (CONV) {
+      tap = k0 / cg.Cin;
+      cin0 = k0 - tap * cg.Cin;
+      shift = (tap / 3 - 1) * cg.W + (tap % 3 - 1);
+    }
 #pragma unroll
     for (int u = 0; u < kPPW; ++u) {
       const int q = wave + 4 * u;  // wave-uniform
       if (q < kABytes / 1024) {
         const int r = q * 16 + p_row;
         const int c = p_chunk ^ ((r >> 2) & 3);
-        glds16(A + (long long)min(m_blk + r, M - 1) * lda + k0 + c * 4, st + q * 1024);
+        if (CONV) {
+          const float* src = ((tap_ok[u & 3] >> tap) & 1u)
+                                 ? A + (long long)(min(m_blk + r, M - 1) + shift) * lda + cin0 + c * 4
+                                 : g_zero_row + c * 4;
+          glds16(src, st + q * 1024);
+        } else {
+          glds16(A + (long long)min(m_blk + r, M - 1) * lda + k0 + c * 4, st + q * 1024);
+        }
       } else {
         const int qb = q - kABytes / 1024;
         const int r = qb * 16 + p_row;
@@ -127,7 +177,8 @@ gemm_nt_glds_kernel(const float* __restrict__ A, long long lda, const float* __r
   }
 
   for (int s = 0; s < nst; ++s) {
-    if (nst - 1 - s >= 1) wait_vm<kPPW>();
+    if (DBG & 16) {}
+    else if (nst - 1 - s >= 1) wait_vm<kPPW>();
     else wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     if (s + kStages - 1 < nst) issue(s + kStages - 1);
@@ -135,11 +186,13 @@ gemm_nt_glds_kernel(const float* __restrict__ A, long long lda, const float* __r
     f4v ra[4][2], rb[2][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      if (DBG & 8) { ra[i][0] = ra[i][1] = (f4v){1.f + s, 2.f, 3.f, 4.f}; continue; }
       ra[i][0] = lds_read128(so + a_off[i][0]);
       ra[i][1] = lds_read128(so + a_off[i][1]);
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
+      if (DBG & 8) { rb[j][0] = rb[j][1] = (f4v){1.f, 2.f + s, 3.f, 4.f}; continue; }
       rb[j][0] = lds_read128(so + b_off[j][0]);
       rb[j][1] = lds_read128(so + b_off[j][1]);
     }
@@ -149,10 +202,29 @@ gemm_nt_glds_kernel(const float* __restrict__ A, long long lda, const float* __r
                  :
                  : "memory");
     Frag fa[4], fb[2];
+    if (DBG & 4) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) fa[i] = make_frag(ra[i][0], ra[i][1]);
+      for (int i = 0; i < 4; ++i) { fa[i].hi = __builtin_bit_cast(bf16x8, ra[i][0]); fa[i].lo = __builtin_bit_cast(bf16x8, ra[i][1]); }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) fb[j] = make_frag(rb[j][0], rb[j][1]);
+      for (int j = 0; j < 2; ++j) { fb[j].hi = __builtin_bit_cast(bf16x8, rb[j][0]); fb[j].lo = __builtin_bit_cast(bf16x8, rb[j][1]); }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = make_frag(ra[i][0], ra[i][1]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = make_frag(rb[j][0], rb[j][1]);
+    }
+    if (DBG & 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j][0] += __builtin_bit_cast(f4v, fa[i].lo).x + __builtin_bit_cast(f4v, fb[j].hi).y;
+          acc[i][j][1] += __builtin_bit_cast(f4v, fa[i].hi).z + __builtin_bit_cast(f4v, fb[j].lo).w;
+          acc[i][j][2] += __builtin_bit_cast(f4v, fa[i].lo).z + __builtin_bit_cast(f4v, fb[j].hi).w;
+          acc[i][j][3] += __builtin_bit_cast(f4v, fa[i].hi).x + __builtin_bit_cast(f4v, fb[j].lo).y;
+        }
+      continue;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -178,7 +250,7 @@ gemm_nt_glds_kernel(const float* __restrict__ A, long long lda, const float* __r
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = m_blk + wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
-        if (row < M) {
+        if (row < M && (!(DBG & 1) || acc[i][j][e] == 1234.5f)) {
           float v = acc[i][j][e] + bv;
           if (relu) v = fmaxf(v, 0.f);
           C[(long long)row * ldc + n] = v;
@@ -186,6 +258,9 @@ gemm_nt_glds_kernel(const float* __restrict__ A, long long lda, const float* __r
       }
   }
 }
+
+typedef void (*kern_t)(const float*, long long, const float*, long long, const float*, float*, long long, int, int, int, int,
+                       int, ConvGeom);
 
 }  // namespace
 
@@ -195,16 +270,45 @@ extern "C" int combo_gemm_nt_x3_f32(const float* A, long long lda, const float* 
       ((uintptr_t)A & 15) || ((uintptr_t)B & 15))
     return COMBO_EINVAL;
   constexpr int lds = kStages * kStage;
+  static const int dbg = [] { const char* e = getenv("COMBO_NT_DBG"); return e ? atoi(e) : 0; }();
+  static const kern_t kern = dbg == 1 ? gemm_nt_glds_kernel<1, false> : dbg == 2 ? gemm_nt_glds_kernel<2, false>
+                           : dbg == 3 ? gemm_nt_glds_kernel<3, false> : dbg == 4 ? gemm_nt_glds_kernel<4, false>
+                           : dbg == 7 ? gemm_nt_glds_kernel<7, false> : dbg == 15 ? gemm_nt_glds_kernel<15, false>
+                           : dbg == 31 ? gemm_nt_glds_kernel<31, false> : dbg == 30 ? gemm_nt_glds_kernel<30, false>
+                           : dbg == 16 ? gemm_nt_glds_kernel<16, false> : gemm_nt_glds_kernel<0, false>;
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_glds_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
   const long long tiles = (long long)((M + kBM - 1) / kBM) * ((N + kBN - 1) / kBN);
   if (tiles > 0x7fffffffLL) return COMBO_EINVAL;
-  hipLaunchKernelGGL(gemm_nt_glds_kernel, dim3((unsigned)tiles), dim3(256), lds, (hipStream_t)stream, A, lda, B, ldb, bias,
-                     C, ldc, M, N, K, relu);
+  static const int remap = [] { const char* e = getenv("COMBO_GEMM_XCD"); return e ? atoi(e) : 1; }();
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, (hipStream_t)stream, A, lda, B, ldb, bias, C, ldc, M, N, K,
+                     relu, remap, ConvGeom{1, 1, K});
+  return (int)hipGetLastError();
+}
+
+extern "C" int combo_conv3x3_nhwc_x3_f32(const float* X, long long ldx, const float* Wm, const float* bias, float* Y,
+                                         long long ldy, int B, int H, int W, int Cin, int Cout, int relu,
+                                         combo_stream_t stream) {
+  const long long M = (long long)B * H * W;
+  if (!X || !Wm || !Y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % kBK != 0 || ldx % 4 != 0 ||
+      ((uintptr_t)X & 15) || ((uintptr_t)Wm & 15) || M > 0x7fffffffLL / 4)
+    return COMBO_EINVAL;
+  constexpr int lds = kStages * kStage;
+  static const kern_t kern = gemm_nt_glds_kernel<0, true>;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  const long long tiles = ((M + kBM - 1) / kBM) * ((Cout + kBN - 1) / kBN);
+  if (tiles > 0x7fffffffLL) return COMBO_EINVAL;
+  static const int remap = [] { const char* e = getenv("COMBO_GEMM_XCD"); return e ? atoi(e) : 1; }();
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, (hipStream_t)stream, X, ldx, Wm, (long long)9 * Cin, bias, Y,
+                     ldy, (int)M, Cout, 9 * Cin, relu, remap, ConvGeom{H, W, Cin});
   return (int)hipGetLastError();
 }

@@ -164,11 +164,21 @@ __device__ __forceinline__ void glds16(const float* g, char* l) {
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-template <int WN, int kStages>
+// CONV (weight gradient of the 3x3 / stride 1 / pad 1 FPN output convolution, see gemm_nt.hip): K = 9*Cin ordered
+// (tap, cin) and a k tile lies inside one tap (Cin % BK == 0), so the X rows of a stage are the token rows shifted by the
+// tap, or a row of zeros where the tap leaves the map.  Token -> (y, x) by multiply-high with host-made reciprocals.
+__device__ __attribute__((aligned(64))) float g_tn_zero_row[256];
+
+struct TnConvGeom {
+  int H, W, Cin;
+  unsigned magicW, magicH;  // ceil(2^32 / W), ceil(2^32 / H): the quotient is exact while tokens * max(H, W) < 2^32 (host check)
+};
+
+template <int WN, int kStages, bool CONV = false>
 __device__ __forceinline__ void
 gemm_tn_glds_body(const float* __restrict__ dY, long long ldy, const float* __restrict__ X, long long ldx,
                   float* __restrict__ out, float* __restrict__ db_part, int M, int N, int K, int mchunk, int bx, int by,
-                  int bz) {
+                  int bz, TnConvGeom cg = TnConvGeom{1, 1, 1, 0u, 0u}) {
   constexpr int WK = 4 / WN, BN = 128 * WN, BK = 64 * WK;
   constexpr int A_BYTES = kTS * BN * 4, B_BYTES = kTS * BK * 4, STAGE = A_BYTES + B_BYTES;
   constexpr int A_PIECES = A_BYTES / 1024, B_PIECES = B_BYTES / 1024, PIECES = A_PIECES + B_PIECES;  // 1-KiB DMA pieces
@@ -183,6 +193,13 @@ gemm_tn_glds_body(const float* __restrict__ dY, long long ldy, const float* __re
   const int nst = (mend - mbeg + kTS - 1) / kTS;
   const int col = lane & 31, kg = lane >> 5;
 
+  int c_tap = 0, c_dy = 0, c_dx = 0, c_ci0 = 0;
+  if (CONV) {
+    c_tap = k_blk / cg.Cin;
+    c_ci0 = k_blk - c_tap * cg.Cin;
+    c_dy = c_tap / 3 - 1;
+    c_dx = c_tap % 3 - 1;
+  }
   // ---- per-lane DMA source columns (constant over the stages), clamped inside the matrix ----
   // piece q of a stage (1 KiB = one wave instruction): q < A_PIECES -> dY rows, else X rows
   auto issue = [&](int s) {
@@ -205,7 +222,17 @@ gemm_tn_glds_body(const float* __restrict__ dY, long long ldy, const float* __re
         else { t = qb; c = k_blk + lane * 4; }
         c = min(c, K - 4);
         const int m = min(m0 + t, M - 1);
-        glds16(X + (long long)m * ldx + c, st + A_BYTES + qb * 1024);
+        if (CONV) {
+          const unsigned row = __umulhi((unsigned)m, cg.magicW);          // m / W
+          const int x = m - (int)row * cg.W;
+          const int y = (int)row - (int)__umulhi(row, cg.magicH) * cg.H;  // (m / W) % H
+          const bool ok = (unsigned)(y + c_dy) < (unsigned)cg.H && (unsigned)(x + c_dx) < (unsigned)cg.W;
+          const int ci = c - k_blk + c_ci0;
+          const float* src = ok ? X + (long long)(m + c_dy * cg.W + c_dx) * ldx + ci : g_tn_zero_row + (ci & 255);
+          glds16(src, st + A_BYTES + qb * 1024);
+        } else {
+          glds16(X + (long long)m * ldx + c, st + A_BYTES + qb * 1024);
+        }
       }
     }
   };
@@ -324,8 +351,27 @@ gemm_tn_glds_body(const float* __restrict__ dY, long long ldy, const float* __re
 template <int WN, int kStages>
 __global__ void __launch_bounds__(256, kStages <= 3 ? 2 : 1)
 gemm_tn_glds_kernel(const float* __restrict__ dY, long long ldy, const float* __restrict__ X, long long ldx,
-                    float* __restrict__ out, float* __restrict__ db_part, int M, int N, int K, int mchunk) {
-  gemm_tn_glds_body<WN, kStages>(dY, ldy, X, ldx, out, db_part, M, N, K, mchunk, blockIdx.x, blockIdx.y, blockIdx.z);
+                    float* __restrict__ out, float* __restrict__ db_part, int M, int N, int K, int mchunk, int remap) {
+  // the tiles of one token chunk (blockIdx.z) read the same dY / X rows: keep them on one XCD (see xcd_contiguous)
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (remap) {
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int l = xcd_contiguous(bx + gx * (by + gy * bz), gx * gy * (int)gridDim.z);
+    bx = l % gx; by = (l / gx) % gy; bz = l / (gx * gy);
+  }
+  gemm_tn_glds_body<WN, kStages>(dY, ldy, X, ldx, out, db_part, M, N, K, mchunk, bx, by, bz);
+}
+
+__global__ void __launch_bounds__(256, 2)
+conv3x3_wgrad_kernel(const float* __restrict__ dY, long long ldy, const float* __restrict__ X, long long ldx,
+                     float* __restrict__ out, int M, int N, int K, int mchunk, int remap, TnConvGeom cg) {
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (remap) {
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int l = xcd_contiguous(bx + gx * (by + gy * bz), gx * gy * (int)gridDim.z);
+    bx = l % gx; by = (l / gx) % gy; bz = l / (gx * gy);
+  }
+  gemm_tn_glds_body<2, 3, true>(dY, ldy, X, ldx, out, nullptr, M, N, K, mchunk, bx, by, bz, cg);
 }
 
 // Grouped launch: many independent weight-gradient problems in ONE kernel.  The decoder's dW GEMMs (M = BT*100 tokens)
@@ -335,7 +381,9 @@ gemm_tn_glds_kernel(const float* __restrict__ dY, long long ldy, const float* __
 constexpr int kMaxGroup = 40;
 struct TnGroupArgs {
   int count;
-  int block_start[kMaxGroup + 1];
+  int remap;
+  int block_start[kMaxGroup + 1];  // multiples of 8 when remap is on, so that (b - start) % 8 is the block's XCD
+  int block_count[kMaxGroup];
   combo_gemm_tn_problem p[kMaxGroup];
 };
 
@@ -346,7 +394,10 @@ gemm_tn_grouped_kernel(const TnGroupArgs args) {
   for (int i = 1; i < args.count; ++i)
     if (b >= args.block_start[i]) pi = i;
   const combo_gemm_tn_problem& pr = args.p[pi];
-  const int local = b - args.block_start[pi];
+  int local = b - args.block_start[pi];
+  if (local >= args.block_count[pi]) return;  // padding block
+  // the tiles of one token chunk read the same dY / X rows: keep them on one XCD (see xcd_contiguous)
+  if (args.remap) local = xcd_contiguous(local, args.block_count[pi]);
   int mchunk = (pr.M + pr.splits - 1) / pr.splits;
   mchunk = (mchunk + 15) / 16 * 16;
   const long long t2 = (long long)((pr.N + 255) / 256) * ((pr.K + 127) / 128) * 256 * 128;
@@ -490,20 +541,48 @@ int combo_gemm_tn_x3_f32(const float* dY, long long ldy, const float* X, long lo
       attr = true;
     }
     const int lds = stages * stage_bytes;
+    static const int remap = [] { const char* e = getenv("COMBO_GEMM_XCD"); return e ? atoi(e) : 1; }();
     const bool v2 = tn_variant(N, K) == 2;
     const dim3 grid = v2 ? dim3((K + 127) / 128, (N + 255) / 256, nz) : dim3((K + 255) / 256, (N + 127) / 128, nz);
     if (v2 && stages == 3)
-      hipLaunchKernelGGL((gemm_tn_glds_kernel<2, 3>), grid, dim3(256), lds, (hipStream_t)stream, dY, ldy, X, ldx, out_partials, db_partials, M, N, K, mchunk);
+      hipLaunchKernelGGL((gemm_tn_glds_kernel<2, 3>), grid, dim3(256), lds, (hipStream_t)stream, dY, ldy, X, ldx, out_partials, db_partials, M, N, K, mchunk, remap);
     else if (v2)
-      hipLaunchKernelGGL((gemm_tn_glds_kernel<2, 5>), grid, dim3(256), lds, (hipStream_t)stream, dY, ldy, X, ldx, out_partials, db_partials, M, N, K, mchunk);
+      hipLaunchKernelGGL((gemm_tn_glds_kernel<2, 5>), grid, dim3(256), lds, (hipStream_t)stream, dY, ldy, X, ldx, out_partials, db_partials, M, N, K, mchunk, remap);
     else if (stages == 3)
-      hipLaunchKernelGGL((gemm_tn_glds_kernel<1, 3>), grid, dim3(256), lds, (hipStream_t)stream, dY, ldy, X, ldx, out_partials, db_partials, M, N, K, mchunk);
+      hipLaunchKernelGGL((gemm_tn_glds_kernel<1, 3>), grid, dim3(256), lds, (hipStream_t)stream, dY, ldy, X, ldx, out_partials, db_partials, M, N, K, mchunk, remap);
     else
-      hipLaunchKernelGGL((gemm_tn_glds_kernel<1, 5>), grid, dim3(256), lds, (hipStream_t)stream, dY, ldy, X, ldx, out_partials, db_partials, M, N, K, mchunk);
+      hipLaunchKernelGGL((gemm_tn_glds_kernel<1, 5>), grid, dim3(256), lds, (hipStream_t)stream, dY, ldy, X, ldx, out_partials, db_partials, M, N, K, mchunk, remap);
     return (int)hipGetLastError();
   }
   hipLaunchKernelGGL(gemm_tn_x3_kernel, dim3((K + 127) / 128, (N + 127) / 128, nz), dim3(256), 0, (hipStream_t)stream, dY,
                      ldy, X, ldx, out_partials, db_partials, M, N, K, mchunk);
+  return (int)hipGetLastError();
+}
+
+int combo_conv3x3_wgrad_x3_f32(const float* dY, long long ldy, const float* X, long long ldx, float* out_partials, int B,
+                               int H, int W, int Cin, int Cout, int splits, combo_stream_t stream) {
+  const long long M = (long long)B * H * W;
+  const int K = 9 * Cin;
+  if (!dY || !X || !out_partials || B <= 0 || H < 2 || W < 2 || M * (H > W ? H : W) >= (1LL << 32) || M > 0x7fffffffLL / 4 || Cin <= 0 ||
+      Cin % 128 != 0 || Cout < 64 || Cout % 4 != 0 || splits <= 0 || ldy % 4 != 0 || ldx % 4 != 0 || ((uintptr_t)dY & 15) ||
+      ((uintptr_t)X & 15))
+    return COMBO_EINVAL;
+  int mchunk = (int)((M + splits - 1) / splits);
+  mchunk = (mchunk + 15) / 16 * 16;
+  if ((M + mchunk - 1) / mchunk != splits) return COMBO_EINVAL;
+  constexpr int lds = 3 * (kTS * 256 * 4 + kTS * 128 * 4);
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  static const int remap = [] { const char* e = getenv("COMBO_GEMM_XCD"); return e ? atoi(e) : 1; }();
+  TnConvGeom cg{H, W, Cin, (unsigned)(0xffffffffu / (unsigned)W + 1u), (unsigned)(0xffffffffu / (unsigned)H + 1u)};
+  const dim3 grid((K + 127) / 128, (Cout + 255) / 256, splits);
+  hipLaunchKernelGGL(conv3x3_wgrad_kernel, grid, dim3(256), lds, (hipStream_t)stream, dY, ldy, X, ldx, out_partials, (int)M,
+                     Cout, K, mchunk, remap, cg);
   return (int)hipGetLastError();
 }
 
@@ -517,6 +596,7 @@ int combo_gemm_tn_x3_grouped_f32(const combo_gemm_tn_problem* problems, int coun
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
+  static const int remap = [] { const char* e = getenv("COMBO_GEMM_XCD"); return e ? atoi(e) : 1; }();
   for (int base = 0; base < count; base += kMaxGroup) {
     TnGroupArgs a;
     a.count = count - base < kMaxGroup ? count - base : kMaxGroup;
@@ -530,9 +610,12 @@ int combo_gemm_tn_x3_grouped_f32(const combo_gemm_tn_problem* problems, int coun
       const long long tiles = tn_variant(pr.N, pr.K) == 2 ? (long long)((pr.N + 255) / 256) * ((pr.K + 127) / 128)
                                                          : (long long)((pr.N + 127) / 128) * ((pr.K + 255) / 256);
       a.block_start[i] = blocks;
+      a.block_count[i] = (int)(tiles * pr.splits);
       a.p[i] = pr;
-      blocks += (int)(tiles * pr.splits);
+      blocks += a.block_count[i];
+      if (remap) blocks = (blocks + 7) & ~7;
     }
+    a.remap = remap;
     a.block_start[a.count] = blocks;
     hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, a);
   }

@@ -33,7 +33,8 @@ def position_embedding_sine(b, h, w, device, num_pos_feats=128, temperature=1000
 def conv1x1_or_conv(conv, x):
     """A stride-1 1x1 convolution on a channels_last fp32 tensor IS a token-major GEMM [B*H*W, Cin] x [Cin, Cout]: route it
     through ops.linear (csrc/gemm_nt.hip forward / dX, deferred grouped weight gradient) - measured 102 + 220 us against
-    MIOpen's fp32 245 + 401 us at 40 x 256 x 56 x 56 (tools/bench_conv1x1.py).  Everything else goes to MIOpen."""
+    MIOpen's fp32 245 + 401 us at 40 x 256 x 56 x 56 (tools/bench_conv1x1.py).  The 3x3 / stride 1 / pad 1 FPN output
+    convolution runs as an implicit GEMM on the same kernels (ops/conv3x3.py).  Everything else goes to MIOpen."""
     if (conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1 and x.is_cuda
             and x.dtype == torch.float32 and not torch.is_autocast_enabled() and x.dim() == 4
             and x.is_contiguous(memory_format=torch.channels_last) and x.shape[1] % 16 == 0):
@@ -41,6 +42,10 @@ def conv1x1_or_conv(conv, x):
         B, C, H, W = x.shape
         y = linear(x.permute(0, 2, 3, 1).reshape(B * H * W, C), conv.weight.view(conv.out_channels, C), conv.bias, defer=True)
         return y.view(B, H, W, conv.out_channels).permute(0, 3, 1, 2)  # NCHW view, channels_last memory
+    if conv.kernel_size == (3, 3):
+        from ..ops import conv3x3
+        if conv3x3.ENABLED and conv3x3.usable(conv, x):
+            return conv3x3.conv3x3(x, conv.weight, conv.bias)  # implicit GEMM on csrc/gemm_nt.hip / gemm_tn.hip
     return F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, conv.groups)
 
 

@@ -210,6 +210,22 @@ int combo_gemm_x3_f32(const float* A, long long lda, int a_rowc, const float* B,
 int combo_gemm_nt_x3_f32(const float* A, long long lda, const float* B, long long ldb, const float* bias, float* C,
                          long long ldc, int M, int N, int K, int relu, combo_stream_t stream);
 
+/*   3x3 / stride 1 / pad 1 convolution on an NHWC fp32 map as an implicit GEMM on the same kernel (replaces the FPN
+ *   output convolution `layer_1` of the reference's pixel decoder, pixel_decoder/msdeformattn.py:281-286,349-352, which
+ *   the reference runs through cuDNN): X = [B*H*W tokens, Cin] (row stride ldx), Wm = the weight as [Cout, 3, 3, Cin]
+ *   (K = 9*Cin contiguous), Y = [B*H*W, Cout] (row stride ldy) (+ bias[Cout]) (+ ReLU).  The input gradient is the same
+ *   call on dY with Wm = the weight as [Cin, 3', 3', Cout] (taps flipped).  Cin % 16 == 0, ldx % 4 == 0, X / Wm 16-byte
+ *   aligned. */
+int combo_conv3x3_nhwc_x3_f32(const float* X, long long ldx, const float* Wm, const float* bias, float* Y, long long ldy,
+                              int B, int H, int W, int Cin, int Cout, int relu, combo_stream_t stream);
+
+/*   Weight gradient of that convolution, split-K over the tokens like combo_gemm_tn_x3_f32: partial z is written at
+ *   out_partials + z*Cout*9*Cin in [Cout, 3, 3, Cin] order; finish with combo_splitk_reduce_f32.  `splits` as for
+ *   combo_gemm_tn_x3_f32 with (M, N, K) = (B*H*W, Cout, 9*Cin).  Cin % 128 == 0, Cout % 4 == 0, Cout >= 64,
+ *   B*H*W*max(H,W) < 2^32. */
+int combo_conv3x3_wgrad_x3_f32(const float* dY, long long ldy, const float* X, long long ldx, float* out_partials, int B,
+                               int H, int W, int Cin, int Cout, int splits, combo_stream_t stream);
+
 /*   Weight gradient dW[N,K] = dY[M,N]^T . X[M,K] (reduction over the M tokens), same 3-way bf16 split, fragments loaded
  *   straight from global memory (no LDS), split-K over M: partial z is written at out_partials + z*N*K and the caller
  *   sums the partials.  `splits` must be a value for which ceil(M / roundup16(ceil(M/splits))) == splits

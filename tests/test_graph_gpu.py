@@ -116,3 +116,28 @@ def test_fusion_dropout_is_fresh_on_every_replay():
     counter.copy_(c)
     y2, _, _ = bifuse.token_op(x, *args, 0.1, seed=77)
     assert torch.equal(y1, y2)
+
+
+def test_graphed_training_actually_learns(rig):
+    """40 replays of the captured step on one batch: the optimiser updates the flat parameter buffer in place and the graph
+    must see the new values (a capture that froze copies of the weights would leave the loss where it started)."""
+    from combo_avs_amd.trainer import GraphedTrainStep
+    model, opt, batches, state = rig
+    snap = opt.flat_param.clone()
+    _reset(opt, snap)
+    old = [(s[0], s[1], s[2], s[3]) for s in opt.segments]
+    for s in opt.segments:
+        s[2] = s[2] * 20.0  # lr x 20 for the test (clip 0.01 keeps every step tiny at the reference's 1e-4 / 1e-5)
+    try:
+        step = GraphedTrainStep(model, opt)
+        totals = []
+        for _ in range(40):
+            losses = step(batches[0])
+            totals.append(float(sum(losses.values())))
+        assert all(t == t for t in totals)
+        assert totals[-1] < 0.97 * totals[0], (totals[0], totals[-1])
+        assert len(step.graphs) == 1
+    finally:
+        for s, o in zip(opt.segments, old):
+            s[2] = o[2]
+        _reset(opt, snap)
