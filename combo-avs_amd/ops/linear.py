@@ -66,11 +66,33 @@ import os as _os
 NT_MIN_ROWS = 16384 if _os.environ.get('COMBO_GEMM_NT', '1') == '1' else 1 << 60  # csrc/gemm_nt.hip needs enough 256-token tiles to fill the chip; below: hipBLASLt's 3xbf16 mode
 
 
+NT_V2 = _os.environ.get('COMBO_GEMM_NT2', '1') == '1'  # csrc/gemm_nt2.hip (persistent, pre-split weights); 0: v1 (A/B)
+
+
+def presplit(b):
+    """bf16 hi/lo image of a 2-D fp32 view [N, K] (any strides: pass `w.t()` for W^T, no copy) for csrc/gemm_nt2.hip."""
+    N, K = b.shape
+    img = torch.empty(N, K, device=b.device, dtype=torch.float32)
+    _lib.check(_lib.lib().combo_presplit_bf16x2_f32(b.data_ptr(), b.stride(0), b.stride(1), N, K, img.data_ptr(),
+                                                    _lib.current_stream()), "combo_presplit_bf16x2_f32")
+    return img
+
+
 def gemm_nt_x3(a, b, bias=None, relu=False):
-    """C[M,N] = a[M,K] @ b[N,K]^T (+ bias) (+ ReLU) on csrc/gemm_nt.hip (fp32-accurate bf16x3 MFMA, LDS-DMA ring)."""
+    """C[M,N] = a[M,K] @ b[N,K]^T (+ bias) (+ ReLU), fp32-accurate bf16x3 MFMA.  b may be any strided 2-D view (e.g.
+    `weight.t()` for dX).  v2 (csrc/gemm_nt2.hip): weight pre-split once, persistent tiles; v1: csrc/gemm_nt.hip."""
     M, K = a.shape
     N = b.shape[0]
     out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    if NT_V2 and K % 16 == 0:
+        img = presplit(b)
+        with _lib.timed("gemm_nt_x3", (M, N, K)):
+            rc = _lib.lib().combo_gemm_nt_x3_pre_f32(a.data_ptr(), a.stride(0), img.data_ptr(), _lib.ptr(bias), out.data_ptr(),
+                                                     N, M, N, K, 1 if relu else 0, _lib.current_stream())
+        _lib.check(rc, "combo_gemm_nt_x3_pre_f32")
+        return out
+    if b.stride(1) != 1:
+        b = b.contiguous()
     with _lib.timed("gemm_nt_x3", (M, N, K)):
         rc = _lib.lib().combo_gemm_nt_x3_f32(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), _lib.ptr(bias),
                                              out.data_ptr(), N, M, N, K, 1 if relu else 0, _lib.current_stream())
@@ -141,7 +163,7 @@ class _LinearLib3x(Function):
             dyc = dy if dy.stride(1) == 1 else dy.contiguous()
             if _nt_ok(dyc, weight.shape[1]):  # (the transposed weight below is contiguous and freshly allocated)
                 # [K,N]: a weight-sized transpose so that dX = dY . W is the same K-contiguous NT kernel
-                dx = gemm_nt_x3(dyc, weight.t().contiguous())
+                dx = gemm_nt_x3(dyc, weight.t())
             else:
                 with _split3(True):
                     dx = dy @ weight
@@ -382,7 +404,7 @@ class _LinearCat(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             if _nt_ok(dy, W.shape[1]):
-                dx = gemm_nt_x3(dy, W.t().contiguous())
+                dx = gemm_nt_x3(dy, W.t())
             else:
                 with _split3(True):
                     dx = dy @ W

@@ -210,6 +210,18 @@ int combo_gemm_x3_f32(const float* A, long long lda, int a_rowc, const float* B,
 int combo_gemm_nt_x3_f32(const float* A, long long lda, const float* B, long long ldb, const float* bias, float* C,
                          long long ldc, int M, int N, int K, int relu, combo_stream_t stream);
 
+/*   v2 of the forward / input-gradient GEMM (csrc/gemm_nt2.hip): persistent workgroups with the next tile's first
+ *   stages in flight under the epilogue stores, 4 x 1 waves, and the weight operand PRE-SPLIT into bf16 hi/lo groups by
+ *   combo_presplit_bf16x2_f32 (element (n, k) = src[n*ld_row + k*ld_col], so W and W^T need no transpose copy; the image
+ *   has N rows of K floats, 16-byte aligned, K % 8 == 0).  Same contract as combo_gemm_nt_x3_f32 otherwise. */
+int combo_presplit_bf16x2_f32(const float* src, long long ld_row, long long ld_col, int N, int K, float* img,
+                              combo_stream_t stream);
+int combo_gemm_nt_x3_pre_f32(const float* A, long long lda, const float* Bimg, const float* bias, float* C, long long ldc,
+                             int M, int N, int K, int relu, combo_stream_t stream);
+/*   combo_conv3x3_nhwc_x3_f32 on the v2 kernel: Wimg = combo_presplit_bf16x2_f32 of the [Cout, 9*Cin] weight matrix. */
+int combo_conv3x3_nhwc_x3_pre_f32(const float* X, long long ldx, const float* Wimg, const float* bias, float* Y,
+                                  long long ldy, int B, int H, int W, int Cin, int Cout, int relu, combo_stream_t stream);
+
 /*   3x3 / stride 1 / pad 1 convolution on an NHWC fp32 map as an implicit GEMM on the same kernel (replaces the FPN
  *   output convolution `layer_1` of the reference's pixel decoder, pixel_decoder/msdeformattn.py:281-286,349-352, which
  *   the reference runs through cuDNN): X = [B*H*W tokens, Cin] (row stride ldx), Wm = the weight as [Cout, 3, 3, Cin]

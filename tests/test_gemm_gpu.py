@@ -181,3 +181,30 @@ def test_gemm_nt_x3_strided_token_operand():
     a = big[:, 128:384]  # row stride 512, 16-byte aligned start
     w = torch.randn(200, 256, device="cuda")
     assert rel_err(gemm_nt_x3(a, w), a.double() @ w.double().t()) < 2e-5
+
+
+@pytest.mark.parametrize("M,K,N", [(41160, 256, 1024), (20001, 64, 288), (777, 2048, 130), (16400, 16, 40)])
+def test_gemm_nt_v2_is_bitwise_v1_and_accepts_strided_weight_views(M, K, N):
+    """csrc/gemm_nt2.hip (persistent tiles, pre-split weight image) must reproduce csrc/gemm_nt.hip bit for bit - the same
+    products in the same order - on full, ragged and tiny tiles, for W and for a W^T view (dX = dY . W without a
+    transpose copy), with and without bias / ReLU."""
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.ops import linear as L
+    torch.manual_seed(M)
+    a = torch.randn(M, K, device="cuda")
+    w = torch.randn(N, K, device="cuda")
+    b = torch.randn(N, device="cuda")
+    prev = L.NT_V2
+    try:
+        L.NT_V2 = False
+        y1 = L.gemm_nt_x3(a, w, b, relu=True)
+        z1 = L.gemm_nt_x3(a, w.t().contiguous().t())
+        L.NT_V2 = True
+        y2 = L.gemm_nt_x3(a, w, b, relu=True)
+        z2 = L.gemm_nt_x3(a, w.t().contiguous().t())  # a [N, K] view with strides (1, N)
+    finally:
+        L.NT_V2 = prev
+    assert torch.equal(y1, y2)
+    assert torch.equal(z1, z2)
+    ref = torch.relu(a.double() @ w.double().t() + b.double())
+    assert rel_err(y2, ref) < 2e-5
