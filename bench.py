@@ -306,11 +306,14 @@ def main():
                 traffic = rec.get("hbm_bytes_per_launch")
         roof = {"kernel": "msda_fwd_tap_d32", "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 4), "traffic": traffic, "avg_launch_us": round(avg_us, 2),
-                "launches": len(kt["fwd_us"]), "algorithmic_bytes_per_launch": fwd_bytes}
+                "launches": len(kt["fwd_us"]), "algorithmic_bytes_per_launch": fwd_bytes,
+                # measured ceilings of this chip (tools/clock_probe.py, profiles/r01_clock_probe.txt): a 1 GiB device copy
+                # moves 4.75 TB/s; hipBLASLt's bf16 GEMM reaches 1.37 PFLOP/s at the 1400 W package limit (sclk ~1.9 GHz)
+                "measured_ceilings": {"hbm_copy_GBps": 4750.0, "hipblaslt_bf16_TFLOPs": 1374.0}}
     # secondary rooflines (same HIP-event pass): the two hand-written 3xbf16 GEMM kernels against the dense bf16 MFMA
     # peak (2.5 PFLOP/s); MFMA flops = 3 products x 2*M*N*K.  Only the large launches (>= 1 GFLOP) are counted.
     kernels = {}
-    for kind in ("gemm_nt_x3", "gemm_tn_x3"):
+    for kind in ("gemm_nt_x3", "gemm_tn_x3", "conv3x3_x3", "conv3x3_wgrad_x3"):  # conv3x3: FPN 3x3 as implicit GEMMs, meta = (tokens, Cout, 9*Cin)
         evs = [(us, meta) for us, meta in kt.get("kernels", {}).get(kind, []) if meta and 2.0 * meta[0] * meta[1] * meta[2] >= 1e9]
         if evs:
             flops = sum(3 * 2.0 * m[0] * m[1] * m[2] for _, m in evs)

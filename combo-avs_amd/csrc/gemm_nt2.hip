@@ -60,9 +60,7 @@ __device__ __forceinline__ void glds16(const float* g, char* l) {
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-constexpr int kBM = 256, kBN = 128, kBK = 16, kStages = 3;
-constexpr int kABytes = kBM * kBK * 4, kBBytes = kBN * kBK * 4, kStage = kABytes + kBBytes;  // 16 + 8 = 24 KiB
-constexpr int kPPW = kStage / 1024 / 4;                                                       // 6 DMA pieces per wave
+constexpr int kBK = 16;
 
 __device__ __attribute__((aligned(64))) float g_zero_row2[16];  // zero-initialised: the source of padded taps
 
@@ -70,16 +68,62 @@ struct ConvGeom2 {
   int H, W, Cin;
 };
 
-template <bool CONV>
-__global__ void __launch_bounds__(256, 2)
+// Tile configuration: WM x WN waves (always 4), each wave owns TI x TJ MFMA tiles of 32 x 32, ST ring stages of BK = 16.
+//   "wide"   4 x 1 waves, 2 x 4 tiles: 256 x 128 block, 3 stages of 24 KiB, two workgroups per CU (the big layers)
+//   "skinny" 2 x 2 waves, 1 x 1 tiles:  64 x  64 block, 16 stages of 8 KiB = a whole K = 256 panel in flight, one
+//            workgroup per CU: the decoder's M = BT*100-token layers are 32 "wide" tiles (1/8 of the chip) but 252 skinny
+//            ones, and with K = 256 every byte of the tile is requested before the first MFMA waits.  Measured 11.1 us
+//            at 4000 x 256 -> 256 (hipBLASLt 13 us inside the step, v1/wide 32 us); opt-in from Python
+//            (COMBO_NT2_SMALL_MIN_ROWS), because the extra weight pre-split launch eats the 2 us: the small decoder
+//            layers sit at the ~10 us launch + latency floor either way
+template <int WM_, int WN_, int TI_, int TJ_, int ST_>
+struct NtCfg {
+  static constexpr int WM = WM_, WN = WN_, TI = TI_, TJ = TJ_, ST = ST_;
+  static constexpr int BM = WM * TI * 32, BN = WN * TJ * 32;
+  static constexpr int A_BYTES = BM * kBK * 4, B_BYTES = BN * kBK * 4, STAGE = A_BYTES + B_BYTES;
+  static constexpr int A_PIECES = A_BYTES / 1024, PIECES = STAGE / 1024, PPW = PIECES / 4, APW = A_PIECES / 4;
+  static constexpr int LDS = ST * STAGE;
+  static_assert(WM * WN == 4 && PIECES % 4 == 0 && A_PIECES % 4 == 0, "4 waves share the DMA pieces evenly");
+  static_assert((ST - 1) * PPW <= 63, "vmcnt is a 6-bit counter");
+};
+typedef NtCfg<4, 1, 2, 4, 3> NtWide;
+typedef NtCfg<2, 2, 1, 1, 16> NtSkinny;
+
+template <int PPW>
+__device__ __forceinline__ void wait_younger(int younger) {  // s_waitcnt vmcnt(younger * PPW): the immediate must be static
+  switch (younger) {
+    case 0: wait_vm<0>(); break;
+    case 1: wait_vm<PPW>(); break;
+    case 2: wait_vm<2 * PPW>(); break;
+    case 3: wait_vm<3 * PPW>(); break;
+    case 4: wait_vm<4 * PPW>(); break;
+    case 5: wait_vm<5 * PPW>(); break;
+    case 6: wait_vm<6 * PPW>(); break;
+    case 7: wait_vm<7 * PPW>(); break;
+    case 8: wait_vm<(8 * PPW) & 63>(); break;
+    case 9: wait_vm<(9 * PPW) & 63>(); break;
+    case 10: wait_vm<(10 * PPW) & 63>(); break;
+    case 11: wait_vm<(11 * PPW) & 63>(); break;
+    case 12: wait_vm<(12 * PPW) & 63>(); break;
+    case 13: wait_vm<(13 * PPW) & 63>(); break;
+    case 14: wait_vm<(14 * PPW) & 63>(); break;
+    default: wait_vm<(15 * PPW) & 63>(); break;
+  }
+}
+
+template <bool CONV, typename Cfg>
+__global__ void __launch_bounds__(256, Cfg::LDS <= 80 * 1024 ? 2 : 1)
 gemm_nt2_kernel(const float* __restrict__ A, long long lda, const float* __restrict__ Bimg, long long ldb,
                 const float* __restrict__ bias, float* __restrict__ C, long long ldc, int M, int N, int K, int relu,
                 int stagger, ConvGeom2 cg) {
+  constexpr int BM = Cfg::BM, BN = Cfg::BN, TI = Cfg::TI, TJ = Cfg::TJ, ST = Cfg::ST, PPW = Cfg::PPW, APW = Cfg::APW;
+  constexpr int A_BYTES = Cfg::A_BYTES, STAGE = Cfg::STAGE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int n_tiles = (N + kBN - 1) / kBN;
-  const int tiles = ((M + kBM - 1) / kBM) * n_tiles;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+  const int n_tiles = (N + BN - 1) / BN;
+  const int tiles = ((M + BM - 1) / BM) * n_tiles;
   const int G = gridDim.x;
   // logical workgroup index: every XCD owns a contiguous range, so the n tiles sharing the A rows of a token tile run on
   // one XCD (one L2) in the same round
@@ -93,14 +137,16 @@ gemm_nt2_kernel(const float* __restrict__ A, long long lda, const float* __restr
   const int p_row = lane >> 2, p_chunk = lane & 3;
   int i_tile = w, i_s = 0, i_slot = 0, issued = 0;
   int i_m_blk = 0, i_n_blk = 0, i_tap = 0, i_cin0 = 0;
-  unsigned tap_ok[4] = {0u, 0u, 0u, 0u};  // CONV: this lane's four A rows -> 9-bit masks of the taps inside the map
+  unsigned tap_ok[APW];  // CONV: this lane's A rows -> 9-bit masks of the taps inside the map
+#pragma unroll
+  for (int u = 0; u < APW; ++u) tap_ok[u] = 0u;
   auto open_tile = [&]() {
-    i_m_blk = (i_tile / n_tiles) * kBM;
-    i_n_blk = (i_tile % n_tiles) * kBN;
+    i_m_blk = (i_tile / n_tiles) * BM;
+    i_n_blk = (i_tile % n_tiles) * BN;
     i_s = 0; i_tap = 0; i_cin0 = 0;
     if (CONV) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < APW; ++u) {
         const int t = min(i_m_blk + (wave + 4 * u) * 16 + p_row, M - 1);
         const int x = t % cg.W, y = (t / cg.W) % cg.H;
         unsigned ok = 0u;
@@ -115,31 +161,32 @@ gemm_nt2_kernel(const float* __restrict__ A, long long lda, const float* __restr
   };
   auto issue_next = [&]() {
     if (i_tile >= tiles) return;
-    char* st = smem + i_slot * kStage;
+    char* st = smem + i_slot * STAGE;
     const int k0 = i_s * kBK;
     const int shift = CONV ? (i_tap / 3 - 1) * cg.W + (i_tap % 3 - 1) : 0;
 #pragma unroll
-    for (int u = 0; u < kPPW; ++u) {
-      const int q = wave + 4 * u;  // wave-uniform piece (1 KiB = 16 rows x 64 B); q < 16: A rows, else B rows
-      if (u < 4) {
+    for (int u = 0; u < PPW; ++u) {
+      const int q = wave + 4 * u;  // wave-uniform piece (1 KiB = 16 rows x 64 B); q < A_PIECES: A rows, else B rows
+      if (u < APW) {
         const int r = q * 16 + p_row;
         const int c = p_chunk ^ ((r >> 2) & 3);  // swizzle on the SOURCE chunk, the LDS image stays lane-linear
         const float* src;
         if (CONV)
-          src = ((tap_ok[u & 3] >> i_tap) & 1u) ? A + (long long)(min(i_m_blk + r, M - 1) + shift) * lda + i_cin0 + c * 4
-                                                : g_zero_row2 + c * 4;
+          src = ((tap_ok[u < APW ? u : 0] >> i_tap) & 1u)
+                    ? A + (long long)(min(i_m_blk + r, M - 1) + shift) * lda + i_cin0 + c * 4
+                    : g_zero_row2 + c * 4;
         else
           src = A + (long long)min(i_m_blk + r, M - 1) * lda + k0 + c * 4;
         glds16(src, st + q * 1024);
       } else {
-        const int qb = q - 16;
+        const int qb = q - Cfg::A_PIECES;
         const int r = qb * 16 + p_row;
         const int c = p_chunk ^ ((r >> 2) & 3);
-        glds16(Bimg + (long long)min(i_n_blk + r, N - 1) * ldb + k0 + c * 4, st + kABytes + qb * 1024);
+        glds16(Bimg + (long long)min(i_n_blk + r, N - 1) * ldb + k0 + c * 4, st + A_BYTES + qb * 1024);
       }
     }
     ++issued;
-    i_slot = i_slot == kStages - 1 ? 0 : i_slot + 1;
+    i_slot = i_slot == ST - 1 ? 0 : i_slot + 1;
     ++i_s;
     if (CONV) {
       i_cin0 += kBK;
@@ -151,90 +198,97 @@ gemm_nt2_kernel(const float* __restrict__ A, long long lda, const float* __restr
     }
   };
   if (i_tile < tiles) open_tile();
-  issue_next();
-  issue_next();
+#pragma unroll 1
+  for (int p = 0; p < ST - 1; ++p) issue_next();
 
   // ---------------- LDS read addresses: lane (row m, k-half g) reads chunks 2g, 2g+1 of its rows ----------------
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int m = lane & 31, g = lane >> 5;
-  const int sw = (m >> 2) & 3;  // rows wave*64 + i*32 + m and j*32 + m all share the swizzle of m
-  const unsigned a_c0 = lds0 + (unsigned)((wave * 64 + m) * 64 + ((2 * g) ^ sw) * 16);
-  const unsigned a_c1 = lds0 + (unsigned)((wave * 64 + m) * 64 + ((2 * g + 1) ^ sw) * 16);
-  const unsigned b_c0 = lds0 + (unsigned)(kABytes + m * 64 + ((2 * g) ^ sw) * 16);
-  const unsigned b_c1 = lds0 + (unsigned)(kABytes + m * 64 + ((2 * g + 1) ^ sw) * 16);
+  const int sw = (m >> 2) & 3;  // a wave's rows are (multiple of 32) + m: they all share the swizzle of m
+  const unsigned a_c0 = lds0 + (unsigned)((wm * TI * 32 + m) * 64 + ((2 * g) ^ sw) * 16);
+  const unsigned a_c1 = lds0 + (unsigned)((wm * TI * 32 + m) * 64 + ((2 * g + 1) ^ sw) * 16);
+  const unsigned b_c0 = lds0 + (unsigned)(A_BYTES + (wn * TJ * 32 + m) * 64 + ((2 * g) ^ sw) * 16);
+  const unsigned b_c1 = lds0 + (unsigned)(A_BYTES + (wn * TJ * 32 + m) * 64 + ((2 * g + 1) ^ sw) * 16);
 
   int consumed = 0, c_slot = 0;
   for (int tile = w; tile < tiles; tile += G) {
-    const int m_blk = (tile / n_tiles) * kBM, n_blk = (tile % n_tiles) * kBN;
-    f32x16 acc[2][4];
+    const int m_blk = (tile / n_tiles) * BM, n_blk = (tile % n_tiles) * BN;
+    f32x16 acc[TI][TJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < TJ; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     for (int s = 0; s < nst; ++s) {
       // the stage to consume has landed once every OLDER vector-memory operation of this wave is done.  Inside a tile
-      // only ring loads are pending (counted wait: one younger stage may stay in flight); the first stage of a tile also
-      // drains the epilogue stores of the previous tile (stores and loads share vmcnt and may retire out of order).
-      if (s == 0 || issued - consumed == 1) wait_vm<0>();
-      else wait_vm<kPPW>();
+      // only ring loads are pending (counted wait: the younger stages stay in flight); the first stage of a later tile
+      // also drains the epilogue stores of the previous tile (stores and loads share vmcnt and may retire out of order).
+      if (s == 0 && tile != w) wait_vm<0>();
+      else wait_younger<PPW>(issued - consumed - 1);
       __builtin_amdgcn_s_barrier();  // everybody's pieces landed; everybody finished reading the slot refilled below
       issue_next();
-      const unsigned so = (unsigned)(c_slot * kStage);
-      f4v ra[2][2];
-      bf16x8 bh[4], bl[4];
-      ra[0][0] = lds_read128<0>(a_c0 + so);
-      ra[0][1] = lds_read128<0>(a_c1 + so);
-      ra[1][0] = lds_read128<2048>(a_c0 + so);
-      ra[1][1] = lds_read128<2048>(a_c1 + so);
-      f4v rb0[4], rb1[4];
-      rb0[0] = lds_read128<0>(b_c0 + so);    rb1[0] = lds_read128<0>(b_c1 + so);
-      rb0[1] = lds_read128<2048>(b_c0 + so); rb1[1] = lds_read128<2048>(b_c1 + so);
-      rb0[2] = lds_read128<4096>(b_c0 + so); rb1[2] = lds_read128<4096>(b_c1 + so);
-      rb0[3] = lds_read128<6144>(b_c0 + so); rb1[3] = lds_read128<6144>(b_c1 + so);
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[1][0]), "+v"(ra[1][1]), "+v"(rb0[0]), "+v"(rb1[0]),
-                     "+v"(rb0[1]), "+v"(rb1[1]), "+v"(rb0[2]), "+v"(rb1[2]), "+v"(rb0[3]), "+v"(rb1[3])
-                   :
-                   : "memory");
+      const unsigned so = (unsigned)(c_slot * STAGE);
+      f4v ra[TI][2], rb[TJ][2];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        bh[j] = __builtin_bit_cast(bf16x8, rb0[j]);
-        bl[j] = __builtin_bit_cast(bf16x8, rb1[j]);
+      for (int i = 0; i < TI; ++i) {
+        ra[i][0] = i == 0 ? lds_read128<0>(a_c0 + so) : lds_read128<2048>(a_c0 + so);
+        ra[i][1] = i == 0 ? lds_read128<0>(a_c1 + so) : lds_read128<2048>(a_c1 + so);
       }
-      bf16x8 ah[2], al[2];
-      split8(ra[0][0], ra[0][1], ah[0], al[0]);
-      split8(ra[1][0], ra[1][1], ah[1], al[1]);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < TJ; ++j) {
+        rb[j][0] = j == 0 ? lds_read128<0>(b_c0 + so) : j == 1 ? lds_read128<2048>(b_c0 + so)
+                 : j == 2 ? lds_read128<4096>(b_c0 + so) : lds_read128<6144>(b_c0 + so);
+        rb[j][1] = j == 0 ? lds_read128<0>(b_c1 + so) : j == 1 ? lds_read128<2048>(b_c1 + so)
+                 : j == 2 ? lds_read128<4096>(b_c1 + so) : lds_read128<6144>(b_c1 + so);
+      }
+      if constexpr (TI == 2 && TJ == 4) {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[1][0]), "+v"(ra[1][1]), "+v"(rb[0][0]), "+v"(rb[0][1]),
+                       "+v"(rb[1][0]), "+v"(rb[1][1]), "+v"(rb[2][0]), "+v"(rb[2][1]), "+v"(rb[3][0]), "+v"(rb[3][1])
+                     :
+                     : "memory");
+      } else {
+        static_assert((TI == 2 && TJ == 4) || (TI == 1 && TJ == 1), "add the register list of a new wave tile here");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(rb[0][0]), "+v"(rb[0][1]) : : "memory");
+      }
+      bf16x8 bh[TJ], bl[TJ], ah[TI], al[TI];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < TJ; ++j) {
+        bh[j] = __builtin_bit_cast(bf16x8, rb[j][0]);
+        bl[j] = __builtin_bit_cast(bf16x8, rb[j][1]);
+      }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TI; ++i) split8(ra[i][0], ra[i][1], ah[i], al[i]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < TI; ++i)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
       ++consumed;
-      c_slot = c_slot == kStages - 1 ? 0 : c_slot + 1;
+      c_slot = c_slot == ST - 1 ? 0 : c_slot + 1;
     }
 
     // epilogue: D tile = 32 tokens x 32 n; lane holds n = lane & 31 and tokens (e&3) + 8*(e>>2) + 4*(lane>>5).  The
     // stores drain while the next tile's first stages (already in flight) land.
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n_blk + j * 32 + m;
+    for (int j = 0; j < TJ; ++j) {
+      const int n = n_blk + (wn * TJ + j) * 32 + m;
       if (n >= N) continue;
       const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const int row = m_blk + wave * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
+          const int row = m_blk + (wm * TI + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
           if (row < M) {
             float v = acc[i][j][e] + bv;
             if (relu) v = fmaxf(v, 0.f);
@@ -252,7 +306,10 @@ presplit_kernel(const float* __restrict__ src, long long ld_row, long long ld_co
   const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   const int kg = K >> 3;
   if (t >= (long long)N * kg) return;
-  const int n = (int)(t / kg), g8 = (int)(t - (long long)n * kg);
+  // neighbouring threads walk the unit-stride direction of the source: k groups for W, rows for a W^T view
+  int n, g8;
+  if (ld_col == 1) { n = (int)(t / kg); g8 = (int)(t - (long long)n * kg); }
+  else { g8 = (int)(t / N); n = (int)(t - (long long)g8 * N); }
   float v[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) v[i] = src[(long long)n * ld_row + (long long)(g8 * 8 + i) * ld_col];
@@ -262,40 +319,52 @@ presplit_kernel(const float* __restrict__ src, long long ld_row, long long ld_co
     h[i] = pack_hi(v[2 * i], v[2 * i + 1]);
     l[i] = pack_rne(v[2 * i] - trunc_hi(v[2 * i]), v[2 * i + 1] - trunc_hi(v[2 * i + 1]));
   }
-  img[t * 2] = make_uint4(h[0], h[1], h[2], h[3]);
-  img[t * 2 + 1] = make_uint4(l[0], l[1], l[2], l[3]);
+  const long long o = ((long long)n * kg + g8) * 2;
+  img[o] = make_uint4(h[0], h[1], h[2], h[3]);
+  img[o + 1] = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+template <bool CONV, typename Cfg>
+int launch_nt2_cfg(const float* A, long long lda, const float* Bimg, const float* bias, float* C, long long ldc, long long M,
+                   int N, int K, int relu, ConvGeom2 cg, int n_cu, combo_stream_t stream) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt2_kernel<CONV, Cfg>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  const long long tiles = ((M + Cfg::BM - 1) / Cfg::BM) * ((N + Cfg::BN - 1) / Cfg::BN);
+  if (tiles > 0x7fffffffLL) return COMBO_EINVAL;
+  static const int stagger_on = [] { const char* e = getenv("COMBO_NT2_STAGGER"); return e ? atoi(e) : 0; }();
+  const long long slots = (Cfg::LDS <= 80 * 1024 ? 2LL : 1LL) * n_cu;  // resident workgroups
+  const int grid = (int)(tiles < slots ? tiles : slots);
+  // half a tile of the main loop, in units of s_sleep(32) = 2048 cycles (a BK = 16 stage costs ~1500 cycles per wave)
+  int stagger = 0;
+  if (stagger_on && Cfg::ST == 3 && tiles > n_cu) {
+    stagger = (K / kBK) * 750 / 2048;
+    if (stagger < 1) stagger = 1;
+    if (stagger > 8) stagger = 8;
+  }
+  hipLaunchKernelGGL((gemm_nt2_kernel<CONV, Cfg>), dim3((unsigned)grid), dim3(256), Cfg::LDS, (hipStream_t)stream, A, lda, Bimg,
+                     (long long)K, bias, C, ldc, (int)M, N, K, relu, stagger, cg);
+  return (int)hipGetLastError();
 }
 
 template <bool CONV>
 int launch_nt2(const float* A, long long lda, const float* Bimg, const float* bias, float* C, long long ldc, long long M, int N,
                int K, int relu, ConvGeom2 cg, combo_stream_t stream) {
-  constexpr int lds = kStages * kStage;
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt2_kernel<CONV>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    attr = true;
-  }
-  const long long tiles = ((M + kBM - 1) / kBM) * ((N + kBN - 1) / kBN);
-  if (tiles > 0x7fffffffLL) return COMBO_EINVAL;
   static const int n_cu = [] {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     return cus > 0 ? cus : 256;
   }();
-  static const int stagger_on = [] { const char* e = getenv("COMBO_NT2_STAGGER"); return e ? atoi(e) : 0; }();
-  const int grid = (int)(tiles < 2LL * n_cu ? tiles : 2LL * n_cu);
-  // half a tile of the main loop, in units of s_sleep(32) = 2048 cycles (a BK = 16 stage costs ~1500 cycles per wave)
-  int stagger = 0;
-  if (stagger_on && tiles > n_cu) {
-    stagger = (K / kBK) * 750 / 2048;
-    if (stagger < 1) stagger = 1;
-    if (stagger > 8) stagger = 8;
-  }
-  hipLaunchKernelGGL(gemm_nt2_kernel<CONV>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, A, lda, Bimg,
-                     (long long)K, bias, C, ldc, (int)M, N, K, relu, stagger, cg);
-  return (int)hipGetLastError();
+  static const int skinny_mode = [] { const char* e = getenv("COMBO_NT2_SKINNY"); return e ? atoi(e) : 1; }();  // 0 never, 2 always
+  const long long wide_tiles = ((M + NtWide::BM - 1) / NtWide::BM) * ((N + NtWide::BN - 1) / NtWide::BN);
+  // skinny tiles when the wide ones would leave most of the chip idle (the decoder's M = BT*100-token layers)
+  const bool skinny = skinny_mode == 2 || (skinny_mode == 1 && wide_tiles * 2 <= n_cu);
+  if (skinny) return launch_nt2_cfg<CONV, NtSkinny>(A, lda, Bimg, bias, C, ldc, M, N, K, relu, cg, n_cu, stream);
+  return launch_nt2_cfg<CONV, NtWide>(A, lda, Bimg, bias, C, ldc, M, N, K, relu, cg, n_cu, stream);
 }
 
 }  // namespace
