@@ -309,7 +309,10 @@ def main():
                 "launches": len(kt["fwd_us"]), "algorithmic_bytes_per_launch": fwd_bytes,
                 # measured ceilings of this chip (tools/clock_probe.py, profiles/r01_clock_probe.txt): a 1 GiB device copy
                 # moves 4.75 TB/s; hipBLASLt's bf16 GEMM reaches 1.37 PFLOP/s at the 1400 W package limit (sclk ~1.9 GHz)
-                "measured_ceilings": {"hbm_copy_GBps": 4750.0, "hipblaslt_bf16_TFLOPs": 1374.0}}
+                "measured_ceilings": {"hbm_copy_GBps": 4750.0, "hipblaslt_bf16_TFLOPs": 1374.0},
+                # by time the largest single kernel of the step is the forward / dX GEMM (~10 %, MFMA-bound, reported in
+                # other_kernels.gemm_nt_x3); this object stays on the north-star's core op, which is HBM-bound
+                "largest_kernel_by_time": "gemm_nt2_kernel (other_kernels.gemm_nt_x3)"}
     # secondary rooflines (same HIP-event pass): the two hand-written 3xbf16 GEMM kernels against the dense bf16 MFMA
     # peak (2.5 PFLOP/s); MFMA flops = 3 products x 2*M*N*K.  Only the large launches (>= 1 GFLOP) are counted.
     kernels = {}
