@@ -243,6 +243,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    trace_on = os.environ.get("COMBO_BENCH_TRACE") == "1"
+
+    def trace(msg):  # progress markers on stderr (debugging aid for multi-rank runs)
+        if trace_on:
+            torch.cuda.synchronize()
+            print(f"[bench rank {rank} +{time.perf_counter() - t_start:.1f}s] {msg}", file=sys.stderr, flush=True)
+    t_start = time.perf_counter()
+
     if args.no_graph:
         def step(b):
             return train_step(model, opt, b)
@@ -254,9 +262,12 @@ def main():
         # forward + loss + backward replayed from one hipGraph (captured during the first warm-up step, after MIOpen's
         # find pass); the MSDeformAttn launches are bracketed by external event-record nodes inside the graph
         graphed = GraphedTrainStep(model, opt)
+        trace("model built")
         train_step(model, opt, batch)  # eager: MIOpen find / hipBLASLt heuristics / lazy init
+        trace("eager step done")
         try:
             graphed(batch)  # captures
+            trace("captured + first replayed step done")
             step = graphed
         except Exception as exc:  # noqa: BLE001 - a failed capture must not cost the run: fall back to eager launches
             print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eager", file=sys.stderr, flush=True)
@@ -266,12 +277,15 @@ def main():
                 return train_step(model, opt, b)
         for _ in range(max(args.warmup - 1, 0)):
             step(batch)
+            trace("warm-up step done")
         sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(batch)
+        trace("timed step done")
     sync()
     elapsed = time.perf_counter() - t0
+    trace("timed region done")
     if not args.no_graph:
         # event records cannot be captured into a hipGraph on ROCm 7 (hipEventRecordExternal is rejected), so the
         # kernel durations come from two eager runs of the very same step right after the timed region

@@ -13,6 +13,8 @@ Parameters are laid out grouped by (lr, weight_decay) so every group is one cont
 """
 import math
 
+import os
+
 import torch
 import torch.distributed as dist
 from torch import nn
@@ -120,7 +122,10 @@ class FlatAdamW:
         return cache[n]
 
     def all_reduce_grads(self):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        # COMBO_FORCE_PG=1 (bench.py's one-rank process group on a 1-GPU box) also runs the collective at world size 1,
+        # so that the RCCL all-reduce of the flat gradient buffer is exercised on the GPU
+        forced = os.environ.get("COMBO_FORCE_PG") == "1"
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or forced):
             world = dist.get_world_size()
             if self.grad_comm_dtype != self.flat_grad.dtype:
                 buf = (self.flat_grad / world).to(self.grad_comm_dtype)  # pre-divide: keeps the sum inside bf16's range
