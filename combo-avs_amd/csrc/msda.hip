@@ -455,23 +455,24 @@ __device__ __forceinline__ void bwd_value_pass(const float* __restrict__ gout, c
           if (coff[j] == c) tgr[j] = tgs[c];
       }
     }
-    float2 xy[kMaxLP];
-    float av[kMaxLP];
+    // The 4 channel lanes of a query share the sample geometry: lane cg computes the points cg, cg+4, cg+8, .. (tap
+    // rows, and the fixed-point factors wt * scale) ONCE and the quad reads them by DPP broadcasts, instead of every lane
+    // recomputing all L*P points (the kernel is VALU-bound: 104 M VALU instructions per launch before this, PMC).
+    constexpr int J = kMaxLP / 4;
+    int my_r[J][4], my_ok[J];
+    float my_v[J][4];
 #pragma unroll
-    for (int pt = 0; pt < kMaxLP; ++pt) {
-      xy[pt] = make_float2(-8.f, -8.f);
-      av[pt] = 0.f;
+    for (int j = 0; j < J; ++j) {
+      const int pt = cg + 4 * j;
+      my_ok[j] = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { my_r[j][k] = S; my_v[j][k] = 0.f; }
       if (pt < LP && live) {
-        xy[pt] = *reinterpret_cast<const float2*>(loc + (qm * LP + pt) * 2);
-        av[pt] = aw[qm * LP + pt];
-      }
-    }
-#pragma unroll
-    for (int pt = 0; pt < kMaxLP; ++pt) {
-      if (pt < LP) {
+        const float2 xy = *reinterpret_cast<const float2*>(loc + (qm * LP + pt) * 2);
+        const float a = aw[qm * LP + pt];
         const int l = pt / P;
         const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)lsi[l];
-        const float h_im = xy[pt].y * H - 0.5f, w_im = xy[pt].x * W - 0.5f;
+        const float h_im = xy.y * H - 0.5f, w_im = xy.x * W - 0.5f;
         if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
           const float hf = floorf(h_im), wf = floorf(w_im);
           const int h0 = (int)hf, w0 = (int)wf;
@@ -479,26 +480,56 @@ __device__ __forceinline__ void bwd_value_pass(const float* __restrict__ gout, c
           const bool t_ok = h0 >= 0, b_ok = h0 + 1 <= H - 1, l_ok = w0 >= 0, r_ok = w0 + 1 <= W - 1;
           const int base = st + h0 * W + w0;
           const int r[4] = {(t_ok && l_ok) ? base : S, (t_ok && r_ok) ? base + 1 : S, (b_ok && l_ok) ? base + W : S,
-                            (b_ok && r_ok) ? base + W + 1 : S};
-          const float a = av[pt];
+                            (b_ok && r_ok) ? base + W + 1 : S};  // row S is a dummy sink for out-of-range taps
           const float wt[4] = {hh * hw * a, hh * lw * a, lh * hw * a, lh * lw * a};
-          if constexpr (PASS == 0) {
-            // lane cg handles tap cg
-            float wk = wt[0];
-            int rk = r[0];
+          my_ok[j] = 1;
 #pragma unroll
-            for (int k = 1; k < 4; ++k)
-              if (cg == k) { wk = wt[k]; rk = r[k]; }
-            __hip_atomic_fetch_add(wsum + rk, __float2int_ru(fabsf(wk) * wscale), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_WORKGROUP);
-          } else {
+          for (int k = 0; k < 4; ++k) {
+            my_r[j][k] = r[k];
+            my_v[j][k] = PASS == 0 ? fabsf(wt[k]) * wscale : wt[k] * rowscale[r[k]];
+          }
+        }
+      }
+    }
+    if constexpr (PASS == 0) {
+      // every lane scatters the taps of ITS points (the same 48 adds per query as one tap of every point per lane)
+#pragma unroll
+      for (int j = 0; j < J; ++j)
+        if (my_ok[j]) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            __hip_atomic_fetch_add(wsum + my_r[j][k], __float2int_ru(my_v[j][k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    } else {
+#pragma unroll
+      for (int pt = 0; pt < kMaxLP; ++pt) {
+        if (pt < LP) {
+          constexpr int kQuad[4] = {0x00, 0x55, 0xAA, 0xFF};  // DPP quad_perm broadcasts of lane 0..3 of the quad
+          const int j = pt >> 2;
+          auto bc = [&](int v) {
+            switch (pt & 3) {
+              case 0: return __builtin_amdgcn_update_dpp(0, v, kQuad[0], 0xf, 0xf, true);
+              case 1: return __builtin_amdgcn_update_dpp(0, v, kQuad[1], 0xf, 0xf, true);
+              case 2: return __builtin_amdgcn_update_dpp(0, v, kQuad[2], 0xf, 0xf, true);
+              default: return __builtin_amdgcn_update_dpp(0, v, kQuad[3], 0xf, 0xf, true);
+            }
+          };
+          // (the broadcasts run for the whole wave: DPP sources must be active lanes; `ok` is uniform within a quad)
+          const int ok = bc(my_ok[j]);
+          int r[4];
+          float ws[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            r[k] = bc(my_r[j][k]);
+            ws[k] = __int_as_float(bc(__float_as_int(my_v[j][k])));
+          }
+          if (ok) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-              int* gp = acc + r[k] * HD + cg * 4;  // row S is a dummy sink for out-of-range taps
-              const float ws = wt[k] * rowscale[r[k]];
+              int* gp = acc + r[k] * HD + cg * 4;
 #pragma unroll
-              for (int j = 0; j < 4; ++j)
-                __hip_atomic_fetch_add(gp + coff[j], __float2int_rn(ws * tgr[j]), __ATOMIC_RELAXED,
+              for (int jj = 0; jj < 4; ++jj)
+                __hip_atomic_fetch_add(gp + coff[jj], __float2int_rn(ws[k] * tgr[jj]), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
             }
           }
