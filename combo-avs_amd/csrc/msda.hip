@@ -247,6 +247,11 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
 }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+
 __device__ __forceinline__ void dma16(const float* g, float* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
@@ -729,12 +734,11 @@ msda_bwd_locw_lds_d32(const float* __restrict__ gout, const float* __restrict__ 
         float sw = hh * hw * d0 + hh * lw * d1 + lh * hw * d2 + lh * lw * d3;  // d out / d w
         float sy = (-hw * d0 - lw * d1 + hw * d2 + lw * d3) * pp.w;              // * a * H
         float sx = (-hh * d0 + hh * d1 - lh * d2 + lh * d3) * pp.z;              // * a * W
-#pragma unroll
-        for (int s = 1; s < 8; s <<= 1) {
-          sw += __shfl_xor(sw, s);
-          sx += __shfl_xor(sx, s);
-          sy += __shfl_xor(sy, s);
-        }
+        // sum over the 8 channel lanes of the query with DPP adds (quad swaps, then the mirror of the 8-lane half row);
+        // `__shfl_xor` went through the LDS pipe (ds_bpermute_b32) three dependent times per point
+        sw += dpp_f<0xB1>(sw); sx += dpp_f<0xB1>(sx); sy += dpp_f<0xB1>(sy);     // quad_perm [1,0,3,2]
+        sw += dpp_f<0x4E>(sw); sx += dpp_f<0x4E>(sx); sy += dpp_f<0x4E>(sy);     // quad_perm [2,3,0,1]
+        sw += dpp_f<0x141>(sw); sx += dpp_f<0x141>(sx); sy += dpp_f<0x141>(sy);  // row_half_mirror
         // lane cg keeps points cg and cg+8 -> coalesced stores below
         if ((pt & 7) == cg) {
           if (pt < 8) { keep_w[0] = sw; keep_x[0] = sx; keep_y[0] = sy; }
@@ -783,10 +787,6 @@ constexpr int kTapQW = 4;  // queries per wave iteration (2 gather steps of 2 qu
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float x) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
-}
 
 template <int LPc>
 __global__ void __launch_bounds__(1024)
