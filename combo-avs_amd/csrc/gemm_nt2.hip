@@ -17,6 +17,7 @@
 // 1092 TF/s on the 125440x2304x256 shape, 479 TF/s at 41160x256->1024 where this kernel does 3x the MFMA work in 2.9x the
 // time), which is why the phases of v1's ablation add up instead of overlapping: at the cap, time follows energy.
 #include <cstdlib>
+#include <type_traits>
 
 #include "combo_common.h"
 
@@ -89,8 +90,13 @@ struct NtCfg {
 typedef NtCfg<4, 1, 2, 4, 3> NtWide;
 typedef NtCfg<2, 2, 1, 1, 16> NtSkinny;
 
-template <int PPW>
+template <int PPW, int ST>
 __device__ __forceinline__ void wait_younger(int younger) {  // s_waitcnt vmcnt(younger * PPW): the immediate must be static
+  if constexpr (ST <= 3) {  // at most one younger stage in flight
+    if (younger == 0) wait_vm<0>();
+    else wait_vm<PPW>();
+    return;
+  }
   switch (younger) {
     case 0: wait_vm<0>(); break;
     case 1: wait_vm<PPW>(); break;
@@ -115,7 +121,7 @@ template <bool CONV, typename Cfg>
 __global__ void __launch_bounds__(256, Cfg::LDS <= 80 * 1024 ? 2 : 1)
 gemm_nt2_kernel(const float* __restrict__ A, long long lda, const float* __restrict__ Bimg, long long ldb,
                 const float* __restrict__ bias, float* __restrict__ C, long long ldc, int M, int N, int K, int relu,
-                int stagger, ConvGeom2 cg) {
+                int stagger, ConvGeom2 cg, int c_bytes) {
   constexpr int BM = Cfg::BM, BN = Cfg::BN, TI = Cfg::TI, TJ = Cfg::TJ, ST = Cfg::ST, PPW = Cfg::PPW, APW = Cfg::APW;
   constexpr int A_BYTES = Cfg::A_BYTES, STAGE = Cfg::STAGE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -129,6 +135,9 @@ gemm_nt2_kernel(const float* __restrict__ A, long long lda, const float* __restr
   // one XCD (one L2) in the same round
   const int w = xcd_contiguous(blockIdx.x, G);
   const int nst = K / kBK;
+  // buffer descriptor over C for the epilogue stores (kernel arguments only: provably wave-uniform); rows >= M fall
+  // outside `c_bytes` and are dropped by the range check
+  const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(C, 0, c_bytes, 0x00020000);
   if (stagger > 0 && (int)blockIdx.x >= G / 2) {  // the second workgroup of each CU starts half a tile late
     for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(32);
   }
@@ -226,7 +235,7 @@ gemm_nt2_kernel(const float* __restrict__ A, long long lda, const float* __restr
       // only ring loads are pending (counted wait: the younger stages stay in flight); the first stage of a later tile
       // also drains the epilogue stores of the previous tile (stores and loads share vmcnt and may retire out of order).
       if (s == 0 && tile != w) wait_vm<0>();
-      else wait_younger<PPW>(issued - consumed - 1);
+      else wait_younger<PPW, ST>(issued - consumed - 1);
       __builtin_amdgcn_s_barrier();  // everybody's pieces landed; everybody finished reading the slot refilled below
       issue_next();
       const unsigned so = (unsigned)(c_slot * STAGE);
@@ -278,24 +287,32 @@ gemm_nt2_kernel(const float* __restrict__ A, long long lda, const float* __restr
     }
 
     // epilogue: D tile = 32 tokens x 32 n; lane holds n = lane & 31 and tokens (e&3) + 8*(e>>2) + 4*(lane>>5).  The
-    // stores drain while the next tile's first stages (already in flight) land.
+    // stores drain while the next tile's first stages (already in flight) land.  They are BUFFER stores: one descriptor over
+    // C (wave-uniform), a 32-bit byte offset per lane that walks the rows by additions of ldc / 5*ldc, and the hardware
+    // range check drops the rows >= M of the last token tile.  (The first version's per-store 64-bit multiply-adds, row
+    // tests and exec masking were ~2 000 VALU instructions per tile: 60 % of the kernel's VALU count by PMC.)
+    auto epilogue = [&](auto relu_tag) {
+      constexpr bool RELU = decltype(relu_tag)::value;
+      const unsigned uld = (unsigned)ldc * 4u, uld5 = 5u * uld;
 #pragma unroll
-    for (int j = 0; j < TJ; ++j) {
-      const int n = n_blk + (wn * TJ + j) * 32 + m;
-      if (n >= N) continue;
-      const float bv = bias ? bias[n] : 0.f;
+      for (int j = 0; j < TJ; ++j) {
+        const int n = n_blk + (wn * TJ + j) * 32 + m;
+        if (n >= N) continue;
+        const float bv = bias ? bias[n] : 0.f;
+        unsigned off = ((unsigned)(m_blk + wm * TI * 32 + 4 * g) * (unsigned)ldc + (unsigned)n) * 4u;
 #pragma unroll
-      for (int i = 0; i < TI; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = m_blk + (wm * TI + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
-          if (row < M) {
+          for (int e = 0; e < 16; ++e) {
             float v = acc[i][j][e] + bv;
-            if (relu) v = fmaxf(v, 0.f);
-            C[(long long)row * ldc + n] = v;
+            if (RELU) v = fmaxf(v, 0.f);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), c_rsrc, off, 0, 0);
+            off += (e & 3) == 3 ? uld5 : uld;  // rows 0-3, 8-11, 16-19, 24-27 (+4g); the next i starts 32 rows on
           }
-        }
-    }
+      }
+    };
+    if (relu) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
   }
 }
 
@@ -346,8 +363,11 @@ int launch_nt2_cfg(const float* A, long long lda, const float* Bimg, const float
     if (stagger < 1) stagger = 1;
     if (stagger > 8) stagger = 8;
   }
+  // extent of C in bytes for the epilogue's buffer descriptor (32-bit offsets)
+  const long long c_bytes = ((M - 1) * ldc + N) * 4;
+  if (c_bytes >= 0x7fffffffLL) return COMBO_EINVAL;
   hipLaunchKernelGGL((gemm_nt2_kernel<CONV, Cfg>), dim3((unsigned)grid), dim3(256), Cfg::LDS, (hipStream_t)stream, A, lda, Bimg,
-                     (long long)K, bias, C, ldc, (int)M, N, K, relu, stagger, cg);
+                     (long long)K, bias, C, ldc, (int)M, N, K, relu, stagger, cg, (int)c_bytes);
   return (int)hipGetLastError();
 }
 

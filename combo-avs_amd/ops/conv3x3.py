@@ -32,7 +32,7 @@ def _conv_tokens(x_tok, wm, bias, B, H, W, cin, cout, relu=False):
     """x_tok [B*H*W, cin] (row stride free), wm [cout, 9*cin] -> [B*H*W, cout]"""
     y = torch.empty(B * H * W, cout, device=x_tok.device, dtype=torch.float32)
     from . import linear as L
-    if L.NT_V2:
+    if L.NT_V2 and B * H * W * cout * 4 < 2 ** 31 - 1:  # (v2 addresses Y with 32-bit byte offsets)
         img = L.presplit(wm)
         with _lib.timed("conv3x3_x3", (B * H * W, cout, 9 * cin)):
             rc = _lib.lib().combo_conv3x3_nhwc_x3_pre_f32(x_tok.data_ptr(), x_tok.stride(0), img.data_ptr(), _lib.ptr(bias),

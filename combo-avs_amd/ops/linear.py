@@ -84,7 +84,7 @@ def gemm_nt_x3(a, b, bias=None, relu=False):
     M, K = a.shape
     N = b.shape[0]
     out = torch.empty(M, N, device=a.device, dtype=torch.float32)
-    if NT_V2 and K % 16 == 0:
+    if NT_V2 and K % 16 == 0 and M * N * 4 < 2 ** 31 - 1:  # (v2 addresses C with 32-bit byte offsets)
         img = presplit(b)
         with _lib.timed("gemm_nt_x3", (M, N, K)):
             rc = _lib.lib().combo_gemm_nt_x3_pre_f32(a.data_ptr(), a.stride(0), img.data_ptr(), _lib.ptr(bias), out.data_ptr(),
