@@ -71,6 +71,7 @@ struct ConvGeom2 {
 
 // Tile configuration: WM x WN waves (always 4), each wave owns TI x TJ MFMA tiles of 32 x 32, ST ring stages of BK = 16.
 //   "wide"   4 x 1 waves, 2 x 4 tiles: 256 x 128 block, 3 stages of 24 KiB, two workgroups per CU (the big layers)
+//   "mid"    2 x 2 waves, 2 x 2 tiles: 128 x 128 block, 3 stages of 16 KiB (M = 100 queries per frame pad to 128, not 256)
 //   "skinny" 2 x 2 waves, 1 x 1 tiles:  64 x  64 block, 16 stages of 8 KiB = a whole K = 256 panel in flight, one
 //            workgroup per CU: the decoder's M = BT*100-token layers are 32 "wide" tiles (1/8 of the chip) but 252 skinny
 //            ones, and with K = 256 every byte of the tile is requested before the first MFMA waits.  Measured 11.1 us
@@ -88,6 +89,7 @@ struct NtCfg {
   static_assert((ST - 1) * PPW <= 63, "vmcnt is a 6-bit counter");
 };
 typedef NtCfg<4, 1, 2, 4, 3> NtWide;
+typedef NtCfg<2, 2, 2, 2, 3> NtMid;      // 128 x 128 block: batched problems with ~100 rows per batch (the mask-logit contraction)
 typedef NtCfg<2, 2, 1, 1, 16> NtSkinny;
 
 template <int PPW, int ST>
@@ -121,7 +123,8 @@ template <bool CONV, typename Cfg>
 __global__ void __launch_bounds__(256, Cfg::LDS <= 80 * 1024 ? 2 : 1)
 gemm_nt2_kernel(const float* __restrict__ A, long long lda, const float* __restrict__ Bimg, long long ldb,
                 const float* __restrict__ bias, float* __restrict__ C, long long ldc, int M, int N, int K, int relu,
-                int stagger, ConvGeom2 cg, int c_bytes) {
+                int stagger, ConvGeom2 cg, int c_bytes, int batch, long long sA, long long sB, long long sC) {
+  // batch > 1: `batch` independent problems of the same shape, operand b at A + b*sA, Bimg + b*sB, C + b*sC (elements)
   constexpr int BM = Cfg::BM, BN = Cfg::BN, TI = Cfg::TI, TJ = Cfg::TJ, ST = Cfg::ST, PPW = Cfg::PPW, APW = Cfg::APW;
   constexpr int A_BYTES = Cfg::A_BYTES, STAGE = Cfg::STAGE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -129,15 +132,13 @@ gemm_nt2_kernel(const float* __restrict__ A, long long lda, const float* __restr
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
   const int n_tiles = (N + BN - 1) / BN;
-  const int tiles = ((M + BM - 1) / BM) * n_tiles;
+  const int tpb = ((M + BM - 1) / BM) * n_tiles;  // tiles per batch entry
+  const int tiles = tpb * batch;
   const int G = gridDim.x;
   // logical workgroup index: every XCD owns a contiguous range, so the n tiles sharing the A rows of a token tile run on
   // one XCD (one L2) in the same round
   const int w = xcd_contiguous(blockIdx.x, G);
   const int nst = K / kBK;
-  // buffer descriptor over C for the epilogue stores (kernel arguments only: provably wave-uniform); rows >= M fall
-  // outside `c_bytes` and are dropped by the range check
-  const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(C, 0, c_bytes, 0x00020000);
   if (stagger > 0 && (int)blockIdx.x >= G / 2) {  // the second workgroup of each CU starts half a tile late
     for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(32);
   }
@@ -149,9 +150,14 @@ gemm_nt2_kernel(const float* __restrict__ A, long long lda, const float* __restr
   unsigned tap_ok[APW];  // CONV: this lane's A rows -> 9-bit masks of the taps inside the map
 #pragma unroll
   for (int u = 0; u < APW; ++u) tap_ok[u] = 0u;
+  const float* i_A = A;
+  const float* i_B = Bimg;
   auto open_tile = [&]() {
-    i_m_blk = (i_tile / n_tiles) * BM;
-    i_n_blk = (i_tile % n_tiles) * BN;
+    const int bi = i_tile / tpb, rem = i_tile - bi * tpb;
+    i_A = A + bi * sA;
+    i_B = Bimg + bi * sB;
+    i_m_blk = (rem / n_tiles) * BM;
+    i_n_blk = (rem % n_tiles) * BN;
     i_s = 0; i_tap = 0; i_cin0 = 0;
     if (CONV) {
 #pragma unroll
@@ -182,16 +188,16 @@ gemm_nt2_kernel(const float* __restrict__ A, long long lda, const float* __restr
         const float* src;
         if (CONV)
           src = ((tap_ok[u < APW ? u : 0] >> i_tap) & 1u)
-                    ? A + (long long)(min(i_m_blk + r, M - 1) + shift) * lda + i_cin0 + c * 4
+                    ? i_A + (long long)(min(i_m_blk + r, M - 1) + shift) * lda + i_cin0 + c * 4
                     : g_zero_row2 + c * 4;
         else
-          src = A + (long long)min(i_m_blk + r, M - 1) * lda + k0 + c * 4;
+          src = i_A + (long long)min(i_m_blk + r, M - 1) * lda + k0 + c * 4;
         glds16(src, st + q * 1024);
       } else {
         const int qb = q - Cfg::A_PIECES;
         const int r = qb * 16 + p_row;
         const int c = p_chunk ^ ((r >> 2) & 3);
-        glds16(Bimg + (long long)min(i_n_blk + r, N - 1) * ldb + k0 + c * 4, st + A_BYTES + qb * 1024);
+        glds16(i_B + (long long)min(i_n_blk + r, N - 1) * ldb + k0 + c * 4, st + A_BYTES + qb * 1024);
       }
     }
     ++issued;
@@ -221,7 +227,11 @@ gemm_nt2_kernel(const float* __restrict__ A, long long lda, const float* __restr
 
   int consumed = 0, c_slot = 0;
   for (int tile = w; tile < tiles; tile += G) {
-    const int m_blk = (tile / n_tiles) * BM, n_blk = (tile % n_tiles) * BN;
+    const int bi = tile / tpb, rem = tile - bi * tpb;
+    const int m_blk = (rem / n_tiles) * BM, n_blk = (rem % n_tiles) * BN;
+    // buffer descriptor over this batch entry's C for the epilogue stores (built from kernel arguments and the
+    // workgroup's tile index: wave-uniform); rows >= M fall outside `c_bytes` and are dropped by the range check
+    const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(C + bi * sC, 0, c_bytes, 0x00020000);
     f32x16 acc[TI][TJ];
 #pragma unroll
     for (int i = 0; i < TI; ++i)
@@ -258,8 +268,14 @@ gemm_nt2_kernel(const float* __restrict__ A, long long lda, const float* __restr
                        "+v"(rb[1][0]), "+v"(rb[1][1]), "+v"(rb[2][0]), "+v"(rb[2][1]), "+v"(rb[3][0]), "+v"(rb[3][1])
                      :
                      : "memory");
+      } else if constexpr (TI == 2 && TJ == 2) {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[1][0]), "+v"(ra[1][1]), "+v"(rb[0][0]), "+v"(rb[0][1]),
+                       "+v"(rb[1][0]), "+v"(rb[1][1])
+                     :
+                     : "memory");
       } else {
-        static_assert((TI == 2 && TJ == 4) || (TI == 1 && TJ == 1), "add the register list of a new wave tile here");
+        static_assert((TI == 2 && TJ == 4) || (TI == 2 && TJ == 2) || (TI == 1 && TJ == 1), "add the register list of a new wave tile here");
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(rb[0][0]), "+v"(rb[0][1]) : : "memory");
       }
       bf16x8 bh[TJ], bl[TJ], ah[TI], al[TI];
@@ -319,10 +335,13 @@ gemm_nt2_kernel(const float* __restrict__ A, long long lda, const float* __restr
 // Weight image for gemm_nt2: element (n, k) = src[n*ld_row + k*ld_col]; per 8 consecutive k a 16-B group of bf16 `hi`
 // (truncated) followed by a 16-B group of bf16 `lo` = rne(x - hi): 4 bytes per element, row stride K floats.
 __global__ void __launch_bounds__(256)
-presplit_kernel(const float* __restrict__ src, long long ld_row, long long ld_col, int N, int K, uint4* __restrict__ img) {
+presplit_kernel(const float* __restrict__ src, long long ld_row, long long ld_col, int N, int K, uint4* __restrict__ img,
+                long long batch_stride) {
   const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   const int kg = K >> 3;
   if (t >= (long long)N * kg) return;
+  src += blockIdx.y * batch_stride;               // batch entry b: source at src + b*batch_stride, image at img + b*N*K floats
+  img += blockIdx.y * ((long long)N * kg * 2);
   // neighbouring threads walk the unit-stride direction of the source: k groups for W, rows for a W^T view
   int n, g8;
   if (ld_col == 1) { n = (int)(t / kg); g8 = (int)(t - (long long)n * kg); }
@@ -341,9 +360,14 @@ presplit_kernel(const float* __restrict__ src, long long ld_row, long long ld_co
   img[o + 1] = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
+struct NtBatch {
+  int batch;
+  long long sA, sB, sC;
+};
+
 template <bool CONV, typename Cfg>
 int launch_nt2_cfg(const float* A, long long lda, const float* Bimg, const float* bias, float* C, long long ldc, long long M,
-                   int N, int K, int relu, ConvGeom2 cg, int n_cu, combo_stream_t stream) {
+                   int N, int K, int relu, ConvGeom2 cg, int n_cu, combo_stream_t stream, NtBatch nb = NtBatch{1, 0, 0, 0}) {
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt2_kernel<CONV, Cfg>),
@@ -351,7 +375,7 @@ int launch_nt2_cfg(const float* A, long long lda, const float* Bimg, const float
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  const long long tiles = ((M + Cfg::BM - 1) / Cfg::BM) * ((N + Cfg::BN - 1) / Cfg::BN);
+  const long long tiles = ((M + Cfg::BM - 1) / Cfg::BM) * ((N + Cfg::BN - 1) / Cfg::BN) * nb.batch;
   if (tiles > 0x7fffffffLL) return COMBO_EINVAL;
   static const int stagger_on = [] { const char* e = getenv("COMBO_NT2_STAGGER"); return e ? atoi(e) : 0; }();
   const long long slots = (Cfg::LDS <= 80 * 1024 ? 2LL : 1LL) * n_cu;  // resident workgroups
@@ -367,7 +391,7 @@ int launch_nt2_cfg(const float* A, long long lda, const float* Bimg, const float
   const long long c_bytes = ((M - 1) * ldc + N) * 4;
   if (c_bytes >= 0x7fffffffLL) return COMBO_EINVAL;
   hipLaunchKernelGGL((gemm_nt2_kernel<CONV, Cfg>), dim3((unsigned)grid), dim3(256), Cfg::LDS, (hipStream_t)stream, A, lda, Bimg,
-                     (long long)K, bias, C, ldc, (int)M, N, K, relu, stagger, cg, (int)c_bytes);
+                     (long long)K, bias, C, ldc, (int)M, N, K, relu, stagger, cg, (int)c_bytes, nb.batch, nb.sA, nb.sB, nb.sC);
   return (int)hipGetLastError();
 }
 
@@ -394,8 +418,38 @@ extern "C" int combo_presplit_bf16x2_f32(const float* src, long long ld_row, lon
   if (!src || !img || N <= 0 || K <= 0 || K % 8 != 0 || ((uintptr_t)img & 15)) return COMBO_EINVAL;
   const long long threads = (long long)N * (K / 8);
   hipLaunchKernelGGL(presplit_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, ld_row,
-                     ld_col, N, K, reinterpret_cast<uint4*>(img));
+                     ld_col, N, K, reinterpret_cast<uint4*>(img), 0LL);
   return (int)hipGetLastError();
+}
+
+extern "C" int combo_presplit_bf16x2_batched_f32(const float* src, long long ld_row, long long ld_col, long long batch_stride,
+                                                 int N, int K, int batch, float* img, combo_stream_t stream) {
+  if (!src || !img || N <= 0 || K <= 0 || K % 8 != 0 || batch <= 0 || batch > 65535 || ((uintptr_t)img & 15)) return COMBO_EINVAL;
+  const long long threads = (long long)N * (K / 8);
+  hipLaunchKernelGGL(presplit_kernel, dim3((unsigned)((threads + 255) / 256), (unsigned)batch), dim3(256), 0, (hipStream_t)stream,
+                     src, ld_row, ld_col, N, K, reinterpret_cast<uint4*>(img), batch_stride);
+  return (int)hipGetLastError();
+}
+
+// `batch` independent GEMMs of one shape (the mask-logit contraction mask_embed @ pixel_embed^T per frame and its input
+// gradient): C_b[M,N] = A_b[M,K] . B_b[N,K]^T, operands at base + b * stride (elements).  128 x 128 tiles when M pads
+// better to 128 than to 256.
+extern "C" int combo_gemm_nt_x3_pre_batched_f32(const float* A, long long lda, long long sA, const float* Bimg, long long sB,
+                                                float* C, long long ldc, long long sC, int M, int N, int K, int batch, int relu,
+                                                combo_stream_t stream) {
+  if (!A || !Bimg || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || K % kBK != 0 || lda % 4 != 0 || sA % 4 != 0 ||
+      sB % 4 != 0 || ((uintptr_t)A & 15) || ((uintptr_t)Bimg & 15))
+    return COMBO_EINVAL;
+  static const int n_cu = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    return cus > 0 ? cus : 256;
+  }();
+  const NtBatch nb{batch, sA, sB, sC};
+  const int pad256 = (M + 255) / 256 * 256, pad128 = (M + 127) / 128 * 128;
+  if (pad128 < pad256)
+    return launch_nt2_cfg<false, NtMid>(A, lda, Bimg, nullptr, C, ldc, M, N, K, relu, ConvGeom2{1, 1, K}, n_cu, stream, nb);
+  return launch_nt2_cfg<false, NtWide>(A, lda, Bimg, nullptr, C, ldc, M, N, K, relu, ConvGeom2{1, 1, K}, n_cu, stream, nb);
 }
 
 extern "C" int combo_gemm_nt_x3_pre_f32(const float* A, long long lda, const float* Bimg, const float* bias, float* C,

@@ -1,9 +1,56 @@
 """`mask_embed @ pixel_embed` + next-layer attention mask (transformer_decoder.py:498-507 of the reference).
-HIP kernels: csrc/attnmask.hip (bilinear-downsample + sigmoid<0.5 + full-row reset in one launch) and
-csrc/masklogit.hip (fp32-MFMA contraction)."""
+HIP kernels: csrc/attnmask.hip (bilinear-downsample + sigmoid<0.5 + full-row reset in one launch); the contraction and its
+two gradients run on the head's own fp32-accurate bf16x3 MFMA kernels (csrc/gemm_nt2.hip batched, 128 x 128 tiles for the
+100 queries of a frame; csrc/gemm_tn.hip grouped, one problem per frame) instead of the library's batched fp32 GEMM:
+the token-major mask features are pre-split ONCE per step and shared by the 10 prediction heads."""
+import ctypes
+import os
+
 import torch
 
 from .. import _lib
+
+HIP_GEMMS = os.environ.get("COMBO_MASKLOGIT_HIP", "1") == "1"  # 0: torch.bmm (A/B measurements)
+# The FORWARD contraction stays on the library's true-fp32 GEMM by default: its output is thresholded at 0 into the next
+# layer's attention mask, and the 2^-16 relative error of the 3-product bf16 split flips about twice as many near-zero
+# cells as fp32 round-off does (tests/test_head_gpu.py::test_decoder_outputs_match_reference: 0.98 % instead of < 0.5 % of
+# the final mask logits off by more than 1e-3) - measured -0.45 ms per step, not taken.  The two gradient GEMMs have no
+# such cliff and run on the HIP kernels (-0.45 ms per step).
+HIP_FORWARD = os.environ.get("COMBO_MASKLOGIT_HIP_FWD", "0") == "1"
+
+
+def _hip_ok(*ts):
+    return HIP_GEMMS and all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0 for t in ts)
+
+
+def presplit_batched(x, transpose):
+    """bf16 hi/lo image (csrc/gemm_nt2.hip) of a contiguous [B, R, C] tensor: [B, R, C] (K = C) or, transposed, [B, C, R]."""
+    B, R, C = x.shape
+    N, K = (C, R) if transpose else (R, C)
+    img = torch.empty(B, N, K, device=x.device, dtype=torch.float32)
+    ld_row, ld_col = (1, C) if transpose else (C, 1)
+    _lib.check(_lib.lib().combo_presplit_bf16x2_batched_f32(x.data_ptr(), ld_row, ld_col, R * C, N, K, B, img.data_ptr(),
+                                                            _lib.current_stream()), "combo_presplit_bf16x2_batched_f32")
+    return img
+
+
+def gemm_nt_batched(a, img, out):
+    """out[b] = a[b] @ B[b]^T for contiguous a [B, M, K], pre-split image [B, N, K], out [B, M, N]"""
+    B, M, K = a.shape
+    N = img.shape[1]
+    with _lib.timed("gemm_nt_x3", (B * M, N, K)):
+        rc = _lib.lib().combo_gemm_nt_x3_pre_batched_f32(a.data_ptr(), K, M * K, img.data_ptr(), N * K, out.data_ptr(), N, M * N,
+                                                         M, N, K, B, 0, _lib.current_stream())
+    _lib.check(rc, "combo_gemm_nt_x3_pre_batched_f32")
+    return out
+
+
+def prepare(mf_tok):
+    """pre-split image of the token-major mask features [BT, HW, C] for mask_logits_into (shared by all heads of a step)"""
+    mf = mf_tok.detach()
+    if HIP_FORWARD and _hip_ok(mf) and mf.shape[2] % 16 == 0:
+        return presplit_batched(mf, transpose=False)
+    return None
 
 
 def attn_mask(logits, target_size, reset_full_rows=True):
@@ -36,6 +83,20 @@ class _MaskLogitsAll(torch.autograd.Function):
         nh, bt, Q, HW = dL.shape
         dL2 = dL.permute(1, 0, 2, 3).reshape(bt, nh * Q, HW)  # one 50 MB re-layout instead of 9 x 128 MB accumulations
         ME = torch.cat(mes, dim=1)  # [BT, nh*Q, C]
+        C = mf_tok.shape[2]
+        if _hip_ok(dL2, mf_tok, ME) and HW % 16 == 0 and C % 4 == 0 and HW % 4 == 0 and nh * Q >= 256 and C >= 64:
+            # dME[b] = dL[b] . MF[b]: batched NT GEMM against the per-frame transposed image of the mask features
+            dME = gemm_nt_batched(dL2, presplit_batched(mf_tok, transpose=True), torch.empty(bt, nh * Q, C, device=dL.device))
+            # dMF[b] = dL[b]^T . ME[b]: reduction over the heads*Q rows = the weight-gradient kernel, one problem per frame
+            from .linear import _TnProblem
+            dMF = torch.empty(bt, HW, C, device=dL.device, dtype=torch.float32)
+            prob = (_TnProblem * bt)()
+            for b in range(bt):
+                prob[b] = _TnProblem(dL2[b].data_ptr(), ME[b].data_ptr(), dMF[b].data_ptr(), 0, HW, C, nh * Q, HW, C, 1)
+            with _lib.timed("gemm_tn_x3_grouped", (2.0 * bt * nh * Q * HW * C, bt)):
+                rc = _lib.lib().combo_gemm_tn_x3_grouped_f32(ctypes.cast(prob, ctypes.c_void_p), bt, _lib.current_stream())
+            _lib.check(rc, "combo_gemm_tn_x3_grouped_f32")
+            return (dMF, None) + tuple(dME[:, i * Q:(i + 1) * Q] for i in range(nh))
         with torch.autocast("cuda", enabled=False):
             dME = torch.bmm(dL2, mf_tok)  # [BT, nh*Q, C]
             dMF = torch.bmm(dL2.transpose(1, 2), ME)  # [BT, HW, C]
@@ -47,8 +108,11 @@ def attach_mask_logit_grads(mf_tok, buffer, mask_embeds):
     return _MaskLogitsAll.apply(mf_tok, buffer, *mask_embeds)
 
 
-def mask_logits_into(mask_embed, mf_tok, out):
-    """no-grad: out[BT,Q,HW] = mask_embed @ mf_tok^T (fp32)"""
+def mask_logits_into(mask_embed, mf_tok, out, mf_img=None):
+    """no-grad: out[BT,Q,HW] = mask_embed @ mf_tok^T (fp32); mf_img = prepare(mf_tok) routes it to csrc/gemm_nt2.hip"""
+    me = mask_embed.detach()
+    if mf_img is not None and _hip_ok(me, out) and me.shape[2] % 16 == 0:
+        return gemm_nt_batched(me, mf_img, out)
     with torch.no_grad(), torch.autocast("cuda", enabled=False):
         torch.bmm(mask_embed.detach().float(), mf_tok.detach().float().transpose(1, 2), out=out)
     return out

@@ -218,6 +218,16 @@ int combo_presplit_bf16x2_f32(const float* src, long long ld_row, long long ld_c
                               combo_stream_t stream);
 int combo_gemm_nt_x3_pre_f32(const float* A, long long lda, const float* Bimg, const float* bias, float* C, long long ldc,
                              int M, int N, int K, int relu, combo_stream_t stream);
+/*   Batched forms: `batch` problems of one shape, operand b at base + b*stride (elements).  They carry the mask-logit
+ *   contraction `einsum("bqc,bchw->bqhw", mask_embed, mask_features)` of every prediction head
+ *   (transformer_decoder/transformer_decoder.py:498-500: A = mask_embed [BT,Q,C], B image = token-major mask features
+ *   [BT,HW,C]) and its gradient w.r.t. mask_embed (A = dLogits [BT,heads*Q,HW], B image = mask features transposed per
+ *   frame, made by the batched pre-split from a strided view).  img of the pre-split: [batch][N][K] floats. */
+int combo_presplit_bf16x2_batched_f32(const float* src, long long ld_row, long long ld_col, long long batch_stride, int N,
+                                      int K, int batch, float* img, combo_stream_t stream);
+int combo_gemm_nt_x3_pre_batched_f32(const float* A, long long lda, long long sA, const float* Bimg, long long sB, float* C,
+                                     long long ldc, long long sC, int M, int N, int K, int batch, int relu,
+                                     combo_stream_t stream);
 /*   combo_conv3x3_nhwc_x3_f32 on the v2 kernel: Wimg = combo_presplit_bf16x2_f32 of the [Cout, 9*Cin] weight matrix. */
 int combo_conv3x3_nhwc_x3_pre_f32(const float* X, long long ldx, const float* Wimg, const float* bias, float* Y,
                                   long long ldy, int B, int H, int W, int Cin, int Cout, int relu, combo_stream_t stream);

@@ -208,3 +208,42 @@ def test_gemm_nt_v2_is_bitwise_v1_and_accepts_strided_weight_views(M, K, N):
     assert torch.equal(z1, z2)
     ref = torch.relu(a.double() @ w.double().t() + b.double())
     assert rel_err(y2, ref) < 2e-5
+
+
+def test_mask_logit_contraction_and_gradients_on_the_hip_gemms():
+    """ops/masklogit.py: `einsum("bqc,bchw->bqhw")` per prediction head on the batched gemm_nt2 kernel (128 x 128 tiles for
+    the 100 queries of a frame, mask features pre-split once) and its two gradients (batched NT GEMM against the
+    transposed image; grouped TN GEMM, one problem per frame) against float64 and against the library path."""
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.ops import masklogit as ML
+    torch.manual_seed(3)
+    bt, Q, HW, C, nh = 3, 100, 56 * 56, 256, 4
+    mf = torch.randn(bt, HW, C, device="cuda", requires_grad=True)
+    mes = [torch.randn(bt, Q, C, device="cuda", requires_grad=True) for _ in range(nh)]
+    g = torch.randn(nh, bt, Q, HW, device="cuda")
+
+    def run(hip):
+        prev, prev_f = ML.HIP_GEMMS, ML.HIP_FORWARD
+        ML.HIP_GEMMS = ML.HIP_FORWARD = hip  # (the product default keeps the forward on the library, see ops/masklogit.py)
+        try:
+            buf = torch.empty(nh, bt, Q, HW, device="cuda")
+            img = ML.prepare(mf)
+            assert (img is not None) == hip
+            for i in range(nh):
+                ML.mask_logits_into(mes[i], mf, buf[i], img)
+            out = ML.attach_mask_logit_grads(mf, buf, mes)
+            grads = torch.autograd.grad(out, [mf] + mes, g)
+            return buf, grads
+        finally:
+            ML.HIP_GEMMS, ML.HIP_FORWARD = prev, prev_f
+    buf_h, gr_h = run(True)
+    buf_l, gr_l = run(False)
+    ref = torch.stack([m.detach().double() @ mf.detach().double().transpose(1, 2) for m in mes])
+    assert rel_err(buf_h, ref) < 2e-5, rel_err(buf_h, ref)
+    gd = g.double()
+    ref_dmf = sum(gd[i].transpose(1, 2) @ mes[i].detach().double() for i in range(nh))
+    assert rel_err(gr_h[0], ref_dmf) < 2e-5, rel_err(gr_h[0], ref_dmf)
+    for i in range(nh):
+        assert rel_err(gr_h[1 + i], gd[i] @ mf.detach().double()) < 2e-5
+    for a, b in zip(gr_h, gr_l):
+        assert rel_err(a, b.double()) < 2e-5
