@@ -342,7 +342,7 @@ def main():
     if grp:  # all weight-gradient GEMMs of the head in one grouped launch per step (ops.linear.deferred_dw)
         tsum = sum(us for us, _ in grp) * 1e-6
         flops = sum(3 * m[0] for _, m in grp)
-        kernels["gemm_tn_x3 (grouped launch, %d problems)" % grp[0][1][1]] = {
+        kernels["gemm_tn_x3 (grouped launches, %d problems per step)" % (sum(m[1] for _, m in grp) // 2)] = {  # (2 eager steps timed)
             "bound": "mfma", "launches_timed": len(grp), "avg_launch_us": round(tsum / len(grp) * 1e6, 1),
             "achieved": round(flops / tsum / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s (bf16 MFMA, 3 products per fp32 MAC)",
             "frac": round(flops / tsum / 2.5e15, 4), "fp32_equivalent_tflops": round(flops / 3 / tsum / 1e12, 1)}
