@@ -49,17 +49,38 @@ msda_prep_fwd_kernel(const float* __restrict__ proj, const float* __restrict__ r
   float* at = attn + (tok * M + h) * LP;
   float lg[kMaxLPp];
   float mx = -3.0e38f;
+  // the L*P logits of a (token, head) are 16-byte aligned when L*P % 4 == 0 (every shipped config: 12): float4 accesses,
+  // a quarter of the vector-memory instructions of the scalar walk
+  const bool vec = (LP & 3) == 0;
+  if (vec) {
+#pragma unroll
+    for (int j = 0; j < kMaxLPp; j += 4)
+      if (j < LP) {
+        const float4 t = *reinterpret_cast<const float4*>(pl + j);
+        lg[j] = t.x; lg[j + 1] = t.y; lg[j + 2] = t.z; lg[j + 3] = t.w;
+      }
+  } else {
+#pragma unroll
+    for (int j = 0; j < kMaxLPp; ++j)
+      if (j < LP) lg[j] = pl[j];
+  }
 #pragma unroll
   for (int j = 0; j < kMaxLPp; ++j)
-    if (j < LP) { lg[j] = pl[j]; mx = fmaxf(mx, lg[j]); }
+    if (j < LP) mx = fmaxf(mx, lg[j]);
   float z = 0.f;
 #pragma unroll
   for (int j = 0; j < kMaxLPp; ++j)
     if (j < LP) { lg[j] = expf(lg[j] - mx); z += lg[j]; }
   const float iz = 1.f / z;
+  if (vec) {
 #pragma unroll
-  for (int j = 0; j < kMaxLPp; ++j)
-    if (j < LP) at[j] = lg[j] * iz;
+    for (int j = 0; j < kMaxLPp; j += 4)
+      if (j < LP) *reinterpret_cast<float4*>(at + j) = make_float4(lg[j] * iz, lg[j + 1] * iz, lg[j + 2] * iz, lg[j + 3] * iz);
+  } else {
+#pragma unroll
+    for (int j = 0; j < kMaxLPp; ++j)
+      if (j < LP) at[j] = lg[j] * iz;
+  }
 }
 
 __global__ void __launch_bounds__(256)
@@ -87,12 +108,34 @@ msda_prep_bwd_kernel(const float* __restrict__ dloc, const float* __restrict__ d
   float* pl = dproj + tok * row + OC + h * LP;
   float a[kMaxLPp], g[kMaxLPp];
   float dot = 0.f;
+  const bool vec = (LP & 3) == 0;  // float4 accesses, see the forward kernel
+  if (vec) {
+#pragma unroll
+    for (int j = 0; j < kMaxLPp; j += 4)
+      if (j < LP) {
+        const float4 ta = *reinterpret_cast<const float4*>(at + j), tg = *reinterpret_cast<const float4*>(da + j);
+        a[j] = ta.x; a[j + 1] = ta.y; a[j + 2] = ta.z; a[j + 3] = ta.w;
+        g[j] = tg.x; g[j + 1] = tg.y; g[j + 2] = tg.z; g[j + 3] = tg.w;
+      }
+  } else {
+#pragma unroll
+    for (int j = 0; j < kMaxLPp; ++j)
+      if (j < LP) { a[j] = at[j]; g[j] = da[j]; }
+  }
 #pragma unroll
   for (int j = 0; j < kMaxLPp; ++j)
-    if (j < LP) { a[j] = at[j]; g[j] = da[j]; dot += a[j] * g[j]; }
+    if (j < LP) dot += a[j] * g[j];
+  if (vec) {
 #pragma unroll
-  for (int j = 0; j < kMaxLPp; ++j)
-    if (j < LP) pl[j] = a[j] * (g[j] - dot);
+    for (int j = 0; j < kMaxLPp; j += 4)
+      if (j < LP)
+        *reinterpret_cast<float4*>(pl + j) = make_float4(a[j] * (g[j] - dot), a[j + 1] * (g[j + 1] - dot), a[j + 2] * (g[j + 2] - dot),
+                                                         a[j + 3] * (g[j + 3] - dot));
+  } else {
+#pragma unroll
+    for (int j = 0; j < kMaxLPp; ++j)
+      if (j < LP) pl[j] = a[j] * (g[j] - dot);
+  }
 }
 
 }  // namespace
@@ -102,7 +145,8 @@ extern "C" {
 int combo_msda_prep_forward_f32(const float* proj, const float* ref, const float* normalizer, long long tokens, int Lq,
                                 int M, int L, int P, int ref_batch_stride, float* loc, float* attn, combo_stream_t stream) {
   if (!proj || !ref || !normalizer || !loc || !attn || tokens <= 0 || Lq <= 0 || M <= 0 || L <= 0 || P <= 0 ||
-      L * P > kMaxLPp || tokens % Lq != 0 || (M * L * P) % 4 != 0 || ((uintptr_t)proj & 15) || ((uintptr_t)loc & 15))
+      L * P > kMaxLPp || tokens % Lq != 0 || (M * L * P) % 4 != 0 || ((uintptr_t)proj & 15) || ((uintptr_t)loc & 15) ||
+      ((uintptr_t)attn & 15))
     return COMBO_EINVAL;
   const long long n = tokens * (M * L * P * 2 / 4) + tokens * M;
   hipLaunchKernelGGL(msda_prep_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, proj, ref,
@@ -113,7 +157,8 @@ int combo_msda_prep_forward_f32(const float* proj, const float* ref, const float
 int combo_msda_prep_backward_f32(const float* dloc, const float* dattn, const float* attn, const float* normalizer,
                                  long long tokens, int M, int L, int P, float* dproj, combo_stream_t stream) {
   if (!dloc || !dattn || !attn || !normalizer || !dproj || tokens <= 0 || M <= 0 || L <= 0 || P <= 0 || L * P > kMaxLPp ||
-      (M * L * P) % 4 != 0 || ((uintptr_t)dloc & 15) || ((uintptr_t)dproj & 15))
+      (M * L * P) % 4 != 0 || ((uintptr_t)dloc & 15) || ((uintptr_t)dproj & 15) || ((uintptr_t)dattn & 15) ||
+      ((uintptr_t)attn & 15))
     return COMBO_EINVAL;
   const long long n = tokens * (M * L * P * 2 / 4) + tokens * M;
   hipLaunchKernelGGL(msda_prep_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dloc, dattn,
