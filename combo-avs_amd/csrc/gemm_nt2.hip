@@ -150,15 +150,29 @@ gemm_nt2_kernel(const float* __restrict__ A, long long lda, const float* __restr
   unsigned tap_ok[APW];  // CONV: this lane's A rows -> 9-bit masks of the taps inside the map
 #pragma unroll
   for (int u = 0; u < APW; ++u) tap_ok[u] = 0u;
-  const float* i_A = A;
-  const float* i_B = Bimg;
+  // per-piece source pointers of the open tile (row clamp, row pitch and chunk swizzle folded in once per tile): a stage
+  // only adds its k offset - the per-stage 64-bit multiply-adds were ~25 of the loop's 82 VALU instructions
+  const float* pa[APW];
+  const float* pb[PPW - APW];
   auto open_tile = [&]() {
     const int bi = i_tile / tpb, rem = i_tile - bi * tpb;
-    i_A = A + bi * sA;
-    i_B = Bimg + bi * sB;
+    const float* i_A = A + bi * sA;
+    const float* i_B = Bimg + bi * sB;
     i_m_blk = (rem / n_tiles) * BM;
     i_n_blk = (rem % n_tiles) * BN;
     i_s = 0; i_tap = 0; i_cin0 = 0;
+#pragma unroll
+    for (int u = 0; u < APW; ++u) {
+      const int r = (wave + 4 * u) * 16 + p_row;
+      const int c = p_chunk ^ ((r >> 2) & 3);  // swizzle on the SOURCE chunk, the LDS image stays lane-linear
+      pa[u] = i_A + (long long)min(i_m_blk + r, M - 1) * lda + c * 4;
+    }
+#pragma unroll
+    for (int u = 0; u < PPW - APW; ++u) {
+      const int r = (wave + 4 * (u + APW) - Cfg::A_PIECES) * 16 + p_row;
+      const int c = p_chunk ^ ((r >> 2) & 3);
+      pb[u] = i_B + (long long)min(i_n_blk + r, N - 1) * ldb + c * 4;
+    }
     if (CONV) {
 #pragma unroll
       for (int u = 0; u < APW; ++u) {
@@ -178,26 +192,20 @@ gemm_nt2_kernel(const float* __restrict__ A, long long lda, const float* __restr
     if (i_tile >= tiles) return;
     char* st = smem + i_slot * STAGE;
     const int k0 = i_s * kBK;
-    const int shift = CONV ? (i_tap / 3 - 1) * cg.W + (i_tap % 3 - 1) : 0;
+    // CONV: the stage's tap shifts the token rows by a wave-uniform element offset
+    const long long a_off = CONV ? (long long)((i_tap / 3 - 1) * cg.W + (i_tap % 3 - 1)) * lda + i_cin0 : (long long)k0;
 #pragma unroll
     for (int u = 0; u < PPW; ++u) {
       const int q = wave + 4 * u;  // wave-uniform piece (1 KiB = 16 rows x 64 B); q < A_PIECES: A rows, else B rows
       if (u < APW) {
-        const int r = q * 16 + p_row;
-        const int c = p_chunk ^ ((r >> 2) & 3);  // swizzle on the SOURCE chunk, the LDS image stays lane-linear
-        const float* src;
-        if (CONV)
-          src = ((tap_ok[u < APW ? u : 0] >> i_tap) & 1u)
-                    ? i_A + (long long)(min(i_m_blk + r, M - 1) + shift) * lda + i_cin0 + c * 4
-                    : g_zero_row2 + c * 4;
-        else
-          src = i_A + (long long)min(i_m_blk + r, M - 1) * lda + k0 + c * 4;
+        const float* src = pa[u < APW ? u : 0] + a_off;
+        if (CONV) {
+          const int c = p_chunk ^ (((q * 16 + p_row) >> 2) & 3);
+          if (!((tap_ok[u < APW ? u : 0] >> i_tap) & 1u)) src = g_zero_row2 + c * 4;
+        }
         glds16(src, st + q * 1024);
       } else {
-        const int qb = q - Cfg::A_PIECES;
-        const int r = qb * 16 + p_row;
-        const int c = p_chunk ^ ((r >> 2) & 3);
-        glds16(i_B + (long long)min(i_n_blk + r, N - 1) * ldb + k0 + c * 4, st + A_BYTES + qb * 1024);
+        glds16(pb[u >= APW ? u - APW : 0] + k0, st + A_BYTES + (q - Cfg::A_PIECES) * 1024);
       }
     }
     ++issued;
