@@ -100,18 +100,23 @@ def gemm_nt_x3(a, b, bias=None, relu=False):
     return out
 
 
-# opt-in (COMBO_NT2_SMALL_MIN_ROWS=1024): the decoder's M = BT*100-token layers on gemm_nt2's skinny configuration.  Measured:
-# 11.1 us vs hipBLASLt's 13 us at 4000x256->256, but the weight pre-split launch costs the difference: 56.8 vs 56.2 ms/step.
+# opt-in (COMBO_NT2_SMALL_MIN_ROWS=1024): the decoder's M = BT*100-token layers on gemm_nt2's skinny configuration.  Measured
+# inside a captured graph (tools/sweep_nt.py, profiles/r01_gemm_routing_sweep.txt): 12.2 us incl. the weight pre-split
+# against hipBLASLt's 10.4 us at 4000x256->256 - the library wins every shape below ~100 wide tiles.
 NT2_SMALL_MIN_ROWS = int(_os.environ.get("COMBO_NT2_SMALL_MIN_ROWS", str(1 << 60)))
 
 
 def _nt_ok(a, n_out, b=None):
-    """csrc/gemm_nt.hip / gemm_nt2.hip win over hipBLASLt's 3xbf16 path once the 256 x 128 tiles fill the chip (measured
-    in tests/test_gemm_gpu.py: 143 vs 258 us at 41160x256->1024, but 38 vs 23 us at ->96 and 139 vs 90 us at
-    16384x2048->256); v2 also has a skinny 64 x 64 configuration with a whole K = 256 panel in flight for the decoder's
-    M = BT*100-token layers (tools/abl_nt.py)."""
+    """Routing between the head's own forward / dX GEMM kernel and hipBLASLt's 3xbf16 mode, from the in-graph sweep
+    (tools/sweep_nt.py): gemm_nt2 (+ its weight pre-split launch) wins once its 256 x 128 tiles number >= ~100 -
+    25 vs 41 us at 31360x256->256, 26 vs 39 us at 4000x256->2048, 33 vs 78 us at 41160x256->288, 95 vs 123 us at
+    16384x2048->256 - and loses on few tiles with a long K (94 vs 37 us at 4000x2048->256) and on the decoder's small
+    layers (18 vs 10 us at 4000x256->256).  v1 (csrc/gemm_nt.hip, COMBO_GEMM_NT2=0) keeps its own, older thresholds."""
     tiles = -(-a.shape[0] // 256) * -(-n_out // 128)
-    big = a.shape[0] >= NT_MIN_ROWS and tiles >= 256 and n_out >= 128
+    if NT_V2:
+        big = a.shape[0] >= 2048 and tiles >= 120 and n_out >= 64 and NT_MIN_ROWS < (1 << 60)
+    else:
+        big = a.shape[0] >= NT_MIN_ROWS and tiles >= 256 and n_out >= 128
     small = NT_V2 and NT2_SMALL_MIN_ROWS <= a.shape[0] < NT_MIN_ROWS and tiles <= 128 and n_out >= 64
     ok = ((big or small) and a.shape[1] % 16 == 0 and a.stride(1) == 1 and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0)
     if b is not None:
