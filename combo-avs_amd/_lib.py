@@ -55,6 +55,7 @@ _SIGNATURES = {
     "combo_presplit_bf16x2_batched_f32": [c_void_p, c_longlong, c_longlong, c_longlong, c_int, c_int, c_int, c_void_p, c_void_p],
     "combo_gemm_nt_x3_pre_batched_f32": [c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_void_p, c_longlong, c_longlong,
                                          c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "combo_gemm_nt_x3_pre_masked_f32": [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_void_p],
     "combo_gemm_nt_x3_pre_f32": [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_void_p],
     "combo_conv3x3_nhwc_x3_pre_f32": [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_longlong] + [c_int] * 6 + [c_void_p],
     "combo_gemm_tn_splits": [c_int, c_int, c_int],

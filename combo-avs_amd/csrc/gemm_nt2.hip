@@ -123,7 +123,10 @@ template <bool CONV, typename Cfg>
 __global__ void __launch_bounds__(256, Cfg::LDS <= 80 * 1024 ? 2 : 1)
 gemm_nt2_kernel(const float* __restrict__ A, long long lda, const float* __restrict__ Bimg, long long ldb,
                 const float* __restrict__ bias, float* __restrict__ C, long long ldc, int M, int N, int K, int relu,
-                int stagger, ConvGeom2 cg, int c_bytes, int batch, long long sA, long long sB, long long sC) {
+                int stagger, ConvGeom2 cg, int c_bytes, int batch, long long sA, long long sB, long long sC,
+                const float* __restrict__ mask) {
+  // mask != nullptr (same shape / pitch as C): C = mask > 0 ? value : 0 - the ReLU backward of the layer whose OUTPUT was
+  // the A operand's producer, folded into the input-gradient GEMM (dH = (dY . W2) o [H > 0] of an FFN)
   // batch > 1: `batch` independent problems of the same shape, operand b at A + b*sA, Bimg + b*sB, C + b*sC (elements)
   constexpr int BM = Cfg::BM, BN = Cfg::BN, TI = Cfg::TI, TJ = Cfg::TJ, ST = Cfg::ST, PPW = Cfg::PPW, APW = Cfg::APW;
   constexpr int A_BYTES = Cfg::A_BYTES, STAGE = Cfg::STAGE;
@@ -315,9 +318,10 @@ gemm_nt2_kernel(const float* __restrict__ A, long long lda, const float* __restr
     // C (wave-uniform), a 32-bit byte offset per lane that walks the rows by additions of ldc / 5*ldc, and the hardware
     // range check drops the rows >= M of the last token tile.  (The first version's per-store 64-bit multiply-adds, row
     // tests and exec masking were ~2 000 VALU instructions per tile: 60 % of the kernel's VALU count by PMC.)
-    auto epilogue = [&](auto relu_tag) {
-      constexpr bool RELU = decltype(relu_tag)::value;
+    auto epilogue = [&](auto relu_tag, auto mask_tag) {
+      constexpr bool RELU = decltype(relu_tag)::value, MASK = decltype(mask_tag)::value;
       const unsigned uld = (unsigned)ldc * 4u, uld5 = 5u * uld;
+      const __amdgpu_buffer_rsrc_t m_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(MASK ? mask + bi * sC : C), 0, c_bytes, 0x00020000);
 #pragma unroll
       for (int j = 0; j < TJ; ++j) {
         const int n = n_blk + (wn * TJ + j) * 32 + m;
@@ -330,13 +334,15 @@ gemm_nt2_kernel(const float* __restrict__ A, long long lda, const float* __restr
           for (int e = 0; e < 16; ++e) {
             float v = acc[i][j][e] + bv;
             if (RELU) v = fmaxf(v, 0.f);
+            if (MASK) v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(m_rsrc, off, 0, 0)) > 0.f ? v : 0.f;
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), c_rsrc, off, 0, 0);
             off += (e & 3) == 3 ? uld5 : uld;  // rows 0-3, 8-11, 16-19, 24-27 (+4g); the next i starts 32 rows on
           }
       }
     };
-    if (relu) epilogue(std::true_type{});
-    else epilogue(std::false_type{});
+    if (mask) epilogue(std::false_type{}, std::true_type{});
+    else if (relu) epilogue(std::true_type{}, std::false_type{});
+    else epilogue(std::false_type{}, std::false_type{});
   }
 }
 
@@ -375,7 +381,8 @@ struct NtBatch {
 
 template <bool CONV, typename Cfg>
 int launch_nt2_cfg(const float* A, long long lda, const float* Bimg, const float* bias, float* C, long long ldc, long long M,
-                   int N, int K, int relu, ConvGeom2 cg, int n_cu, combo_stream_t stream, NtBatch nb = NtBatch{1, 0, 0, 0}) {
+                   int N, int K, int relu, ConvGeom2 cg, int n_cu, combo_stream_t stream, NtBatch nb = NtBatch{1, 0, 0, 0},
+                   const float* mask = nullptr) {
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt2_kernel<CONV, Cfg>),
@@ -399,13 +406,13 @@ int launch_nt2_cfg(const float* A, long long lda, const float* Bimg, const float
   const long long c_bytes = ((M - 1) * ldc + N) * 4;
   if (c_bytes >= 0x7fffffffLL) return COMBO_EINVAL;
   hipLaunchKernelGGL((gemm_nt2_kernel<CONV, Cfg>), dim3((unsigned)grid), dim3(256), Cfg::LDS, (hipStream_t)stream, A, lda, Bimg,
-                     (long long)K, bias, C, ldc, (int)M, N, K, relu, stagger, cg, (int)c_bytes, nb.batch, nb.sA, nb.sB, nb.sC);
+                     (long long)K, bias, C, ldc, (int)M, N, K, relu, stagger, cg, (int)c_bytes, nb.batch, nb.sA, nb.sB, nb.sC, mask);
   return (int)hipGetLastError();
 }
 
 template <bool CONV>
 int launch_nt2(const float* A, long long lda, const float* Bimg, const float* bias, float* C, long long ldc, long long M, int N,
-               int K, int relu, ConvGeom2 cg, combo_stream_t stream) {
+               int K, int relu, ConvGeom2 cg, combo_stream_t stream, const float* mask = nullptr) {
   static const int n_cu = [] {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
@@ -415,8 +422,8 @@ int launch_nt2(const float* A, long long lda, const float* Bimg, const float* bi
   const long long wide_tiles = ((M + NtWide::BM - 1) / NtWide::BM) * ((N + NtWide::BN - 1) / NtWide::BN);
   // skinny tiles when the wide ones would leave most of the chip idle (the decoder's M = BT*100-token layers)
   const bool skinny = skinny_mode == 2 || (skinny_mode == 1 && wide_tiles * 2 <= n_cu);
-  if (skinny) return launch_nt2_cfg<CONV, NtSkinny>(A, lda, Bimg, bias, C, ldc, M, N, K, relu, cg, n_cu, stream);
-  return launch_nt2_cfg<CONV, NtWide>(A, lda, Bimg, bias, C, ldc, M, N, K, relu, cg, n_cu, stream);
+  if (skinny) return launch_nt2_cfg<CONV, NtSkinny>(A, lda, Bimg, bias, C, ldc, M, N, K, relu, cg, n_cu, stream, NtBatch{1, 0, 0, 0}, mask);
+  return launch_nt2_cfg<CONV, NtWide>(A, lda, Bimg, bias, C, ldc, M, N, K, relu, cg, n_cu, stream, NtBatch{1, 0, 0, 0}, mask);
 }
 
 }  // namespace
@@ -466,6 +473,14 @@ extern "C" int combo_gemm_nt_x3_pre_f32(const float* A, long long lda, const flo
       ((uintptr_t)Bimg & 15))
     return COMBO_EINVAL;
   return launch_nt2<false>(A, lda, Bimg, bias, C, ldc, M, N, K, relu, ConvGeom2{1, 1, K}, stream);
+}
+
+extern "C" int combo_gemm_nt_x3_pre_masked_f32(const float* A, long long lda, const float* Bimg, const float* mask, float* C,
+                                               long long ldc, int M, int N, int K, combo_stream_t stream) {
+  if (!A || !Bimg || !C || !mask || M <= 0 || N <= 0 || K <= 0 || K % kBK != 0 || lda % 4 != 0 || ((uintptr_t)A & 15) ||
+      ((uintptr_t)Bimg & 15))
+    return COMBO_EINVAL;
+  return launch_nt2<false>(A, lda, Bimg, nullptr, C, ldc, M, N, K, 0, ConvGeom2{1, 1, K}, stream, mask);
 }
 
 extern "C" int combo_conv3x3_nhwc_x3_pre_f32(const float* X, long long ldx, const float* Wimg, const float* bias, float* Y,

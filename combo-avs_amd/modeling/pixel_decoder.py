@@ -19,7 +19,7 @@ from torch.nn.init import constant_, normal_, xavier_uniform_
 
 from ..msda import MSDeformAttnFunction
 from ..registry import SEM_SEG_HEADS_REGISTRY, ShapeSpec
-from ..ops.linear import Linear, linear
+from ..ops.linear import Linear, ffn, linear
 from ..ops.upsample import upsample_bilinear
 from .layers import conv1x1_or_conv, norm_act, Conv2d, c2_xavier_fill, get_norm, position_embedding_sine
 
@@ -117,7 +117,10 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None, normalizer=None):
         src2 = self.self_attn(src + pos, reference_points, src, spatial_shapes, level_start_index, padding_mask, normalizer)
         src = self.norm1(src + self.dropout1(src2))
-        src2 = self.linear2(self.dropout2(linear(src, self.linear1.weight, self.linear1.bias, relu=True, defer=True)))
+        if self.dropout2.p == 0.0:  # (every shipped config) FFN with the ReLU backward folded into linear2's dX GEMM
+            src2 = ffn(src, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias)
+        else:
+            src2 = self.linear2(self.dropout2(linear(src, self.linear1.weight, self.linear1.bias, relu=True, defer=True)))
         return self.norm2(src + self.dropout3(src2))
 
 

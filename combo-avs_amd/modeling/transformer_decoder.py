@@ -15,7 +15,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from ..registry import TRANSFORMER_DECODER_REGISTRY
-from ..ops.linear import Linear, in_proj, linear
+from ..ops.linear import Linear, ffn, in_proj, linear
 from .layers import MLP, position_embedding_sine
 
 
@@ -107,7 +107,7 @@ class FFNLayer(nn.Module):
                 nn.init.xavier_uniform_(p)
 
     def forward(self, tgt):
-        return self.norm(tgt + self.linear2(linear(tgt, self.linear1.weight, self.linear1.bias, relu=True, defer=True)))  # :178-182
+        return self.norm(tgt + ffn(tgt, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias))  # :178-182
 
 
 @TRANSFORMER_DECODER_REGISTRY.register()

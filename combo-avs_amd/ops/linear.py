@@ -78,12 +78,22 @@ def presplit(b):
     return img
 
 
-def gemm_nt_x3(a, b, bias=None, relu=False):
+def gemm_nt_x3(a, b, bias=None, relu=False, relu_mask=None):
     """C[M,N] = a[M,K] @ b[N,K]^T (+ bias) (+ ReLU), fp32-accurate bf16x3 MFMA.  b may be any strided 2-D view (e.g.
     `weight.t()` for dX).  v2 (csrc/gemm_nt2.hip): weight pre-split once, persistent tiles; v1: csrc/gemm_nt.hip."""
     M, K = a.shape
     N = b.shape[0]
     out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    if relu_mask is not None:  # C = relu_mask > 0 ? a @ b^T : 0 (the ReLU backward of the consumer, csrc/gemm_nt2.hip)
+        assert bias is None and not relu and relu_mask.shape == (M, N) and relu_mask.is_contiguous()
+        if NT_V2 and K % 16 == 0 and M * N * 4 < 2 ** 31 - 1:
+            img = presplit(b)
+            with _lib.timed("gemm_nt_x3", (M, N, K)):
+                rc = _lib.lib().combo_gemm_nt_x3_pre_masked_f32(a.data_ptr(), a.stride(0), img.data_ptr(), relu_mask.data_ptr(),
+                                                                out.data_ptr(), N, M, N, K, _lib.current_stream())
+            _lib.check(rc, "combo_gemm_nt_x3_pre_masked_f32")
+            return out
+        return relu_grad(gemm_nt_x3(a, b), relu_mask)
     if NT_V2 and K % 16 == 0 and M * N * 4 < 2 ** 31 - 1:  # (v2 addresses C with 32-bit byte offsets)
         img = presplit(b)
         with _lib.timed("gemm_nt_x3", (M, N, K)):
@@ -151,8 +161,11 @@ class _split3:
 
 class _LinearLib3x(Function):
     @staticmethod
-    def forward(ctx, x2d, weight, bias, relu, defer=False):
-        ctx.defer = defer
+    def forward(ctx, x2d, weight, bias, relu, defer=False, mask_dx=False, grad_masked=False):
+        """mask_dx: x2d is the ReLU output of the producing layer and feeds nothing else - the input gradient is returned
+        already multiplied by [x2d > 0] (folded into the dX GEMM's epilogue); grad_masked (with relu): the consumer does
+        exactly that, so the incoming gradient needs no ReLU-gradient pass.  Set in pairs by `ffn` below."""
+        ctx.defer, ctx.mask_dx, ctx.grad_masked = defer, mask_dx, grad_masked
         if _nt_ok(x2d, weight.shape[0], weight) and (bias is None or bias.is_contiguous()):
             y = gemm_nt_x3(x2d, weight, bias, relu)  # bias + ReLU in the epilogue
         else:
@@ -169,17 +182,18 @@ class _LinearLib3x(Function):
     @once_differentiable
     def backward(ctx, dy):
         x2d, weight, y = ctx.saved_tensors
-        if ctx.relu:
+        if ctx.relu and not ctx.grad_masked:
             dy = relu_grad(dy, y)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dyc = dy if dy.stride(1) == 1 else dy.contiguous()
-            if _nt_ok(dyc, weight.shape[1]):  # (the transposed weight below is contiguous and freshly allocated)
-                # [K,N]: a weight-sized transpose so that dX = dY . W is the same K-contiguous NT kernel
-                dx = gemm_nt_x3(dyc, weight.t())
+            if _nt_ok(dyc, weight.shape[1]):  # (W^T is read through a strided view by the weight pre-split: no transpose copy)
+                dx = gemm_nt_x3(dyc, weight.t(), relu_mask=x2d if ctx.mask_dx else None)
             else:
                 with _split3(True):
                     dx = dy @ weight
+                if ctx.mask_dx:
+                    dx = relu_grad(dx, x2d)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             if ctx.defer and _dw_queue is not None:
@@ -188,7 +202,7 @@ class _LinearLib3x(Function):
                 ent = _dw_index.get(key)
                 if ent is not None and _deferrable(dyc, x2d, ent[1]):
                     ent[0].append((dyc, x2d))  # another use of the same weight: joins the entry, autograd gets "no gradient"
-                    return dx, None, None, None, None
+                    return dx, None, None, None, None, None, None
                 if ent is None:
                     dw_t = torch.empty_like(weight)
                     db_t = torch.empty(weight.shape[0], device=weight.device, dtype=weight.dtype) if want_db else None
@@ -196,7 +210,7 @@ class _LinearLib3x(Function):
                         ent = [[(dyc, x2d)], dw_t, db_t]
                         _dw_queue.append(ent)  # computed by the grouped launch when deferred_dw() closes
                         _dw_index[key] = ent
-                        return dx, dw_t, db_t, None, None
+                        return dx, dw_t, db_t, None, None, None, None
             if dy.stride(1) == 1 and x2d.stride(1) == 1 and dy.shape[0] >= 512:
                 # long-reduction / tiny-output shape: 3x faster than the library GEMM; db rides along
                 r = gemm_tn_x3(dy, x2d, with_bias_grad=want_db)
@@ -206,7 +220,7 @@ class _LinearLib3x(Function):
                     dw = dy.t() @ x2d
         if want_db and db is None:
             db = dy.sum(0)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None, None
 
 
 class _TnProblem(ctypes.Structure):  # combo_gemm_tn_problem (include/combo_avs.h)
@@ -484,14 +498,15 @@ class _LinearX3(Function):
         return dx, dw, db, None
 
 
-def linear(x, weight, bias=None, relu=False, defer=False):
-    """F.linear(x, weight, bias) [+ ReLU].  fp32 CUDA tensors with enough rows go to the bf16x3 MFMA kernel."""
+def linear(x, weight, bias=None, relu=False, defer=False, mask_dx=False, grad_masked=False):
+    """F.linear(x, weight, bias) [+ ReLU].  fp32 CUDA tensors with enough rows go to the bf16x3 MFMA kernel.
+    mask_dx / grad_masked: see _LinearLib3x.forward (only honoured on that path; use `ffn`)."""
     K = x.shape[-1]
     N = weight.shape[0]
     rows = x.numel() // K
     if (_IMPL == "library3x" and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32
             and rows >= MIN_ROWS and not torch.is_autocast_enabled()):
-        y = _LinearLib3x.apply(x.reshape(rows, K), weight, bias, relu, defer)
+        y = _LinearLib3x.apply(x.reshape(rows, K), weight, bias, relu, defer, mask_dx, grad_masked)
         return y.view(*x.shape[:-1], N)
     if (_IMPL == "x3" and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and rows >= MIN_ROWS and K % 4 == 0
             and N % 4 == 0 and rows % 4 == 0 and not torch.is_autocast_enabled()
@@ -500,6 +515,21 @@ def linear(x, weight, bias=None, relu=False, defer=False):
         return y.view(*x.shape[:-1], N)
     y = torch.nn.functional.linear(x, weight, bias)
     return torch.relu(y) if relu else y
+
+
+def ffn(x, w1, b1, w2, b2, defer=True):
+    """linear2(relu(linear1(x))) of the transformer FFN blocks (msdeformattn.py:125-134, transformer_decoder.py:178-182).
+    On the HIP GEMM path the ReLU backward is folded into the second layer's input-gradient GEMM (its epilogue multiplies
+    dH = dY . W2 by [H > 0]): no ReLU-gradient pass over the 1024- / 2048-wide hidden tensor (read dH + H, write dH)."""
+    K = x.shape[-1]
+    rows = x.numel() // K
+    fused = (_IMPL == "library3x" and x.is_cuda and x.dtype == torch.float32 and w1.dtype == torch.float32
+             and rows >= MIN_ROWS and not torch.is_autocast_enabled() and FFN_FUSED_RELU_GRAD)
+    h = linear(x, w1, b1, relu=True, defer=defer, grad_masked=fused)
+    return linear(h, w2, b2, defer=defer, mask_dx=fused)
+
+
+FFN_FUSED_RELU_GRAD = _os.environ.get("COMBO_FFN_FUSED_RELU_GRAD", "1") == "1"  # 0: separate ReLU-gradient kernel (A/B)
 
 
 class Linear(torch.nn.Linear):

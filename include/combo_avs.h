@@ -218,6 +218,12 @@ int combo_presplit_bf16x2_f32(const float* src, long long ld_row, long long ld_c
                               combo_stream_t stream);
 int combo_gemm_nt_x3_pre_f32(const float* A, long long lda, const float* Bimg, const float* bias, float* C, long long ldc,
                              int M, int N, int K, int relu, combo_stream_t stream);
+/*   combo_gemm_nt_x3_pre_f32 with the ReLU backward of the consumer folded into the epilogue: C = mask > 0 ? A.B^T : 0,
+ *   mask of the shape and row pitch of C.  The input-gradient GEMM of an FFN's second layer, dH = (dY . W2) o [H > 0]
+ *   (pixel_decoder/msdeformattn.py:125-134, transformer_decoder.py:178-182): the ReLU-gradient pass over the 1024- /
+ *   2048-wide hidden tensor disappears. */
+int combo_gemm_nt_x3_pre_masked_f32(const float* A, long long lda, const float* Bimg, const float* mask, float* C,
+                                    long long ldc, int M, int N, int K, combo_stream_t stream);
 /*   Batched forms: `batch` problems of one shape, operand b at base + b*stride (elements).  They carry the mask-logit
  *   contraction `einsum("bqc,bchw->bqhw", mask_embed, mask_features)` of every prediction head
  *   (transformer_decoder/transformer_decoder.py:498-500: A = mask_embed [BT,Q,C], B image = token-major mask features

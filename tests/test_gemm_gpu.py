@@ -247,3 +247,40 @@ def test_mask_logit_contraction_and_gradients_on_the_hip_gemms():
         assert rel_err(gr_h[1 + i], gd[i] @ mf.detach().double()) < 2e-5
     for a, b in zip(gr_h, gr_l):
         assert rel_err(a, b.double()) < 2e-5
+
+
+@pytest.mark.parametrize("M,C,Hd", [(41160, 256, 1024), (4000, 256, 2048), (700, 256, 512)])
+def test_ffn_relu_gradient_folded_into_the_dx_gemm(M, C, Hd):
+    """ops.linear.ffn: linear2(relu(linear1(x))) with the ReLU backward applied in the epilogue of linear2's input-gradient
+    GEMM (csrc/gemm_nt2.hip, mask operand) must give the gradients of the unfused chain bit for bit where both take the
+    HIP path, and float64's to 2e-5 everywhere (small shapes fall back to the library + the ReLU-gradient kernel)."""
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.ops import linear as L
+    torch.manual_seed(C + Hd)
+    x = torch.randn(M, C, device="cuda", requires_grad=True)
+    w1 = (torch.randn(Hd, C, device="cuda") / C ** 0.5).requires_grad_(True)
+    b1 = torch.randn(Hd, device="cuda", requires_grad=True)
+    w2 = (torch.randn(C, Hd, device="cuda") / Hd ** 0.5).requires_grad_(True)
+    b2 = torch.randn(C, device="cuda", requires_grad=True)
+    g = torch.randn(M, C, device="cuda")
+
+    def run(fused):
+        prev, L.FFN_FUSED_RELU_GRAD = L.FFN_FUSED_RELU_GRAD, fused
+        try:
+            y = L.ffn(x, w1, b1, w2, b2, defer=False)
+            return y.detach(), torch.autograd.grad(y, (x, w1, b1, w2, b2), g)
+        finally:
+            L.FFN_FUSED_RELU_GRAD = prev
+    y_f, g_f = run(True)
+    y_u, g_u = run(False)
+    assert torch.equal(y_f, y_u)
+    for a, b in zip(g_f, g_u):
+        assert rel_err(a, b) < 1e-6, rel_err(a, b)
+    xd, w1d, b1d, w2d, b2d = (t.detach().double().requires_grad_(True) for t in (x, w1, b1, w2, b2))
+    hd = torch.nn.functional.linear(xd, w1d, b1d)
+    hd = hd * (torch.nn.functional.linear(x.detach(), w1.detach(), b1.detach()) > 0)  # the fp32 activation pattern
+    yd = torch.nn.functional.linear(hd, w2d, b2d)
+    gd = torch.autograd.grad(yd, (xd, w1d, b1d, w2d, b2d), g.double())
+    assert rel_err(y_f, yd) < 5e-5
+    for a, b in zip(g_f, gd):
+        assert rel_err(a, b) < 5e-5, rel_err(a, b)
