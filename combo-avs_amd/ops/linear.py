@@ -18,7 +18,7 @@ MIN_ROWS = 512  # below this the op is launch/weight-bandwidth bound and the lib
 #   hipBLASLt serves that mode with a 3-way bf16 split as well (measured error 4.4e-6 vs 2.9e-7 for plain fp32, i.e.
 #   the same class as csrc/gemm_x3.hip; tools/blas_test.py).  Forward and dX run 2.2x faster in that mode, the
 #   TN-layout dW GEMM is slower (809 vs 491 us), so dW stays in plain fp32 mode.
-_IMPL = "library3x"
+_IMPL = __import__("os").environ.get("COMBO_LINEAR_IMPL", "library3x")  # "library": plain fp32 library GEMMs (parity experiments)
 
 
 def set_impl(name):

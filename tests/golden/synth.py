@@ -8,6 +8,8 @@ in the fixtures by `gen_golden.py`; the values are produced here from a name-der
 import hashlib
 import math
 
+import os
+
 import numpy as np
 import torch
 
@@ -106,6 +108,8 @@ def check_digest(t: torch.Tensor, d, name: str, rtol: float, atol: float, k: int
     err = np.abs(a - b)
     tol = atol + rtol * np.abs(b)
     bad = float((err > tol).mean())
+    if os.environ.get("COMBO_TEST_VERBOSE") == "1":  # headroom report: `COMBO_TEST_VERBOSE=1 pytest -s ...`
+        print(f"[digest] {name}: {bad * 100:.3f}% of {len(a)} samples beyond atol {atol:g} + rtol {rtol:g} (allowed {frac_bad * 100:.3f}%), max err {err.max():.3e}")
     assert bad <= frac_bad, f"{name}: {bad * 100:.3f}% of sampled entries exceed tol (max err {err.max():.3e})"
     scale = max(abs(float(d["l2"])), 1e-12)
     if frac_bad == 0.0:
