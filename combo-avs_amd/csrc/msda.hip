@@ -792,9 +792,12 @@ template <int LPc>
 __global__ void __launch_bounds__(1024)
 msda_fwd_tap_d32(const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
                  const float* __restrict__ loc, const float* __restrict__ aw, int B, int S, int M, int L, int Lq, int P,
-                 int QT, float* __restrict__ out, int dbg) {
+                 int QT, float* __restrict__ out, int dbg, unsigned long long* __restrict__ ts) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int D = 32, QW = kTapQW, PRE = (QW * LPc + 63) / 64;
+  // ts != nullptr: device-side timing of this launch (works inside a replayed hipGraph, where HIP refuses event records):
+  // ts = {min start, workgroups done, sum of durations, launches} in wall-clock ticks, see combo_msda_set_timing_buffer
+  if (ts && threadIdx.x == 0) atomicMin(&ts[0], (unsigned long long)wall_clock64());
   float* slab = reinterpret_cast<float*>(smem);
   const int NW = blockDim.x >> 6;
   const unsigned slab_bytes = (unsigned)(S + 1) * D * 4;
@@ -958,6 +961,19 @@ msda_fwd_tap_d32(const float* __restrict__ value, const int64_t* __restrict__ sh
       __builtin_amdgcn_wave_barrier();
     }
   }
+  if (ts) {  // the last workgroup to finish closes the measurement: duration = its end - the earliest start
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned long long t1 = wall_clock64();
+      __threadfence();
+      if (atomicAdd(&ts[1], 1ull) == (unsigned long long)gridDim.x - 1ull) {
+        const unsigned long long t0 = atomicExch(&ts[0], ~0ull);  // (also re-arms the slot for the next replay)
+        atomicExch(&ts[1], 0ull);
+        atomicAdd(&ts[2], t1 - t0);
+        atomicAdd(&ts[3], 1ull);
+      }
+    }
+  }
 }
 
 inline bool check_common(int B, int S, int M, int D, int L, int Lq, int P) {
@@ -970,6 +986,17 @@ size_t bwd_value_lds_bytes(int S) {
   return (size_t)(S + 1) * 64 + (size_t)((S + 1 + 3) & ~3) * 4 + (size_t)(kBwdVThreads / 64) * 20 * 4;
 }
 constexpr size_t kLdsLimit = 160 * 1024;
+
+// device-side launch timing (combo_msda_set_timing_buffer): a ring of 4 x u64 slots, one per launch of the forward
+// core; a launch captured into a hipGraph keeps its slot, so every replay adds its duration to the same slot
+unsigned long long* g_timing_base = nullptr;
+int g_timing_slots = 0, g_timing_next = 0;
+inline unsigned long long* next_timing_slot() {
+  if (!g_timing_base || g_timing_slots <= 0) return nullptr;
+  unsigned long long* p = g_timing_base + 4LL * (g_timing_next % g_timing_slots);
+  ++g_timing_next;
+  return p;
+}
 
 template <typename T>
 int msda_forward(const T* value, const int64_t* shapes, const int64_t* lsi, const T* loc, const T* aw, int B, int S,
@@ -1019,7 +1046,7 @@ int msda_forward(const T* value, const int64_t* shapes, const int64_t* lsi, cons
           attr12 = true;
         }
         hipLaunchKernelGGL(msda_fwd_tap_d32<12>, dim3(grid), dim3(nw * 64), lds, stream, value, shapes, lsi, loc, aw, B,
-                           S, M, L, Lq, P, QT, out, dbg);
+                           S, M, L, Lq, P, QT, out, dbg, next_timing_slot());
       } else {
         if (!attr16) {
           hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_fwd_tap_d32<16>),
@@ -1028,7 +1055,7 @@ int msda_forward(const T* value, const int64_t* shapes, const int64_t* lsi, cons
           attr16 = true;
         }
         hipLaunchKernelGGL(msda_fwd_tap_d32<16>, dim3(grid), dim3(nw * 64), lds, stream, value, shapes, lsi, loc, aw, B,
-                           S, M, L, Lq, P, QT, out, dbg);
+                           S, M, L, Lq, P, QT, out, dbg, next_timing_slot());
       }
       return (int)hipGetLastError();
     }
@@ -1141,6 +1168,22 @@ int combo_msda_backward_needs_zero(int S, int D, int L, int P, int elem_bytes, i
   const bool lds_ok = elem_bytes == 4 && D == 32 && S < 65535 && L * P <= kMaxLP && fwd_lds_bytes(S, L, P, 8) <= kLdsLimit &&
                       bwd_value_lds_bytes(S) <= kLdsLimit;
   return (lds_ok && algo != 1) ? 0 : 1;
+}
+
+// Device-side timing of the MSDeformAttn forward launches: `buf` = slots x 4 uint64 on the device, initialised by the
+// caller to {~0, 0, 0, 0} per slot; every following forward launch (tap kernel) gets the next slot and adds
+// (last workgroup end - first workgroup start) in wall-clock ticks to slot[2] and 1 to slot[3] - also when the launch is a
+// node of a replayed hipGraph.  buf == NULL switches it off.  combo_wall_clock_khz: tick rate of those timestamps.
+int combo_msda_set_timing_buffer(void* buf, int slots) {
+  g_timing_base = reinterpret_cast<unsigned long long*>(buf);
+  g_timing_slots = buf ? slots : 0;
+  g_timing_next = 0;
+  return 0;
+}
+int combo_wall_clock_khz(void) {
+  int dev = 0, khz = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) return 0;
+  return khz;
 }
 
 int combo_msda_forward_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,

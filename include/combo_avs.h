@@ -35,6 +35,13 @@ typedef void* combo_stream_t;
 
 /* Library / device introspection (host only, no GPU needed). */
 int combo_abi_version(void);
+
+/* Measurement aid (bench.py): device-side timing of the MSDeformAttn forward core.  HIP refuses event records inside a
+ * captured hipGraph on ROCm 7, so the kernel itself takes wall-clock timestamps: `buf` = slots x 4 uint64 on the device,
+ * initialised to {~0, 0, 0, 0} per slot; every following forward launch takes the next slot (a graph node keeps its slot
+ * over all replays) and adds its duration in ticks to slot[2] and 1 to slot[3].  NULL switches it off. */
+int combo_msda_set_timing_buffer(void* buf, int slots);
+int combo_wall_clock_khz(void);
 const char* combo_build_arch(void); /* "gfx950" */
 
 /* Timing events on the launch stream (measurement plumbing for bench.py; the reference has no counterpart - it times
