@@ -175,7 +175,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--clips", type=int, default=8, help="clips per GPU (BASELINE config 2: 8)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"], help="host-PyTorch backbone compute dtype")
+    ap.add_argument("--dtype", default="fp32", choices=["bf16", "fp32"],
+                    help="host-PyTorch backbone compute dtype.  fp32 = the reference's S4 recipe (SOLVER.AMP.ENABLED False, "
+                         "configs/avs_s4/R50-AVSS4-SemanticSegmentation.yaml:44-45) and the BASELINE metric; bf16 = backbones "
+                         "under bf16 autocast, a throughput mode that is NOT the quoted metric")
     ap.add_argument("--head-dtype", default="fp32", choices=["bf16", "fp32"], help="dense layers of the head")
     ap.add_argument("--grad-comm", default="fp32", choices=["fp32", "bf16"],
                     help="dtype of the gradient all-reduce (fp32 = the reference's DDP semantics; bf16 halves the xGMI bytes)")
@@ -251,27 +254,30 @@ def main():
             print(f"[bench rank {rank} +{time.perf_counter() - t_start:.1f}s] {msg}", file=sys.stderr, flush=True)
     t_start = time.perf_counter()
 
+    # several distinct synthetic batches of one signature, rotated over the steps (inputs resident in HBM; the graphed step
+    # copies the batch of the step into its static input buffers, 12 MB device-to-device)
+    batches = [batch] + [synth_batch(args.clips, T, H, W, dev, seed=1000 * (i + 1) + rank) for i in range(3)]
+    from combo_avs_amd import _lib as _clib
+    n_slots = 4096
+    ts_buf = torch.zeros(n_slots, 4, dtype=torch.int64, device=dev)
+    ts_buf[:, 0] = -1  # ~0ull
     if args.no_graph:
         def step(b):
             return train_step(model, opt, b)
-        for _ in range(args.warmup):
-            step(batch)
+        for i in range(args.warmup):
+            step(batches[i % len(batches)])
         sync()
         msda.start_timing()
     else:
         # forward + loss + backward replayed from one hipGraph (captured during the first warm-up step, after MIOpen's
-        # find pass); the MSDeformAttn launches are bracketed by external event-record nodes inside the graph
+        # find pass).  HIP cannot record events inside a captured graph, so the instrumented kernels (GEMMs, MSDeformAttn
+        # core, decoder attention) time themselves: every launch gets a slot {min start, done, sum of ticks, launches} of
+        # `ts_buf`; graph nodes keep theirs over the replays (csrc/combo_common.h, csrc/timing.hip)
         graphed = GraphedTrainStep(model, opt)
-        # device-side timing of the MSDeformAttn forward launches INSIDE the graph replays (HIP cannot record events in a
-        # captured graph): every launch gets a slot {min start, done, sum of ticks, launches}; nodes keep theirs over replays
-        n_slots = 256
-        ts_buf = torch.zeros(n_slots, 4, dtype=torch.int64, device=dev)
-        ts_buf[:, 0] = -1  # ~0ull
-        from combo_avs_amd import _lib as _clib
-        _clib.check(_clib.lib().combo_msda_set_timing_buffer(ts_buf.data_ptr(), n_slots), "combo_msda_set_timing_buffer")
         trace("model built")
-        train_step(model, opt, batch)  # eager: MIOpen find / hipBLASLt heuristics / lazy init
+        train_step(model, opt, batch)  # eager: MIOpen find / lazy init
         trace("eager step done")
+        _clib.check(_clib.lib().combo_timing_set_buffer(ts_buf.data_ptr(), n_slots), "combo_timing_set_buffer")
         try:
             graphed(batch)  # captures
             trace("captured + first replayed step done")
@@ -282,36 +288,46 @@ def main():
 
             def step(b):
                 return train_step(model, opt, b)
-        for _ in range(max(args.warmup - 1, 0)):
-            step(batch)
+        for i in range(max(args.warmup - 1, 0)):
+            step(batches[i % len(batches)])
             trace("warm-up step done")
         sync()
         ts_buf[:, 2:] = 0  # count only the launches of the timed region
         sync()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(batch)
+    marks[0].record()
+    for i in range(args.steps):
+        step(batches[i % len(batches)])
+        marks[i + 1].record()  # (an event on the stream between graph launches: no host sync inside the timed region)
         trace("timed step done")
     sync()
     elapsed = time.perf_counter() - t0
     trace("timed region done")
-    graph_fwd_us = None
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2] if step_ms else None
+    per_kind = {}
     if not args.no_graph:
         torch.cuda.synchronize()
         tsv = ts_buf.cpu()
-        _clib.lib().combo_msda_set_timing_buffer(None, 0)
-        khz = _clib.lib().combo_wall_clock_khz()
-        n_l = int(tsv[:, 3].sum())
-        if khz > 0 and n_l > 0:
-            graph_fwd_us = float(tsv[:, 2].sum()) / n_l / khz * 1e3
-            graph_fwd_launches = n_l
-    if not args.no_graph:
-        # event records cannot be captured into a hipGraph on ROCm 7 (hipEventRecordExternal is rejected), so the
-        # kernel durations come from two eager runs of the very same step right after the timed region
-        msda.start_timing()
-        for _ in range(2):
-            train_step(model, opt, batch)
-    kt = msda.stop_timing()
+        lib = _clib.lib()
+        used = lib.combo_timing_slots_used()
+        lib.combo_timing_set_buffer(None, 0)
+        khz = lib.combo_wall_clock_khz()
+        import ctypes
+        for sl in range(min(used, n_slots)):
+            kind, work = ctypes.c_int(0), ctypes.c_double(0.0)
+            lib.combo_timing_slot_info(sl, ctypes.byref(kind), ctypes.byref(work))
+            n_l = int(tsv[sl, 3])
+            if khz > 0 and n_l > 0:
+                d = per_kind.setdefault(kind.value, {"us": 0.0, "launches": 0, "work": 0.0, "nodes": 0})
+                d["us"] += float(tsv[sl, 2]) / khz * 1e3
+                d["launches"] += n_l
+                d["work"] += work.value * n_l
+                d["nodes"] += 1
+    kt = {"fwd_us": [], "bwd_us": [], "kernels": {}}
+    if args.no_graph:
+        kt = msda.stop_timing()
     if dist.is_initialized():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -319,71 +335,53 @@ def main():
 
     frames = args.clips * T * world * args.steps
     value = frames / elapsed
-    # roofline of the dominant HIP kernel: MSDeformAttn forward core. Algorithmic bytes per frame-layer = 3.29 MB
-    # (value 1.05 + loc 0.79 + w 0.40 + out 1.05); one launch processes clips*T frames.
     bt = args.clips * T
-    S, M, D, L, Pn = 1029, 8, 32, 3, 4
-    fwd_bytes = bt * (S * M * D * 4 * 2 + S * M * L * Pn * 3 * 4)
-    roof = None
-    if kt["fwd_us"] or graph_fwd_us:
-        eager_us = sum(kt["fwd_us"]) / len(kt["fwd_us"]) if kt["fwd_us"] else None
-        # launch duration inside the TIMED graph replays (device-side timestamps of the kernel itself) when available,
-        # else the HIP-event figure of the eager steps after the timed region
-        avg_us = graph_fwd_us if graph_fwd_us else eager_us
-        achieved = fwd_bytes / (avg_us * 1e-6) / 1e9
-        # HBM traffic per launch from the PMC pass committed under profiles/ (FETCH_SIZE doubled as the gfx950 guide
-        # prescribes for 16-B/lane streams, + WRITE_SIZE); only valid for the shape it was collected on.
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_msda_pmc.json")
-        if os.path.exists(pmc):
-            with open(pmc) as f:
-                rec = json.load(f).get("msda_fwd_tap_d32", {})
-            if rec.get("frames_per_launch") == bt:
-                traffic = rec.get("hbm_bytes_per_launch")
-        roof = {"kernel": "msda_fwd_tap_d32", "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 4), "traffic": traffic, "avg_launch_us": round(avg_us, 2),
-                "launches": graph_fwd_launches if graph_fwd_us else len(kt["fwd_us"]),
-                "timing": ("device-side wall-clock timestamps of the kernel over the launches of the timed graph replays"
-                           if graph_fwd_us else "HIP events around the launches of two eager steps after the timed region"),
-                "eager_hip_event_us": round(eager_us, 2) if eager_us else None,
-                "algorithmic_bytes_per_launch": fwd_bytes,
-                # measured ceilings of this chip (tools/clock_probe.py, profiles/r01_clock_probe.txt): a 1 GiB device copy
-                # moves 4.75 TB/s; hipBLASLt's bf16 GEMM reaches 1.37 PFLOP/s at the 1400 W package limit (sclk ~1.9 GHz)
-                "measured_ceilings": {"hbm_copy_GBps": 4750.0, "hipblaslt_bf16_TFLOPs": 1374.0},
-                # by time the largest single kernel of the step is the forward / dX GEMM (~10 %, MFMA-bound, reported in
-                # other_kernels.gemm_nt_x3); this object stays on the north-star's core op, which is HBM-bound
-                "largest_kernel_by_time": "gemm_nt2_kernel (other_kernels.gemm_nt_x3)"}
-    # secondary rooflines (same HIP-event pass): the two hand-written 3xbf16 GEMM kernels against the dense bf16 MFMA
-    # peak (2.5 PFLOP/s); MFMA flops = 3 products x 2*M*N*K.  Only the large launches (>= 1 GFLOP) are counted.
-    kernels = {}
-    for kind in ("gemm_nt_x3", "gemm_tn_x3", "conv3x3_x3", "conv3x3_wgrad_x3"):  # conv3x3: FPN 3x3 as implicit GEMMs, meta = (tokens, Cout, 9*Cin)
-        evs = [(us, meta) for us, meta in kt.get("kernels", {}).get(kind, []) if meta and 2.0 * meta[0] * meta[1] * meta[2] >= 1e9]
-        if evs:
-            flops = sum(3 * 2.0 * m[0] * m[1] * m[2] for _, m in evs)
-            tsum = sum(us for us, _ in evs) * 1e-6
-            kernels[kind] = {"bound": "mfma", "launches_timed": len(evs), "avg_launch_us": round(tsum / len(evs) * 1e6, 1),
-                             "achieved": round(flops / tsum / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s (bf16 MFMA, 3 products per fp32 MAC)",
-                             "frac": round(flops / tsum / 2.5e15, 4), "fp32_equivalent_tflops": round(flops / 3 / tsum / 1e12, 1)}
-    grp = kt.get("kernels", {}).get("gemm_tn_x3_grouped", [])
-    if grp:  # all weight-gradient GEMMs of the head in one grouped launch per step (ops.linear.deferred_dw)
-        tsum = sum(us for us, _ in grp) * 1e-6
-        flops = sum(3 * m[0] for _, m in grp)
-        kernels["gemm_tn_x3 (grouped launches, %d problems per step)" % (sum(m[1] for _, m in grp) // 2)] = {  # (2 eager steps timed)
-            "bound": "mfma", "launches_timed": len(grp), "avg_launch_us": round(tsum / len(grp) * 1e6, 1),
-            "achieved": round(flops / tsum / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s (bf16 MFMA, 3 products per fp32 MAC)",
-            "frac": round(flops / tsum / 2.5e15, 4), "fp32_equivalent_tflops": round(flops / 3 / tsum / 1e12, 1)}
-    bwd = kt.get("bwd_us") or []
-    if bwd:
-        bwd_bytes = bt * 5.53e6  # SURVEY 8(d)-style count: value grad 1.05 + loc/w in 1.19 + grads out 1.19 + grad_out 1.05 + value 1.05 MB
-        kernels["msda_bwd (value + loc/w kernels)"] = {"bound": "hbm", "avg_launch_us": round(sum(bwd) / len(bwd), 1),
-                                                       "achieved": round(bwd_bytes / (sum(bwd) / len(bwd) * 1e-6) / 1e9, 1),
-                                                       "peak": 8000.0, "unit": "GB/s",
-                                                       "frac": round(bwd_bytes / (sum(bwd) / len(bwd) * 1e-6) / 8e12, 4)}
+    # Rooflines, one per instrumented kernel family, from the launches of the TIMED steps (device-side timestamps):
+    #   achieved = algorithmic work of the launches (bytes: SURVEY 8(d) 3.29 MB per frame-layer x frames for the MSDeformAttn
+    #   core; flops: 2*M*N*K for the GEMMs) / their summed duration.  Peaks from MI355X_MICROARCH.md: HBM 8 TB/s, fp32 MFMA
+    #   157.3 TFLOP/s (the forward GEMMs compute in exact fp32), bf16 MFMA 2.5 PFLOP/s (the gradient GEMMs issue 3 bf16
+    #   products per fp32 MAC: `achieved` counts the USEFUL 2*M*N*K, `issued` the 3x).
+    KINDS = {0: ("msda_fwd_tap_d32", "hbm", 8000.0, "GB/s", 1e9), 1: ("gemm_nt_f32_kernel", "mfma", 157.3, "TFLOP/s", 1e12),
+             2: ("gemm_nt2_kernel", "mfma", 2500.0, "TFLOP/s", 1e12), 3: ("gemm_tn_grouped_kernel", "mfma", 2500.0, "TFLOP/s", 1e12),
+             4: ("attn_fwd_kernel", "mfma", 157.3, "TFLOP/s", 1e12), 5: ("attn_bwd_kernel", "mfma", 2500.0, "TFLOP/s", 1e12),
+             6: ("msda_bwd", "hbm", 8000.0, "GB/s", 1e9)}
+    pmc = {}
+    pmc_path = os.path.join(ROOT, "profiles", "r02_pmc.json")
+    if os.path.exists(pmc_path):
+        with open(pmc_path) as f:
+            pmc = json.load(f)
+    rooflines = []
+    for kind, d in per_kind.items():
+        name, bound, peak, unit, scale = KINDS.get(kind, (f"kind{kind}", "mfma", 2500.0, "TFLOP/s", 1e12))
+        ach = d["work"] / (d["us"] * 1e-6) / scale
+        rec = pmc.get(name, {}) if pmc.get("frames_per_launch") == bt else {}
+        r = {"kernel": name, "bound": bound, "achieved": round(ach, 1), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
+             "traffic": rec.get("hbm_bytes_per_launch"), "traffic_commit": pmc.get("commit") if rec else None,
+             "avg_launch_us": round(d["us"] / d["launches"], 2), "launches": d["launches"],
+             "launches_per_step": d["launches"] // max(args.steps, 1), "ms_per_step": round(d["us"] / max(args.steps, 1) / 1e3, 3),
+             "algorithmic_work_per_step": d["work"] / max(args.steps, 1),
+             "timing": "device-side wall-clock timestamps of the kernel over the launches of the timed graph replays"}
+        if kind in (2, 3, 5):
+            r["issued_tflops_bf16"] = round(3 * ach, 1)
+            r["note"] = "useful 2*M*N*K flops over the dense bf16 peak; the kernel issues 3 bf16 products per fp32 MAC"
+        rooflines.append(r)
+    rooflines.sort(key=lambda r: -r["ms_per_step"])
+    roof = rooflines[0] if rooflines else None
+    kernels = {r["kernel"]: r for r in rooflines[1:]}
+    if args.no_graph and kt.get("fwd_us"):  # eager run: HIP events on the launch stream around the MSDeformAttn core
+        S, M_, D, L, Pn = 1029, 8, 32, 3, 4
+        fwd_bytes = bt * (S * M_ * D * 4 * 2 + S * M_ * L * Pn * 3 * 4)
+        avg_us = sum(kt["fwd_us"]) / len(kt["fwd_us"])
+        ach = fwd_bytes / (avg_us * 1e-6) / 1e9
+        roof = {"kernel": "msda_fwd_tap_d32", "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(ach / 8000.0, 4), "traffic": None, "avg_launch_us": round(avg_us, 2), "launches": len(kt["fwd_us"]),
+                "timing": "HIP events on the launch stream around the launches of the timed eager steps"}
     if rank == 0:
         out = {
             "metric": "train frames/sec (224x224, 5-frame clips)", "value": round(value, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "ms_per_step_median": round(median_ms, 3) if median_ms else None,
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": f"COMBO-{'R50' if args.backbone == 'r50' else 'PVTv2-B5'} S4, bs={args.clips} clips x 5 frames x 224x224 per GPU, full train step "
                                    "(fwd + 39-term loss + bwd + all-reduce + clip + AdamW), random-init weights",

@@ -43,20 +43,22 @@ _SIGNATURES = {
     "combo_bifuse_forward_f32": [c_void_p] * 3 + [c_float] + [c_void_p] * 8 + [c_float, ctypes.c_ulonglong, c_void_p] + [c_int] * 4 + [c_void_p] * 7,
     "combo_bifuse_backward1_f32": [c_void_p] * 3 + [c_float] + [c_void_p] * 7 + [c_float, ctypes.c_ulonglong, c_void_p] + [c_void_p] * 3 + [c_int] * 4 + [c_void_p] * 5,
     "combo_bifuse_backward2_f32": [c_void_p] * 3 + [c_float] + [c_void_p] * 5 + [c_float, ctypes.c_ulonglong, c_void_p] + [c_void_p] * 4 + [c_int] * 4 + [c_void_p] * 5,
-    "combo_gemm_x3_splits": [c_int, c_int],
-    "combo_gemm_x3_f32": [c_void_p, c_longlong, c_int, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_longlong] + [c_int] * 5 + [c_longlong, c_void_p],
     "combo_matcher_cost_f32": [c_void_p] * 6 + [c_int] * 9 + [c_float] * 3 + [c_void_p] * 3,
     "combo_sem_mix": [c_int, c_int] + [c_void_p] * 4 + [c_int] * 3 + [c_void_p] * 3,
     "combo_semantic_inference_f32": [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p, c_void_p],
-    "combo_gemm_nt_x3_f32": [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_void_p],
-    "combo_conv3x3_nhwc_x3_f32": [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_longlong] + [c_int] * 6 + [c_void_p],
     "combo_conv3x3_wgrad_x3_f32": [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p] + [c_int] * 6 + [c_void_p],
     "combo_presplit_bf16x2_f32": [c_void_p, c_longlong, c_longlong, c_int, c_int, c_void_p, c_void_p],
     "combo_presplit_bf16x2_batched_f32": [c_void_p, c_longlong, c_longlong, c_longlong, c_int, c_int, c_int, c_void_p, c_void_p],
     "combo_gemm_nt_x3_pre_batched_f32": [c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_void_p, c_longlong, c_longlong,
                                          c_int, c_int, c_int, c_int, c_int, c_void_p],
     "combo_gemm_nt_x3_pre_masked_f32": [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_void_p],
-    "combo_msda_set_timing_buffer": [c_void_p, c_int],
+    "combo_timing_set_buffer": [c_void_p, c_int],
+    "combo_timing_slots_used": [],
+    "combo_timing_slot_info": [c_int, c_void_p, c_void_p],
+    "combo_gemm_nt_f32": [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_void_p],
+    "combo_gemm_nt_batched_f32": [c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_longlong,
+                                  c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "combo_conv3x3_nhwc_f32": [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_longlong] + [c_int] * 6 + [c_void_p],
     "combo_wall_clock_khz": [],
     "combo_gemm_nt_x3_pre_f32": [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_void_p],
     "combo_conv3x3_nhwc_x3_pre_f32": [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_longlong] + [c_int] * 6 + [c_void_p],

@@ -27,10 +27,6 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef float f4v __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ unsigned pack_hi(float a, float b) {
-  return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
-}
-__device__ __forceinline__ float trunc_hi(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
 __device__ __forceinline__ unsigned pack_rne(float a, float b) {
   unsigned r;
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -41,8 +37,8 @@ __device__ __forceinline__ void split8(const f4v a, const f4v b, bf16x8& hi, bf1
   unsigned h[4], l[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    h[t] = pack_hi(v[2 * t], v[2 * t + 1]);
-    l[t] = pack_rne(v[2 * t] - trunc_hi(v[2 * t]), v[2 * t + 1] - trunc_hi(v[2 * t + 1]));
+    h[t] = pack_rne(v[2 * t], v[2 * t + 1]);  // hi = rne_bf16(x): the dropped lo.lo term is <= 2^-16 |x.w| and unbiased
+    l[t] = pack_rne(v[2 * t] - __uint_as_float(h[t] << 16), v[2 * t + 1] - __uint_as_float(h[t] & 0xffff0000u));
   }
   hi = __builtin_bit_cast(bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
   lo = __builtin_bit_cast(bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
@@ -124,7 +120,8 @@ __global__ void __launch_bounds__(256, Cfg::LDS <= 80 * 1024 ? 2 : 1)
 gemm_nt2_kernel(const float* __restrict__ A, long long lda, const float* __restrict__ Bimg, long long ldb,
                 const float* __restrict__ bias, float* __restrict__ C, long long ldc, int M, int N, int K, int relu,
                 int stagger, ConvGeom2 cg, int c_bytes, int batch, long long sA, long long sB, long long sC,
-                const float* __restrict__ mask) {
+                const float* __restrict__ mask, unsigned long long* ts) {
+  combo_ts_begin(ts);
   // mask != nullptr (same shape / pitch as C): C = mask > 0 ? value : 0 - the ReLU backward of the layer whose OUTPUT was
   // the A operand's producer, folded into the input-gradient GEMM (dH = (dY . W2) o [H > 0] of an FFN)
   // batch > 1: `batch` independent problems of the same shape, operand b at A + b*sA, Bimg + b*sB, C + b*sC (elements)
@@ -344,6 +341,7 @@ gemm_nt2_kernel(const float* __restrict__ A, long long lda, const float* __restr
     else if (relu) epilogue(std::true_type{}, std::false_type{});
     else epilogue(std::false_type{}, std::false_type{});
   }
+  combo_ts_end(ts);
 }
 
 // Weight image for gemm_nt2: element (n, k) = src[n*ld_row + k*ld_col]; per 8 consecutive k a 16-B group of bf16 `hi`
@@ -366,8 +364,8 @@ presplit_kernel(const float* __restrict__ src, long long ld_row, long long ld_co
   unsigned h[4], l[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    h[i] = pack_hi(v[2 * i], v[2 * i + 1]);
-    l[i] = pack_rne(v[2 * i] - trunc_hi(v[2 * i]), v[2 * i + 1] - trunc_hi(v[2 * i + 1]));
+    h[i] = pack_rne(v[2 * i], v[2 * i + 1]);
+    l[i] = pack_rne(v[2 * i] - __uint_as_float(h[i] << 16), v[2 * i + 1] - __uint_as_float(h[i] & 0xffff0000u));
   }
   const long long o = ((long long)n * kg + g8) * 2;
   img[o] = make_uint4(h[0], h[1], h[2], h[3]);
@@ -406,7 +404,8 @@ int launch_nt2_cfg(const float* A, long long lda, const float* Bimg, const float
   const long long c_bytes = ((M - 1) * ldc + N) * 4;
   if (c_bytes >= 0x7fffffffLL) return COMBO_EINVAL;
   hipLaunchKernelGGL((gemm_nt2_kernel<CONV, Cfg>), dim3((unsigned)grid), dim3(256), Cfg::LDS, (hipStream_t)stream, A, lda, Bimg,
-                     (long long)K, bias, C, ldc, (int)M, N, K, relu, stagger, cg, (int)c_bytes, nb.batch, nb.sA, nb.sB, nb.sC, mask);
+                     (long long)K, bias, C, ldc, (int)M, N, K, relu, stagger, cg, (int)c_bytes, nb.batch, nb.sA, nb.sB, nb.sC, mask,
+                     combo_timing_next_slot(COMBO_TS_GEMM_X3, 2.0 * M * N * K * nb.batch));
   return (int)hipGetLastError();
 }
 

@@ -15,10 +15,6 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-__device__ __forceinline__ unsigned pack_hi(float a, float b) {
-  return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
-}
-__device__ __forceinline__ float trunc_hi(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
 __device__ __forceinline__ unsigned pack_rne(float a, float b) {
   unsigned r;
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -34,8 +30,8 @@ __device__ __forceinline__ Frag make_frag(const float (&v)[8]) {
   unsigned h[4], l[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    h[t] = pack_hi(v[2 * t], v[2 * t + 1]);
-    l[t] = pack_rne(v[2 * t] - trunc_hi(v[2 * t]), v[2 * t + 1] - trunc_hi(v[2 * t + 1]));
+    h[t] = pack_rne(v[2 * t], v[2 * t + 1]);  // hi = rne_bf16(x): the dropped lo.lo term is <= 2^-16 |x.w| and unbiased
+    l[t] = pack_rne(v[2 * t] - __uint_as_float(h[t] << 16), v[2 * t + 1] - __uint_as_float(h[t] & 0xffff0000u));
   }
   f.hi = __builtin_bit_cast(bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
   f.lo = __builtin_bit_cast(bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
@@ -384,33 +380,37 @@ struct TnGroupArgs {
   int remap;
   int block_start[kMaxGroup + 1];  // multiples of 8 when remap is on, so that (b - start) % 8 is the block's XCD
   int block_count[kMaxGroup];
+  unsigned long long* ts;  // device-side timing slot (combo_common.h) or nullptr
   combo_gemm_tn_problem p[kMaxGroup];
 };
 
 __global__ void __launch_bounds__(256, 2)
 gemm_tn_grouped_kernel(const TnGroupArgs args) {
+  combo_ts_begin(args.ts);
   const int b = blockIdx.x;
   int pi = 0;
   for (int i = 1; i < args.count; ++i)
     if (b >= args.block_start[i]) pi = i;
   const combo_gemm_tn_problem& pr = args.p[pi];
   int local = b - args.block_start[pi];
-  if (local >= args.block_count[pi]) return;  // padding block
-  // the tiles of one token chunk read the same dY / X rows: keep them on one XCD (see xcd_contiguous)
-  if (args.remap) local = xcd_contiguous(local, args.block_count[pi]);
-  int mchunk = (pr.M + pr.splits - 1) / pr.splits;
-  mchunk = (mchunk + 15) / 16 * 16;
-  const long long t2 = (long long)((pr.N + 255) / 256) * ((pr.K + 127) / 128) * 256 * 128;
-  const long long t1 = (long long)((pr.N + 127) / 128) * ((pr.K + 255) / 256) * 128 * 256;
-  if (t2 <= t1) {
-    const int tk = (pr.K + 127) / 128, tn = (pr.N + 255) / 256;
-    gemm_tn_glds_body<2, 3>(pr.dY, pr.ldy, pr.X, pr.ldx, pr.partials, pr.db_partials, pr.M, pr.N, pr.K, mchunk, local % tk,
-                            (local / tk) % tn, local / (tk * tn));
-  } else {
-    const int tk = (pr.K + 255) / 256, tn = (pr.N + 127) / 128;
-    gemm_tn_glds_body<1, 3>(pr.dY, pr.ldy, pr.X, pr.ldx, pr.partials, pr.db_partials, pr.M, pr.N, pr.K, mchunk, local % tk,
-                            (local / tk) % tn, local / (tk * tn));
+  if (local < args.block_count[pi]) {  // (else: padding block)
+    // the tiles of one token chunk read the same dY / X rows: keep them on one XCD (see xcd_contiguous)
+    if (args.remap) local = xcd_contiguous(local, args.block_count[pi]);
+    int mchunk = (pr.M + pr.splits - 1) / pr.splits;
+    mchunk = (mchunk + 15) / 16 * 16;
+    const long long t2 = (long long)((pr.N + 255) / 256) * ((pr.K + 127) / 128) * 256 * 128;
+    const long long t1 = (long long)((pr.N + 127) / 128) * ((pr.K + 255) / 256) * 128 * 256;
+    if (t2 <= t1) {
+      const int tk = (pr.K + 127) / 128, tn = (pr.N + 255) / 256;
+      gemm_tn_glds_body<2, 3>(pr.dY, pr.ldy, pr.X, pr.ldx, pr.partials, pr.db_partials, pr.M, pr.N, pr.K, mchunk, local % tk,
+                              (local / tk) % tn, local / (tk * tn));
+    } else {
+      const int tk = (pr.K + 255) / 256, tn = (pr.N + 127) / 128;
+      gemm_tn_glds_body<1, 3>(pr.dY, pr.ldy, pr.X, pr.ldx, pr.partials, pr.db_partials, pr.M, pr.N, pr.K, mchunk, local % tk,
+                              (local / tk) % tn, local / (tk * tn));
+    }
   }
+  combo_ts_end(args.ts);
 }
 
 inline bool glds_ok(const float* dY, long long ldy, const float* X, long long ldx, int M, int N, int K) {
@@ -617,6 +617,9 @@ int combo_gemm_tn_x3_grouped_f32(const combo_gemm_tn_problem* problems, int coun
     }
     a.remap = remap;
     a.block_start[a.count] = blocks;
+    double flops = 0.0;
+    for (int i = 0; i < a.count; ++i) flops += 2.0 * a.p[i].M * a.p[i].N * a.p[i].K;
+    a.ts = combo_timing_next_slot(COMBO_TS_GEMM_TN, flops);
     hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, a);
   }
   return (int)hipGetLastError();

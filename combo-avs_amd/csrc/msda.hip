@@ -987,16 +987,6 @@ size_t bwd_value_lds_bytes(int S) {
 }
 constexpr size_t kLdsLimit = 160 * 1024;
 
-// device-side launch timing (combo_msda_set_timing_buffer): a ring of 4 x u64 slots, one per launch of the forward
-// core; a launch captured into a hipGraph keeps its slot, so every replay adds its duration to the same slot
-unsigned long long* g_timing_base = nullptr;
-int g_timing_slots = 0, g_timing_next = 0;
-inline unsigned long long* next_timing_slot() {
-  if (!g_timing_base || g_timing_slots <= 0) return nullptr;
-  unsigned long long* p = g_timing_base + 4LL * (g_timing_next % g_timing_slots);
-  ++g_timing_next;
-  return p;
-}
 
 template <typename T>
 int msda_forward(const T* value, const int64_t* shapes, const int64_t* lsi, const T* loc, const T* aw, int B, int S,
@@ -1046,7 +1036,7 @@ int msda_forward(const T* value, const int64_t* shapes, const int64_t* lsi, cons
           attr12 = true;
         }
         hipLaunchKernelGGL(msda_fwd_tap_d32<12>, dim3(grid), dim3(nw * 64), lds, stream, value, shapes, lsi, loc, aw, B,
-                           S, M, L, Lq, P, QT, out, dbg, next_timing_slot());
+                           S, M, L, Lq, P, QT, out, dbg, combo_timing_next_slot(COMBO_TS_MSDA_FWD, (double)B * ((double)(S + Lq) * M * D + 3.0 * Lq * M * L * P) * 4.0));
       } else {
         if (!attr16) {
           hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_fwd_tap_d32<16>),
@@ -1055,7 +1045,7 @@ int msda_forward(const T* value, const int64_t* shapes, const int64_t* lsi, cons
           attr16 = true;
         }
         hipLaunchKernelGGL(msda_fwd_tap_d32<16>, dim3(grid), dim3(nw * 64), lds, stream, value, shapes, lsi, loc, aw, B,
-                           S, M, L, Lq, P, QT, out, dbg, next_timing_slot());
+                           S, M, L, Lq, P, QT, out, dbg, combo_timing_next_slot(COMBO_TS_MSDA_FWD, (double)B * ((double)(S + Lq) * M * D + 3.0 * Lq * M * L * P) * 4.0));
       }
       return (int)hipGetLastError();
     }
@@ -1168,22 +1158,6 @@ int combo_msda_backward_needs_zero(int S, int D, int L, int P, int elem_bytes, i
   const bool lds_ok = elem_bytes == 4 && D == 32 && S < 65535 && L * P <= kMaxLP && fwd_lds_bytes(S, L, P, 8) <= kLdsLimit &&
                       bwd_value_lds_bytes(S) <= kLdsLimit;
   return (lds_ok && algo != 1) ? 0 : 1;
-}
-
-// Device-side timing of the MSDeformAttn forward launches: `buf` = slots x 4 uint64 on the device, initialised by the
-// caller to {~0, 0, 0, 0} per slot; every following forward launch (tap kernel) gets the next slot and adds
-// (last workgroup end - first workgroup start) in wall-clock ticks to slot[2] and 1 to slot[3] - also when the launch is a
-// node of a replayed hipGraph.  buf == NULL switches it off.  combo_wall_clock_khz: tick rate of those timestamps.
-int combo_msda_set_timing_buffer(void* buf, int slots) {
-  g_timing_base = reinterpret_cast<unsigned long long*>(buf);
-  g_timing_slots = buf ? slots : 0;
-  g_timing_next = 0;
-  return 0;
-}
-int combo_wall_clock_khz(void) {
-  int dev = 0, khz = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) return 0;
-  return khz;
 }
 
 int combo_msda_forward_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,

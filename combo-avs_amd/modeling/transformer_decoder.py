@@ -215,7 +215,6 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         # one buffer for the mask logits of all prediction heads; head i fills slice i (values, no grad) ...
         logit_buf = torch.empty(nheads_pred, bt, self.num_queries, h_m * w_m, device=mf_tok.device, dtype=torch.float32)
         predictions_class, mask_embeds = [], []
-        self._mf_img = masklogit.prepare(mf_tok)  # bf16 hi/lo image of the mask features, shared by the 10 heads of this step
         outputs_class, mask_embed, blocked = self.forward_prediction_heads(output, mf_tok, (h_m, w_m), size_list[0], logit_buf[0])
         predictions_class.append(outputs_class)
         mask_embeds.append(mask_embed)
@@ -230,7 +229,6 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
             predictions_class.append(outputs_class)
             mask_embeds.append(mask_embed)
         assert len(predictions_class) == self.num_layers + 1
-        self._mf_img = None
         # ... and ONE autograd node carries the gradient of all heads back to mask_features / the mask embeddings
         logits_all = masklogit.attach_mask_logit_grads(mf_tok, logit_buf, mask_embeds)
         parts = logits_all.unbind(0)  # ONE backward node (a stack of the 10 head gradients), not 19 zero-padded slices
@@ -252,6 +250,6 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         dec = self.decoder_norm(output)
         outputs_class = self.class_embed(dec)
         mask_embed = self.mask_embed(dec)
-        masklogit.mask_logits_into(mask_embed, mf_tok, logits_out, getattr(self, "_mf_img", None))
+        masklogit.mask_logits_into(mask_embed, mf_tok, logits_out)
         blocked = masklogit.attn_mask(logits_out.view(output.shape[0], self.num_queries, hw[0], hw[1]), attn_mask_target_size, True)
         return outputs_class, mask_embed, blocked

@@ -4,10 +4,11 @@ Replaces the cuDNN convolution behind the FPN output layer `layer_1` of the refe
 (pixel_decoder/msdeformattn.py:281-286, used at :349-352): 256 -> 256 channels on the 56 x 56 map, 3.7 GFLOP per frame,
 the largest dense op of the head.  MIOpen's fp32 kernels needed 1.19 + 1.24 + 1.24 ms (forward, input
 gradient, weight gradient) at 40 frames; here
-  forward  Y  = conv(X, W)        csrc/gemm_nt.hip, CONV = true (A rows gathered per tap, zero row for the padding)
-  dX          = conv(dY, W')      the same kernel, W' = taps flipped, channels swapped
-  dW          = dY^T . im2col(X)  csrc/gemm_tn.hip, CONV = true (split-K over the tokens + the fused reduce)
-all with the 3-way bf16 split (fp32 accuracy, error ~2^-16 relative).  No im2col buffer exists anywhere.
+  forward  Y  = conv(X, W)        csrc/gemm_f32.hip, CONV = true: exact fp32 MFMA (A rows gathered per tap, zero row for
+                                  the padding) - forward values feed the decoder's mask thresholds
+  dX          = conv(dY, W')      csrc/gemm_nt2.hip, CONV = true, W' = taps flipped, channels swapped (3-product bf16 split)
+  dW          = dY^T . im2col(X)  csrc/gemm_tn.hip, CONV = true (3-product split, split-K over the tokens + the fused reduce)
+No im2col buffer exists anywhere.
 """
 import torch
 from torch.autograd import Function
@@ -28,22 +29,24 @@ def usable(conv, x):
             and x.shape[0] * x.shape[2] * x.shape[3] * max(x.shape[2], x.shape[3]) < 2 ** 31)
 
 
-def _conv_tokens(x_tok, wm, bias, B, H, W, cin, cout, relu=False):
-    """x_tok [B*H*W, cin] (row stride free), wm [cout, 9*cin] -> [B*H*W, cout]"""
+def _conv_tokens(x_tok, wm, bias, B, H, W, cin, cout, exact, relu=False):
+    """x_tok [B*H*W, cin] (row stride free), wm [cout, 9*cin] -> [B*H*W, cout].  exact: fp32 MFMA (the forward value);
+    else the 3-product bf16 split (the input gradient)."""
     y = torch.empty(B * H * W, cout, device=x_tok.device, dtype=torch.float32)
-    from . import linear as L
-    if L.NT_V2 and B * H * W * cout * 4 < 2 ** 31 - 1:  # (v2 addresses Y with 32-bit byte offsets)
-        img = L.presplit(wm)
-        with _lib.timed("conv3x3_x3", (B * H * W, cout, 9 * cin)):
-            rc = _lib.lib().combo_conv3x3_nhwc_x3_pre_f32(x_tok.data_ptr(), x_tok.stride(0), img.data_ptr(), _lib.ptr(bias),
-                                                          y.data_ptr(), cout, B, H, W, cin, cout, 1 if relu else 0,
-                                                          _lib.current_stream())
-        _lib.check(rc, "combo_conv3x3_nhwc_x3_pre_f32")
+    assert B * H * W * cout * 4 < 2 ** 31 - 1  # (the kernels address Y with 32-bit byte offsets)
+    lib, st = _lib.lib(), _lib.current_stream()
+    if exact:
+        with _lib.timed("conv3x3_f32", (B * H * W, cout, 9 * cin)):
+            rc = lib.combo_conv3x3_nhwc_f32(x_tok.data_ptr(), x_tok.stride(0), wm.data_ptr(), _lib.ptr(bias), y.data_ptr(), cout,
+                                            B, H, W, cin, cout, 1 if relu else 0, st)
+        _lib.check(rc, "combo_conv3x3_nhwc_f32")
         return y
+    from . import linear as L
+    img = L.presplit(wm)
     with _lib.timed("conv3x3_x3", (B * H * W, cout, 9 * cin)):
-        rc = _lib.lib().combo_conv3x3_nhwc_x3_f32(x_tok.data_ptr(), x_tok.stride(0), wm.data_ptr(), _lib.ptr(bias), y.data_ptr(),
-                                                  cout, B, H, W, cin, cout, 1 if relu else 0, _lib.current_stream())
-    _lib.check(rc, "combo_conv3x3_nhwc_x3_f32")
+        rc = lib.combo_conv3x3_nhwc_x3_pre_f32(x_tok.data_ptr(), x_tok.stride(0), img.data_ptr(), _lib.ptr(bias), y.data_ptr(),
+                                               cout, B, H, W, cin, cout, 1 if relu else 0, st)
+    _lib.check(rc, "combo_conv3x3_nhwc_x3_pre_f32")
     return y
 
 
@@ -80,7 +83,7 @@ class _Conv3x3(Function):
         B, cin, H, W = x.shape
         cout = weight.shape[0]
         wm = weight.permute(0, 2, 3, 1).reshape(cout, 9 * cin)  # [cout, ky, kx, cin]: one small copy per step
-        y = _conv_tokens(_tokens(x), wm, bias, B, H, W, cin, cout)
+        y = _conv_tokens(_tokens(x), wm, bias, B, H, W, cin, cout, exact=True)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         return y.view(B, H, W, cout).permute(0, 3, 1, 2)  # NCHW view, channels_last memory
@@ -98,7 +101,7 @@ class _Conv3x3(Function):
         if ctx.needs_input_grad[0]:
             # dX[t, ci] = sum_{tap, co} dY[t - shift(tap), co] W[co, ci, tap]: a convolution of dY with the flipped taps
             wt = weight.flip(2, 3).permute(1, 2, 3, 0).reshape(cin, 9 * cout)
-            dx = _conv_tokens(dy_tok, wt, None, B, H, W, cout, cin).view(B, H, W, cin).permute(0, 3, 1, 2)
+            dx = _conv_tokens(dy_tok, wt, None, B, H, W, cout, cin, exact=False).view(B, H, W, cin).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
             dw = _wgrad_tokens(dy_tok, _tokens(x), B, H, W, cin, cout).permute(0, 3, 1, 2)
             if dw.shape != weight.shape or not dw.is_contiguous():

@@ -1,26 +1,18 @@
 """`mask_embed @ pixel_embed` + next-layer attention mask (transformer_decoder.py:498-507 of the reference).
-HIP kernels: csrc/attnmask.hip (bilinear-downsample + sigmoid<0.5 + full-row reset in one launch); the contraction and its
-two gradients run on the head's own fp32-accurate bf16x3 MFMA kernels (csrc/gemm_nt2.hip batched, 128 x 128 tiles for the
-100 queries of a frame; csrc/gemm_tn.hip grouped, one problem per frame) instead of the library's batched fp32 GEMM:
-the token-major mask features are pre-split ONCE per step and shared by the 10 prediction heads."""
+HIP kernels: the forward contraction of every prediction head is a batched exact-fp32 MFMA GEMM (csrc/gemm_f32.hip, one
+problem per frame: [Q,C] x [HW,C]^T - its output is thresholded at 0 into the next layer's attention mask, so it computes in
+true fp32); csrc/attnmask.hip turns the logits into the mask (bilinear-downsample + sigmoid<0.5 + full-row reset in one
+launch); the two gradient GEMMs run ONCE over the concatenated heads on the 3-product bf16 kernels (csrc/gemm_nt2.hip
+batched, csrc/gemm_tn.hip grouped, one problem per frame)."""
 import ctypes
-import os
 
 import torch
 
 from .. import _lib
 
-HIP_GEMMS = os.environ.get("COMBO_MASKLOGIT_HIP", "1") == "1"  # 0: torch.bmm (A/B measurements)
-# The FORWARD contraction stays on the library's true-fp32 GEMM by default: its output is thresholded at 0 into the next
-# layer's attention mask, and the 2^-16 relative error of the 3-product bf16 split flips about twice as many near-zero
-# cells as fp32 round-off does (tests/test_head_gpu.py::test_decoder_outputs_match_reference: 0.98 % instead of < 0.5 % of
-# the final mask logits off by more than 1e-3) - measured -0.45 ms per step, not taken.  The two gradient GEMMs have no
-# such cliff and run on the HIP kernels (-0.45 ms per step).
-HIP_FORWARD = os.environ.get("COMBO_MASKLOGIT_HIP_FWD", "0") == "1"
-
 
 def _hip_ok(*ts):
-    return HIP_GEMMS and all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0 for t in ts)
+    return all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0 for t in ts)
 
 
 def presplit_batched(x, transpose):
@@ -43,14 +35,6 @@ def gemm_nt_batched(a, img, out):
                                                          M, N, K, B, 0, _lib.current_stream())
     _lib.check(rc, "combo_gemm_nt_x3_pre_batched_f32")
     return out
-
-
-def prepare(mf_tok):
-    """pre-split image of the token-major mask features [BT, HW, C] for mask_logits_into (shared by all heads of a step)"""
-    mf = mf_tok.detach()
-    if HIP_FORWARD and _hip_ok(mf) and mf.shape[2] % 16 == 0:
-        return presplit_batched(mf, transpose=False)
-    return None
 
 
 def attn_mask(logits, target_size, reset_full_rows=True):
@@ -108,21 +92,15 @@ def attach_mask_logit_grads(mf_tok, buffer, mask_embeds):
     return _MaskLogitsAll.apply(mf_tok, buffer, *mask_embeds)
 
 
-def mask_logits_into(mask_embed, mf_tok, out, mf_img=None):
-    """no-grad: out[BT,Q,HW] = mask_embed @ mf_tok^T (fp32); mf_img = prepare(mf_tok) routes it to csrc/gemm_nt2.hip"""
-    me = mask_embed.detach()
-    if mf_img is not None and _hip_ok(me, out) and me.shape[2] % 16 == 0:
-        return gemm_nt_batched(me, mf_img, out)
-    with torch.no_grad(), torch.autocast("cuda", enabled=False):
-        torch.bmm(mask_embed.detach().float(), mf_tok.detach().float().transpose(1, 2), out=out)
+def mask_logits_into(mask_embed, mf_tok, out):
+    """no-grad: out[BT,Q,HW] = mask_embed @ mf_tok^T in exact fp32 (csrc/gemm_f32.hip, batched over the frames)"""
+    me, mf = mask_embed.detach(), mf_tok.detach()
+    B, Q, C = me.shape
+    HW = mf.shape[1]
+    if not (_hip_ok(me, mf, out) and C % 16 == 0 and Q * HW * 4 < 2 ** 31 - 1):
+        raise RuntimeError("mask_logits_into: fp32 contiguous 16-byte aligned CUDA tensors with C % 16 == 0 expected")
+    with _lib.timed("gemm_nt_f32", (B * Q, HW, C)):
+        rc = _lib.lib().combo_gemm_nt_batched_f32(me.data_ptr(), C, Q * C, mf.data_ptr(), C, HW * C, out.data_ptr(), HW, Q * HW,
+                                                  Q, HW, C, B, 0, _lib.current_stream())
+    _lib.check(rc, "combo_gemm_nt_batched_f32")
     return out
-
-
-def mask_logits_and_attn_mask(mask_embed, mf_tok, hw, target_size):
-    """mask_embed [BT,Q,C], mf_tok [BT,HW,C] token-major -> (logits [BT,Q,H,W], blocked bool [BT,Q,h*w]).
-    The returned mask already has fully-blocked rows reset (it is only ever consumed by the next layer)."""
-    bt, Q, _ = mask_embed.shape
-    with torch.autocast("cuda", enabled=False):  # mask logits are always produced in fp32
-        logits = torch.bmm(mask_embed.float(), mf_tok.float().transpose(1, 2)).view(bt, Q, hw[0], hw[1])
-    blocked = attn_mask(logits.detach().float().contiguous(), target_size, True)
-    return logits, blocked

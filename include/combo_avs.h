@@ -36,11 +36,18 @@ typedef void* combo_stream_t;
 /* Library / device introspection (host only, no GPU needed). */
 int combo_abi_version(void);
 
-/* Measurement aid (bench.py): device-side timing of the MSDeformAttn forward core.  HIP refuses event records inside a
- * captured hipGraph on ROCm 7, so the kernel itself takes wall-clock timestamps: `buf` = slots x 4 uint64 on the device,
- * initialised to {~0, 0, 0, 0} per slot; every following forward launch takes the next slot (a graph node keeps its slot
- * over all replays) and adds its duration in ticks to slot[2] and 1 to slot[3].  NULL switches it off. */
-int combo_msda_set_timing_buffer(void* buf, int slots);
+/* Measurement aid (bench.py): device-side timing of the instrumented kernels.  HIP refuses event records inside a
+ * captured hipGraph on ROCm 7, so the kernels take wall-clock timestamps themselves: `buf` = slots x 4 uint64 on the
+ * device, initialised to {~0, 0, 0, 0} per slot; every following instrumented launch takes the next slot (a graph node
+ * keeps its slot over all replays) and adds (last workgroup end - first workgroup start) in ticks to slot[2] and 1 to
+ * slot[3].  combo_timing_slot_info returns what the host recorded for a slot: kind (0 MSDeformAttn forward core,
+ * 1 fp32-MFMA GEMM, 2 3xbf16 forward/dX GEMM, 3 weight-gradient GEMM, 4/5 decoder attention forward/backward,
+ * 6 MSDeformAttn backward) and its algorithmic work per launch (bytes for the HBM-bound kinds 0 and 6, flops
+ * 2*M*N*K for the others).  buf == NULL switches timing off.  The reference has no counterpart (it times whole
+ * iterations with detectron2's IterationTimer, models/evaluation/evaluator.py:149-228). */
+int combo_timing_set_buffer(void* buf, int slots);
+int combo_timing_slots_used(void);
+int combo_timing_slot_info(int slot, int* kind, double* work);
 int combo_wall_clock_khz(void);
 const char* combo_build_arch(void); /* "gfx950" */
 
@@ -197,30 +204,38 @@ int combo_bifuse_backward2_f32(const float* x, const float* ln_w, const float* l
                                float* du_part, float* dc_part, float* dln_part, combo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
- * a4/a5/a11/a12  dense layers of the head: fp32-accurate GEMM on the bf16 matrix cores (3-way bf16 split)
- *   replaces the nn.Linear calls of the encoder / decoder (pixel_decoder/msdeformattn.py:119-134,
- *   ops/modules/ms_deform_attn.py:102-108,128, transformer_decoder.py:99-118,50-58,178-182,216-219) and their
- *   backward GEMMs:  C[M,N] = sum_k A(m,k) * B(n,k)  (+ bias[n], + ReLU)
- *   a_rowc / b_rowc = 0: operand stored [rows][K] (k contiguous, leading dimension ld);
- *                   = 1: operand stored [K][rows] (row contiguous) - used for dX = dY.W and dW = dY^T.X.
- *   splits > 1: split-K; partial result z is written at C + z*split_stride (no bias/relu), the caller sums
- *   combo_gemm_x3_splits(K, splits) partials.  All extents that are walked with float4 loads must be multiples of 4.
+ * a4/a5/a11/a12  dense layers of the head
+ *   replace the nn.Linear calls of the encoder / decoder (pixel_decoder/msdeformattn.py:119-134,
+ *   ops/modules/ms_deform_attn.py:102-108,128, transformer_decoder.py:99-118,50-58,178-182,216-219), the 1x1 / 3x3
+ *   convolutions of the pixel decoder (msdeformattn.py:215-224, 271-286) and their backward GEMMs:
+ *   forward in exact fp32 (combo_gemm_nt_f32 ...), gradients with the 3-product bf16 split (combo_gemm_nt_x3_* for dX,
+ *   combo_gemm_tn_x3_* for dW).
  * ---------------------------------------------------------------------------------------------- */
-int combo_gemm_x3_splits(int K, int requested);
-int combo_gemm_x3_f32(const float* A, long long lda, int a_rowc, const float* B, long long ldb, int b_rowc,
-                      const float* bias, float* C, long long ldc, int M, int N, int K, int relu, int splits,
-                      long long split_stride, combo_stream_t stream);
+/*   FORWARD dense layers in exact fp32 on the matrix cores (csrc/gemm_f32.hip, v_mfma_f32_32x32x2_f32: f32 in, f32
+ *   accumulate, one rounding per product): C[M,N] = A[M,K] . B[N,K]^T (+ bias[N]) (+ ReLU), both operands K-contiguous
+ *   (A = tokens, B = the nn.Linear weight as stored).  Every forward nn.Linear / 1x1 convolution of the head runs here
+ *   (same reference lines as the block above): their outputs end in the decoder's `sigmoid(logit) < 0.5` attention masks
+ *   (transformer_decoder.py:502-507), where the 2^-17 relative error of the 3-product split flips near-zero cells.
+ *   K % 16 == 0, lda/ldb % 4 == 0, A and B 16-byte aligned, C addressed with 32-bit byte offsets.
+ *   _batched: `batch` problems of one shape, operand b at base + b*stride (elements): the mask-logit contraction
+ *   einsum("bqc,bchw->bqhw") of every prediction head (transformer_decoder.py:498-500), A = mask_embed [BT,Q,C],
+ *   B = token-major mask features [BT,HW,C].
+ *   combo_conv3x3_nhwc_f32: the FPN output convolution (msdeformattn.py:281-286, 349-352) as an implicit GEMM on the
+ *   same loop (layout contract: see combo_conv3x3_nhwc_x3_pre_f32 below). */
+int combo_gemm_nt_f32(const float* A, long long lda, const float* B, long long ldb, const float* bias, float* C,
+                      long long ldc, int M, int N, int K, int relu, combo_stream_t stream);
+int combo_gemm_nt_batched_f32(const float* A, long long lda, long long sA, const float* B, long long ldb, long long sB,
+                              float* C, long long ldc, long long sC, int M, int N, int K, int batch, int relu,
+                              combo_stream_t stream);
+int combo_conv3x3_nhwc_f32(const float* X, long long ldx, const float* Wm, const float* bias, float* Y, long long ldy,
+                           int B, int H, int W, int Cin, int Cout, int relu, combo_stream_t stream);
 
-/*   Forward / input-gradient GEMM C[M,N] = A[M,K] . B[N,K]^T (+ bias[N]) (+ ReLU) with the same 3-way bf16 split, both
- *   operands K-contiguous (A = tokens, B = an nn.Linear weight; for dX = dY . W pass B = W^T).  LDS-DMA ring with a
- *   source-side chunk swizzle (csrc/gemm_nt.hip).  K % 16 == 0, lda/ldb % 4 == 0, A and B 16-byte aligned. */
-int combo_gemm_nt_x3_f32(const float* A, long long lda, const float* B, long long ldb, const float* bias, float* C,
-                         long long ldc, int M, int N, int K, int relu, combo_stream_t stream);
-
-/*   v2 of the forward / input-gradient GEMM (csrc/gemm_nt2.hip): persistent workgroups with the next tile's first
- *   stages in flight under the epilogue stores, 4 x 1 waves, and the weight operand PRE-SPLIT into bf16 hi/lo groups by
- *   combo_presplit_bf16x2_f32 (element (n, k) = src[n*ld_row + k*ld_col], so W and W^T need no transpose copy; the image
- *   has N rows of K floats, 16-byte aligned, K % 8 == 0).  Same contract as combo_gemm_nt_x3_f32 otherwise. */
+/*   Input-gradient GEMM C[M,N] = A[M,K] . B[N,K]^T (+ bias[N]) (+ ReLU) with the 3-product bf16 split (x.w ~ hi.hi +
+ *   hi.lo + lo.hi, hi = rne_bf16, ~2^-17 relative per product) on the bf16 matrix cores (csrc/gemm_nt2.hip): persistent
+ *   workgroups with the next tile's first stages in flight under the epilogue stores, LDS-DMA ring with a source-side chunk
+ *   swizzle, and the weight operand PRE-SPLIT into bf16 hi/lo groups by combo_presplit_bf16x2_f32 (element (n, k) =
+ *   src[n*ld_row + k*ld_col], so for dX = dY . W the image of W^T needs no transpose copy; the image has N rows of K
+ *   floats, 16-byte aligned, K % 8 == 0).  K % 16 == 0, lda % 4 == 0, A and the image 16-byte aligned. */
 int combo_presplit_bf16x2_f32(const float* src, long long ld_row, long long ld_col, int N, int K, float* img,
                               combo_stream_t stream);
 int combo_gemm_nt_x3_pre_f32(const float* A, long long lda, const float* Bimg, const float* bias, float* C, long long ldc,
@@ -241,18 +256,14 @@ int combo_presplit_bf16x2_batched_f32(const float* src, long long ld_row, long l
 int combo_gemm_nt_x3_pre_batched_f32(const float* A, long long lda, long long sA, const float* Bimg, long long sB, float* C,
                                      long long ldc, long long sC, int M, int N, int K, int batch, int relu,
                                      combo_stream_t stream);
-/*   combo_conv3x3_nhwc_x3_f32 on the v2 kernel: Wimg = combo_presplit_bf16x2_f32 of the [Cout, 9*Cin] weight matrix. */
+/*   3x3 / stride 1 / pad 1 convolution on an NHWC fp32 map as an implicit GEMM (the FPN output convolution `layer_1` of
+ *   the reference's pixel decoder, pixel_decoder/msdeformattn.py:281-286,349-352, which the reference runs through cuDNN):
+ *   X = [B*H*W tokens, Cin] (row stride ldx), weight as [Cout, 3, 3, Cin] (K = 9*Cin contiguous), Y = [B*H*W, Cout] (row
+ *   stride ldy) (+ bias[Cout]) (+ ReLU).  combo_conv3x3_nhwc_f32 (above): forward, exact fp32, Wm = that weight matrix.
+ *   combo_conv3x3_nhwc_x3_pre_f32: the input gradient - the same call on dY with the weight as [Cin, 3', 3', Cout] (taps
+ *   flipped), 3-product split, Wimg = combo_presplit_bf16x2_f32 of that matrix.  Cin % 16 == 0, ldx % 4 == 0. */
 int combo_conv3x3_nhwc_x3_pre_f32(const float* X, long long ldx, const float* Wimg, const float* bias, float* Y,
                                   long long ldy, int B, int H, int W, int Cin, int Cout, int relu, combo_stream_t stream);
-
-/*   3x3 / stride 1 / pad 1 convolution on an NHWC fp32 map as an implicit GEMM on the same kernel (replaces the FPN
- *   output convolution `layer_1` of the reference's pixel decoder, pixel_decoder/msdeformattn.py:281-286,349-352, which
- *   the reference runs through cuDNN): X = [B*H*W tokens, Cin] (row stride ldx), Wm = the weight as [Cout, 3, 3, Cin]
- *   (K = 9*Cin contiguous), Y = [B*H*W, Cout] (row stride ldy) (+ bias[Cout]) (+ ReLU).  The input gradient is the same
- *   call on dY with Wm = the weight as [Cin, 3', 3', Cout] (taps flipped).  Cin % 16 == 0, ldx % 4 == 0, X / Wm 16-byte
- *   aligned. */
-int combo_conv3x3_nhwc_x3_f32(const float* X, long long ldx, const float* Wm, const float* bias, float* Y, long long ldy,
-                              int B, int H, int W, int Cin, int Cout, int relu, combo_stream_t stream);
 
 /*   Weight gradient of that convolution, split-K over the tokens like combo_gemm_tn_x3_f32: partial z is written at
  *   out_partials + z*Cout*9*Cin in [Cout, 3, 3, Cin] order; finish with combo_splitk_reduce_f32.  `splits` as for

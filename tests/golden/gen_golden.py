@@ -278,7 +278,7 @@ def gen_head_and_criterion(R):
         idx = matcher(fin, targets)
         crit[f"{mode}/match_src"] = np.stack([i.numpy() for i, _ in idx])
         crit[f"{mode}/match_tgt"] = np.stack([j.numpy() for _, j in idx])
-        if mode in ("s4", "all"):
+        if True:  # gradient digests for every mode (round 2: the AVSS variant as well)
             gi = list(feats.values()) + [audio] + [named[n] for n in grad_params]
             grads = torch.autograd.grad(total, gi, retain_graph=True, allow_unused=True)
             names = [f"feat.{k}" for k in feats] + ["feat.audio"] + grad_params

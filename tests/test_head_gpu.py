@@ -45,48 +45,50 @@ def head_run():
 
 
 def test_decoder_outputs_match_reference(head_run):
+    """BASELINE.json north_star: mask logits within 1e-3 rel (fp32) of the reference - checked at the stated bound on the
+    PRODUCT DEFAULT path, no outlier budget: every sampled mask logit of all 10 prediction heads within
+    1e-3 * RMS(head) + 1e-3 * |ref| (the logits have RMS ~5; near-zero entries are judged against the head's scale).
+    Forward dense layers run in exact fp32 (csrc/gemm_f32.hip), so attention-mask cells flip only where fp32 round-off
+    itself straddles 0 (transformer_decoder.py:493-509)."""
     z, head, feats, audio, out = head_run
     logits = [a["pred_logits"] for a in out["aux_outputs"]] + [out["pred_logits"]]
     masks = [a["pred_masks"] for a in out["aux_outputs"]] + [out["pred_masks"]]
     got, ref = torch.stack(logits).detach().cpu().numpy(), z["dec/pred_logits"]
-    bad = np.abs(got - ref) > 2e-3 + 2e-3 * np.abs(ref)
-    # a flipped attention-mask bit (cell logit within float round-off of 0) perturbs single queries: allow 0.2 % outliers
-    assert bad.mean() <= 2e-3, (bad.sum(), np.abs(got - ref).max())
+    bad = np.abs(got - ref) > 1e-3 * np.sqrt((ref ** 2).mean()) + 1e-3 * np.abs(ref)
+    assert bad.sum() == 0, (bad.sum(), np.abs(got - ref).max())
     for i, m in enumerate(masks):
-        # BASELINE.json north_star: mask logits within 1e-3 rel (fp32); logits have RMS ~5, so atol 1e-3*RMS.
-        # The product's dense layers compute fp32 products from three bf16 MFMA products (relative error 2^-16, fp32 has
-        # 2^-24): a cell of a 7x7 / 14x14 / 28x28 attention mask whose logit lies within ~1e-4 of the threshold can flip,
-        # which perturbs that one query in the following layers.  Measured on MI355X with the product defaults
-        # (COMBO_TEST_VERBOSE=1): 0 % of the sampled logits beyond tolerance up to head 6, 0.07 % / 0.42 % / 0.66 % at heads
-        # 7 / 8 / 9; with true-fp32 library GEMMs 0 % everywhere (next test).  Budget: 1 % per head.
-        synth.check_digest(m.cpu(), synth.unpack(f"dec/pred_masks{i}", z), f"dec/pred_masks{i}", rtol=1e-3, atol=5e-3,
-                           frac_bad=0.01)
+        d = synth.unpack(f"dec/pred_masks{i}", z)
+        rms = float(d["l2"]) / np.sqrt(float(d["numel"]))
+        synth.check_digest(m.cpu(), d, f"dec/pred_masks{i}", rtol=1e-3, atol=1e-3 * rms, frac_bad=0.0)
     assert len(out["middles_attn_mask"]) == 9 and out["middles_attn_mask"][0].shape == (5, 100, 3136)
 
 
-def test_decoder_outputs_with_true_fp32_gemms_have_no_outliers():
-    """The same head with every dense layer on the library's plain fp32 GEMM (`ops.linear.set_impl("library")`): all 10
-    mask-logit heads within tolerance with NO outlier budget.  Together with the test above this attributes every
-    deviation of the product path to the documented 3-product bf16 arithmetic of its GEMM kernels - not to the HIP
-    kernels' logic (MSDeformAttn, fusion, attention masks, layout handling are identical in both runs)."""
-    from combo_avs_amd.ops import linear as L
-    z = np.load(os.path.join(G, "head.npz"))
-    spec = json.loads(str(z["spec"]))
-    prev = L._IMPL
-    L.set_impl("library")
-    try:
-        head, _ = build_head()
-        head.load_state_dict(synth.synth_state_dict(spec, 0))
-        head = head.cuda().eval()
-        feats, audio = gen_inputs.head_inputs()
-        with torch.no_grad():
-            out = head({k: v.cuda() for k, v in feats.items()}, audio.cuda())
-        torch.cuda.synchronize()
-    finally:
-        L.set_impl(prev)
+def test_attention_masks_match_reference_bit_for_bit_up_to_round_off(head_run):
+    """The thresholded masks themselves: recompute `sigmoid(bilinear_down(logits)) < 0.5` from the product's logits with
+    the mask kernel and from the golden sample positions' sign; cells may differ only where the golden logit lies within
+    fp32 round-off of the threshold (counted)."""
+    from combo_avs_amd.ops import masklogit
+    z, head, feats, audio, out = head_run
     masks = [a["pred_masks"] for a in out["aux_outputs"]] + [out["pred_masks"]]
+    flips = 0
     for i, m in enumerate(masks):
-        synth.check_digest(m.cpu(), synth.unpack(f"dec/pred_masks{i}", z), f"dec/pred_masks{i}", rtol=1e-3, atol=1e-3, frac_bad=0.0)
+        d = synth.unpack(f"dec/pred_masks{i}", z)
+        idx = synth.digest_indices(m.numel(), 4096, f"dec/pred_masks{i}")
+        got = m.detach().reshape(-1).cpu().numpy()[idx].astype(np.float64)
+        ref = np.asarray(d["sample"]).astype(np.float64)
+        differ = (got < 0) != (ref < 0)
+        rms = float(d["l2"]) / np.sqrt(float(d["numel"]))
+        assert np.all(np.abs(ref[differ]) < 1e-5 * rms), (i, np.abs(ref[differ]).max())
+        flips += int(differ.sum())
+        # the mask kernel on the product's logits == the reference rule applied by torch on the same logits
+        tgt = [(7, 7), (14, 14), (28, 28)][i % 3]
+        blocked = masklogit.attn_mask(m.detach().contiguous(), tgt, True)
+        down = torch.nn.functional.interpolate(m.detach(), size=tgt, mode="bilinear", align_corners=False)
+        ref_blocked = (down.sigmoid().flatten(2) < 0.5)
+        ref_blocked[ref_blocked.all(-1)] = False
+        near = (down.flatten(2).abs() < 1e-5 * rms)
+        assert bool(((blocked == ref_blocked) | near).all())
+    assert flips <= 2, flips
 
 
 def test_intermediates_match_reference(head_run):
@@ -147,10 +149,10 @@ def test_criterion_matches_reference(head_run, mode):
     keys = json.loads(str(zc[f"{mode}/keys"]))
     assert sorted(losses.keys()) == keys
     got = np.array([float(losses[k]) for k in keys])
-    np.testing.assert_allclose(got, zc[f"{mode}/values"], rtol=5e-3, atol=5e-4)
+    np.testing.assert_allclose(got, zc[f"{mode}/values"], rtol=2e-3, atol=2e-4)
     total = sum(losses[k] * wd[k] for k in keys)
-    np.testing.assert_allclose(float(total), float(zc[f"{mode}/total"]), rtol=2e-3)
-    if mode == "ss":
+    np.testing.assert_allclose(float(total), float(zc[f"{mode}/total"]), rtol=1e-3)
+    if f"{mode}/grad/feat.audio/sample" not in zc.files:
         return
     grad_params = json.loads(str(zc["grad_params"]))
     named = dict(head.named_parameters())
@@ -160,7 +162,8 @@ def test_criterion_matches_reference(head_run, mode):
     for n, g in zip(names, grads):
         d = synth.unpack(f"{mode}/grad/{n}", zc)
         scale = float(d["l2"]) / max(np.sqrt(float(d["numel"])), 1.0)
-        synth.check_digest(g.cpu(), d, f"{mode}/grad/{n}", rtol=2e-2, atol=2e-2 * scale + 1e-9, frac_bad=0.02)
+        # gradients pass through the 3-product bf16 backward GEMMs (2^-17 per product): 2e-3 of the tensor's RMS
+        synth.check_digest(g.cpu(), d, f"{mode}/grad/{n}", rtol=2e-3, atol=2e-3 * scale + 1e-9, frac_bad=0.002)
 
 
 def test_fast_matching_path_agrees_with_replay(head_run):

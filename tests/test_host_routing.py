@@ -6,12 +6,17 @@ import torch.nn.functional as F
 
 
 class _FakeCuda:
-    """shape/stride/pointer view of a would-be CUDA tensor for the routing predicate (no GPU in this container)"""
+    """shape/stride/pointer view of a would-be CUDA tensor for the kernel-contract predicates (no GPU in this container)"""
+    is_cuda = True
+    dtype = torch.float32
 
     def __init__(self, rows, cols, stride0=None, ptr=4096):
         self.shape = (rows, cols)
         self._s = (stride0 or cols, 1)
         self._p = ptr
+
+    def dim(self):
+        return 2
 
     def stride(self, i):
         return self._s[i]
@@ -20,20 +25,22 @@ class _FakeCuda:
         return self._p
 
 
-def test_gemm_routing_follows_the_in_graph_sweep():
+def test_kernel_contract_predicates():
+    """ops.linear routes every fp32 CUDA layer to the head's own kernels; only operands outside the kernels' contracts
+    (K % 16, 16-byte alignment, row pitch % 4, 32-bit addressable output) go through torch."""
     import combo_avs_amd  # noqa: F401
     from combo_avs_amd.ops import linear as L
-    assert L.NT_V2
-    ok = lambda M, K, N: L._nt_ok(_FakeCuda(M, K), N)  # noqa: E731
-    # wins of profiles/r01_gemm_routing_sweep.txt
-    assert ok(41160, 256, 1024) and ok(41160, 256, 256) and ok(31360, 256, 256) and ok(4000, 256, 2048) and ok(41160, 256, 288)
-    assert ok(16384, 2048, 256) and ok(125440, 256, 256)
-    # losses: few tiles (long K or small M), tiny N, unaligned operands
-    assert not ok(4000, 2048, 256) and not ok(4000, 256, 256) and not ok(1960, 256, 256) and not ok(7840, 256, 256)
-    assert not ok(41160, 256, 3)
-    assert not L._nt_ok(_FakeCuda(41160, 250), 1024)            # K % 16
-    assert not L._nt_ok(_FakeCuda(41160, 256, ptr=4100), 1024)  # 16-byte alignment
-    assert not L._nt_ok(_FakeCuda(41160, 256, stride0=258), 1024)  # row pitch % 4
+    ok = lambda M, K, N, **kw: L.f32_ok(_FakeCuda(M, K, **kw), _FakeCuda(N, K))  # noqa: E731
+    for M, K, N in ((41160, 256, 1024), (4000, 256, 256), (1960, 256, 512), (40, 128, 4096), (4000, 256, 3), (1, 16, 1)):
+        assert ok(M, K, N)
+    assert not ok(41160, 250, 1024)               # K % 16
+    assert not ok(41160, 256, 1024, ptr=4100)     # 16-byte alignment
+    assert not ok(41160, 256, 1024, stride0=258)  # row pitch % 4
+    assert not ok(1 << 20, 256, 1024)             # output beyond 32-bit byte offsets
+    assert L.x3_ok(_FakeCuda(4000, 256), 256) and not L.x3_ok(_FakeCuda(4000, 3), 256)
+    # deferred weight gradients: destination / operand contracts of the grouped kernel
+    assert L._dest_ok(torch.empty(256, 256)) and not L._dest_ok(torch.empty(3, 256)) and not L._dest_ok(torch.empty(256, 40))
+    assert L._use_ok(_FakeCuda(4000, 256), _FakeCuda(4000, 256)) and not L._use_ok(_FakeCuda(40, 256), _FakeCuda(40, 256))
 
 
 def test_conv3x3_applicability():

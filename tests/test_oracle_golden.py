@@ -176,15 +176,14 @@ def test_criterion_losses_and_grads(head_run, mode):
     idx = O.hungarian_matcher(out["pred_logits"][sel].detach(), out["pred_masks"][sel].detach(), targets)
     assert np.array_equal(np.stack([i.numpy() for i, _ in idx]), zc[f"{mode}/match_src"])
     assert np.array_equal(np.stack([j.numpy() for _, j in idx]), zc[f"{mode}/match_tgt"])
-    if mode == "ss":
-        return
     grad_params = json.loads(str(zc["grad_params"]))
     for p in grad_params:
         P[p].requires_grad_(True)
     # P entries were not requiring grad during the forward above -> recompute the forward with grads on
     out2 = O.head_forward(P, "", feats, audio)
     torch.manual_seed(11)
-    losses2 = O.set_criterion(out2, targets, 2)
+    losses2 = (O.set_criterion(out2, targets, 2, gt_frame_index=torch.where(gt_flag == 1)[0]) if mode == "ss"
+               else O.set_criterion(out2, targets, 2))
     total2 = sum(losses2[k] * wd[k] for k in keys)
     gi = list(feats.values()) + [audio] + [P[p] for p in grad_params]
     grads = torch.autograd.grad(total2, gi, allow_unused=True)
@@ -192,7 +191,11 @@ def test_criterion_losses_and_grads(head_run, mode):
     for n, g in zip(names, grads):
         d = synth.unpack(f"{mode}/grad/{n}", zc)
         scale = float(d["l2"]) / max(np.sqrt(float(d["numel"])), 1.0)
-        synth.check_digest(g, d, f"{mode}/grad/{n}", rtol=5e-3, atol=5e-3 * scale + 1e-9, frac_bad=0.01)
+        # Noise floor of this comparison: the oracle differs from the reference only by fp32 re-association, yet in the modes
+        # with ground truth on every frame up to 1.6 % of the sampled gradient entries of the 7x7-level parameters move by more
+        # than 5e-3 of the tensor's RMS (s4: none) - a near-zero attention-mask cell or a top-k tie of the importance
+        # sampling that falls the other way changes one query's gradient wholesale.  The GPU tests inherit this floor.
+        synth.check_digest(g, d, f"{mode}/grad/{n}", rtol=5e-3, atol=5e-3 * scale + 1e-9, frac_bad=0.01 if mode == "s4" else 0.03)
     for p in grad_params:
         P[p].requires_grad_(False)
 

@@ -48,7 +48,6 @@ M2, K2, N2 = 41160, 256, 1024
 a3 = torch.randn(M2, K2, device="cuda", dtype=torch.bfloat16); b3 = torch.randn(N2, K2, device="cuda", dtype=torch.bfloat16)
 run("hipBLASLt bf16 41160x256x1024 NT", lambda: torch.matmul(a3, b3.t()), 2.0 * M2 * N2 * K2)
 af = torch.randn(M, K, device="cuda"); wf = torch.randn(N, K, device="cuda"); out = torch.empty(M, N, device="cuda"); img = presplit(wf)
-run("gemm_nt v1 125440x2304x256 (x3)", lambda: L.combo_gemm_nt_x3_f32(af.data_ptr(), K, wf.data_ptr(), K, None, out.data_ptr(), N, M, N, K, 0, st), 6.0 * M * N * K)
 run("gemm_nt v2 125440x2304x256 (x3)", lambda: L.combo_gemm_nt_x3_pre_f32(af.data_ptr(), K, img.data_ptr(), None, out.data_ptr(), N, M, N, K, 0, st), 6.0 * M * N * K)
 x = torch.randn(1 << 28, device="cuda"); y = torch.empty_like(x)
 run("copy 1 GiB (GB/s in TF col /1e3)", lambda: y.copy_(x), 2.0 * x.numel() * 4)
