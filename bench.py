@@ -312,9 +312,9 @@ def main():
         tsv = ts_buf.cpu()
         lib = _clib.lib()
         used = lib.combo_timing_slots_used()
-        lib.combo_timing_set_buffer(None, 0)
         khz = lib.combo_wall_clock_khz()
         import ctypes
+        lib.combo_timing_slot_info.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]
         for sl in range(min(used, n_slots)):
             kind, work = ctypes.c_int(0), ctypes.c_double(0.0)
             lib.combo_timing_slot_info(sl, ctypes.byref(kind), ctypes.byref(work))
@@ -325,6 +325,7 @@ def main():
                 d["launches"] += n_l
                 d["work"] += work.value * n_l
                 d["nodes"] += 1
+        lib.combo_timing_set_buffer(None, 0)
     kt = {"fwd_us": [], "bwd_us": [], "kernels": {}}
     if args.no_graph:
         kt = msda.stop_timing()

@@ -6,23 +6,31 @@
 // against fp32's 2^-24.  Every FORWARD dense layer of the head ends, a few layers later, in `sigmoid(logit) < 0.5` (the
 // attention masks of the decoder, transformer_decoder.py:502-507): a cell whose logit lies within the error band of 0
 // flips, and the flip perturbs that query in all following layers - 0.07 / 0.42 / 0.66 % of the mask logits of prediction
-// heads 7 / 8 / 9 ended beyond the north-star's 1e-3 tolerance.  With true-fp32 GEMMs the same head has no outlier
+// heads 7 / 8 / 9 ended beyond the north-star's 1e-3 tolerance.  With fp32 GEMMs the same head has no outlier
 // (tests/test_head_gpu.py).  So the forward path computes in fp32; the gradient GEMMs (no threshold downstream, tolerance
 // 2e-3) keep the 3-product split, which is ~1.9x faster.
 //
 // Roofline: MFMA-bound.  The f32 MFMA issues once per 64 cycles per SIMD = 64 flop/clk/SIMD = 157.3 TFLOP/s on the chip
-// (the fp32 vector rate, 1/16 of bf16).  Per wave and BK = 16 stage a 2 x 4 tile set is 64 MFMAs = 4096 cycles against
-// 12 ds_read_b128 and 6 LDS-DMA pieces: the operand traffic is a rounding error, so the design keeps gemm_nt2's proven
-// streaming skeleton unchanged (persistent workgroups, XCD-contiguous tile order, LDS-DMA ring with the chunk swizzle on
-// the SOURCE address, counted vmcnt across a raw s_barrier, buffer-store epilogue) and spends its thought on tile
-// quantisation instead - at 64 cycles per MFMA an idle SIMD is the only way to lose time:
-//   wide   256 x 128 (4 x 1 waves, 2 x 4 tiles, 2 workgroups/CU)  large M, N >= 128
-//   mid    128 x 128 (2 x 2 waves, 2 x 2 tiles, 3 workgroups/CU)  M ~ 100 per batch entry (mask logits), mid-sized layers
-//   skinny  64 x  64 (2 x 2 waves, 1 x 1 tiles, ring = a K = 256 panel) the decoder's 4000-token layers: 252 tiles
-// chosen per call by the smallest "busiest CU" load (launch_f32 below).
+// (the fp32 vector rate, 1/16 of bf16); operand traffic is a rounding error next to that (12 ds_read_b128 and 6 LDS-DMA
+// pieces per 64 MFMAs), so the only way to lose time is an idle matrix pipe.  v1 of this file (gemm_nt2's skeleton: two
+// workgroups per CU taking turns) measured 48-74 % of the peak: equal tiles keep the two workgroups in phase, so both sit in
+// their epilogue (128 scattered dword stores per lane) or at the per-stage barrier at the same time.  v2 makes ONE wave per
+// SIMD keep its pipe busy on its own:
+//   * one persistent workgroup per CU (4 waves, 512 registers each), LDS-DMA ring of BK = 16 stages as before (chunk swizzle
+//     on the SOURCE address, counted vmcnt across a raw s_barrier);
+//   * rolling half-stage operand prefetch: while the MFMAs of k = 0..7 of a stage issue, the k = 8..15 fragments are read
+//     from LDS into the registers the previous half just freed (and vice versa, across stage and tile boundaries), so no
+//     MFMA ever waits on an LDS read and the one barrier per stage falls between two MFMA blocks;
+//   * the last half-stage of a tile runs sub-tile-major (4 dependent MFMAs per 32 x 32 sub-tile: the dependent latency of
+//     this MFMA equals its issue interval) and stores the previous, finished sub-tile meanwhile: the epilogue hides behind
+//     MFMAs, and the next tile's first fragments are already in registers when it ends;
+//   * MFMA operands swapped (D = W . X^T): a lane then owns 4 consecutive n of one token, i.e. dwordx4 stores - 4 instead
+//     of 16 store instructions per 32 x 32 sub-tile.
+// Tile shapes (chosen per call by the smallest "busiest CU" load, launch_f32 below):
+//   wide   256 x 128 (4 x 1 waves, 2 x 4 sub-tiles)   mid 128 x 128 (2 x 2 waves, 2 x 2)   skinny 64 x 64 (2 x 2 waves, 1 x 1)
 //
-// k order inside a stage: lane (row m, half g) holds k = 8g .. 8g+7 of its rows (two 16-byte chunks); MFMA step t pairs
-// k = t (g = 0) with k = 8 + t (g = 1) for both operands - any pairing is a valid contraction order.
+// k order inside a stage: lane (row r, half g) holds k = 8g .. 8g+7 of its rows (two 16-byte chunks c = 0, 1); MFMA step
+// t = 4c + e pairs k = t (g = 0) with k = 8 + t (g = 1) for both operands - any pairing is a valid contraction order.
 #include <cstdlib>
 #include <type_traits>
 
@@ -47,6 +55,8 @@ __device__ __forceinline__ void glds16(const float* g, char* l) {
 }
 
 constexpr int kBK = 16;
+constexpr int kMaxBiasN = 4096;  // the bias vector lives in LDS for the epilogue (ordinary global loads next to the LDS-DMA
+                                 // stream make hipcc drain the whole ring with s_waitcnt vmcnt(0))
 
 __device__ __attribute__((aligned(64))) float g_zero_row_f32[16];  // zero-initialised: the source of padded conv taps
 
@@ -54,61 +64,35 @@ struct ConvGeomF {
   int H, W, Cin;
 };
 
-template <int WM_, int WN_, int TI_, int TJ_, int ST_, int WGS_>
+template <int WM_, int WN_, int TI_, int TJ_, int ST_>
 struct F32Cfg {
-  static constexpr int WM = WM_, WN = WN_, TI = TI_, TJ = TJ_, ST = ST_, WGS = WGS_;  // WGS: resident workgroups per CU
+  static constexpr int WM = WM_, WN = WN_, TI = TI_, TJ = TJ_, ST = ST_;
   static constexpr int BM = WM * TI * 32, BN = WN * TJ * 32;
   static constexpr int A_BYTES = BM * kBK * 4, B_BYTES = BN * kBK * 4, STAGE = A_BYTES + B_BYTES;
   static constexpr int A_PIECES = A_BYTES / 1024, PIECES = STAGE / 1024, PPW = PIECES / 4, APW = A_PIECES / 4;
-  static constexpr int LDS = ST * STAGE;
+  static constexpr int RING = ST * STAGE;
+  static constexpr int LDS = RING + kMaxBiasN * 4;  // ring + the bias vector (read by the epilogue with ds_read)
   static_assert(WM * WN == 4 && PIECES % 4 == 0 && A_PIECES % 4 == 0, "4 waves share the DMA pieces evenly");
-  static_assert((ST - 1) * PPW <= 63, "vmcnt is a 6-bit counter");
-  static_assert(LDS * WGS <= 160 * 1024, "LDS budget of a CU");
+  static_assert(ST >= 3 && (ST - 2) * PPW <= 63, "vmcnt is a 6-bit counter");
+  static_assert(LDS <= 160 * 1024, "LDS budget of a CU");
 };
-typedef F32Cfg<4, 1, 2, 4, 3, 2> FWide;
-typedef F32Cfg<2, 2, 2, 2, 3, 3> FMid;
-typedef F32Cfg<2, 2, 1, 1, 16, 1> FSkinny;
-
-template <int PPW, int ST>
-__device__ __forceinline__ void wait_younger(int younger) {  // s_waitcnt vmcnt(younger * PPW): the immediate must be static
-  if constexpr (ST <= 3) {
-    if (younger == 0) wait_vm<0>();
-    else wait_vm<PPW>();
-    return;
-  }
-  switch (younger) {
-    case 0: wait_vm<0>(); break;
-    case 1: wait_vm<PPW>(); break;
-    case 2: wait_vm<2 * PPW>(); break;
-    case 3: wait_vm<3 * PPW>(); break;
-    case 4: wait_vm<4 * PPW>(); break;
-    case 5: wait_vm<5 * PPW>(); break;
-    case 6: wait_vm<6 * PPW>(); break;
-    case 7: wait_vm<7 * PPW>(); break;
-    case 8: wait_vm<(8 * PPW) & 63>(); break;
-    case 9: wait_vm<(9 * PPW) & 63>(); break;
-    case 10: wait_vm<(10 * PPW) & 63>(); break;
-    case 11: wait_vm<(11 * PPW) & 63>(); break;
-    case 12: wait_vm<(12 * PPW) & 63>(); break;
-    case 13: wait_vm<(13 * PPW) & 63>(); break;
-    case 14: wait_vm<(14 * PPW) & 63>(); break;
-    default: wait_vm<(15 * PPW) & 63>(); break;
-  }
-}
+typedef F32Cfg<4, 1, 2, 4, 5> FWide;     // 24 KiB stages, 120 KiB ring
+typedef F32Cfg<2, 2, 2, 2, 8> FMid;      // 16 KiB stages, 128 KiB ring
+typedef F32Cfg<2, 2, 1, 1, 16> FSkinny;  //  8 KiB stages, 128 KiB ring = a whole K = 256 panel in flight
 
 struct F32Args {
   const float* A; long long lda;
   const float* B; long long ldb;
   const float* bias;      // [N] or nullptr
   float* C; long long ldc;
-  int M, N, K, relu, c_bytes, batch;
+  int M, N, K, relu, c_bytes, batch, vec_store, dbg;  // dbg: ablation bits (COMBO_F32_DBG, tools/bench_f32.py): 1 no DMA, 2 no LDS reads, 4 no barrier, 8 no stores
   long long sA, sB, sC;   // batch strides (elements)
   ConvGeomF cg;
   unsigned long long* ts; // device-side timing slot (combo_common.h) or nullptr
 };
 
 template <bool CONV, typename Cfg>
-__global__ void __launch_bounds__(256, Cfg::WGS)
+__global__ void __launch_bounds__(256, 1)
 gemm_nt_f32_kernel(const F32Args p) {
   constexpr int BM = Cfg::BM, BN = Cfg::BN, TI = Cfg::TI, TJ = Cfg::TJ, ST = Cfg::ST, PPW = Cfg::PPW, APW = Cfg::APW;
   constexpr int A_BYTES = Cfg::A_BYTES, STAGE = Cfg::STAGE;
@@ -128,6 +112,18 @@ gemm_nt_f32_kernel(const F32Args p) {
   const int G = gridDim.x;
   const int w = xcd_contiguous(blockIdx.x, G);  // every XCD owns a contiguous tile range: the n tiles of a token tile share an L2
   const int nst = K / kBK;
+  if (w >= tiles) {  // (grid <= tiles by construction; kept for safety: no workgroup may skip the barriers below)
+    combo_ts_end(p.ts);
+    return;
+  }
+
+  // the bias vector goes to LDS once (zero beyond N), before any LDS-DMA is in flight
+  const unsigned bias_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + (unsigned)Cfg::RING;
+  if (p.bias) {
+    float* bl = reinterpret_cast<float*>(smem + Cfg::RING);
+    for (int n = threadIdx.x; n < kMaxBiasN; n += 256) bl[n] = n < N ? p.bias[n] : 0.f;
+    __syncthreads();
+  }
 
   // ---------------- issue cursor: (tile, stage) of the next stage to stream into the ring ----------------
   const int p_row = lane >> 2, p_chunk = lane & 3;
@@ -138,7 +134,7 @@ gemm_nt_f32_kernel(const F32Args p) {
   for (int u = 0; u < APW; ++u) tap_ok[u] = 0u;
   const float* pa[APW];
   const float* pb[PPW - APW];
-  auto open_tile = [&]() {
+  auto open_tile = [&]() __attribute__((always_inline)) {
     const int bi = i_tile / tpb, rem = i_tile - bi * tpb;
     const float* i_A = A + bi * p.sA;
     const float* i_B = Bm + bi * p.sB;
@@ -172,25 +168,26 @@ gemm_nt_f32_kernel(const F32Args p) {
       }
     }
   };
-  auto issue_next = [&]() {
-    if (i_tile >= tiles) return;
+  // one DMA piece (1 KiB = 16 rows x 64 B, wave-uniform destination) of the stage under the issue cursor
+  auto issue_piece = [&](auto u_tag) __attribute__((always_inline)) {
+    constexpr int u = decltype(u_tag)::value;
+    if (i_tile >= tiles || (p.dbg & 1)) return;
     char* st = smem + i_slot * STAGE;
-    const int k0 = i_s * kBK;
-    const long long a_off = CONV ? (long long)((i_tap / 3 - 1) * cg.W + (i_tap % 3 - 1)) * lda + i_cin0 : (long long)k0;
-#pragma unroll
-    for (int u = 0; u < PPW; ++u) {
-      const int q = wave + 4 * u;  // wave-uniform piece (1 KiB = 16 rows x 64 B); q < A_PIECES: A rows, else B rows
-      if (u < APW) {
-        const float* src = pa[u < APW ? u : 0] + a_off;
-        if (CONV) {
-          const int c = p_chunk ^ (((q * 16 + p_row) >> 2) & 3);
-          if (!((tap_ok[u < APW ? u : 0] >> i_tap) & 1u)) src = g_zero_row_f32 + c * 4;
-        }
-        glds16(src, st + q * 1024);
-      } else {
-        glds16(pb[u >= APW ? u - APW : 0] + k0, st + A_BYTES + (q - Cfg::A_PIECES) * 1024);
+    const int q = wave + 4 * u;  // q < A_PIECES: A rows, else B rows
+    if constexpr (u < APW) {
+      const long long a_off = CONV ? (long long)((i_tap / 3 - 1) * cg.W + (i_tap % 3 - 1)) * lda + i_cin0 : (long long)(i_s * kBK);
+      const float* src = pa[u] + a_off;
+      if (CONV) {
+        const int c = p_chunk ^ (((q * 16 + p_row) >> 2) & 3);
+        if (!((tap_ok[u] >> i_tap) & 1u)) src = g_zero_row_f32 + c * 4;
       }
+      glds16(src, st + q * 1024);
+    } else {
+      glds16(pb[u - APW] + i_s * kBK, st + A_BYTES + (q - Cfg::A_PIECES) * 1024);
     }
+  };
+  auto issue_finish = [&]() __attribute__((always_inline)) {  // advance the cursor past the stage just issued
+    if (i_tile >= tiles) return;
     ++issued;
     i_slot = i_slot == ST - 1 ? 0 : i_slot + 1;
     ++i_s;
@@ -203,121 +200,237 @@ gemm_nt_f32_kernel(const F32Args p) {
       if (i_tile < tiles) open_tile();
     }
   };
-  if (i_tile < tiles) open_tile();
+  auto issue_next = [&]() __attribute__((always_inline)) {
+    issue_piece(std::integral_constant<int, 0>{});
+    if constexpr (PPW > 1) issue_piece(std::integral_constant<int, 1>{});
+    if constexpr (PPW > 2) issue_piece(std::integral_constant<int, 2>{});
+    if constexpr (PPW > 3) issue_piece(std::integral_constant<int, 3>{});
+    if constexpr (PPW > 4) issue_piece(std::integral_constant<int, 4>{});
+    if constexpr (PPW > 5) issue_piece(std::integral_constant<int, 5>{});
+    static_assert(PPW <= 6, "add the pieces of a larger stage here");
+    issue_finish();
+  };
+  open_tile();
 #pragma unroll 1
   for (int q = 0; q < ST - 1; ++q) issue_next();
 
-  // ---------------- LDS read addresses: lane (row m, k-half g) reads chunks 2g, 2g+1 of its rows ----------------
+  // ---------------- LDS read addresses: lane (row r, k-half g) reads chunks 2g, 2g+1 of its rows ----------------
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const int m = lane & 31, g = lane >> 5;
-  const int sw = (m >> 2) & 3;  // a wave's rows are (multiple of 32) + m: they all share the swizzle of m
-  const unsigned a_c0 = lds0 + (unsigned)((wm * TI * 32 + m) * 64 + ((2 * g) ^ sw) * 16);
-  const unsigned a_c1 = lds0 + (unsigned)((wm * TI * 32 + m) * 64 + ((2 * g + 1) ^ sw) * 16);
-  const unsigned b_c0 = lds0 + (unsigned)(A_BYTES + (wn * TJ * 32 + m) * 64 + ((2 * g) ^ sw) * 16);
-  const unsigned b_c1 = lds0 + (unsigned)(A_BYTES + (wn * TJ * 32 + m) * 64 + ((2 * g + 1) ^ sw) * 16);
+  const int r = lane & 31, g = lane >> 5;
+  const int sw = (r >> 2) & 3;  // a wave's rows are (multiple of 32) + r: they all share the swizzle of r
+  const unsigned a_c0 = lds0 + (unsigned)((wm * TI * 32 + r) * 64 + ((2 * g) ^ sw) * 16);
+  const unsigned a_c1 = lds0 + (unsigned)((wm * TI * 32 + r) * 64 + ((2 * g + 1) ^ sw) * 16);
+  const unsigned b_c0 = lds0 + (unsigned)(A_BYTES + (wn * TJ * 32 + r) * 64 + ((2 * g) ^ sw) * 16);
+  const unsigned b_c1 = lds0 + (unsigned)(A_BYTES + (wn * TJ * 32 + r) * 64 + ((2 * g + 1) ^ sw) * 16);
 
-  int consumed = 0, c_slot = 0;
-  for (int tile = w; tile < tiles; tile += G) {
-    const int bi = tile / tpb, rem = tile - bi * tpb;
-    const int m_blk = (rem / n_tiles) * BM, n_blk = (rem % n_tiles) * BN;
-    const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.C + bi * p.sC, 0, p.c_bytes, 0x00020000);
-    // number of this wave's 32-row / 32-column sub-tiles that touch the matrix (wave-uniform)
-    const int imax = min(TI, max(0, (M - m_blk - wm * TI * 32 + 31) / 32));
-    const int jmax = min(TJ, max(0, (N - n_blk - wn * TJ * 32 + 31) / 32));
-    const bool full = imax == TI && jmax == TJ;
-    f32x16 acc[TI][TJ];
+  // operand fragments: fa[i][c] = token rows (MFMA src B), fb[j][c] = weight rows (MFMA src A); c = chunk = half of a stage
+  f4v fa[TI][2], fb[TJ][2];
 #pragma unroll
-    for (int i = 0; i < TI; ++i)
+  for (int i = 0; i < TI; ++i) fa[i][0] = fa[i][1] = f4v{1.f, 1.f, 1.f, 1.f};  // (only observable under the no-LDS-read ablation)
 #pragma unroll
-      for (int j = 0; j < TJ; ++j)
+  for (int j = 0; j < TJ; ++j) fb[j][0] = fb[j][1] = f4v{1.f, 1.f, 1.f, 1.f};
+  auto read_half = [&](auto c_tag, unsigned so) __attribute__((always_inline)) {  // issue the ds_reads of chunk c of the stage in ring slot offset `so`
+    constexpr int c = decltype(c_tag)::value;
+    if (p.dbg & 2) return;
+    const unsigned ab = (c == 0 ? a_c0 : a_c1) + so, bb = (c == 0 ? b_c0 : b_c1) + so;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    for (int s = 0; s < nst; ++s) {
-      // the stage to consume has landed once every OLDER vector-memory operation of this wave is done; the first stage of
-      // a later tile also drains the epilogue stores of the previous tile (stores and loads share vmcnt)
-      if (s == 0 && tile != w) wait_vm<0>();
-      else wait_younger<PPW, ST>(issued - consumed - 1);
-      __builtin_amdgcn_s_barrier();  // everybody's pieces landed; everybody finished reading the slot refilled below
-      issue_next();
-      const unsigned so = (unsigned)(c_slot * STAGE);
-      f4v ra[TI][2], rb[TJ][2];
+    for (int i = 0; i < TI; ++i) fa[i][c] = i == 0 ? lds_read128<0>(ab) : lds_read128<2048>(ab);
 #pragma unroll
-      for (int i = 0; i < TI; ++i) {
-        ra[i][0] = i == 0 ? lds_read128<0>(a_c0 + so) : lds_read128<2048>(a_c0 + so);
-        ra[i][1] = i == 0 ? lds_read128<0>(a_c1 + so) : lds_read128<2048>(a_c1 + so);
-      }
-#pragma unroll
-      for (int j = 0; j < TJ; ++j) {
-        rb[j][0] = j == 0 ? lds_read128<0>(b_c0 + so) : j == 1 ? lds_read128<2048>(b_c0 + so)
-                 : j == 2 ? lds_read128<4096>(b_c0 + so) : lds_read128<6144>(b_c0 + so);
-        rb[j][1] = j == 0 ? lds_read128<0>(b_c1 + so) : j == 1 ? lds_read128<2048>(b_c1 + so)
-                 : j == 2 ? lds_read128<4096>(b_c1 + so) : lds_read128<6144>(b_c1 + so);
-      }
-      if constexpr (TI == 2 && TJ == 4) {
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[1][0]), "+v"(ra[1][1]), "+v"(rb[0][0]), "+v"(rb[0][1]),
-                       "+v"(rb[1][0]), "+v"(rb[1][1]), "+v"(rb[2][0]), "+v"(rb[2][1]), "+v"(rb[3][0]), "+v"(rb[3][1])
-                     :
-                     : "memory");
-      } else if constexpr (TI == 2 && TJ == 2) {
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[1][0]), "+v"(ra[1][1]), "+v"(rb[0][0]), "+v"(rb[0][1]),
-                       "+v"(rb[1][0]), "+v"(rb[1][1])
-                     :
-                     : "memory");
-      } else {
-        static_assert((TI == 2 && TJ == 4) || (TI == 2 && TJ == 2) || (TI == 1 && TJ == 1), "add the register list of a new wave tile here");
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(rb[0][0]), "+v"(rb[0][1]) : : "memory");
-      }
-      __builtin_amdgcn_sched_barrier(0);  // (register-only MFMAs may not be hoisted above the inline-asm wait)
-      if (full) {
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-#pragma unroll
-          for (int i = 0; i < TI; ++i)
-#pragma unroll
-            for (int j = 0; j < TJ; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[i][t >> 2][t & 3], rb[j][t >> 2][t & 3], acc[i][j], 0, 0, 0);
-      } else {  // edge tile: 32 x 32 sub-tiles that lie wholly outside the matrix are skipped (64 cycles each)
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-          for (int j = 0; j < TJ; ++j)
-            if (i < imax && j < jmax) {
-#pragma unroll
-              for (int t = 0; t < 8; ++t)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[i][t >> 2][t & 3], rb[j][t >> 2][t & 3], acc[i][j], 0, 0, 0);
-            }
-      }
-      ++consumed;
-      c_slot = c_slot == ST - 1 ? 0 : c_slot + 1;
+    for (int j = 0; j < TJ; ++j)
+      fb[j][c] = j == 0 ? lds_read128<0>(bb) : j == 1 ? lds_read128<2048>(bb) : j == 2 ? lds_read128<4096>(bb) : lds_read128<6144>(bb);
+    __builtin_amdgcn_sched_barrier(0);  // the reads go out BEFORE the MFMAs that cover their latency
+  };
+  auto wait_half = [&](auto c_tag) __attribute__((always_inline)) {  // lgkmcnt(0) tied to the registers of chunk c (hipcc may not move their uses above it)
+    constexpr int c = decltype(c_tag)::value;
+    __builtin_amdgcn_sched_barrier(0);  // (and the MFMAs issued before the wait stay before it: they cover the read latency)
+    if constexpr (TI == 2 && TJ == 4) {
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(fa[0][c]), "+v"(fa[1][c]), "+v"(fb[0][c]), "+v"(fb[1][c]), "+v"(fb[2][c]), "+v"(fb[3][c]) : : "memory");
+    } else if constexpr (TI == 2 && TJ == 2) {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0][c]), "+v"(fa[1][c]), "+v"(fb[0][c]), "+v"(fb[1][c]) : : "memory");
+    } else {
+      static_assert((TI == 2 && TJ == 4) || (TI == 2 && TJ == 2) || (TI == 1 && TJ == 1), "add the register list of a new wave tile here");
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0][c]), "+v"(fb[0][c]) : : "memory");
     }
+    __builtin_amdgcn_sched_barrier(0);  // (register-only MFMAs may not be hoisted above the inline-asm wait)
+  };
 
-    // epilogue: D tile = 32 tokens x 32 n; lane holds n = lane & 31 and tokens (e&3) + 8*(e>>2) + 4*(lane>>5).  Buffer
-    // stores through one descriptor over C: the hardware range check drops the rows >= M of the last token tile.
-    auto epilogue = [&](auto relu_tag) {
-      constexpr bool RELU = decltype(relu_tag)::value;
-      const unsigned uld = (unsigned)p.ldc * 4u, uld5 = 5u * uld;
+  f32x16 acc[TI][TJ];
+
+  // epilogue of one 32 x 32 sub-tile: lane (token r, half g) owns n = 8q + 4g + (0..3), q = 0..3 (operands swapped, see top)
+  struct EpiCtx { int m_blk, n_blk; };
+  auto store_sub = [&](auto ij_tag, const EpiCtx& ec, const __amdgpu_buffer_rsrc_t c_rsrc) __attribute__((always_inline)) {
+    constexpr int IJ = decltype(ij_tag)::value, i = IJ / TJ, j = IJ % TJ;
+    const int row = ec.m_blk + (wm * TI + i) * 32 + r;
+    const int nb = ec.n_blk + (wn * TJ + j) * 32 + 4 * g;
+    if (p.dbg & 8) {  // keep the accumulators alive without storing them
 #pragma unroll
-      for (int j = 0; j < TJ; ++j) {
-        const int n = n_blk + (wn * TJ + j) * 32 + m;
-        if (n >= N) continue;
-        const float bv = p.bias ? p.bias[n] : 0.f;
-        unsigned off = ((unsigned)(m_blk + wm * TI * 32 + 4 * g) * (unsigned)p.ldc + (unsigned)n) * 4u;
+      for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(acc[i][j][e]));
+      return;
+    }
+    if (p.vec_store) {
+      f4v bv[4];
+      if (p.bias) {
 #pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            float v = acc[i][j][e] + bv;
-            if (RELU) v = fmaxf(v, 0.f);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), c_rsrc, off, 0, 0);
-            off += (e & 3) == 3 ? uld5 : uld;  // rows 0-3, 8-11, 16-19, 24-27 (+4g); the next i starts 32 rows on
-          }
+        for (int q = 0; q < 4; ++q) bv[q] = lds_read128<0>(bias_lds + (unsigned)min(nb + 8 * q, kMaxBiasN - 4) * 4u);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]) : : "memory");
       }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n0 = nb + 8 * q;
+        f4v v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        if (p.bias) v += bv[q];
+        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        // rows >= M fall outside the descriptor's range and are dropped; columns >= N are steered there as well
+        unsigned off = n0 < N ? ((unsigned)row * (unsigned)p.ldc + (unsigned)n0) * 4u : 0xfffffff0u;
+        if (p.dbg & 16) {  // ablation: the same bytes in a full-line pattern (8 rows x 128 B per instruction; WRONG layout)
+          const int row2 = ec.m_blk + (wm * TI + i) * 32 + (lane >> 3) + 8 * q, n2 = ec.n_blk + (wn * TJ + j) * 32 + (lane & 7) * 4;
+          off = n2 < N ? ((unsigned)row2 * (unsigned)p.ldc + (unsigned)n2) * 4u : 0xfffffff0u;
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), c_rsrc, off, 0, 0);
+      }
+    } else {  // N or ldc not a multiple of 4 (the 3-wide class head): scalar stores
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = nb + 8 * (e >> 2) + (e & 3);
+        float v = acc[i][j][e];
+        if (p.bias) {
+          float b;
+          asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(b) : "v"(bias_lds + (unsigned)min(n, kMaxBiasN - 1) * 4u) : "memory");
+          v += b;
+        }
+        if (p.relu) v = fmaxf(v, 0.f);
+        const unsigned off = n < N ? ((unsigned)row * (unsigned)p.ldc + (unsigned)n) * 4u : 0xfffffff0u;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), c_rsrc, off, 0, 0);
+      }
+    }
+  };
+
+  // one half-stage of MFMAs (k-steps 4c .. 4c+3).  FIRST: the first k-step of a tile starts from zero.  ISSUE: the LDS-DMA
+  // pieces of the stage entering the ring are issued between the MFMAs (an MFMA occupies the pipe for 64 cycles = ~15 issue
+  // slots; a DMA piece costs ~60 cycles of issue), so the matrix pipe never waits for the address arithmetic
+  auto mfma_half = [&](auto c_tag, auto first_tag, auto issue_tag) __attribute__((always_inline)) {
+    constexpr int c = decltype(c_tag)::value;
+    constexpr bool FIRST = decltype(first_tag)::value, ISSUE = decltype(issue_tag)::value;
+    constexpr int NM = 4 * TI * TJ;                       // MFMAs in this half
+    constexpr int STRIDE = NM / (PPW + 1) > 0 ? NM / (PPW + 1) : 1;  // one piece every STRIDE MFMAs, then the cursor update
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+          if (FIRST && c == 0 && e == 0) {
+            f32x16 z;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) z[q] = 0.f;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j][c][e], fa[i][c][e], z, 0, 0, 0);
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j][c][e], fa[i][c][e], acc[i][j], 0, 0, 0);
+          }
+          if constexpr (ISSUE) {
+            const int idx = (e * TI + i) * TJ + j;  // (compile-time after unrolling)
+            if (idx % STRIDE == 0 && idx / STRIDE <= PPW) {
+              __builtin_amdgcn_sched_barrier(0);
+              const int u = idx / STRIDE;
+              if (u == 0) issue_piece(std::integral_constant<int, 0>{});
+              if (u == 1 && PPW > 1) issue_piece(std::integral_constant<int, (PPW > 1 ? 1 : 0)>{});
+              if (u == 2 && PPW > 2) issue_piece(std::integral_constant<int, (PPW > 2 ? 2 : 0)>{});
+              if (u == 3 && PPW > 3) issue_piece(std::integral_constant<int, (PPW > 3 ? 3 : 0)>{});
+              if (u == 4 && PPW > 4) issue_piece(std::integral_constant<int, (PPW > 4 ? 4 : 0)>{});
+              if (u == 5 && PPW > 5) issue_piece(std::integral_constant<int, (PPW > 5 ? 5 : 0)>{});
+              if (u == PPW) issue_finish();
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+  };
+  // the LAST half-stage of a tile, sub-tile-major: the 4 k-steps of a sub-tile issue back to back (the dependent-accumulator
+  // latency of this MFMA equals its issue interval), and the finished PREVIOUS sub-tile is stored meanwhile - the epilogue
+  // hides behind the MFMAs except for the last sub-tile's four stores
+  auto mfma_tail = [&](const EpiCtx& ec, const __amdgpu_buffer_rsrc_t c_rsrc) __attribute__((always_inline)) {
+    auto sub = [&](auto ij_tag) __attribute__((always_inline)) {
+      constexpr int IJ = decltype(ij_tag)::value, i = IJ / TJ, j = IJ % TJ;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j][1][e], fa[i][1][e], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (IJ > 0) store_sub(std::integral_constant<int, IJ - 1>{}, ec, c_rsrc);
+      __builtin_amdgcn_sched_barrier(0);
     };
-    if (p.relu) epilogue(std::true_type{});
-    else epilogue(std::false_type{});
+    sub(std::integral_constant<int, 0>{});
+    if constexpr (TI * TJ >= 4) {
+      sub(std::integral_constant<int, 1>{}); sub(std::integral_constant<int, 2>{}); sub(std::integral_constant<int, 3>{});
+    }
+    if constexpr (TI * TJ == 8) {
+      sub(std::integral_constant<int, 4>{}); sub(std::integral_constant<int, 5>{}); sub(std::integral_constant<int, 6>{});
+      sub(std::integral_constant<int, 7>{});
+    }
+    store_sub(std::integral_constant<int, TI * TJ - 1>{}, ec, c_rsrc);
+  };
+
+  // ---------------- the stage stream ----------------
+  // State at the top of stage gs: its chunk 0 is in fa/fb[.][0]; stages up to gs + ST - 2 are landed / in flight.
+  //   half 0: read chunk 1 of gs; MFMAs k = 0..7 with the DMA pieces of stage gs + ST - 1 in between (its ring slot held
+  //           stage gs - 1, which every wave finished reading before the previous barrier)
+  //   middle: stage gs + 1 must have landed for everybody: counted vmcnt (ST - 2 younger stages stay in flight) + barrier
+  //   half 1: read chunk 0 of gs + 1; MFMAs k = 8..15
+  constexpr int kYoung = (ST - 2) * PPW;
+  static_assert(kYoung <= 63, "vmcnt is a 6-bit counter");
+  if (issued == ST - 1) wait_vm<kYoung>();  // priming: stage 0 landed, ST - 2 stages stay in flight
+  else wait_vm<0>();
+  __builtin_amdgcn_s_barrier();
+  int c_slot = 0;  // ring slot of the stage being computed
+  int left = ((tiles - w + G - 1) / G) * nst;  // stages this workgroup still has to compute
+  read_half(std::integral_constant<int, 0>{}, 0u);
+  wait_half(std::integral_constant<int, 0>{});
+
+  auto mid_stage = [&]() __attribute__((always_inline)) {
+    --left;
+    if (left > 0) {
+      // in steady state exactly ST - 2 younger stages are in flight; when the cursor has run out, drain everything
+      // (epilogue stores in between only make the wait longer, never shorter)
+      if (i_tile < tiles || left >= ST - 1) wait_vm<kYoung>();
+      else wait_vm<0>();
+      if (!(p.dbg & 4)) __builtin_amdgcn_s_barrier();
+      c_slot = c_slot == ST - 1 ? 0 : c_slot + 1;
+      read_half(std::integral_constant<int, 0>{}, (unsigned)(c_slot * STAGE));
+    }
+  };
+
+  const int my_tiles = (tiles - w + G - 1) / G;
+#pragma unroll 1
+  for (int t = 0; t < my_tiles; ++t) {
+    const int tile = w + t * G;
+    const int bi = tile / tpb, rem = tile - bi * tpb;
+    const EpiCtx ec{(rem / n_tiles) * BM, (rem % n_tiles) * BN};
+    const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.C + bi * p.sC, 0, p.c_bytes, 0x00020000);
+    // ---- stage 0 (peeled: its first k-step starts the accumulators from zero)
+    read_half(std::integral_constant<int, 1>{}, (unsigned)(c_slot * STAGE));
+    mfma_half(std::integral_constant<int, 0>{}, std::true_type{}, std::true_type{});
+    wait_half(std::integral_constant<int, 1>{});
+    mid_stage();
+    if (nst == 1) mfma_tail(ec, c_rsrc);
+    else mfma_half(std::integral_constant<int, 1>{}, std::false_type{}, std::false_type{});
+    if (left > 0) wait_half(std::integral_constant<int, 0>{});
+    // ---- stages 1 .. nst-2
+#pragma unroll 1
+    for (int s = 1; s < nst - 1; ++s) {
+      read_half(std::integral_constant<int, 1>{}, (unsigned)(c_slot * STAGE));
+      mfma_half(std::integral_constant<int, 0>{}, std::false_type{}, std::true_type{});
+      wait_half(std::integral_constant<int, 1>{});
+      mid_stage();
+      mfma_half(std::integral_constant<int, 1>{}, std::false_type{}, std::false_type{});
+      wait_half(std::integral_constant<int, 0>{});
+    }
+    // ---- last stage (its second half carries the epilogue)
+    if (nst > 1) {
+      read_half(std::integral_constant<int, 1>{}, (unsigned)(c_slot * STAGE));
+      mfma_half(std::integral_constant<int, 0>{}, std::false_type{}, std::true_type{});
+      wait_half(std::integral_constant<int, 1>{});
+      mid_stage();
+      mfma_tail(ec, c_rsrc);
+      if (left > 0) wait_half(std::integral_constant<int, 0>{});
+    }
   }
   combo_ts_end(p.ts);
 }
@@ -342,20 +455,21 @@ int launch_cfg(F32Args a, hipStream_t stream) {
   }
   const long long tiles = ((a.M + Cfg::BM - 1LL) / Cfg::BM) * ((a.N + Cfg::BN - 1LL) / Cfg::BN) * a.batch;
   if (tiles > 0x7fffffffLL) return COMBO_EINVAL;
-  const long long slots = (long long)Cfg::WGS * n_cu_cached();
+  const long long slots = n_cu_cached();  // one persistent workgroup per CU
   const int grid = (int)(tiles < slots ? tiles : slots);
   a.ts = combo_timing_next_slot(COMBO_TS_GEMM_F32, 2.0 * a.M * a.N * a.K * a.batch);
   hipLaunchKernelGGL((gemm_nt_f32_kernel<CONV, Cfg>), dim3((unsigned)grid), dim3(256), Cfg::LDS, stream, a);
   return (int)hipGetLastError();
 }
 
-// Tile choice.  The kernel is MFMA-bound, so its time is the load of the busiest CU: tiles spread round-robin over the CUs
-// (persistent workgroups, XCD-contiguous), each costing BM*BN*K MACs; the smallest "ceil(tiles / CUs) * BM * BN" wins, ties
-// go to the larger tile (fewer operand bytes per flop: 64 x 64 tiles pull 16 flop/B from L2, enough only for small problems).
+// Tile choice.  The kernel is MFMA-bound, so its time is the load of the busiest CU: tiles are dealt round-robin to one
+// workgroup per CU, each costing BM*BN*K MACs.  Measured on MI355X (tools/bench_f32.py with COMBO_F32_TILE = 1 / 2 / 3 over the
+// head's shapes, profiles/r02_gemm_f32_tiles.txt): wide vs mid follows the smaller "ceil(tiles / CUs) * BM * BN" (a tie goes
+// to wide for short K, to mid from K = 1024 on); the 64 x 64 tiles pull 16 flop per operand byte from L2 and only win when
+// their busiest-CU load is at least 20 % smaller (the decoder's 4000-token layers: 252 tiles instead of 32).
 template <bool CONV>
-int launch_f32(F32Args a, hipStream_t stream, int force) {
-  static const int env_force = [] { const char* e = getenv("COMBO_F32_TILE"); return e ? atoi(e) : 0; }();  // 1 wide, 2 mid, 3 skinny (A/B)
-  if (!force) force = env_force;
+int launch_f32(F32Args a, hipStream_t stream) {
+  static const int force = [] { const char* e = getenv("COMBO_F32_TILE"); return e ? atoi(e) : 0; }();  // 1 wide, 2 mid, 3 skinny (A/B)
   const long long cus = n_cu_cached();
   auto load = [&](int bm, int bn) {
     const long long t = ((a.M + bm - 1LL) / bm) * ((a.N + bn - 1LL) / bn) * a.batch;
@@ -364,11 +478,9 @@ int launch_f32(F32Args a, hipStream_t stream, int force) {
   int pick = force;
   if (!pick) {
     const long long lw = load(256, 128), lm = load(128, 128), ls = load(64, 64);
-    pick = 1;
-    long long best = lw;
-    if (lm < best) { best = lm; pick = 2; }
-    const double flops = 2.0 * a.M * a.N * a.K * a.batch;
-    if (ls < best && (flops < 3.0e9 || ls * 4 <= best * 3)) pick = 3;  // skinny: small problems, or >= 25 % less load
+    pick = lw < lm ? 1 : lm < lw ? 2 : (a.K >= 1024 ? 2 : 1);
+    const long long best = lw < lm ? lw : lm;
+    if (ls * 5 <= best * 4) pick = 3;
   }
   if (pick == 3) return launch_cfg<CONV, FSkinny>(a, stream);
   if (pick == 2) return launch_cfg<CONV, FMid>(a, stream);
@@ -378,34 +490,45 @@ int launch_f32(F32Args a, hipStream_t stream, int force) {
 bool args_ok(const float* A, long long lda, const float* B, long long ldb, const float* C, long long ldc, long long M, int N, int K,
              int batch) {
   return A && B && C && M > 0 && N > 0 && K > 0 && batch > 0 && K % kBK == 0 && lda % 4 == 0 && ldb % 4 == 0 &&
-         !((uintptr_t)A & 15) && !((uintptr_t)B & 15) && M <= 0x7fffffffLL && ((M - 1) * ldc + N) * 4 < 0x7fffffffLL;
+         !((uintptr_t)A & 15) && !((uintptr_t)B & 15) && M <= 0x7fffffffLL && ((M - 1) * ldc + N) * 4 < 0x7ffffff0LL;
+}
+
+int dbg_bits() {
+  static const int d = [] { const char* e = getenv("COMBO_F32_DBG"); return e ? atoi(e) : 0; }();
+  return d;
+}
+
+int vec_ok(const float* C, long long ldc, long long sC, int N, const float* bias) {
+  (void)bias;
+  return (N % 4 == 0 && ldc % 4 == 0 && sC % 4 == 0 && !((uintptr_t)C & 15)) ? 1 : 0;
 }
 
 }  // namespace
 
 extern "C" int combo_gemm_nt_f32(const float* A, long long lda, const float* B, long long ldb, const float* bias, float* C,
                                  long long ldc, int M, int N, int K, int relu, combo_stream_t stream) {
-  if (!args_ok(A, lda, B, ldb, C, ldc, M, N, K, 1)) return COMBO_EINVAL;
-  F32Args a{A, lda, B, ldb, bias, C, ldc, M, N, K, relu, (int)(((M - 1LL) * ldc + N) * 4), 1, 0, 0, 0, ConvGeomF{1, 1, K}, nullptr};
-  return launch_f32<false>(a, (hipStream_t)stream, 0);
+  if (!args_ok(A, lda, B, ldb, C, ldc, M, N, K, 1) || (bias && N > kMaxBiasN)) return COMBO_EINVAL;
+  F32Args a{A, lda, B, ldb, bias, C, ldc, M, N, K, relu, (int)(((M - 1LL) * ldc + N) * 4), 1, vec_ok(C, ldc, 0, N, bias), dbg_bits(), 0, 0, 0,
+            ConvGeomF{1, 1, K}, nullptr};
+  return launch_f32<false>(a, (hipStream_t)stream);
 }
 
 extern "C" int combo_gemm_nt_batched_f32(const float* A, long long lda, long long sA, const float* B, long long ldb, long long sB,
                                          float* C, long long ldc, long long sC, int M, int N, int K, int batch, int relu,
                                          combo_stream_t stream) {
   if (!args_ok(A, lda, B, ldb, C, ldc, M, N, K, batch) || sA % 4 != 0 || sB % 4 != 0) return COMBO_EINVAL;
-  F32Args a{A, lda, B, ldb, nullptr, C, ldc, M, N, K, relu, (int)(((M - 1LL) * ldc + N) * 4), batch, sA, sB, sC,
-            ConvGeomF{1, 1, K}, nullptr};
-  return launch_f32<false>(a, (hipStream_t)stream, 0);
+  F32Args a{A, lda, B, ldb, nullptr, C, ldc, M, N, K, relu, (int)(((M - 1LL) * ldc + N) * 4), batch, vec_ok(C, ldc, sC, N, nullptr),
+            dbg_bits(), sA, sB, sC, ConvGeomF{1, 1, K}, nullptr};
+  return launch_f32<false>(a, (hipStream_t)stream);
 }
 
 extern "C" int combo_conv3x3_nhwc_f32(const float* X, long long ldx, const float* Wm, const float* bias, float* Y, long long ldy,
                                       int B, int H, int W, int Cin, int Cout, int relu, combo_stream_t stream) {
   const long long M = (long long)B * H * W;
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % kBK != 0 || M > 0x7fffffffLL / 4 ||
-      !args_ok(X, ldx, Wm, 9LL * Cin, Y, ldy, M, Cout, 9 * Cin, 1))
+      !args_ok(X, ldx, Wm, 9LL * Cin, Y, ldy, M, Cout, 9 * Cin, 1) || (bias && Cout > kMaxBiasN))
     return COMBO_EINVAL;
-  F32Args a{X, ldx, Wm, 9LL * Cin, bias, Y, ldy, (int)M, Cout, 9 * Cin, relu, (int)(((M - 1) * ldy + Cout) * 4), 1, 0, 0, 0,
-            ConvGeomF{H, W, Cin}, nullptr};
-  return launch_f32<true>(a, (hipStream_t)stream, 0);
+  F32Args a{X, ldx, Wm, 9LL * Cin, bias, Y, ldy, (int)M, Cout, 9 * Cin, relu, (int)(((M - 1) * ldy + Cout) * 4), 1,
+            vec_ok(Y, ldy, 0, Cout, bias), dbg_bits(), 0, 0, 0, ConvGeomF{H, W, Cin}, nullptr};
+  return launch_f32<true>(a, (hipStream_t)stream);
 }

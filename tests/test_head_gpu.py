@@ -159,11 +159,22 @@ def test_criterion_matches_reference(head_run, mode):
     gi = list(feats.values()) + [audio] + [named[n] for n in grad_params]
     grads = torch.autograd.grad(total, gi, retain_graph=True, allow_unused=True)
     names = [f"feat.{k}" for k in feats] + ["feat.audio"] + grad_params
+    # Gradients pass through the 3-product bf16 backward GEMMs (2^-17 per product): every sampled entry within 2e-3 of the
+    # tensor's RMS + 2e-3 relative, for at most 0.2 % of the samples in S4 mode.  In the modes with ground truth on EVERY frame
+    # the comparison itself has a noise floor: the fp32 CPU oracle - which differs from the reference by re-association only -
+    # already moves up to 1.6 % of the sampled entries by more than 5e-3 RMS there (tests/test_oracle_golden.py), because a
+    # near-zero attention-mask cell or a top-k tie of the importance sampling that falls the other way changes one query's
+    # gradient wholesale; the budget for those modes is that floor.
+    budget = 0.002 if mode == "s4" else 0.02
+    worst = []
     for n, g in zip(names, grads):
         d = synth.unpack(f"{mode}/grad/{n}", zc)
         scale = float(d["l2"]) / max(np.sqrt(float(d["numel"])), 1.0)
-        # gradients pass through the 3-product bf16 backward GEMMs (2^-17 per product): 2e-3 of the tensor's RMS
-        synth.check_digest(g.cpu(), d, f"{mode}/grad/{n}", rtol=2e-3, atol=2e-3 * scale + 1e-9, frac_bad=0.002)
+        try:
+            synth.check_digest(g.cpu(), d, f"{mode}/grad/{n}", rtol=2e-3, atol=2e-3 * scale + 1e-9, frac_bad=budget)
+        except AssertionError as e:
+            worst.append(str(e))
+    assert not worst, worst
 
 
 def test_fast_matching_path_agrees_with_replay(head_run):
