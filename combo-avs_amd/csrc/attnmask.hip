@@ -13,13 +13,13 @@
 namespace {
 
 __global__ void __launch_bounds__(256)
-attn_mask_kernel(const float* __restrict__ logits, int N, int H, int W, int h, int w, int reset_full_rows,
+attn_mask_kernel(const float* __restrict__ logits, int N, int H, int W, int h, int w, int reset_full_rows, int pitch,
                  unsigned char* __restrict__ blocked) {
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (wave >= N) return;
   const float* src = logits + (long long)wave * H * W;
-  unsigned char* dst = blocked + (long long)wave * h * w;
+  unsigned char* dst = blocked + (long long)wave * pitch;  // row pitch >= h*w; the padding cells are written as blocked
   const float sh = (float)H / (float)h, sw = (float)W / (float)w;
   const int n = h * w;
   bool all_blocked = true;
@@ -44,15 +44,21 @@ attn_mask_kernel(const float* __restrict__ logits, int N, int H, int W, int h, i
   const bool row_full = __all(all_blocked) && reset_full_rows;
   cnt = 0;
   for (int i = lane; i < n; i += 64, ++cnt) dst[i] = row_full ? 0 : (unsigned char)((bits >> cnt) & 1u);
+  for (int i = n + lane; i < pitch; i += 64) dst[i] = 1;
 }
 
 }  // namespace
 
-extern "C" int combo_attn_mask_f32(const float* logits, int N, int H, int W, int h, int w, int reset_full_rows,
-                                   unsigned char* blocked, combo_stream_t stream) {
-  if (!logits || !blocked || N <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0 || h * w > 2048) return COMBO_EINVAL;
+extern "C" int combo_attn_mask_pitched_f32(const float* logits, int N, int H, int W, int h, int w, int reset_full_rows, int pitch,
+                                           unsigned char* blocked, combo_stream_t stream) {
+  if (!logits || !blocked || N <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0 || h * w > 2048 || pitch < h * w) return COMBO_EINVAL;
   const int waves_per_block = 4;
   hipLaunchKernelGGL(attn_mask_kernel, dim3((N + waves_per_block - 1) / waves_per_block), dim3(256), 0,
-                     (hipStream_t)stream, logits, N, H, W, h, w, reset_full_rows, blocked);
+                     (hipStream_t)stream, logits, N, H, W, h, w, reset_full_rows, pitch, blocked);
   return (int)hipGetLastError();
+}
+
+extern "C" int combo_attn_mask_f32(const float* logits, int N, int H, int W, int h, int w, int reset_full_rows,
+                                   unsigned char* blocked, combo_stream_t stream) {
+  return combo_attn_mask_pitched_f32(logits, N, H, W, h, w, reset_full_rows, h * w, blocked, stream);
 }

@@ -4,7 +4,8 @@ parameter names (so reference checkpoints load 1:1) and the same output dict.
 
 MI355X notes: activations are batch-first [BT, Q, C] / token-major [BT, hw, C] (the reference is sequence-first);
 position encodings are cached; the boolean attention mask is kept as ONE [BT, Q, hw] tensor and broadcast over
-the 8 heads instead of being materialised 8x (transformer_decoder.py:504); the "fully blocked row" reset
+the 8 heads instead of being materialised 8x (transformer_decoder.py:504) and feeds the head's own attention kernels
+(csrc/attention.hip: exact-fp32 MFMA, transposed score tiles); the "fully blocked row" reset
 (:458, a nonzero()+index_put => host sync in the reference) is a sync-free logical op; mask logits come from a
 token-major pixel embedding so the contraction is a K-contiguous NT GEMM.
 """
@@ -41,18 +42,16 @@ class _MHAParams(nn.Module):
         nn.init.constant_(self.out_proj.bias, 0.0)
 
     def forward(self, query, key, value, blocked=None):
-        """batch-first: query [B,Lq,E], key/value [B,Lk,E]; blocked: bool [B,Lq,Lk], True = masked out."""
+        """batch-first: query [B,Lq,E], key/value [B,Lk,E]; blocked: uint8 [B,Lq,pitch] (1 = masked out, rows padded to a
+        multiple of 4 bytes, ops.masklogit.attn_mask_padded) or None."""
+        from ..ops.attention import attention
         E, H = self.embed_dim, self.num_heads
         B, Lq, _ = query.shape
         Lk = key.shape[1]
         # (these weights are used once per forward: their dW GEMMs may be deferred into the grouped launch, ops/linear.py)
         q, k, v = in_proj(query, key, value, self.in_proj_weight, self.in_proj_bias, same_qk=query is key, defer=True)
-        q = q.view(B, Lq, H, E // H).transpose(1, 2)
-        k = k.view(B, Lk, H, E // H).transpose(1, 2)
-        v = v.view(B, Lk, H, E // H).transpose(1, 2)
-        mask = None if blocked is None else (~blocked)[:, None]  # SDPA: True = may attend
-        o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
-        return self.out_proj(o.transpose(1, 2).reshape(B, Lq, E))
+        o = attention(q.reshape(B * Lq, E), k.reshape(B * Lk, E), v.reshape(B * Lk, E), blocked, B, H)  # csrc/attention.hip
+        return self.out_proj(o.view(B, Lq, E))
 
 
 class SelfAttentionLayer(nn.Module):
@@ -251,5 +250,5 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         outputs_class = self.class_embed(dec)
         mask_embed = self.mask_embed(dec)
         masklogit.mask_logits_into(mask_embed, mf_tok, logits_out)
-        blocked = masklogit.attn_mask(logits_out.view(output.shape[0], self.num_queries, hw[0], hw[1]), attn_mask_target_size, True)
+        blocked = masklogit.attn_mask_padded(logits_out.view(output.shape[0], self.num_queries, hw[0], hw[1]), attn_mask_target_size, True)
         return outputs_class, mask_embed, blocked

@@ -37,15 +37,23 @@ def gemm_nt_batched(a, img, out):
     return out
 
 
-def attn_mask(logits, target_size, reset_full_rows=True):
-    """logits [BT,Q,H,W] fp32 -> blocked bool [BT,Q,h*w] (True = masked out), row reset of :458 applied."""
+def attn_mask_padded(logits, target_size, reset_full_rows=True):
+    """logits [BT,Q,H,W] fp32 -> blocked uint8 [BT,Q,pitch] (1 = masked out; pitch = h*w rounded up to 4, padding cells
+    blocked), row reset of :458 applied.  This is the form csrc/attention.hip reads."""
     _lib.require_cuda(logits)
     bt, Q, H, W = logits.shape
     h, w = target_size
-    out = torch.empty((bt, Q, h * w), dtype=torch.uint8, device=logits.device)
-    _lib.check(_lib.lib().combo_attn_mask_f32(logits.data_ptr(), bt * Q, H, W, h, w, 1 if reset_full_rows else 0,
-                                              out.data_ptr(), _lib.current_stream()), "combo_attn_mask_f32")
-    return out.view(torch.bool)
+    pitch = (h * w + 3) // 4 * 4
+    out = torch.empty((bt, Q, pitch), dtype=torch.uint8, device=logits.device)
+    _lib.check(_lib.lib().combo_attn_mask_pitched_f32(logits.data_ptr(), bt * Q, H, W, h, w, 1 if reset_full_rows else 0, pitch,
+                                                      out.data_ptr(), _lib.current_stream()), "combo_attn_mask_pitched_f32")
+    return out
+
+
+def attn_mask(logits, target_size, reset_full_rows=True):
+    """logits [BT,Q,H,W] fp32 -> blocked bool [BT,Q,h*w] (True = masked out), row reset of :458 applied."""
+    h, w = target_size
+    return attn_mask_padded(logits, target_size, reset_full_rows)[:, :, :h * w].view(torch.bool)
 
 
 class _MaskLogitsAll(torch.autograd.Function):

@@ -325,6 +325,28 @@ int combo_splitk_reduce_f32(const float* partials, int splits, long long n, floa
  * ---------------------------------------------------------------------------------------------- */
 int combo_attn_mask_f32(const float* logits, int N, int H, int W, int h, int w, int reset_full_rows,
                         unsigned char* blocked, combo_stream_t stream);
+/*   _pitched: rows of `blocked` are `pitch` >= h*w bytes apart and the padding cells are written as blocked: with pitch a
+ *   multiple of 4 the attention kernels below read the 4 keys of a register group with one dword load. */
+int combo_attn_mask_pitched_f32(const float* logits, int N, int H, int W, int h, int w, int reset_full_rows, int pitch,
+                                unsigned char* blocked, combo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a12  masked multi-head attention of the decoder layers, head_dim = 32 (csrc/attention.hip)
+ *   replaces nn.MultiheadAttention's core `softmax(q k^T * scale + mask) v` as called by CrossAttentionLayer / SelfAttentionLayer
+ *   (transformer_decoder/transformer_decoder.py:99-118, 50-58; the packed in_proj / out_proj GEMMs are combo_gemm_nt_f32).
+ *   q [B, Lq, >= H*32] (row stride ldq), k / v [B, Lk, .] (ldk / ldv), head h at column h*32; blocked: bytes [B, Lq, pitch]
+ *   (1 = masked out, shared by the H heads; NULL = no mask), pitch % 4 == 0; scale = head_dim^-0.5 is applied to q.
+ *   forward:  out [B, Lq, H*32], lse [B, H, Lq] (log-sum-exp of the scaled masked scores, saved for backward), exact fp32 MFMA.
+ *   backward: dq [B, Lq, H*32], dk / dv [B, Lk, H*32] from dout; delta_ws: [B, H, Lq] workspace.  A query whose keys are all
+ *   blocked yields zeros (the reference would produce NaN; the decoder never passes such a row: :458 resets it).
+ * ---------------------------------------------------------------------------------------------- */
+int combo_attention_forward_f32(const float* q, long long ldq, const float* k, long long ldk, const float* v, long long ldv,
+                                const unsigned char* blocked, int pitch, int B, int H, int Lq, int Lk, float scale, float* out,
+                                float* lse, combo_stream_t stream);
+int combo_attention_backward_f32(const float* q, long long ldq, const float* k, long long ldk, const float* v, long long ldv,
+                                 const unsigned char* blocked, int pitch, int B, int H, int Lq, int Lk, float scale,
+                                 const float* out, const float* lse, const float* dout, float* delta_ws, float* dq, float* dk,
+                                 float* dv, combo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a14  Hungarian-matcher cost matrices, all (decoder output x frame) problems at once
