@@ -21,6 +21,7 @@ _SIGNATURES = {
     "combo_dwconv3x3_wgrad_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "combo_fold_cast_grouped": [c_void_p, c_int, c_void_p],
     "combo_bias_act_bf16": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p],
+    "combo_bias_act_f32": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p],
     "combo_relu_grad_bf16": [c_void_p, c_void_p, c_longlong, c_void_p, c_void_p],
     "combo_relu_grad_f32": [c_void_p, c_void_p, c_longlong, c_void_p, c_void_p],
     "combo_msda_backward_needs_zero": [c_int] * 6,
@@ -67,6 +68,8 @@ _SIGNATURES = {
     "combo_gemm_tn_x3_grouped_f32": [c_void_p, c_int, c_void_p],
     "combo_splitk_reduce_grouped_f32": [c_void_p, c_int, c_void_p],
     "combo_ln_param_grad_grouped_f32": [c_void_p, c_int, c_void_p],
+    "combo_add_layernorm_forward_f32": [c_void_p] * 4 + [c_float, c_longlong, c_int] + [c_void_p] * 5,
+    "combo_layernorm_backward_f32": [c_void_p] * 5 + [c_longlong, c_int, c_void_p, c_void_p],
     "combo_splitk_reduce_f32": [c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "combo_uncertain_points_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p],
     "combo_mask_loss_forward_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p],

@@ -68,9 +68,34 @@ relu_grad_f32_kernel(const float* __restrict__ dy, const float* __restrict__ y, 
   reinterpret_cast<float4*>(dx)[i] = make_float4(v.x > 0.f ? g.x : 0.f, v.y > 0.f ? g.y : 0.f, v.z > 0.f ? g.z : 0.f, v.w > 0.f ? g.w : 0.f);
 }
 
+// fp32 variant of bias_act_kernel (the reference's S4 recipe runs the backbones in fp32: SOLVER.AMP.ENABLED False); 4 channels per thread
+__global__ void __launch_bounds__(256)
+bias_act_f32_kernel(float* __restrict__ y, const float* __restrict__ bias, const float* __restrict__ res, long long n4, int C4, int relu) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4 v = reinterpret_cast<const float4*>(y)[i];
+  const float4 b = reinterpret_cast<const float4*>(bias)[(int)(i % C4)];
+  v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+  if (res) {
+    const float4 r = reinterpret_cast<const float4*>(res)[i];
+    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+  }
+  if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+  reinterpret_cast<float4*>(y)[i] = v;
+}
+
 }  // namespace
 
 extern "C" {
+
+int combo_bias_act_f32(float* y, const float* bias, const float* residual, long long tokens, int C, int relu, combo_stream_t stream) {
+  if (!y || !bias || tokens <= 0 || C <= 0 || C % 4 != 0 || ((uintptr_t)y & 15) || ((uintptr_t)bias & 15) || ((uintptr_t)residual & 15))
+    return COMBO_EINVAL;
+  const long long n4 = tokens * (C / 4);
+  hipLaunchKernelGGL(bias_act_f32_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, bias, residual, n4,
+                     C / 4, relu);
+  return (int)hipGetLastError();
+}
 
 int combo_relu_grad_f32(const float* dy, const float* y, long long n, float* dx, combo_stream_t stream) {
   if (!dy || !y || !dx || n <= 0 || n % 4 != 0 || ((uintptr_t)dy & 15) || ((uintptr_t)y & 15) || ((uintptr_t)dx & 15))

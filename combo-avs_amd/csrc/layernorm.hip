@@ -1,0 +1,104 @@
+// Residual add + LayerNorm, forward and input gradient, for the post-norm layers of the head:
+//   encoder   src = LN(src + attn(src)), src = LN(src + ffn(src))           pixel_decoder/msdeformattn.py:119-134
+//   decoder   tgt = LN(tgt + xattn), LN(tgt + selfattn), LN(tgt + ffn(tgt))  transformer_decoder/transformer_decoder.py:99-118, 50-58, 178-182
+//   decoder_norm (no residual), applied before each of the 10 prediction heads :494
+// ATen runs these as an add kernel (2 reads + 1 write), a LayerNorm kernel (1 read + 1 write) and, backward, a
+// layer_norm_grad_input kernel + the accumulation add of the two branches.  Here: ONE pass forward (reads x and r, writes
+// z = x + r once - it is what the backward needs - and y), ONE pass backward (dz serves both branches: the caller returns the
+// same tensor for x and r).  The parameter gradients stay in the deferred grouped launch (csrc/lngrad.hip).
+// HBM-bound: 16 B per lane per tensor, one wave per row (C = 64 * VEC channels), statistics by DPP/shuffle inside the wave,
+// two-pass variance on the registers (no E[x^2] - E[x]^2 cancellation).
+#include "combo_common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int VEC>  // channels per lane: C = 64 * VEC, VEC in {2, 4, 8}
+__global__ void __launch_bounds__(256)
+add_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ w, const float* __restrict__ b,
+                  float eps, long long rows, float* __restrict__ z, float* __restrict__ y, float* __restrict__ mean,
+                  float* __restrict__ rstd) {
+  constexpr int C = 64 * VEC;
+  const long long row = blockIdx.x * 4LL + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const long long off = row * C + lane * VEC;
+  float v[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) v[i] = x[off + i];
+  if (r) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) v[i] += r[off + i];
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) s += v[i];
+  const float mu = wave_sum(s) * (1.f / C);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) q += (v[i] - mu) * (v[i] - mu);
+  const float rs = rsqrtf(wave_sum(q) * (1.f / C) + eps);
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    if (z) z[off + i] = v[i];
+    y[off + i] = (v[i] - mu) * rs * w[lane * VEC + i] + b[lane * VEC + i];
+  }
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+// dz = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)),  g = dy * w,  xhat = (z - mean) * rstd
+template <int VEC>
+__global__ void __launch_bounds__(256)
+ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ rstd,
+              const float* __restrict__ w, long long rows, float* __restrict__ dz) {
+  constexpr int C = 64 * VEC;
+  const long long row = blockIdx.x * 4LL + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const long long off = row * C + lane * VEC;
+  const float mu = mean[row], rs = rstd[row];
+  float g[VEC], xh[VEC];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    g[i] = dy[off + i] * w[lane * VEC + i];
+    xh[i] = (z[off + i] - mu) * rs;
+    s1 += g[i];
+    s2 += g[i] * xh[i];
+  }
+  s1 = wave_sum(s1) * (1.f / C);
+  s2 = wave_sum(s2) * (1.f / C);
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) dz[off + i] = rs * (g[i] - s1 - xh[i] * s2);
+}
+
+}  // namespace
+
+extern "C" int combo_add_layernorm_forward_f32(const float* x, const float* r, const float* w, const float* b, float eps, long long rows,
+                                               int C, float* z, float* y, float* mean, float* rstd, combo_stream_t stream) {
+  if (!x || !w || !b || !y || !mean || !rstd || rows <= 0 || (C != 128 && C != 256 && C != 512) ||
+      (((uintptr_t)x | (uintptr_t)r | (uintptr_t)z | (uintptr_t)y | (uintptr_t)w | (uintptr_t)b) & 15))
+    return COMBO_EINVAL;
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  if (C == 128) hipLaunchKernelGGL(add_ln_fwd_kernel<2>, grid, block, 0, (hipStream_t)stream, x, r, w, b, eps, rows, z, y, mean, rstd);
+  else if (C == 256) hipLaunchKernelGGL(add_ln_fwd_kernel<4>, grid, block, 0, (hipStream_t)stream, x, r, w, b, eps, rows, z, y, mean, rstd);
+  else hipLaunchKernelGGL(add_ln_fwd_kernel<8>, grid, block, 0, (hipStream_t)stream, x, r, w, b, eps, rows, z, y, mean, rstd);
+  return (int)hipGetLastError();
+}
+
+extern "C" int combo_layernorm_backward_f32(const float* dy, const float* z, const float* mean, const float* rstd, const float* w,
+                                            long long rows, int C, float* dz, combo_stream_t stream) {
+  if (!dy || !z || !mean || !rstd || !w || !dz || rows <= 0 || (C != 128 && C != 256 && C != 512) ||
+      (((uintptr_t)dy | (uintptr_t)z | (uintptr_t)dz | (uintptr_t)w) & 15))
+    return COMBO_EINVAL;
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  if (C == 128) hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, (hipStream_t)stream, dy, z, mean, rstd, w, rows, dz);
+  else if (C == 256) hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, (hipStream_t)stream, dy, z, mean, rstd, w, rows, dz);
+  else hipLaunchKernelGGL(ln_bwd_kernel<8>, grid, block, 0, (hipStream_t)stream, dy, z, mean, rstd, w, rows, dz);
+  return (int)hipGetLastError();
+}

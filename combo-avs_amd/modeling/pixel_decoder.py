@@ -116,12 +116,12 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None, normalizer=None):
         src2 = self.self_attn(src + pos, reference_points, src, spatial_shapes, level_start_index, padding_mask, normalizer)
-        src = self.norm1(src + self.dropout1(src2))
+        src = self.norm1(src, self.dropout1(src2))  # LN(src + src2) in one pass (csrc/layernorm.hip)
         if self.dropout2.p == 0.0:  # (every shipped config) FFN with the ReLU backward folded into linear2's dX GEMM
             src2 = ffn(src, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias)
         else:
             src2 = self.linear2(self.dropout2(linear(src, self.linear1.weight, self.linear1.bias, relu=True, defer=True)))
-        return self.norm2(src + self.dropout3(src2))
+        return self.norm2(src, self.dropout3(src2))
 
 
 class MSDeformAttnTransformerEncoder(nn.Module):

@@ -69,7 +69,7 @@ class SelfAttentionLayer(nn.Module):
 
     def forward(self, tgt, query_pos):
         qk = tgt + query_pos
-        return self.norm(tgt + self.self_attn(qk, qk, tgt))  # transformer_decoder.py:50-58
+        return self.norm(tgt, self.self_attn(qk, qk, tgt))  # LN(tgt + attn), transformer_decoder.py:50-58
 
 
 class CrossAttentionLayer(nn.Module):
@@ -87,7 +87,7 @@ class CrossAttentionLayer(nn.Module):
 
     def forward(self, tgt, memory, blocked, pos, query_pos):
         tgt2 = self.multihead_attn(tgt + query_pos, memory + pos, memory, blocked)  # :99-118
-        return self.norm(tgt + tgt2)
+        return self.norm(tgt, tgt2)  # LN(tgt + tgt2) in one pass (csrc/layernorm.hip)
 
 
 class FFNLayer(nn.Module):
@@ -106,7 +106,7 @@ class FFNLayer(nn.Module):
                 nn.init.xavier_uniform_(p)
 
     def forward(self, tgt):
-        return self.norm(tgt + ffn(tgt, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias))  # :178-182
+        return self.norm(tgt, ffn(tgt, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias))  # :178-182
 
 
 @TRANSFORMER_DECODER_REGISTRY.register()

@@ -1,5 +1,5 @@
 """Fused epilogue of the backbone convolutions (csrc/biasact.hip): y <- relu(y + bias[c] (+ residual)), in place on the
-convolution output (bf16, channels_last), one pass; backward dx = dy * (y > 0) for both the convolution branch and the
+convolution output (bf16 or fp32, channels_last), one pass; backward dx = dy * (y > 0) for both the convolution branch and the
 residual branch."""
 import torch
 from torch.autograd import Function
@@ -9,7 +9,7 @@ from .. import _lib
 
 
 def fusable(y, residual=None):
-    ok = (y.is_cuda and y.dtype == torch.bfloat16 and y.dim() == 4 and y.shape[1] % 8 == 0
+    ok = (y.is_cuda and y.dtype in (torch.bfloat16, torch.float32) and y.dim() == 4 and y.shape[1] % 8 == 0
           and y.is_contiguous(memory_format=torch.channels_last))
     if residual is not None:
         ok = ok and residual.dtype == y.dtype and residual.shape == y.shape and residual.is_contiguous(memory_format=torch.channels_last)
@@ -20,8 +20,9 @@ class _BiasAct(Function):
     @staticmethod
     def forward(ctx, y, bias, residual, relu):
         N, C, H, W = y.shape
-        _lib.check(_lib.lib().combo_bias_act_bf16(y.data_ptr(), bias.data_ptr(), _lib.ptr(residual), N * H * W, C, 1 if relu else 0,
-                                                  _lib.current_stream()), "combo_bias_act_bf16")
+        fn = _lib.lib().combo_bias_act_f32 if y.dtype == torch.float32 else _lib.lib().combo_bias_act_bf16
+        _lib.check(fn(y.data_ptr(), bias.float().data_ptr() if bias.dtype != torch.float32 else bias.data_ptr(), _lib.ptr(residual),
+                      N * H * W, C, 1 if relu else 0, _lib.current_stream()), "combo_bias_act")
         ctx.mark_dirty(y)
         ctx.relu, ctx.has_res = relu, residual is not None
         if relu:
@@ -36,8 +37,8 @@ class _BiasAct(Function):
             (y,) = ctx.saved_tensors
             dy = dy.contiguous(memory_format=torch.channels_last)
             dx = torch.empty_like(dy)
-            _lib.check(_lib.lib().combo_relu_grad_bf16(dy.data_ptr(), y.data_ptr(), dy.numel(), dx.data_ptr(), _lib.current_stream()),
-                       "combo_relu_grad_bf16")
+            fn = _lib.lib().combo_relu_grad_f32 if dy.dtype == torch.float32 else _lib.lib().combo_relu_grad_bf16
+            _lib.check(fn(dy.data_ptr(), y.data_ptr(), dy.numel(), dx.data_ptr(), _lib.current_stream()), "combo_relu_grad")
         return dx, None, (dx if ctx.has_res else None), None
 
 

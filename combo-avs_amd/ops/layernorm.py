@@ -1,55 +1,84 @@
-"""nn.LayerNorm whose PARAMETER gradients can be deferred into one grouped launch (csrc/lngrad.hip) at the end of the
-backward pass (ops.linear.deferred_dw).  Forward and the input gradient are ATen's kernels; only the two per-layer
-gamma/beta reduction kernels (off the critical path, ~100 launches per step) are replaced."""
+"""Residual add + LayerNorm of the head's post-norm layers on csrc/layernorm.hip (one pass forward, one pass backward), with
+the PARAMETER gradients deferred into one grouped launch (csrc/lngrad.hip) at the end of the backward pass
+(ops.linear.deferred_dw).  `LayerNorm(x, residual=r)` == nn.LayerNorm(x + r)."""
 import torch
 from torch import nn
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
+from .. import _lib
 from . import linear as _linear_mod
 
 
-class _LayerNorm(Function):
+def _own_ok(x, C):
+    return (x.is_cuda and x.dtype == torch.float32 and C in (128, 256, 512) and not torch.is_autocast_enabled())
+
+
+class _AddLayerNorm(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, eps):
+    def forward(ctx, x, r, weight, bias, eps, defer):
         C = x.shape[-1]
-        y, mean, rstd = torch.native_layer_norm(x, (C,), weight, bias, eps)
-        ctx.save_for_backward(x, mean, rstd, weight, bias)
-        return y
+        x2 = x.reshape(-1, C)
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        rows = x2.shape[0]
+        r2 = None
+        if r is not None:
+            r2 = r.reshape(-1, C)
+            r2 = r2 if r2.is_contiguous() else r2.contiguous()
+        y = torch.empty_like(x2)
+        z = torch.empty_like(x2) if r is not None else None  # the normalised tensor the backward pass needs (z = x without r)
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+        _lib.check(_lib.lib().combo_add_layernorm_forward_f32(x2.data_ptr(), _lib.ptr(r2), weight.data_ptr(), bias.data_ptr(), eps, rows, C,
+                                                              _lib.ptr(z), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                              _lib.current_stream()), "combo_add_layernorm_forward_f32")
+        ctx.save_for_backward(z if z is not None else x2, mean, rstd, weight)
+        ctx.has_r, ctx.defer, ctx.shape = r is not None, defer, x.shape
+        return y.view(x.shape)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        x, mean, rstd, weight, bias = ctx.saved_tensors
-        C = x.shape[-1]
-        dy = dy.contiguous()
-        q = _linear_mod._ln_queue
-        deferred = (q is not None and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
-                    and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]))
-        mask = [ctx.needs_input_grad[0], ctx.needs_input_grad[1] and not deferred, ctx.needs_input_grad[2] and not deferred]
-        dx, dw, db = torch.ops.aten.native_layer_norm_backward(dy, x, [C], mean, rstd, weight, bias, mask)
-        if deferred:
-            use = (dy.view(-1, C), x.view(-1, C), mean.reshape(-1), rstd.reshape(-1))
-            key = ("ln", weight.data_ptr())
-            ent = _linear_mod._dw_index.get(key)
-            if ent is not None:  # another application of the same LayerNorm: joins the entry, autograd gets "no gradient"
-                ent[0].append(use)
-                return dx, None, None, None
-            out = torch.empty(2, C, device=x.device, dtype=torch.float32)  # filled when deferred_dw() closes
-            ent = [[use], out]
-            q.append(ent)
-            _linear_mod._dw_index[key] = ent
-            dw, db = out[0], out[1]
-        return dx, dw, db, None
+        z, mean, rstd, weight = ctx.saved_tensors
+        C = z.shape[1]
+        dy2 = dy.reshape(-1, C)
+        dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
+        dz = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            dz = torch.empty_like(z)
+            _lib.check(_lib.lib().combo_layernorm_backward_f32(dy2.data_ptr(), z.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                               weight.data_ptr(), z.shape[0], C, dz.data_ptr(), _lib.current_stream()),
+                       "combo_layernorm_backward_f32")
+            dz = dz.view(ctx.shape)
+        dw = db = None
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            q = _linear_mod._ln_queue
+            use = (dy2, z, mean, rstd)
+            if ctx.defer and q is not None:
+                key = ("ln", weight.data_ptr())
+                ent = _linear_mod._dw_index.get(key)
+                if ent is not None:  # another application of the same LayerNorm: joins the entry, autograd gets "no gradient"
+                    ent[0].append(use)
+                else:
+                    out = torch.empty(2, C, device=z.device, dtype=torch.float32)  # filled when deferred_dw() closes
+                    ent = [[use], out]
+                    q.append(ent)
+                    _linear_mod._dw_index[key] = ent
+                    dw, db = out[0], out[1]
+            else:
+                out = torch.empty(2, C, device=z.device, dtype=torch.float32)
+                _linear_mod._flush_ln([[[use], out]])
+                dw, db = out[0], out[1]
+        return dz, (dz if ctx.has_r else None), dw, db, None, None
 
 
 class LayerNorm(nn.LayerNorm):
-    """Same parameters / state-dict as nn.LayerNorm.  `defer_dw = True`: the parameter gradients may join the grouped launch
-    of ops.linear.deferred_dw (repeated applications of one instance are summed there)."""
+    """Same parameters / state-dict as nn.LayerNorm; `forward(x, residual=None)` = LN(x + residual).  `defer_dw = True`: the
+    parameter gradients may join the grouped launch of ops.linear.deferred_dw (repeated applications of one instance are summed
+    there)."""
     defer_dw = False
 
-    def forward(self, x):
-        if self.defer_dw and x.is_cuda and x.dtype == torch.float32 and self.elementwise_affine and torch.is_grad_enabled() \
-                and not torch.is_autocast_enabled():
-            return _LayerNorm.apply(x.contiguous(), self.weight, self.bias, self.eps)
-        return super().forward(x)
+    def forward(self, x, residual=None):
+        if self.elementwise_affine and _own_ok(x, x.shape[-1]) and (residual is None or residual.shape == x.shape):
+            return _AddLayerNorm.apply(x, residual, self.weight, self.bias, self.eps, self.defer_dw)
+        return super().forward(x if residual is None else x + residual)

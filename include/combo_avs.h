@@ -80,6 +80,8 @@ int combo_fold_cast_grouped(const combo_fold_problem* problems, int count, combo
 int combo_bias_act_bf16(void* y, const float* bias, const void* residual, long long tokens, int C, int relu,
                         combo_stream_t stream);
 int combo_relu_grad_bf16(const void* dy, const void* y, long long n, void* dx, combo_stream_t stream);
+/* fp32 activations (the reference's S4 recipe: SOLVER.AMP.ENABLED False, configs/avs_s4/R50-AVSS4-SemanticSegmentation.yaml:44-45); C % 4 == 0 */
+int combo_bias_act_f32(float* y, const float* bias, const float* residual, long long tokens, int C, int relu, combo_stream_t stream);
 /* fp32 variant for the head's Linear+ReLU layers (MLP.forward transformer_decoder.py:216-219, FFN :178-182, encoder FFN). */
 int combo_relu_grad_f32(const float* dy, const float* y, long long n, float* dx, combo_stream_t stream);
 
@@ -309,6 +311,16 @@ typedef struct {
   int C, tokens_per_slice;
 } combo_ln_grad_problem;
 int combo_ln_param_grad_grouped_f32(const combo_ln_grad_problem* problems, int count, combo_stream_t stream);
+
+/*   Residual add + LayerNorm in one pass (csrc/layernorm.hip): z = x + r (r NULL: z = x, not written when z is NULL),
+ *   y = (z - mean) * rstd * w + b over the last dimension C in {128, 256, 512}; mean / rstd [rows] are saved for the backward
+ *   pass, which returns dz = d(loss)/dz (the gradient of BOTH x and r).  Replaces `self.norm(tgt + tgt2)` of the post-norm
+ *   layers (transformer_decoder/transformer_decoder.py:99-118, 50-58, 178-182; pixel_decoder/msdeformattn.py:119-134) and
+ *   decoder_norm (:494).  All tensors contiguous [rows, C], 16-byte aligned. */
+int combo_add_layernorm_forward_f32(const float* x, const float* r, const float* w, const float* b, float eps, long long rows,
+                                    int C, float* z, float* y, float* mean, float* rstd, combo_stream_t stream);
+int combo_layernorm_backward_f32(const float* dy, const float* z, const float* mean, const float* rstd, const float* w,
+                                 long long rows, int C, float* dz, combo_stream_t stream);
 
 /*   Finishes a split-K result in ONE launch: out[i] = sum_z partials[z*n + i] (n % 4 == 0, 16-byte aligned) and, when
  *   nb > 0, db[j] = sum_z db_partials[z*nb + j]; fixed summation order.  `out` may be a row block of a larger matrix

@@ -389,3 +389,39 @@ def test_upsample2x_bilinear_nhwc_vs_torch(B, C, H, W):
     dx, = torch.autograd.grad(y, x, g.contiguous(memory_format=torch.channels_last))
     dxr, = torch.autograd.grad(yr, xr, g)
     assert (dx - dxr).abs().max() <= 1e-5 * dxr.abs().max() + 1e-6
+
+
+@pytest.mark.parametrize("rows,C,with_res", [(41160, 256, True), (4000, 256, True), (4000, 256, False), (37, 128, True), (5, 512, False)])
+def test_add_layernorm_forward_backward_vs_torch(rows, C, with_res):
+    """ops.layernorm.LayerNorm(x, residual): LN(x + r) in one pass (csrc/layernorm.hip) == nn.LayerNorm(x + r) in float64,
+    values, input gradients (the same tensor serves both branches) and the parameter gradients, immediate and deferred
+    (reference: post-norm layers of msdeformattn.py:119-134 and transformer_decoder.py:50-58, 99-118, 178-182)."""
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.ops import linear as L
+    from combo_avs_amd.ops.layernorm import LayerNorm
+    torch.manual_seed(rows + C)
+    ln = LayerNorm(C).cuda()
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.1 * torch.randn(C))
+        ln.bias.copy_(0.1 * torch.randn(C))
+    x = (torch.randn(rows, C, device="cuda") * 2 + 0.5).requires_grad_(True)
+    r = torch.randn(rows, C, device="cuda", requires_grad=True) if with_res else None
+    g = torch.randn(rows, C, device="cuda")
+    xd = x.detach().double().requires_grad_(True)
+    rd = r.detach().double().requires_grad_(True) if with_res else None
+    wd, bd = ln.weight.detach().double().requires_grad_(True), ln.bias.detach().double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xd + rd if with_res else xd, (C,), wd, bd, ln.eps)
+    ref_g = torch.autograd.grad(ref, [xd] + ([rd] if with_res else []) + [wd, bd], g.double())
+    for deferred in (False, True):
+        ln.defer_dw = deferred
+        inputs = [x] + ([r] if with_res else []) + [ln.weight, ln.bias]
+        if deferred:
+            with L.deferred_dw():
+                y = ln(x, r)
+                got = torch.autograd.grad(y, inputs, g)
+        else:
+            y = ln(x, r)
+            got = torch.autograd.grad(y, inputs, g)
+        assert ((y.double() - ref).abs().max() / ref.abs().max()).item() < 1e-6
+        for a, b in zip(got, ref_g):
+            assert ((a.double() - b).norm() / b.norm()).item() < 2e-6
