@@ -107,8 +107,9 @@ def _ln(x, mod, wts):
     if x.is_cuda and torch.is_grad_enabled() and mod.weight.requires_grad:
         # every LayerNorm of the backbone is applied once per forward: its parameter gradients may be deferred into the
         # grouped launch (ops/layernorm.py), ~320 fewer reduction kernels per backbone backward
-        from .ops.layernorm import _LayerNorm
-        return _LayerNorm.apply(x.contiguous(), mod.weight, mod.bias, mod.eps)
+        from .ops.layernorm import _AddLayerNorm, _own_ok
+        if _own_ok(x, x.shape[-1]):
+            return _AddLayerNorm.apply(x, None, mod.weight, mod.bias, mod.eps, True)  # csrc/layernorm.hip
     return F.layer_norm(x, mod.normalized_shape, mod.weight, mod.bias, mod.eps)
 
 

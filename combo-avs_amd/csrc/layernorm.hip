@@ -18,7 +18,7 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-template <int VEC>  // channels per lane: C = 64 * VEC, VEC in {2, 4, 8}
+template <int VEC>  // channels per lane: C = 64 * VEC, VEC in {1, 2, 4, 5, 8} (64 / 320 = PVTv2's widths)
 __global__ void __launch_bounds__(256)
 add_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ w, const float* __restrict__ b,
                   float eps, long long rows, float* __restrict__ z, float* __restrict__ y, float* __restrict__ mean,
@@ -77,28 +77,38 @@ ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z, const f
   for (int i = 0; i < VEC; ++i) dz[off + i] = rs * (g[i] - s1 - xh[i] * s2);
 }
 
+inline bool c_ok(int C) { return C == 64 || C == 128 || C == 256 || C == 320 || C == 512; }
+
 }  // namespace
 
 extern "C" int combo_add_layernorm_forward_f32(const float* x, const float* r, const float* w, const float* b, float eps, long long rows,
                                                int C, float* z, float* y, float* mean, float* rstd, combo_stream_t stream) {
-  if (!x || !w || !b || !y || !mean || !rstd || rows <= 0 || (C != 128 && C != 256 && C != 512) ||
+  if (!x || !w || !b || !y || !mean || !rstd || rows <= 0 || !c_ok(C) ||
       (((uintptr_t)x | (uintptr_t)r | (uintptr_t)z | (uintptr_t)y | (uintptr_t)w | (uintptr_t)b) & 15))
     return COMBO_EINVAL;
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-  if (C == 128) hipLaunchKernelGGL(add_ln_fwd_kernel<2>, grid, block, 0, (hipStream_t)stream, x, r, w, b, eps, rows, z, y, mean, rstd);
-  else if (C == 256) hipLaunchKernelGGL(add_ln_fwd_kernel<4>, grid, block, 0, (hipStream_t)stream, x, r, w, b, eps, rows, z, y, mean, rstd);
-  else hipLaunchKernelGGL(add_ln_fwd_kernel<8>, grid, block, 0, (hipStream_t)stream, x, r, w, b, eps, rows, z, y, mean, rstd);
+  switch (C / 64) {
+    case 1: hipLaunchKernelGGL(add_ln_fwd_kernel<1>, grid, block, 0, (hipStream_t)stream, x, r, w, b, eps, rows, z, y, mean, rstd); break;
+    case 2: hipLaunchKernelGGL(add_ln_fwd_kernel<2>, grid, block, 0, (hipStream_t)stream, x, r, w, b, eps, rows, z, y, mean, rstd); break;
+    case 4: hipLaunchKernelGGL(add_ln_fwd_kernel<4>, grid, block, 0, (hipStream_t)stream, x, r, w, b, eps, rows, z, y, mean, rstd); break;
+    case 5: hipLaunchKernelGGL(add_ln_fwd_kernel<5>, grid, block, 0, (hipStream_t)stream, x, r, w, b, eps, rows, z, y, mean, rstd); break;
+    default: hipLaunchKernelGGL(add_ln_fwd_kernel<8>, grid, block, 0, (hipStream_t)stream, x, r, w, b, eps, rows, z, y, mean, rstd); break;
+  }
   return (int)hipGetLastError();
 }
 
 extern "C" int combo_layernorm_backward_f32(const float* dy, const float* z, const float* mean, const float* rstd, const float* w,
                                             long long rows, int C, float* dz, combo_stream_t stream) {
-  if (!dy || !z || !mean || !rstd || !w || !dz || rows <= 0 || (C != 128 && C != 256 && C != 512) ||
+  if (!dy || !z || !mean || !rstd || !w || !dz || rows <= 0 || !c_ok(C) ||
       (((uintptr_t)dy | (uintptr_t)z | (uintptr_t)dz | (uintptr_t)w) & 15))
     return COMBO_EINVAL;
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-  if (C == 128) hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, (hipStream_t)stream, dy, z, mean, rstd, w, rows, dz);
-  else if (C == 256) hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, (hipStream_t)stream, dy, z, mean, rstd, w, rows, dz);
-  else hipLaunchKernelGGL(ln_bwd_kernel<8>, grid, block, 0, (hipStream_t)stream, dy, z, mean, rstd, w, rows, dz);
+  switch (C / 64) {
+    case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, (hipStream_t)stream, dy, z, mean, rstd, w, rows, dz); break;
+    case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, (hipStream_t)stream, dy, z, mean, rstd, w, rows, dz); break;
+    case 4: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, (hipStream_t)stream, dy, z, mean, rstd, w, rows, dz); break;
+    case 5: hipLaunchKernelGGL(ln_bwd_kernel<5>, grid, block, 0, (hipStream_t)stream, dy, z, mean, rstd, w, rows, dz); break;
+    default: hipLaunchKernelGGL(ln_bwd_kernel<8>, grid, block, 0, (hipStream_t)stream, dy, z, mean, rstd, w, rows, dz); break;
+  }
   return (int)hipGetLastError();
 }

@@ -11,7 +11,7 @@ from . import linear as _linear_mod
 
 
 def _own_ok(x, C):
-    return (x.is_cuda and x.dtype == torch.float32 and C in (128, 256, 512) and not torch.is_autocast_enabled())
+    return (x.is_cuda and x.dtype == torch.float32 and C in (64, 128, 256, 320, 512) and not torch.is_autocast_enabled())
 
 
 class _AddLayerNorm(Function):

@@ -313,7 +313,7 @@ typedef struct {
 int combo_ln_param_grad_grouped_f32(const combo_ln_grad_problem* problems, int count, combo_stream_t stream);
 
 /*   Residual add + LayerNorm in one pass (csrc/layernorm.hip): z = x + r (r NULL: z = x, not written when z is NULL),
- *   y = (z - mean) * rstd * w + b over the last dimension C in {128, 256, 512}; mean / rstd [rows] are saved for the backward
+ *   y = (z - mean) * rstd * w + b over the last dimension C in {64, 128, 256, 320, 512}; mean / rstd [rows] are saved for the backward
  *   pass, which returns dz = d(loss)/dz (the gradient of BOTH x and r).  Replaces `self.norm(tgt + tgt2)` of the post-norm
  *   layers (transformer_decoder/transformer_decoder.py:99-118, 50-58, 178-182; pixel_decoder/msdeformattn.py:119-134) and
  *   decoder_norm (:494).  All tensors contiguous [rows, C], 16-byte aligned. */
