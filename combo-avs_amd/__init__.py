@@ -14,3 +14,6 @@ from .config import (CfgNode, add_audio_config, add_fuse_config, add_maskformer2
 from .registry import (BACKBONE_REGISTRY, META_ARCH_REGISTRY, SEM_SEG_HEADS_REGISTRY,  # noqa: E402,F401
                        TRANSFORMER_DECODER_REGISTRY)
 from . import backbone, backbone_pvt  # noqa: E402,F401  (populate BACKBONE_REGISTRY: build_resnet_backbone, build_pvtv2_b5_backbone)
+
+from . import d2_register  # noqa: E402
+d2_register.install_if_detectron2()  # no-op without detectron2; never replaces names that are already registered

@@ -123,22 +123,25 @@ def get_cfg():
 
 
 def add_audio_config(cfg):  # models/config.py:6-12
-    cfg.MODEL.AUDIO = CfgNode({
+    CN = type(cfg)  # sub-nodes of the cfg's own node type: the same function extends a detectron2 CfgNode (d2_register.py)
+    cfg.MODEL.AUDIO = CN({
         "FREEZE_AUDIO_EXTRACTOR": True, "PRETRAINED_VGGISH_MODEL_PATH": "./torchvggish/vggish-10086976.pth",
         "PREPROCESS_AUDIO_TO_LOG_MEL": True, "POSTPROCESS_LOG_MEL_WITH_PCA": False,
         "PRETRAINED_PCA_PARAMS_PATH": "./torchvggish/vggish_pca_params-970ea276.pth"})
 
 
 def add_fuse_config(cfg):  # models/config.py:15-32
-    cfg.MODEL.FUSE_CONFIG = CfgNode({
+    CN = type(cfg)
+    cfg.MODEL.FUSE_CONFIG = CN({
         "FUSION_STEP": "early", "TYPE": "MHA-B", "AUDIO_DIM": 1024, "FUSED_BACKBONE": [], "FUSED_BACKBONE_DIM": [],
         "NUM_FRAMES": 5, "QUERIES_FUSE_TYPE": "add", "AUDIO_OUT_DIM": 256})
-    cfg.MODEL.MOBILE_SAM = CfgNode({"USE_MOBILE_SAM": False, "CHECKPOINT": ""})
-    cfg.MODEL.PRE_SAM = CfgNode({"USE_PRE_SAM": False, "PRE_SAM_DIM": [256, 512, 1024, 2048],
+    cfg.MODEL.MOBILE_SAM = CN({"USE_MOBILE_SAM": False, "CHECKPOINT": ""})
+    cfg.MODEL.PRE_SAM = CN({"USE_PRE_SAM": False, "PRE_SAM_DIM": [256, 512, 1024, 2048],
                                  "PRE_SAM_FEATURE_SIZE": [56, 28, 14, 7]})
 
 
 def add_maskformer2_config(cfg):  # models/config.py:35-149
+    CN = type(cfg)
     cfg.INPUT.AUGMENTATION = True
     cfg.INPUT.DATASET_MAPPER_NAME = "mask_former_semantic"
     cfg.INPUT.COLOR_AUG_SSD = False
@@ -147,7 +150,7 @@ def add_maskformer2_config(cfg):  # models/config.py:35-149
     cfg.SOLVER.WEIGHT_DECAY_EMBED = 0.0
     cfg.SOLVER.OPTIMIZER = "ADAMW"
     cfg.SOLVER.BACKBONE_MULTIPLIER = 0.1
-    cfg.MODEL.MASK_FORMER = CfgNode({
+    cfg.MODEL.MASK_FORMER = CN({
         "DEEP_SUPERVISION": True, "NO_OBJECT_WEIGHT": 0.1, "CLASS_WEIGHT": 1.0, "DICE_WEIGHT": 1.0, "MASK_WEIGHT": 20.0,
         "COSINE_WEIGHT": 1.0, "NHEADS": 8, "DROPOUT": 0.1, "DIM_FEEDFORWARD": 2048, "ENC_LAYERS": 0, "DEC_LAYERS": 6,
         "PRE_NORM": False, "HIDDEN_DIM": 256, "NUM_OBJECT_QUERIES": 100, "TRANSFORMER_IN_FEATURE": "res5",
@@ -159,7 +162,7 @@ def add_maskformer2_config(cfg):  # models/config.py:35-149
     cfg.MODEL.SEM_SEG_HEAD.MASK_DIM = 256
     cfg.MODEL.SEM_SEG_HEAD.TRANSFORMER_ENC_LAYERS = 0
     cfg.MODEL.SEM_SEG_HEAD.PIXEL_DECODER_NAME = "BasePixelDecoder"
-    cfg.MODEL.PVT = CfgNode({"OUT_FEATURES": ["res2", "res3", "res4", "res5"]})
+    cfg.MODEL.PVT = CN({"OUT_FEATURES": ["res2", "res3", "res4", "res5"]})
     cfg.INPUT.IMAGE_SIZE = 1024
     cfg.INPUT.MIN_SCALE = 0.1
     cfg.INPUT.MAX_SCALE = 2.0
