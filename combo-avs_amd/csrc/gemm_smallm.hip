@@ -1,0 +1,136 @@
+// Weight-streaming forward GEMM for a handful of rows: Y[M,N] = X[M,K] . W[N,K]^T (+ bias) (+ ReLU), M <= 64, exact fp32.
+// The case is audio_mlp (reference: models/modeling/misc/audio_transformation.py:5-14: 128 -> 4096 -> 4096 -> 256 on the
+// BT fused audio tokens): 73 MB of fp32 weights are read once per step for 40 rows - a GEMV regime.  A tiled GEMM leaves the
+// chip idle (gemm_f32's 64 x 64 tiles: 64 workgroups, each grinding 131 K MFMA cycles over one weight panel); here the
+// WEIGHT is the streamed operand and every CU takes an equal share of it:
+//   * v_mfma_f32_16x16x4_f32 with A = 16 weight rows (output features), B = X^T (16 rows of X per tile, 1..4 tiles): a lane
+//     reads 16 bytes (4 consecutive k) of its weight row per load - 1 KiB per wave instruction, straight to registers, 8
+//     loads in flight per lane, no LDS round trip (GEMV rule: the streamed operand is used once per workgroup);
+//   * MFMA step t takes element t of every lane's float4, i.e. k-slot kq <-> k = 4 kq + t of the 16-k group - X is loaded
+//     with the same enumeration (X is 640 KB and lives in L2 / L1);
+//   * balance: 12 MFMAs (3 row tiles x 4 steps) x 32 cycles per KiB of weights per wave = 10.7 B/clk/CU = 6.5 TB/s on 256 CUs,
+//     i.e. the matrix pipe and HBM saturate together;
+//   * grid = (N / 16 feature tiles) x (K splits): the 4 waves of a workgroup take a quarter of its K range each and are
+//     summed through LDS; splits > 1 (the 4096 -> 256 layer: only 16 feature tiles) write partials that a small epilogue
+//     kernel finishes (bias, ReLU) in a fixed order - deterministic, no atomics.
+#include "combo_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+template <int MT>  // row tiles of 16: M <= 16 * MT
+__global__ void __launch_bounds__(256)
+gemm_smallm_kernel(const float* __restrict__ X, long long ldx, const float* __restrict__ W, long long ldw,
+                   const float* __restrict__ bias, float* __restrict__ Y, long long ldy, float* __restrict__ partial, int M, int N,
+                   int K, int kchunk, int relu) {
+  __shared__ f32x4 red[4][MT][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int n0 = blockIdx.x * 16, split = blockIdx.y;
+  const int kb = split * kchunk + wave * (kchunk / 4), ke = kb + kchunk / 4;  // this wave's k range (a multiple of 16 long)
+  const float* wrow = W + (long long)min(n0 + i, N - 1) * ldw + 4 * kq;
+  const float* xrow[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) xrow[t] = X + (long long)min(16 * t + i, M - 1) * ldx + 4 * kq;
+  f32x4 acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int U = 8;  // 16-k groups per batch of weight loads
+  for (int k0 = kb; k0 < ke; k0 += 16 * U) {
+    f32x4 wv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = min(k0 + 16 * u, ke - 16);  // (the last batch of a short range re-reads its final group; masked below)
+      wv[u] = *reinterpret_cast<const f32x4*>(wrow + k);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (k0 + 16 * u >= ke) break;
+      f32x4 xv[MT];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) xv[t] = *reinterpret_cast<const f32x4*>(xrow[t] + k0 + 16 * u);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][e], xv[t][e], acc[t], 0, 0, 0);
+    }
+  }
+  // D[n = 4 kq + r][m = i]: sum the 4 waves through LDS, then lane (m, kq) owns 4 consecutive features of row m
+#pragma unroll
+  for (int t = 0; t < MT; ++t) red[wave][t][lane] = acc[t];
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      f32x4 s = red[0][t][lane];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        const f32x4 o = red[w][t][lane];
+        s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+      }
+      const int m = 16 * t + i, n = n0 + 4 * kq;
+      if (m >= M) continue;
+      float v[4] = {s.x, s.y, s.z, s.w};
+      if (partial) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < N) partial[((long long)split * M + m) * N + n + r] = v[r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n + r >= N) continue;
+          float y = v[r] + (bias ? bias[n + r] : 0.f);
+          if (relu) y = fmaxf(y, 0.f);
+          Y[(long long)m * ldy + n + r] = y;
+        }
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+smallm_finish_kernel(const float* __restrict__ partial, int splits, const float* __restrict__ bias, float* __restrict__ Y,
+                     long long ldy, int M, int N, int relu) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= M * N) return;
+  const int m = t / N, n = t - m * N;
+  float s = bias ? bias[n] : 0.f;
+  for (int z = 0; z < splits; ++z) s += partial[((long long)z * M + m) * N + n];
+  Y[(long long)m * ldy + n] = relu ? fmaxf(s, 0.f) : s;
+}
+
+}  // namespace
+
+extern "C" int combo_gemm_smallm_splits(int M, int N, int K) {
+  // enough workgroups to give every CU a share of the weight stream; every wave needs a k range that is a multiple of 16
+  (void)M;
+  int n_cu = 256, dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+  const int n_tiles = (N + 15) / 16;
+  int splits = 1;
+  while (n_tiles * splits < n_cu && K % (splits * 2 * 64) == 0 && K / (splits * 2) >= 64) splits *= 2;
+  return splits;
+}
+
+extern "C" int combo_gemm_smallm_f32(const float* X, long long ldx, const float* W, long long ldw, const float* bias, float* Y,
+                                     long long ldy, float* partial_ws, int splits, int M, int N, int K, int relu,
+                                     combo_stream_t stream) {
+  if (!X || !W || !Y || M <= 0 || M > 64 || N <= 0 || K <= 0 || splits <= 0 || K % (64 * splits) != 0 || ldx % 4 != 0 || ldw % 4 != 0 ||
+      (((uintptr_t)X | (uintptr_t)W) & 15) || (splits > 1 && !partial_ws))
+    return COMBO_EINVAL;
+  const dim3 grid((N + 15) / 16, splits), block(256);
+  const int kchunk = K / splits;
+  float* part = splits > 1 ? partial_ws : nullptr;
+  const int mt = (M + 15) / 16;
+#define COMBO_SMALLM(MT) \
+  hipLaunchKernelGGL(gemm_smallm_kernel<MT>, grid, block, 0, (hipStream_t)stream, X, ldx, W, ldw, bias, Y, ldy, part, M, N, K, kchunk, relu)
+  if (mt == 1) COMBO_SMALLM(1);
+  else if (mt == 2) COMBO_SMALLM(2);
+  else if (mt == 3) COMBO_SMALLM(3);
+  else COMBO_SMALLM(4);
+#undef COMBO_SMALLM
+  if (splits > 1)
+    hipLaunchKernelGGL(smallm_finish_kernel, dim3((M * N + 255) / 256), block, 0, (hipStream_t)stream, part, splits, bias, Y, ldy, M, N, relu);
+  return (int)hipGetLastError();
+}

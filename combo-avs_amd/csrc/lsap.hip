@@ -6,6 +6,12 @@
 // candidate tuples: 4 for S4/MS3 (G = 2), 46 656 at the supported maximum G = 6.  One wave per problem; no host
 // round trip, so the training step has no device->host synchronisation left.  Ties are broken towards the smaller
 // candidate index (scipy's choice among equal-cost optima is unspecified as well).
+// Non-finite costs (a diverged step: NaN / Inf logits) are read as the largest finite cost, so the kernel ALWAYS returns valid,
+// distinct query indices - scipy raises ValueError there (matcher.py:133); here the NaN simply reaches the loss, and the
+// downstream gathers (criterion mask_index) can never be driven out of bounds (round 1: a NaN cost left the arg-min at its
+// 0x7fffffff sentinel, which the mask-loss kernels then used as a row index - a hardware exception, not an error message).
+#include <math.h>
+
 #include "combo_common.h"
 
 namespace {
@@ -16,19 +22,20 @@ __global__ void __launch_bounds__(64)
 lsap_small_kernel(const float* __restrict__ cost, const int* __restrict__ gcount, int N, int Q, int Gpad,
                   long long* __restrict__ row_for_col) {
   const int n = blockIdx.x, lane = threadIdx.x;
-  const int G = gcount[n];
+  const int G = min(max(gcount[n], 0), min(Gpad, GMAX));
   const float* C = cost + (long long)n * Q * Gpad;
   __shared__ int cand[GMAX][GMAX];
   __shared__ float candc[GMAX][GMAX];
   // ---- the G cheapest rows of every column (G rounds of a wave arg-min with exclusion) ----
   for (int g = 0; g < G; ++g) {
     for (int r = 0; r < G; ++r) {
-      float best = 3.0e38f;
+      float best = INFINITY;
       int bi = 0x7fffffff;
       for (int q = lane; q < Q; q += 64) {
         bool used = false;
         for (int p = 0; p < r; ++p) used |= (cand[g][p] == q);
-        const float c = C[q * Gpad + g];
+        float c = C[q * Gpad + g];
+        c = (c == c && fabsf(c) < 3.0e38f) ? c : 3.0e38f;  // NaN / Inf -> the largest finite cost
         if (!used && (c < best || (c == best && q < bi))) { best = c; bi = q; }
       }
 #pragma unroll
@@ -44,7 +51,7 @@ lsap_small_kernel(const float* __restrict__ cost, const int* __restrict__ gcount
   // ---- enumerate the G^G tuples ----
   int total = 1;
   for (int g = 0; g < G; ++g) total *= G;
-  float best = 3.0e38f;
+  float best = INFINITY;
   int bt = 0x7fffffff;
   for (int t = lane; t < total; t += 64) {
     int idx = t, rows[GMAX];
@@ -71,6 +78,7 @@ lsap_small_kernel(const float* __restrict__ cost, const int* __restrict__ gcount
       int idx = bt;
       for (int g = 0; g < lane; ++g) idx /= G;
       out = cand[lane][idx % G];
+      out = out < 0 ? 0 : (out >= Q ? Q - 1 : out);  // (unreachable with the sanitised costs; never an out-of-range row)
     }
     row_for_col[(long long)n * Gpad + lane] = out;
   }

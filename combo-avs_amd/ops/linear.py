@@ -131,8 +131,25 @@ def relu_grad(dy, y):
     return dy * (y > 0)
 
 
+def gemm_smallm_f32(a, w, bias=None, relu=False):
+    """a[M <= 64, K] @ w[N, K]^T (+ bias) (+ ReLU): the weight-streaming kernel for audio_mlp (csrc/gemm_smallm.hip)"""
+    M, K = a.shape
+    N = w.shape[0]
+    lib = _lib.lib()
+    splits = lib.combo_gemm_smallm_splits(M, N, K)
+    out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    part = torch.empty(splits, M, N, device=a.device, dtype=torch.float32) if splits > 1 else None
+    with _lib.timed("gemm_smallm_f32", (M, N, K)):
+        rc = lib.combo_gemm_smallm_f32(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), _lib.ptr(bias), out.data_ptr(), N,
+                                       _lib.ptr(part), splits, M, N, K, 1 if relu else 0, _lib.current_stream())
+    _lib.check(rc, "combo_gemm_smallm_f32")
+    return out
+
+
 def forward_gemm(x2d, weight, bias, relu, out=None):
     if f32_ok(x2d, weight) and (bias is None or bias.is_contiguous()):
+        if out is None and x2d.shape[0] <= 64 and x2d.shape[1] % 64 == 0 and weight.shape[0] * x2d.shape[1] >= (1 << 18):
+            return gemm_smallm_f32(x2d, weight, bias, relu)  # a few rows against a large weight: stream the weight
         return gemm_nt_f32(x2d, weight, bias, relu, out)
     y = torch.nn.functional.linear(x2d, weight, bias)  # shapes outside the kernel's contract (see the module docstring)
     if relu:

@@ -232,6 +232,14 @@ int combo_gemm_nt_batched_f32(const float* A, long long lda, long long sA, const
 int combo_conv3x3_nhwc_f32(const float* X, long long ldx, const float* Wm, const float* bias, float* Y, long long ldy,
                            int B, int H, int W, int Cin, int Cout, int relu, combo_stream_t stream);
 
+/*   a10  audio_mlp (models/modeling/misc/audio_transformation.py:5-14: 128 -> 4096 -> 4096 -> 256 with ReLU on the BT fused
+ *   audio tokens): weight-streaming forward GEMM for M <= 64 rows, exact fp32 (csrc/gemm_smallm.hip).  Y[M,N] = X[M,K] .
+ *   W[N,K]^T (+ bias) (+ ReLU); splits = combo_gemm_smallm_splits(M, N, K) K-splits (partial_ws: [splits, M, N] floats when
+ *   splits > 1, finished in a fixed order by a second small launch).  K % (64 * splits) == 0, ldx / ldw % 4 == 0. */
+int combo_gemm_smallm_splits(int M, int N, int K);
+int combo_gemm_smallm_f32(const float* X, long long ldx, const float* W, long long ldw, const float* bias, float* Y, long long ldy,
+                          float* partial_ws, int splits, int M, int N, int K, int relu, combo_stream_t stream);
+
 /*   Input-gradient GEMM C[M,N] = A[M,K] . B[N,K]^T (+ bias[N]) (+ ReLU) with the 3-product bf16 split (x.w ~ hi.hi +
  *   hi.lo + lo.hi, hi = rne_bf16, ~2^-17 relative per product) on the bf16 matrix cores (csrc/gemm_nt2.hip): persistent
  *   workgroups with the next tile's first stages in flight under the epilogue stores, LDS-DMA ring with a source-side chunk

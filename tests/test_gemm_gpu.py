@@ -277,3 +277,26 @@ def test_ffn_relu_gradient_folded_into_the_dx_gemm(M, C, Hd):
     assert rel_err(y_f, yd) < 5e-5
     for a, b in zip(g_f, gd):
         assert rel_err(a, b) < 5e-5, rel_err(a, b)
+
+
+@pytest.mark.parametrize("M,K,N,relu", [(40, 128, 4096, True), (40, 4096, 4096, True), (40, 4096, 256, False), (5, 4096, 4096, True),
+                                          (64, 256, 1024, False), (17, 192, 1000, True)])
+def test_gemm_smallm_weight_streaming(M, K, N, relu, capsys):
+    """csrc/gemm_smallm.hip (audio_mlp, audio_transformation.py:13-14): a few rows against a large weight, exact fp32, with and
+    without K splits, ragged N; timing of the 67 MB layer against its HBM time."""
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.ops.linear import gemm_smallm_f32
+    torch.manual_seed(M + K + N)
+    a = torch.randn(M, K, device="cuda")
+    w = torch.randn(N, K, device="cuda") * 0.05
+    b = torch.randn(N, device="cuda")
+    got = gemm_smallm_f32(a, w, b, relu)
+    ref = a.double() @ w.double().t() + b.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    assert rel_err(got, ref) < 6e-7 * max(1.0, (K / 256) ** 0.5), rel_err(got, ref)
+    if K * N >= 1 << 24:
+        us = _t(lambda: gemm_smallm_f32(a, w, b, relu), 20)
+        with capsys.disabled():
+            print(f"\n[smallm {M}x{K}->{N}] {us:.1f} us = {K * N * 4 / us / 1e6:.2f} TB/s of weights "
+                  f"(library: {_t(lambda: torch.nn.functional.linear(a, w, b), 20):.1f} us)")
