@@ -19,16 +19,17 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-template <int MT>  // row tiles of 16: M <= 16 * MT
-__global__ void __launch_bounds__(256)
+template <int MT, int NW>  // row tiles of 16: M <= 16 * MT; NW waves per workgroup share its K range (16: four per SIMD hide the
+                           // HBM latency of the weight loads by themselves; 4 for short K)
+__global__ void __launch_bounds__(NW * 64)
 gemm_smallm_kernel(const float* __restrict__ X, long long ldx, const float* __restrict__ W, long long ldw,
                    const float* __restrict__ bias, float* __restrict__ Y, long long ldy, float* __restrict__ partial, int M, int N,
                    int K, int kchunk, int relu) {
-  __shared__ f32x4 red[4][MT][64];
+  __shared__ f32x4 red[NW][MT][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, kq = lane >> 4;
   const int n0 = blockIdx.x * 16, split = blockIdx.y;
-  const int kb = split * kchunk + wave * (kchunk / 4), ke = kb + kchunk / 4;  // this wave's k range (a multiple of 16 long)
+  const int kb = split * kchunk + wave * (kchunk / NW), ke = kb + kchunk / NW;  // this wave's k range (a multiple of 16 long)
   const float* wrow = W + (long long)min(n0 + i, N - 1) * ldw + 4 * kq;
   const float* xrow[MT];
 #pragma unroll
@@ -65,7 +66,7 @@ gemm_smallm_kernel(const float* __restrict__ X, long long ldx, const float* __re
     for (int t = 0; t < MT; ++t) {
       f32x4 s = red[0][t][lane];
 #pragma unroll
-      for (int w = 1; w < 4; ++w) {
+      for (int w = 1; w < NW; ++w) {
         const f32x4 o = red[w][t][lane];
         s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
       }
@@ -119,18 +120,26 @@ extern "C" int combo_gemm_smallm_f32(const float* X, long long ldx, const float*
   if (!X || !W || !Y || M <= 0 || M > 64 || N <= 0 || K <= 0 || splits <= 0 || K % (64 * splits) != 0 || ldx % 4 != 0 || ldw % 4 != 0 ||
       (((uintptr_t)X | (uintptr_t)W) & 15) || (splits > 1 && !partial_ws))
     return COMBO_EINVAL;
-  const dim3 grid((N + 15) / 16, splits), block(256);
+  const dim3 grid((N + 15) / 16, splits);
   const int kchunk = K / splits;
   float* part = splits > 1 ? partial_ws : nullptr;
   const int mt = (M + 15) / 16;
-#define COMBO_SMALLM(MT) \
-  hipLaunchKernelGGL(gemm_smallm_kernel<MT>, grid, block, 0, (hipStream_t)stream, X, ldx, W, ldw, bias, Y, ldy, part, M, N, K, kchunk, relu)
+  const bool wide = kchunk % 256 == 0;  // 16 waves per workgroup when every wave still gets whole 16-k groups
+#define COMBO_SMALLM(MT)                                                                                                          \
+  do {                                                                                                                            \
+    if (wide)                                                                                                                     \
+      hipLaunchKernelGGL((gemm_smallm_kernel<MT, 16>), grid, dim3(1024), 0, (hipStream_t)stream, X, ldx, W, ldw, bias, Y, ldy, part, \
+                         M, N, K, kchunk, relu);                                                                                  \
+    else                                                                                                                          \
+      hipLaunchKernelGGL((gemm_smallm_kernel<MT, 4>), grid, dim3(256), 0, (hipStream_t)stream, X, ldx, W, ldw, bias, Y, ldy, part,   \
+                         M, N, K, kchunk, relu);                                                                                  \
+  } while (0)
   if (mt == 1) COMBO_SMALLM(1);
   else if (mt == 2) COMBO_SMALLM(2);
   else if (mt == 3) COMBO_SMALLM(3);
   else COMBO_SMALLM(4);
 #undef COMBO_SMALLM
   if (splits > 1)
-    hipLaunchKernelGGL(smallm_finish_kernel, dim3((M * N + 255) / 256), block, 0, (hipStream_t)stream, part, splits, bias, Y, ldy, M, N, relu);
+    hipLaunchKernelGGL(smallm_finish_kernel, dim3((M * N + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, splits, bias, Y, ldy, M, N, relu);
   return (int)hipGetLastError();
 }
