@@ -625,3 +625,44 @@ def maskformer_forward(P, batched_inputs, num_classes=2, training=True, rand=tor
     losses = set_criterion(out, targets, num_classes, None, world_size, rand)
     wd = loss_weights()
     return {k: v * wd[k] for k, v in losses.items()}  # :384-391
+
+
+# ---------------------------------------------------------------------------------------- evaluator metric
+def mask_iou(pred, target, eps=1e-7):
+    """models/evaluation/sem_seg_evaluation.py:66-92: pred [N,H,W] probabilities (thresholded at 0.5), target [N,H,W] 0/1.
+    A frame with EMPTY ground truth scores the agreement of the backgrounds over all pixels (:83-89)."""
+    n = pred.shape[0]
+    p = (pred > 0.5).to(target.dtype)
+    pixels = pred.shape[-1] * pred.shape[-2]
+    empty = target.sum((1, 2)) == 0
+    inter = (p * target).sum((1, 2))
+    union = torch.max(p, target).sum((1, 2))
+    inter = torch.where(empty, ((1 - target) * (1 - p)).sum((1, 2)), inter)
+    union = torch.where(empty, torch.full_like(union, float(pixels)), union)
+    return (inter / (union + eps)).sum() / n
+
+
+def eval_fmeasure(pred, gt, pr_num=255):
+    """:95-137: maximum over 255 thresholds of the F-beta (beta^2 = 0.3) curve averaged over the frames with non-empty ground
+    truth; NaN entries of a frame's curve (0/0) count as 0."""
+    beta2 = 0.3
+    th = torch.linspace(0, 1 - 1e-10, pr_num)
+    curves = []
+    for i in range(pred.shape[0]):
+        if gt[i].mean() == 0.0:
+            continue
+        y = (pred[i][None] >= th[:, None, None]).float()
+        tp = (y * gt[i][None]).sum((1, 2))
+        prec, rec = tp / (y.sum((1, 2)) + 1e-20), tp / (gt[i].sum() + 1e-20)
+        f = (1 + beta2) * prec * rec / (beta2 * prec + rec)
+        curves.append(torch.nan_to_num(f, nan=0.0))
+    if not curves:
+        return 0.0
+    return float(torch.stack(curves).mean(0).max())
+
+
+def s4_clip_metrics(sem_seg, gts):
+    """SemSegEvaluator.process :219-245 for one batch: sem_seg [N,K,H,W] (the model's eval output per frame) -> softmax over K
+    (a SECOND softmax: the inference tail already mixed class probabilities, Appendix A) -> channel 1 -> (mIoU, F-score)."""
+    probs = F.softmax(sem_seg, dim=1)[:, 1]
+    return float(mask_iou(probs, gts)), eval_fmeasure(probs, gts)
