@@ -33,22 +33,54 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 
-def synth_batch(n_clips, T, H, W, device, seed, K=2):
-    """BASELINE.md §3 synthetic inputs: uint8 frames / Maskiges, N(0,1) log-mels, one blob GT on frame 0 (S4)."""
+def synth_batch(n_clips, T, H, W, device, seed, K=2, gt="first", avss=False):
+    """BASELINE.md section 3 synthetic inputs: uint8 frames / Maskiges, N(0,1) log-mels and ground truth as the reference's
+    dataset mappers hand it over (avss4_semantic_dataset_mapper.py:203-240):
+      gt = "first": one complementary {background, blob} pair on frame 0 only (S4 training);
+      gt = "all":   every frame annotated (MS3 / AVSS): 1-4 instances of distinct classes out of K with blob masks;
+      avss: adds the all-ones `vid_temporal_mask_flag` / `gt_temporal_mask_flag` of a full-length AVSS clip."""
     g = torch.Generator().manual_seed(seed)
     batch = []
     yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+
+    def blob():
+        cx, cy = (torch.rand(2, generator=g) * 0.5 + 0.25) * torch.tensor([W, H])
+        r = (torch.rand(1, generator=g) * 0.2 + 0.1) * min(H, W)
+        return ((xx - cx) ** 2 + (yy - cy) ** 2) < r * r
     for _ in range(n_clips):
         images = torch.randint(0, 256, (T, 3, H, W), generator=g, dtype=torch.uint8)
         pre = torch.randint(0, 256, (T, 3, H, W), generator=g, dtype=torch.uint8)
         mel = torch.randn(T, 1, 96, 64, generator=g)
-        cx, cy = (torch.rand(2, generator=g) * 0.5 + 0.25) * torch.tensor([W, H])
-        r = (torch.rand(1, generator=g) * 0.2 + 0.1) * min(H, W)
-        blob = ((xx - cx) ** 2 + (yy - cy) ** 2) < r * r
-        inst = {"gt_classes": torch.tensor([0, 1], dtype=torch.int64), "gt_masks": torch.stack([~blob, blob])}
-        batch.append({"images": images.to(device), "pre_masks": pre.to(device), "audio_log_mel": mel.to(device),
-                      "instances": [{k: v.to(device) for k, v in inst.items()}]})
+        instances = []
+        for f in range(T if gt == "all" else 1):
+            if K == 2:
+                b = blob()
+                inst = {"gt_classes": torch.tensor([0, 1], dtype=torch.int64), "gt_masks": torch.stack([~b, b])}
+            else:
+                n = int(torch.randint(1, 5, (1,), generator=g))
+                cls = torch.randperm(K, generator=g)[:n].sort().values
+                inst = {"gt_classes": cls.to(torch.int64), "gt_masks": torch.stack([blob() for _ in range(n)])}
+            instances.append({k: v.to(device) for k, v in inst.items()})
+        item = {"images": images.to(device), "pre_masks": pre.to(device), "audio_log_mel": mel.to(device), "instances": instances}
+        if avss:
+            item["vid_temporal_mask_flag"] = torch.ones(T, device=device)
+            item["gt_temporal_mask_flag"] = torch.ones(T, device=device)
+        batch.append(item)
     return batch
+
+
+# BASELINE.json configs as runnable workloads (`--config`): yaml, frames per clip, resolution, clips per GPU, classes,
+# ground-truth layout, backbone / head compute dtype ("f32" = the S4 / MS3 recipe; "bf16" = the AVSS recipe's AMP, run as bf16 autocast)
+WORKLOADS = {
+    "r50_s4": dict(yaml="avs_s4/COMBO_R50_bs8_90k.yaml", T=5, HW=224, clips=8, K=2, gt="first", avss=False, dtype="fp32",
+                   name="COMBO-R50 S4 (BASELINE configs[1])"),
+    "pvt_s4": dict(yaml="avs_s4/COMBO_PVTV2B5_bs8_90k.yaml", T=5, HW=224, clips=8, K=2, gt="first", avss=False, dtype="bf16",
+                   name="COMBO-PVTv2-B5 S4"),
+    "pvt_avss_512": dict(yaml="avs_ss/COMBO_PVTV2B5_bs8_90k.yaml", T=10, HW=512, clips=8, K=71, gt="all", avss=True, dtype="bf16",
+                         name="COMBO-PVTv2-B5 AVSS 512x512 (BASELINE configs[3], synthetic resolution)"),
+    "pvt_ms3_t10": dict(yaml="avs_ms3/COMBO_PVTV2B5_bs8_20k.yaml", T=10, HW=224, clips=4, K=2, gt="all", avss=False, dtype="bf16",
+                        opts=("MODEL.FUSE_CONFIG.NUM_FRAMES", 10), name="COMBO-PVTv2-B5 MS3, 10-frame clips (BASELINE configs[4], synthetic T)"),
+}
 
 
 def _usable_cores():
@@ -174,8 +206,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--clips", type=int, default=8, help="clips per GPU (BASELINE config 2: 8)")
-    ap.add_argument("--dtype", default="fp32", choices=["bf16", "fp32"],
+    ap.add_argument("--config", default="r50_s4", choices=sorted(WORKLOADS),
+                    help="workload: r50_s4 = BASELINE configs[1] (default, the quoted metric); pvt_avss_512 / pvt_ms3_t10 = configs[3] / [4]")
+    ap.add_argument("--clips", type=int, default=None, help="clips per GPU (default: the workload's, 8 for BASELINE config 2)")
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp32"],
                     help="host-PyTorch backbone compute dtype.  fp32 = the reference's S4 recipe (SOLVER.AMP.ENABLED False, "
                          "configs/avs_s4/R50-AVSS4-SemanticSegmentation.yaml:44-45) and the BASELINE metric; bf16 = backbones "
                          "under bf16 autocast, a throughput mode that is NOT the quoted metric")
@@ -194,6 +228,13 @@ def main():
     if args.cpu_baseline_child:
         cpu_baseline_child()
         return
+    if args.backbone == "pvt" and args.config == "r50_s4":
+        args.config = "pvt_s4"
+    wl = WORKLOADS[args.config]
+    if args.clips is None:
+        args.clips = wl["clips"]
+    if args.dtype is None:
+        args.dtype = wl["dtype"]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -222,8 +263,7 @@ def main():
         # MIOpen exhaustive find for the host-PyTorch backbone convolutions (+8 % frames/s; costs ~2 min of search in
         # the first warm-up step on a box with an empty MIOpen user db; COMBO_MIOPEN_BENCHMARK=0 skips it)
         torch.backends.cudnn.benchmark = True
-    cfg_file = "COMBO_R50_bs8_90k.yaml" if args.backbone == "r50" else "COMBO_PVTV2B5_bs8_90k.yaml"
-    cfg = combo_cfg(os.path.join(ROOT, "configs/avs_s4", cfg_file))
+    cfg = combo_cfg(os.path.join(ROOT, "configs", wl["yaml"]), opts=wl.get("opts", ()))
     torch.manual_seed(0)  # identical random-init weights on every rank (DDP broadcast equivalent)
     model = build_model(cfg).to(dev).train()
     if args.dtype == "bf16":
@@ -233,8 +273,11 @@ def main():
     opt = FlatAdamW(model, base_lr=cfg.SOLVER.BASE_LR, weight_decay=cfg.SOLVER.WEIGHT_DECAY,
                     backbone_multiplier=cfg.SOLVER.BACKBONE_MULTIPLIER, clip_value=cfg.SOLVER.CLIP_GRADIENTS.CLIP_VALUE,
                     grad_comm_dtype=torch.bfloat16 if args.grad_comm == "bf16" else torch.float32)
-    T, H, W = 5, 224, 224
-    batch = synth_batch(args.clips, T, H, W, dev, seed=100 + rank)
+    T, H, W = wl["T"], wl["HW"], wl["HW"]
+
+    def make_batch(seed):
+        return synth_batch(args.clips, T, H, W, dev, seed=seed, K=wl["K"], gt=wl["gt"], avss=wl["avss"])
+    batch = make_batch(100 + rank)
     if args.mode == "infer":
         infer_bench(args, model, batch, world, rank, dev)
         if dist.is_initialized():
@@ -256,7 +299,7 @@ def main():
 
     # several distinct synthetic batches of one signature, rotated over the steps (inputs resident in HBM; the graphed step
     # copies the batch of the step into its static input buffers, 12 MB device-to-device)
-    batches = [batch] + [synth_batch(args.clips, T, H, W, dev, seed=1000 * (i + 1) + rank) for i in range(3)]
+    batches = [batch] + [make_batch(1000 * (i + 1) + rank) for i in range(3)]
     from combo_avs_amd import _lib as _clib
     n_slots = 4096
     ts_buf = torch.zeros(n_slots, 4, dtype=torch.int64, device=dev)
@@ -379,13 +422,14 @@ def main():
                 "timing": "HIP events on the launch stream around the launches of the timed eager steps"}
     if rank == 0:
         out = {
-            "metric": "train frames/sec (224x224, 5-frame clips)", "value": round(value, 2), "unit": "frames/s",
+            "metric": f"train frames/sec ({H}x{W}, {T}-frame clips)", "value": round(value, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "ms_per_step_median": round(median_ms, 3) if median_ms else None,
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": f"COMBO-{'R50' if args.backbone == 'r50' else 'PVTv2-B5'} S4, bs={args.clips} clips x 5 frames x 224x224 per GPU, full train step "
+            "config": {"workload": f"{wl['name']}: bs={args.clips} clips x {T} frames x {H}x{W} per GPU, K={wl['K']}, full train step "
                                    "(fwd + 39-term loss + bwd + all-reduce + clip + AdamW), random-init weights",
+                       "name": args.config,
                        "launch": "eager" if args.no_graph else "hipGraph (fwd+loss+bwd captured; all-reduce + AdamW eager)",
                        "grad_all_reduce": args.grad_comm,
                        "global_batch_clips": args.clips * world, "frames_per_clip": T, "parallelism": f"dp{world}",
@@ -393,7 +437,7 @@ def main():
             "roofline": roof,
             "other_kernels": kernels,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == "r50_s4":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if dist.is_initialized():

@@ -159,6 +159,30 @@ def test_large_level_generic_path_512():
     torch.testing.assert_close(gw, rg[2], rtol=1e-4, atol=2e-5)
 
 
+def test_512_shape_bs8_oracle_at_b2_and_properties_at_full_size():
+    """BASELINE configs[3] encoder shape (PVTv2-B5 @512: levels 16^2 / 32^2 / 64^2, S = 5376) at B = 8: the first two frames
+    against the CPU oracle (forward + all gradients), the full batch through size-independent properties (linearity in
+    value, adjointness <out, g> == <value, grad_value>)."""
+    shapes = ((16, 16), (32, 32), (64, 64))
+    B = 8
+    v, shapes, loc, w = prod_inputs(B=B, shapes=shapes, seed_tag="big8")
+    g = synth.synth_tensor("big8.g", (B, 5376, 256), 0)
+    out, gv, gl, gw = run_hip(v, shapes, loc, w, g)
+    v2, l2, w2 = (t[:2].clone().requires_grad_(True) for t in (v, loc, w))
+    ref = O.ms_deform_attn_core(v2, shapes, l2, w2)
+    rg = torch.autograd.grad(ref, (v2, l2, w2), g[:2])
+    torch.testing.assert_close(out[:2], ref.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(gv[:2], rg[0], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(gw[:2], rg[2], rtol=1e-4, atol=2e-5)
+    vb = synth.synth_tensor("big8.v2", tuple(v.shape), 0)
+    o2 = run_hip(vb, shapes, loc, w)[0]
+    o12 = run_hip(2.0 * v + 3.0 * vb, shapes, loc, w)[0]
+    torch.testing.assert_close(o12, 2.0 * out + 3.0 * o2, rtol=1e-4, atol=1e-4)
+    lhs = (out.double() * g.double()).sum().item()
+    rhs = (v.double() * gv.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0) + 1e-2
+
+
 def test_error_behaviour():
     from combo_avs_amd import msda
     v, shapes, loc, w = prod_inputs(B=1)
