@@ -23,8 +23,8 @@ attn_mask_kernel(const float* __restrict__ logits, int N, int H, int W, int h, i
   const float sh = (float)H / (float)h, sw = (float)W / (float)w;
   const int n = h * w;
   bool all_blocked = true;
-  // up to 16 cells per lane kept in a bitmask (h*w <= 1024)
-  unsigned int bits = 0;
+  // up to 64 cells per lane kept in a bitmask (h*w <= 4096: the 64 x 64 level of a 512 x 512 input)
+  unsigned long long bits = 0;
   int cnt = 0;
   for (int i = lane; i < n; i += 64, ++cnt) {
     const int oy = i / w, ox = i - oy * w;
@@ -38,12 +38,12 @@ attn_mask_kernel(const float* __restrict__ logits, int N, int H, int W, int h, i
     const float* p = src + y0 * W + x0;
     const float v = ly0 * (lx0 * p[0] + lx1 * p[xp]) + ly1 * (lx0 * p[yp * W] + lx1 * p[yp * W + xp]);
     const bool b = (1.f / (1.f + expf(-v))) < 0.5f;
-    bits |= (b ? 1u : 0u) << cnt;
+    bits |= (b ? 1ull : 0ull) << cnt;
     all_blocked &= b;
   }
   const bool row_full = __all(all_blocked) && reset_full_rows;
   cnt = 0;
-  for (int i = lane; i < n; i += 64, ++cnt) dst[i] = row_full ? 0 : (unsigned char)((bits >> cnt) & 1u);
+  for (int i = lane; i < n; i += 64, ++cnt) dst[i] = row_full ? 0 : (unsigned char)((bits >> cnt) & 1ull);
   for (int i = n + lane; i < pitch; i += 64) dst[i] = 1;
 }
 
@@ -51,7 +51,7 @@ attn_mask_kernel(const float* __restrict__ logits, int N, int H, int W, int h, i
 
 extern "C" int combo_attn_mask_pitched_f32(const float* logits, int N, int H, int W, int h, int w, int reset_full_rows, int pitch,
                                            unsigned char* blocked, combo_stream_t stream) {
-  if (!logits || !blocked || N <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0 || h * w > 2048 || pitch < h * w) return COMBO_EINVAL;
+  if (!logits || !blocked || N <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0 || h * w > 4096 || pitch < h * w) return COMBO_EINVAL;
   const int waves_per_block = 4;
   hipLaunchKernelGGL(attn_mask_kernel, dim3((N + waves_per_block - 1) / waves_per_block), dim3(256), 0,
                      (hipStream_t)stream, logits, N, H, W, h, w, reset_full_rows, pitch, blocked);
