@@ -242,6 +242,14 @@ mask_loss_bwd_kernel(const float* __restrict__ masks, const long long* __restric
   else { for (int i = tid; i < h * w; i += THREADS) dst[i] = gimg[i]; }
 }
 
+// the mask maps of a 512 x 512 input are 128 x 128 fp32 = 64 KiB (+ as much again for the gradient map): above the 64 KiB a
+// kernel gets without asking
+constexpr size_t kMaxLds = 152 * 1024;
+int big_lds(const void* fn) {
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+  return e == hipSuccess ? 0 : (int)e;
+}
+
 }  // namespace
 
 extern "C" {
@@ -249,8 +257,9 @@ extern "C" {
 int combo_uncertain_points_f32(const float* masks, const long long* mask_index, int NM, int h, int w, const float* over_points,
                                int NS, const float* extra_points, int NR, int k, float* coords_out, combo_stream_t stream) {
   if (!masks || !mask_index || !over_points || !coords_out || NM <= 0 || h <= 0 || w <= 0 || NS <= 0 || k <= 0 || k > NS ||
-      NR < 0 || (NR > 0 && !extra_points) || (size_t)h * w * 4 + 2048 * 4 > 60 * 1024)
+      NR < 0 || (NR > 0 && !extra_points) || (size_t)h * w * 4 + 2048 * 4 > kMaxLds)
     return COMBO_EINVAL;
+  if (int e = big_lds(reinterpret_cast<const void*>(uncertain_select_kernel))) return e;
   hipLaunchKernelGGL(uncertain_select_kernel, dim3(NM), dim3(THREADS), (size_t)h * w * 4 + 2048 * 4, (hipStream_t)stream, masks,
                      mask_index, h, w, over_points, NS, extra_points, NR, k, coords_out);
   return (int)hipGetLastError();
@@ -259,8 +268,9 @@ int combo_uncertain_points_f32(const float* masks, const long long* mask_index, 
 int combo_mask_loss_forward_f32(const float* masks, const long long* mask_index, int NM, int h, int w, const float* gt,
                                 const long long* gt_index, int H, int W, const float* coords, int P, float* stats,
                                 combo_stream_t stream) {
-  if (!masks || !mask_index || !gt || !gt_index || !coords || !stats || NM <= 0 || P <= 0 || (size_t)h * w * 4 > 60 * 1024)
+  if (!masks || !mask_index || !gt || !gt_index || !coords || !stats || NM <= 0 || P <= 0 || (size_t)h * w * 4 > kMaxLds)
     return COMBO_EINVAL;
+  if (int e = big_lds(reinterpret_cast<const void*>(mask_loss_fwd_kernel))) return e;
   hipLaunchKernelGGL(mask_loss_fwd_kernel, dim3(NM), dim3(THREADS), (size_t)h * w * 4, (hipStream_t)stream, masks, mask_index,
                      h, w, gt, gt_index, H, W, coords, P, stats);
   return (int)hipGetLastError();
@@ -271,8 +281,9 @@ int combo_mask_loss_backward_f32(const float* masks, const long long* mask_index
                                  const float* g_bce, const float* g_dice, float* grad_masks, int accumulate,
                                  combo_stream_t stream) {
   if (!masks || !mask_index || !gt || !gt_index || !coords || !stats || !g_bce || !g_dice || !grad_masks || NM <= 0 ||
-      P <= 0 || (size_t)h * w * 8 > 60 * 1024)
+      P <= 0 || (size_t)h * w * 8 > kMaxLds)
     return COMBO_EINVAL;
+  if (int e = big_lds(reinterpret_cast<const void*>(mask_loss_bwd_kernel))) return e;
   hipLaunchKernelGGL(mask_loss_bwd_kernel, dim3(NM), dim3(THREADS), (size_t)h * w * 8, (hipStream_t)stream, masks, mask_index,
                      h, w, gt, gt_index, H, W, coords, P, stats, g_bce, g_dice, grad_masks, accumulate);
   return (int)hipGetLastError();

@@ -134,13 +134,14 @@ def test_avss_recipe_k71_ten_frames_trains(capsys):
     torch.cuda.synchronize()
     assert len(losses) == 39 and all(torch.isfinite(v) for v in losses.values()), losses
     assert (opt.flat_param - before).abs().max() > 0
-    # a 7-frame clip: the mapper hands over 7 frames but 10 (zero-padded) audio segments with flags (maskformer_model.py:300-331
-    # filters the audio tokens by vid_temporal_mask_flag; criterion_ss.py:243-257 selects frames by gt_temporal_mask_flag)
-    batch[0]["vid_temporal_mask_flag"][7:] = 0
-    batch[0]["gt_temporal_mask_flag"][7:] = 0
-    batch[0]["instances"] = batch[0]["instances"][:7]
-    batch[0]["images"] = batch[0]["images"][:7]
-    batch[0]["pre_masks"] = batch[0]["pre_masks"][:7]
+    # a 5-frame clip of the AVSS v1 subsets: 5 frames but 10 (zero-padded) audio segments with flags (maskformer_model.py:300-331
+    # filters the audio tokens by vid_temporal_mask_flag; criterion_ss.py:243-257 selects frames by gt_temporal_mask_flag; the
+    # cosine loss folds frames in groups of 5, criterion.py:208-231, so clips are 5 or 10 frames long)
+    batch[0]["vid_temporal_mask_flag"][5:] = 0
+    batch[0]["gt_temporal_mask_flag"][5:] = 0
+    batch[0]["instances"] = batch[0]["instances"][:5]
+    batch[0]["images"] = batch[0]["images"][:5]
+    batch[0]["pre_masks"] = batch[0]["pre_masks"][:5]
     losses = train_step(model, opt, batch)
     assert all(torch.isfinite(v) for v in losses.values())
 
