@@ -9,8 +9,6 @@ weights each step (w' = w * scale, b' = shift) and the conv runs with bias; acti
 The fold of ALL convolutions of a ResNet (+ the cast to the compute dtype, + the way back for the gradients) is ONE
 autograd node built on multi-tensor (`torch._foreach_*`) kernels: ~4 launches per backbone and direction instead of
 ~10 tiny launches per convolution (53 convolutions x 2 backbones); scale/shift are cached (the statistics are frozen)."""
-import os
-
 import torch
 from torch import nn
 from torch.nn import functional as F
@@ -71,9 +69,6 @@ class _FoldAll(torch.autograd.Function):
         return (None, None) + tuple(out)
 
 
-CONV_GRAD_X3 = os.environ.get("COMBO_BACKBONE_GRAD_X3", "1") == "1"  # 0: the library's fp32 backward kernels (A/B)
-
-
 class ConvBN(nn.Conv2d):
     """conv (no bias) + FrozenBN, folded: conv(x, w*scale) + shift."""
 
@@ -84,9 +79,6 @@ class ConvBN(nn.Conv2d):
 
     def forward(self, x, folded=None, bias=True):
         if folded is not None:  # (w * scale, shift) prepared for the whole backbone by ResNet.forward
-            if not bias and CONV_GRAD_X3:
-                from .ops.convgrad import conv2d
-                return conv2d(x, folded[0], self.stride, self.padding)  # fp32 forward; gradients on the head's x3 GEMM kernels
             return F.conv2d(x, folded[0], folded[1] if bias else None, self.stride, self.padding)
         scale, shift = self.norm.scale_shift()
         w = self.weight * scale[:, None, None, None]

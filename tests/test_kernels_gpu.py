@@ -425,25 +425,3 @@ def test_add_layernorm_forward_backward_vs_torch(rows, C, with_res):
         assert ((y.double() - ref).abs().max() / ref.abs().max()).item() < 1e-6
         for a, b in zip(got, ref_g):
             assert ((a.double() - b).norm() / b.norm()).item() < 2e-6
-
-
-@pytest.mark.parametrize("B,cin,cout,H,W,k", [(4, 256, 64, 56, 56, 1), (3, 512, 128, 28, 28, 1), (2, 128, 128, 28, 28, 3), (2, 256, 256, 14, 14, 3)])
-def test_backbone_conv_gradients_on_the_x3_kernels(B, cin, cout, H, W, k):
-    """ops.convgrad.conv2d: fp32 library forward, gradients on csrc/gemm_nt2.hip / gemm_tn.hip (3-product bf16 split) for the
-    stride-1 1x1 and 3x3 convolutions of the fp32 ResNet-50 encoders; against float64."""
-    import combo_avs_amd  # noqa: F401
-    from combo_avs_amd.ops import convgrad
-    torch.manual_seed(cin + cout + k)
-    x = torch.randn(B, cin, H, W, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
-    w = (torch.randn(cout, cin, k, k, device="cuda") / (cin * k * k) ** 0.5).requires_grad_(True)
-    g = torch.randn(B, cout, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
-    assert convgrad.kind(x, w, 1, k // 2) == k
-    y = convgrad.conv2d(x, w, 1, k // 2)
-    gx, gw = torch.autograd.grad(y, (x, w), g)
-    xd, wd = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
-    yd = torch.nn.functional.conv2d(xd, wd, None, 1, k // 2)
-    rx, rw = torch.autograd.grad(yd, (xd, wd), g.double())
-    rel = lambda a, b: ((a.double() - b).norm() / b.norm()).item()  # noqa: E731
-    assert rel(y, yd) < 2e-6
-    assert rel(gx, rx) < 1e-5 and rel(gw, rw) < 1e-5
-    assert convgrad.kind(x, w, 2, k // 2) == 0  # stride 2: left to the library
