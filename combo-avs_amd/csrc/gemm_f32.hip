@@ -464,27 +464,66 @@ int launch_cfg(F32Args a, hipStream_t stream) {
 
 // Tile choice.  The kernel is MFMA-bound, so its time is the load of the busiest CU: tiles are dealt round-robin to one
 // workgroup per CU, each costing BM*BN*K MACs.  Measured on MI355X (tools/bench_f32.py with COMBO_F32_TILE = 1 / 2 / 3 over the
-// head's shapes, profiles/r02_gemm_f32_tiles.txt): wide vs mid follows the smaller "ceil(tiles / CUs) * BM * BN" (a tie goes
-// to wide for short K, to mid from K = 1024 on); the 64 x 64 tiles pull 16 flop per operand byte from L2 and only win when
-// their busiest-CU load is at least 20 % smaller (the decoder's 4000-token layers: 252 tiles instead of 32).
+// head's shapes, profiles/r02_gemm_f32_tiles.txt): the smallest "ceil(tiles / CUs) * BM * BN * (measured time per MAC of the
+// tile shape)" wins - small tiles pay more per MAC (tile boundaries; 64 x 64 tiles pull 16 flop per operand byte from L2) and
+// only win where they fill the chip better (the decoder's 4000-token layers: 252 tiles instead of 32).
+// Wave quantisation: 1288 wide tiles on 256 CUs are 5.03 rounds = 6 rounds of time.  When the last round is mostly empty the
+// call is SPLIT BY ROWS into two launches: whole rounds of large tiles, then the remaining rows on smaller tiles (41160 x 1024:
+// 1280 wide tiles + 200 rows as 64 skinny tiles = 5.1 rounds of work instead of 6).
+struct Plan {
+  int cfg;             // 1 wide, 2 mid, 3 skinny
+  long long rows_main; // rows of the first launch (== M: single launch)
+  int cfg_rest;
+  double cost;         // busiest-CU MACs / K
+};
+
+template <bool CONV>
+int launch_one(F32Args a, hipStream_t stream, int cfg) {
+  if (cfg == 3) return launch_cfg<CONV, FSkinny>(a, stream);
+  if (cfg == 2) return launch_cfg<CONV, FMid>(a, stream);
+  return launch_cfg<CONV, FWide>(a, stream);
+}
+
 template <bool CONV>
 int launch_f32(F32Args a, hipStream_t stream) {
   static const int force = [] { const char* e = getenv("COMBO_F32_TILE"); return e ? atoi(e) : 0; }();  // 1 wide, 2 mid, 3 skinny (A/B)
+  static const int no_split = [] { const char* e = getenv("COMBO_F32_NOSPLIT"); return e ? atoi(e) : 0; }();
+  if (force) return launch_one<CONV>(a, stream, force);
   const long long cus = n_cu_cached();
-  auto load = [&](int bm, int bn) {
-    const long long t = ((a.M + bm - 1LL) / bm) * ((a.N + bn - 1LL) / bn) * a.batch;
-    return ((t + cus - 1) / cus) * bm * bn;
-  };
-  int pick = force;
-  if (!pick) {
-    const long long lw = load(256, 128), lm = load(128, 128), ls = load(64, 64);
-    pick = lw < lm ? 1 : lm < lw ? 2 : (a.K >= 1024 ? 2 : 1);
-    const long long best = lw < lm ? lw : lm;
-    if (ls * 5 <= best * 4) pick = 3;
+  const int bm[4] = {0, 256, 128, 64}, bn[4] = {0, 128, 128, 64};
+  auto tiles = [&](int c, long long rows) { return ((rows + bm[c] - 1) / bm[c]) * ((a.N + bn[c] - 1LL) / bn[c]) * a.batch; };
+  // measured time per MAC relative to the wide tile (per-tile overheads weigh more on small tiles): 232 us / 6 rounds wide,
+  // 231 us / 11 rounds mid, 272 us / 41 rounds skinny at 41160 x 256 -> 1024
+  const double eff[4] = {0.0, 1.0, 1.085, 1.37};
+  auto load = [&](int c, long long rows) { return (double)((tiles(c, rows) + cus - 1) / cus) * bm[c] * bn[c] * eff[c]; };
+  Plan best{1, a.M, 0, load(1, a.M)};
+  for (int c = 2; c <= 3; ++c)
+    if (load(c, a.M) < best.cost) best = Plan{c, a.M, 0, load(c, a.M)};
+  if (!CONV && a.batch == 1 && !no_split) {
+    // a second launch costs ~6 us: ~1.2 M MACs of a CU at this kernel's rate, in units of MACs / K
+    const double penalty = 1.2e6 / a.K;
+    for (int c = 1; c <= 2; ++c) {
+      const long long tn = (a.N + bn[c] - 1LL) / bn[c], tm = (a.M + bm[c] - 1LL) / bm[c];
+      const long long rounds = tm * tn / cus;
+      if (rounds < 1) continue;
+      const long long tm_main = rounds * cus / tn, rows_main = tm_main * bm[c];
+      if (rows_main <= 0 || rows_main >= a.M) continue;
+      for (int r = c + 1; r <= 3; ++r) {
+        const double cost = load(c, rows_main) + load(r, a.M - rows_main) + penalty;
+        if (cost < best.cost * 0.97) best = Plan{c, rows_main, r, cost};
+      }
+    }
   }
-  if (pick == 3) return launch_cfg<CONV, FSkinny>(a, stream);
-  if (pick == 2) return launch_cfg<CONV, FMid>(a, stream);
-  return launch_cfg<CONV, FWide>(a, stream);
+  if (best.rows_main >= a.M) return launch_one<CONV>(a, stream, best.cfg);
+  F32Args m = a, r = a;
+  m.M = (int)best.rows_main;
+  m.c_bytes = (int)(((m.M - 1LL) * a.ldc + a.N) * 4);
+  if (int e = launch_one<CONV>(m, stream, best.cfg)) return e;
+  r.A = a.A + best.rows_main * a.lda;
+  r.C = a.C + best.rows_main * a.ldc;
+  r.M = (int)(a.M - best.rows_main);
+  r.c_bytes = (int)(((r.M - 1LL) * a.ldc + a.N) * 4);
+  return launch_one<CONV>(r, stream, best.cfg_rest);
 }
 
 bool args_ok(const float* A, long long lda, const float* B, long long ldb, const float* C, long long ldc, long long M, int N, int K,

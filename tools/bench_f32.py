@@ -25,9 +25,14 @@ if args.shapes == "small":
 
 
 def timeit(fn, n):
-    for _ in range(max(5, n // 5)):
-        fn()
-    torch.cuda.synchronize()
+    # ~0.3 s of back-to-back launches first: the clocks need that long to settle (a cold 50-launch sample under-reports this
+    # kernel by ~15 %: 222 vs 193 us at 41160 x 256 -> 1024, tools/clock_probe_f32.py)
+    import time
+    t0 = time.time()
+    while time.time() - t0 < 0.3:
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(n):
