@@ -302,8 +302,8 @@ def main():
     batches = [batch] + [make_batch(1000 * (i + 1) + rank) for i in range(3)]
     from combo_avs_amd import _lib as _clib
     n_slots = 4096
-    ts_buf = torch.zeros(n_slots, 4, dtype=torch.int64, device=dev)
-    ts_buf[:, 0] = -1  # ~0ull
+    ts_buf = torch.zeros(n_slots, 256, dtype=torch.int64, device=dev)  # csrc/combo_common.h: 16 sub-slots of 16 words
+    ts_buf[:, 0::16] = -1  # ~0ull: earliest-start words
     if args.no_graph:
         def step(b):
             return train_step(model, opt, b)
@@ -334,14 +334,17 @@ def main():
         for i in range(max(args.warmup - 1, 0)):
             step(batches[i % len(batches)])
             trace("warm-up step done")
+        _clib.lib().combo_timing_fold(_clib.current_stream())
         sync()
-        ts_buf[:, 2:] = 0  # count only the launches of the timed region
+        ts_buf[:, 2:4] = 0  # count only the launches of the timed region
         sync()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
         step(batches[i % len(batches)])
+        if not args.no_graph:
+            _clib.lib().combo_timing_fold(_clib.current_stream())  # one tiny launch: slot sums += last end - first start
         marks[i + 1].record()  # (an event on the stream between graph launches: no host sync inside the timed region)
         trace("timed step done")
     sync()
@@ -362,12 +365,20 @@ def main():
             kind, work = ctypes.c_int(0), ctypes.c_double(0.0)
             lib.combo_timing_slot_info(sl, ctypes.byref(kind), ctypes.byref(work))
             n_l = int(tsv[sl, 3])
+            if khz > 0 and n_l > 0 and os.environ.get("COMBO_BENCH_DUMP_SLOTS") and str(kind.value) in os.environ["COMBO_BENCH_DUMP_SLOTS"].split(","):
+                print(f"[slot {sl}] kind {kind.value} work {work.value:.4g} avg_us {float(tsv[sl, 2]) / khz * 1e3 / n_l:.1f}", file=sys.stderr)
             if khz > 0 and n_l > 0:
-                d = per_kind.setdefault(kind.value, {"us": 0.0, "launches": 0, "work": 0.0, "nodes": 0})
-                d["us"] += float(tsv[sl, 2]) / khz * 1e3
+                d = per_kind.setdefault(kind.value, {"us": 0.0, "launches": 0, "work": 0.0, "nodes": 0, "big_us": 0.0, "big_work": 0.0,
+                                                     "big_launches": 0})
+                us = float(tsv[sl, 2]) / khz * 1e3
+                d["us"] += us
                 d["launches"] += n_l
                 d["work"] += work.value * n_l
                 d["nodes"] += 1
+                if work.value >= 2e9:  # launches of >= 2 GFLOP (GB for the HBM-bound kinds): the layers that can fill the chip
+                    d["big_us"] += us
+                    d["big_work"] += work.value * n_l
+                    d["big_launches"] += n_l
         lib.combo_timing_set_buffer(None, 0)
     kt = {"fwd_us": [], "bwd_us": [], "kernels": {}}
     if args.no_graph:
@@ -405,6 +416,11 @@ def main():
              "launches_per_step": d["launches"] // max(args.steps, 1), "ms_per_step": round(d["us"] / max(args.steps, 1) / 1e3, 3),
              "algorithmic_work_per_step": d["work"] / max(args.steps, 1),
              "timing": "device-side wall-clock timestamps of the kernel over the launches of the timed graph replays"}
+        if d["big_launches"] and kind not in (0, 6):
+            big = d["big_work"] / (d["big_us"] * 1e-6) / scale
+            r["large_launches"] = {"min_gflop": 2, "launches_per_step": d["big_launches"] // max(args.steps, 1),
+                                   "ms_per_step": round(d["big_us"] / max(args.steps, 1) / 1e3, 3), "achieved": round(big, 1),
+                                   "frac": round(big / peak, 4)}
         if kind in (2, 3):
             r["issued_tflops_bf16"] = round(3 * ach, 1)
             r["note"] = "useful 2*M*N*K flops over the dense bf16 peak; the kernel issues 3 bf16 products per fp32 MAC"

@@ -49,12 +49,14 @@ _SIGNATURES = {
     "combo_semantic_inference_f32": [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p, c_void_p],
     "combo_conv3x3_wgrad_x3_f32": [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p] + [c_int] * 6 + [c_void_p],
     "combo_presplit_bf16x2_f32": [c_void_p, c_longlong, c_longlong, c_int, c_int, c_void_p, c_void_p],
+    "combo_presplit_bf16x2_grouped_f32": [c_void_p, c_int, c_void_p],
     "combo_presplit_bf16x2_batched_f32": [c_void_p, c_longlong, c_longlong, c_longlong, c_int, c_int, c_int, c_void_p, c_void_p],
     "combo_gemm_nt_x3_pre_batched_f32": [c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_void_p, c_longlong, c_longlong,
                                          c_int, c_int, c_int, c_int, c_int, c_void_p],
     "combo_gemm_nt_x3_pre_masked_f32": [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_void_p],
     "combo_timing_set_buffer": [c_void_p, c_int],
     "combo_timing_slots_used": [],
+    "combo_timing_fold": [c_void_p],
     "combo_timing_slot_info": [c_int, c_void_p, c_void_p],
     "combo_gemm_smallm_splits": [c_int, c_int, c_int],
     "combo_gemm_smallm_f32": [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_void_p] + [c_int] * 5 + [c_void_p],
@@ -81,8 +83,9 @@ _SIGNATURES = {
     "combo_lsap_small_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "combo_attn_mask_f32": [c_void_p] + [c_int] * 6 + [c_void_p, c_void_p],
     "combo_attn_mask_pitched_f32": [c_void_p] + [c_int] * 7 + [c_void_p, c_void_p],
-    "combo_attention_forward_f32": [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p] + [c_int] * 5 + [c_float, c_void_p, c_void_p, c_void_p],
-    "combo_attention_backward_f32": [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p] + [c_int] * 5 + [c_float] + [c_void_p] * 8,
+    "combo_attention_forward_f32": [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_int, c_void_p] + [c_int] * 5 + [c_float, c_void_p, c_void_p, c_void_p],
+    "combo_attn_mask_bits_f32": [c_void_p] + [c_int] * 7 + [c_void_p, c_int, c_void_p, c_void_p],
+    "combo_attention_backward_f32": [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_int, c_void_p] + [c_int] * 5 + [c_float] + [c_void_p] * 8,
     "combo_adamw_f32": [c_void_p] * 4 + [c_longlong, c_void_p] + [c_float] * 7 + [c_void_p],
 }
 _RESTYPES = {"combo_build_arch": ctypes.c_char_p}

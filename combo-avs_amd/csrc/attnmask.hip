@@ -14,7 +14,7 @@ namespace {
 
 __global__ void __launch_bounds__(256)
 attn_mask_kernel(const float* __restrict__ logits, int N, int H, int W, int h, int w, int reset_full_rows, int pitch,
-                 unsigned char* __restrict__ blocked) {
+                 unsigned char* __restrict__ blocked, int wpitch, unsigned* __restrict__ bitrows) {
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (wave >= N) return;
@@ -42,9 +42,25 @@ attn_mask_kernel(const float* __restrict__ logits, int N, int H, int W, int h, i
     all_blocked &= b;
   }
   const bool row_full = __all(all_blocked) && reset_full_rows;
-  cnt = 0;
-  for (int i = lane; i < n; i += 64, ++cnt) dst[i] = row_full ? 0 : (unsigned char)((bits >> cnt) & 1ull);
-  for (int i = n + lane; i < pitch; i += 64) dst[i] = 1;
+  if (blocked) {
+    cnt = 0;
+    for (int i = lane; i < n; i += 64, ++cnt) dst[i] = row_full ? 0 : (unsigned char)((bits >> cnt) & 1ull);
+    for (int i = n + lane; i < pitch; i += 64) dst[i] = 1;
+  }
+  if (bitrows) {
+    // the same row bit-packed for the attention kernels: bit k of word j = cell 32 j + k; cells >= h*w read as blocked
+    unsigned* brow = bitrows + (long long)wave * wpitch;
+    const int chunks = (n + 63) / 64;
+    for (int cc = 0; cc < chunks; ++cc) {
+      const bool b = (cc * 64 + lane >= n) || (!row_full && ((bits >> cc) & 1ull));
+      const unsigned long long word = __ballot(b);
+      if (lane == 0) {
+        brow[2 * cc] = (unsigned)word;
+        if (2 * cc + 1 < wpitch) brow[2 * cc + 1] = (unsigned)(word >> 32);
+      }
+    }
+    for (int j = 2 * chunks + lane; j < wpitch; j += 64) brow[j] = 0xffffffffu;
+  }
 }
 
 }  // namespace
@@ -54,7 +70,18 @@ extern "C" int combo_attn_mask_pitched_f32(const float* logits, int N, int H, in
   if (!logits || !blocked || N <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0 || h * w > 4096 || pitch < h * w) return COMBO_EINVAL;
   const int waves_per_block = 4;
   hipLaunchKernelGGL(attn_mask_kernel, dim3((N + waves_per_block - 1) / waves_per_block), dim3(256), 0,
-                     (hipStream_t)stream, logits, N, H, W, h, w, reset_full_rows, pitch, blocked);
+                     (hipStream_t)stream, logits, N, H, W, h, w, reset_full_rows, pitch, blocked, 0, (unsigned*)nullptr);
+  return (int)hipGetLastError();
+}
+
+extern "C" int combo_attn_mask_bits_f32(const float* logits, int N, int H, int W, int h, int w, int reset_full_rows, int pitch,
+                                        unsigned char* blocked, int wpitch, unsigned* bits, combo_stream_t stream) {
+  if (!logits || !bits || N <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0 || h * w > 4096 || (blocked && pitch < h * w) ||
+      wpitch < (h * w + 31) / 32)
+    return COMBO_EINVAL;
+  const int waves_per_block = 4;
+  hipLaunchKernelGGL(attn_mask_kernel, dim3((N + waves_per_block - 1) / waves_per_block), dim3(256), 0,
+                     (hipStream_t)stream, logits, N, H, W, h, w, reset_full_rows, pitch, blocked, wpitch, bits);
   return (int)hipGetLastError();
 }
 

@@ -119,9 +119,10 @@ gemm_nt_f32_kernel(const F32Args p) {
 
   // the bias vector goes to LDS once (zero beyond N), before any LDS-DMA is in flight
   const unsigned bias_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + (unsigned)Cfg::RING;
+  const int n_pad = min(kMaxBiasN, (N + 3) & ~3);  // only the N values that exist are staged (one pass for N <= 256)
   if (p.bias) {
     float* bl = reinterpret_cast<float*>(smem + Cfg::RING);
-    for (int n = threadIdx.x; n < kMaxBiasN; n += 256) bl[n] = n < N ? p.bias[n] : 0.f;
+    for (int n = threadIdx.x; n < n_pad; n += 256) bl[n] = n < N ? p.bias[n] : 0.f;
     __syncthreads();
   }
 
@@ -272,7 +273,7 @@ gemm_nt_f32_kernel(const F32Args p) {
       f4v bv[4];
       if (p.bias) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bv[q] = lds_read128<0>(bias_lds + (unsigned)min(nb + 8 * q, kMaxBiasN - 4) * 4u);
+        for (int q = 0; q < 4; ++q) bv[q] = lds_read128<0>(bias_lds + (unsigned)min(nb + 8 * q, n_pad - 4) * 4u);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]) : : "memory");
       }
 #pragma unroll
@@ -296,7 +297,7 @@ gemm_nt_f32_kernel(const F32Args p) {
         float v = acc[i][j][e];
         if (p.bias) {
           float b;
-          asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(b) : "v"(bias_lds + (unsigned)min(n, kMaxBiasN - 1) * 4u) : "memory");
+          asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(b) : "v"(bias_lds + (unsigned)min(n, n_pad - 1) * 4u) : "memory");
           v += b;
         }
         if (p.relu) v = fmaxf(v, 0.f);

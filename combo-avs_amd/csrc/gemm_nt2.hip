@@ -345,7 +345,7 @@ gemm_nt2_kernel(const float* __restrict__ A, long long lda, const float* __restr
 }
 
 // Weight image for gemm_nt2: element (n, k) = src[n*ld_row + k*ld_col]; per 8 consecutive k a 16-B group of bf16 `hi`
-// (truncated) followed by a 16-B group of bf16 `lo` = rne(x - hi): 4 bytes per element, row stride K floats.
+// = rne(x) followed by a 16-B group of bf16 `lo` = rne(x - hi): 4 bytes per element, row stride K floats.
 __global__ void __launch_bounds__(256)
 presplit_kernel(const float* __restrict__ src, long long ld_row, long long ld_col, int N, int K, uint4* __restrict__ img,
                 long long batch_stride) {
@@ -370,6 +370,43 @@ presplit_kernel(const float* __restrict__ src, long long ld_row, long long ld_co
   const long long o = ((long long)n * kg + g8) * 2;
   img[o] = make_uint4(h[0], h[1], h[2], h[3]);
   img[o + 1] = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+// Grouped form: every weight whose input-gradient GEMM the backward pass will run, split by ONE launch (per 64 problems)
+// instead of one ~5 us launch per weight (148 per training step).  img_ld: floats per image row (>= K): several sources may
+// fill k ranges of one image (the two weights of a column-concatenated layer).
+constexpr int kMaxSplitGroup = 64;
+struct SplitGroupArgs {
+  int count;
+  long long thread_start[kMaxSplitGroup + 1];
+  combo_presplit_problem p[kMaxSplitGroup];
+};
+
+__global__ void __launch_bounds__(256)
+presplit_grouped_kernel(const SplitGroupArgs args) {
+  const long long t0 = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (t0 >= args.thread_start[args.count]) return;
+  int pi = 0;
+  for (int i = 1; i < args.count; ++i)
+    if (t0 >= args.thread_start[i]) pi = i;
+  const combo_presplit_problem& pr = args.p[pi];
+  const long long t = t0 - args.thread_start[pi];
+  const int kg = pr.K >> 3;
+  int n, g8;
+  if (pr.ld_col == 1) { n = (int)(t / kg); g8 = (int)(t - (long long)n * kg); }
+  else { g8 = (int)(t / pr.N); n = (int)(t - (long long)g8 * pr.N); }
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = pr.src[(long long)n * pr.ld_row + (long long)(g8 * 8 + i) * pr.ld_col];
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h[i] = pack_rne(v[2 * i], v[2 * i + 1]);
+    l[i] = pack_rne(v[2 * i] - __uint_as_float(h[i] << 16), v[2 * i + 1] - __uint_as_float(h[i] & 0xffff0000u));
+  }
+  uint4* img = reinterpret_cast<uint4*>(pr.img) + (long long)n * (pr.img_ld >> 2) + g8 * 2;
+  img[0] = make_uint4(h[0], h[1], h[2], h[3]);
+  img[1] = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
 struct NtBatch {
@@ -434,6 +471,29 @@ extern "C" int combo_presplit_bf16x2_f32(const float* src, long long ld_row, lon
   hipLaunchKernelGGL(presplit_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, ld_row,
                      ld_col, N, K, reinterpret_cast<uint4*>(img), 0LL);
   return (int)hipGetLastError();
+}
+
+extern "C" int combo_presplit_bf16x2_grouped_f32(const combo_presplit_problem* problems, int count, combo_stream_t stream) {
+  if (!problems || count <= 0) return COMBO_EINVAL;
+  for (int base = 0; base < count; base += kMaxSplitGroup) {
+    SplitGroupArgs a;
+    a.count = count - base < kMaxSplitGroup ? count - base : kMaxSplitGroup;
+    long long threads = 0;
+    for (int i = 0; i < a.count; ++i) {
+      const combo_presplit_problem& pr = problems[base + i];
+      if (!pr.src || !pr.img || pr.N <= 0 || pr.K <= 0 || pr.K % 8 != 0 || pr.img_ld < pr.K || pr.img_ld % 8 != 0 ||
+          ((uintptr_t)pr.img & 31))
+        return COMBO_EINVAL;
+      a.thread_start[i] = threads;
+      a.p[i] = pr;
+      threads += ((long long)pr.N * (pr.K / 8) + 255) / 256 * 256;  // a workgroup never straddles two problems
+    }
+    a.thread_start[a.count] = threads;
+    hipLaunchKernelGGL(presplit_grouped_kernel, dim3((unsigned)(threads / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+  }
+  return 0;
 }
 
 extern "C" int combo_presplit_bf16x2_batched_f32(const float* src, long long ld_row, long long ld_col, long long batch_stride,

@@ -8,12 +8,30 @@ unsigned long long* g_base = nullptr;
 int g_slots = 0, g_next = 0;
 struct SlotInfo { int kind; double work; };
 std::vector<SlotInfo> g_info;
+
+__global__ void timing_fold_kernel(unsigned long long* base, int slots) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= slots) return;
+  unsigned long long* ts = base + (long long)COMBO_TS_SLOT_U64 * i;
+  unsigned long long t0 = ~0ull, t1 = 0ull;
+  for (int s = 0; s < COMBO_TS_SUBS; ++s) {
+    unsigned long long* sub = ts + s * COMBO_TS_SUB_U64;
+    t0 = sub[0] < t0 ? sub[0] : t0;
+    t1 = sub[1] > t1 ? sub[1] : t1;
+    sub[0] = ~0ull;
+    sub[1] = 0ull;
+  }
+  if (t1 != 0ull && t0 != ~0ull) {
+    ts[2] += t1 - t0;
+    ts[3] += 1ull;
+  }
+}
 }  // namespace
 
 unsigned long long* combo_timing_next_slot(int kind, double work) {
   if (!g_base || g_next >= g_slots) return nullptr;  // out of slots: later launches run untimed
   g_info[g_next] = SlotInfo{kind, work};
-  return g_base + 4LL * g_next++;
+  return g_base + (long long)COMBO_TS_SLOT_U64 * g_next++;
 }
 
 extern "C" {
@@ -27,6 +45,12 @@ int combo_timing_set_buffer(void* buf, int slots) {
 }
 
 int combo_timing_slots_used(void) { return g_next; }
+
+int combo_timing_fold(combo_stream_t stream) {
+  if (!g_base || g_next <= 0) return 0;
+  hipLaunchKernelGGL(timing_fold_kernel, dim3((g_next + 255) / 256), dim3(256), 0, (hipStream_t)stream, g_base, g_next);
+  return (int)hipGetLastError();
+}
 
 int combo_timing_slot_info(int slot, int* kind, double* work) {
   if (slot < 0 || slot >= g_next) return COMBO_EINVAL;

@@ -19,7 +19,7 @@ def _rows_ok(t):
 
 class _Attention(Function):
     @staticmethod
-    def forward(ctx, q, k, v, blocked, B, H):
+    def forward(ctx, q, k, v, blocked, B, H, bits=None):
         Lq, Lk = q.shape[0] // B, k.shape[0] // B
         E = H * 32
         assert _rows_ok(q) and _rows_ok(k) and _rows_ok(v) and q.shape[1] == E and k.shape[1] == E and v.shape[1] == E
@@ -28,21 +28,26 @@ class _Attention(Function):
             assert blocked.dtype == torch.uint8 and blocked.is_contiguous() and blocked.shape[:2] == (B, Lq)
             pitch = blocked.shape[2]
             assert pitch % 4 == 0 and pitch >= Lk
+        wpitch = 0
+        if bits is not None:
+            assert bits.dtype == torch.int32 and bits.is_contiguous() and bits.shape[:2] == (B, Lq) and bits.shape[2] * 32 >= Lk
+            wpitch = bits.shape[2]
         out = torch.empty(B * Lq, E, device=q.device, dtype=torch.float32)
         lse = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32)
         scale = 32 ** -0.5
         _lib.check(_lib.lib().combo_attention_forward_f32(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
-                                                          _lib.ptr(blocked), pitch, B, H, Lq, Lk, scale, out.data_ptr(), lse.data_ptr(),
-                                                          _lib.current_stream()), "combo_attention_forward_f32")
-        ctx.save_for_backward(q, k, v, blocked, out, lse)
-        ctx.dims = (B, H, Lq, Lk, pitch, scale)
+                                                          _lib.ptr(blocked), pitch, _lib.ptr(bits), wpitch, B, H, Lq, Lk, scale,
+                                                          out.data_ptr(), lse.data_ptr(), _lib.current_stream()),
+                   "combo_attention_forward_f32")
+        ctx.save_for_backward(q, k, v, blocked, out, lse, bits)
+        ctx.dims = (B, H, Lq, Lk, pitch, scale, wpitch)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
-        q, k, v, blocked, out, lse = ctx.saved_tensors
-        B, H, Lq, Lk, pitch, scale = ctx.dims
+        q, k, v, blocked, out, lse, bits = ctx.saved_tensors
+        B, H, Lq, Lk, pitch, scale, wpitch = ctx.dims
         E = H * 32
         dout = dout.contiguous()
         dq = torch.empty(B * Lq, E, device=q.device, dtype=torch.float32)
@@ -50,12 +55,16 @@ class _Attention(Function):
         dv = torch.empty(B * Lk, E, device=q.device, dtype=torch.float32)
         delta = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32)
         _lib.check(_lib.lib().combo_attention_backward_f32(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
-                                                           _lib.ptr(blocked), pitch, B, H, Lq, Lk, scale, out.data_ptr(), lse.data_ptr(),
+                                                           _lib.ptr(blocked), pitch, _lib.ptr(bits), wpitch, B, H, Lq, Lk, scale,
+                                                           out.data_ptr(), lse.data_ptr(),
                                                            dout.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(),
                                                            dv.data_ptr(), _lib.current_stream()), "combo_attention_backward_f32")
-        return dq, dk, dv, None, None, None
+        return dq, dk, dv, None, None, None, None
 
 
 def attention(q, k, v, blocked, B, H):
-    """q [B*Lq, H*32], k / v [B*Lk, H*32] row views, blocked uint8 [B, Lq, pitch] or None -> [B*Lq, H*32]"""
+    """q [B*Lq, H*32], k / v [B*Lk, H*32] row views, blocked: uint8 [B, Lq, pitch], an ops.masklogit.PackedMask (bytes + the
+    bit-packed rows the forward kernel prefers) or None -> [B*Lq, H*32]"""
+    if blocked is not None and not torch.is_tensor(blocked):
+        return _Attention.apply(q, k, v, blocked.bytes, B, H, blocked.bits)
     return _Attention.apply(q, k, v, blocked, B, H)

@@ -58,20 +58,84 @@ def presplit(b):
     return img
 
 
+class _SplitProblem(ctypes.Structure):  # combo_presplit_problem (include/combo_avs.h)
+    _fields_ = [("src", ctypes.c_void_p), ("img", ctypes.c_void_p), ("ld_row", ctypes.c_longlong), ("ld_col", ctypes.c_longlong),
+                ("img_ld", ctypes.c_longlong), ("N", ctypes.c_int), ("K", ctypes.c_int)]
+
+
+_split_images = None  # key -> image, while a grouped_presplit() context is open: weights announced by the forward pass
+_split_pending = []   # [(b view [N,K], image view [N,K] (row pitch = the image's))] not yet split
+
+
+def _split_key(b):
+    return (b.data_ptr(), tuple(b.shape), tuple(b.stride()))
+
+
+def expect_input_grad(*weights):
+    """Forward-pass announcement: the backward pass will run dX = dY . cat(weights, 0) (weights [N_i, K] as stored).  Inside
+    grouped_presplit() the pre-split images of ALL announced weights are made by one grouped launch when the first of them is
+    needed (csrc/gemm_nt2.hip presplit_grouped_kernel) instead of one launch per weight and step (148 in the S4 step)."""
+    if _split_images is None or not weights[0].is_cuda or any(w.dtype != torch.float32 or w.shape[0] % 8 for w in weights):
+        return
+    key = tuple(_split_key(w) for w in weights)
+    if key in _split_images:
+        return
+    K, n_tot = weights[0].shape[1], sum(w.shape[0] for w in weights)
+    img = torch.empty(K, n_tot, device=weights[0].device, dtype=torch.float32)  # operand b = cat(weights).t(): [K, n_tot]
+    _split_images[key] = img
+    off = 0
+    for w in weights:
+        _split_pending.append((w.t(), img[:, off:off + w.shape[0]]))
+        off += w.shape[0]
+
+
+class grouped_presplit:
+    """Spans the forward AND backward pass of one training step (trainer.train_step / GraphedTrainStep): forward nodes announce
+    the weights whose input-gradient GEMMs will run (expect_input_grad), the first of those GEMMs splits all of them at once."""
+
+    def __enter__(self):
+        global _split_images
+        self.prev, _split_images = (_split_images, _split_pending[:]), {}
+        del _split_pending[:]
+        return self
+
+    def __exit__(self, *exc):
+        global _split_images
+        _split_images = self.prev[0]
+        _split_pending[:] = self.prev[1]
+        return False
+
+
+def _expected_image(*weights):
+    """-> the image announced by expect_input_grad(*weights) (splitting everything still pending first), or None"""
+    if _split_images is None:
+        return None
+    img = _split_images.get(tuple(_split_key(w) for w in weights))
+    if img is not None and _split_pending:
+        pr = (_SplitProblem * len(_split_pending))()
+        for i, (b, dst) in enumerate(_split_pending):
+            pr[i] = _SplitProblem(b.data_ptr(), dst.data_ptr(), b.stride(0), b.stride(1), dst.stride(0), b.shape[0], b.shape[1])
+        _lib.check(_lib.lib().combo_presplit_bf16x2_grouped_f32(ctypes.cast(pr, ctypes.c_void_p), len(_split_pending),
+                                                                _lib.current_stream()), "combo_presplit_bf16x2_grouped_f32")
+        del _split_pending[:]
+    return img
+
+
 def x3_ok(a, n_out):
     """operands of csrc/gemm_nt2.hip (A rows; the B image is made by `presplit`)"""
     return (a.is_cuda and a.dtype == torch.float32 and a.dim() == 2 and a.shape[1] % 16 == 0 and a.shape[0] > 0
             and _aligned_rows(a) and a.shape[0] * n_out * 4 < 2 ** 31 - 1)
 
 
-def gemm_nt_x3(a, b, bias=None, relu=False, relu_mask=None):
+def gemm_nt_x3(a, b, bias=None, relu=False, relu_mask=None, img=None):
     """C[M,N] = a[M,K] @ b[N,K]^T (+ bias) (+ ReLU) with the 3-product bf16 split (~2^-17 relative per product): the
     input-gradient GEMM dX = dY . W (b = `weight.t()`, any strided 2-D view).  relu_mask [M,N]: C = relu_mask > 0 ? C : 0
     (the ReLU backward of the layer that produced the operand, folded into the epilogue)."""
     M, K = a.shape
     N = b.shape[0]
     out = torch.empty(M, N, device=a.device, dtype=torch.float32)
-    img = presplit(b)
+    if img is None:
+        img = presplit(b)
     lib, st = _lib.lib(), _lib.current_stream()
     with _lib.timed("gemm_nt_x3", (M, N, K)):
         if relu_mask is not None:
@@ -161,11 +225,16 @@ def forward_gemm(x2d, weight, bias, relu, out=None):
 
 
 def input_grad_gemm(dy, weight, relu_mask=None):
-    """dX = dy @ weight (weight [N,K] as stored), optionally multiplied by [relu_mask > 0]"""
+    """dX = dy @ weight (weight [N,K] as stored, or a tuple of weights standing for their row concatenation), optionally
+    multiplied by [relu_mask > 0]"""
+    ws = weight if isinstance(weight, tuple) else (weight,)
     dyc = dy if _aligned_rows(dy) else dy.contiguous()
-    if x3_ok(dyc, weight.shape[1]) and weight.dtype == torch.float32:
-        return gemm_nt_x3(dyc, weight.t(), relu_mask=relu_mask)
-    dx = dy @ weight
+    if x3_ok(dyc, ws[0].shape[1]) and ws[0].dtype == torch.float32:
+        img = _expected_image(*ws)
+        if img is not None:
+            return gemm_nt_x3(dyc, img, relu_mask=relu_mask, img=img)  # img [K, N] has the shape of the operand view
+        return gemm_nt_x3(dyc, (ws[0] if len(ws) == 1 else torch.cat(ws, 0)).t(), relu_mask=relu_mask)
+    dx = dy @ (ws[0] if len(ws) == 1 else torch.cat(ws, 0))
     return relu_grad(dx, relu_mask) if relu_mask is not None else dx
 
 
@@ -369,6 +438,8 @@ class _Linear(Function):
         exactly that, so the incoming gradient needs no ReLU-gradient pass.  Set in pairs by `ffn` below."""
         ctx.defer, ctx.mask_dx, ctx.grad_masked = defer, mask_dx, grad_masked
         y = forward_gemm(x2d, weight, bias, relu)
+        if ctx.needs_input_grad[0]:
+            expect_input_grad(weight)
         ctx.save_for_backward(x2d, weight, y if relu else None)
         ctx.relu = relu
         ctx.has_bias = bias is not None
@@ -408,6 +479,16 @@ class _InProj(Function):
             q = forward_gemm(xq, W[:E], b[:E], False)
             k = forward_gemm(xk, W[E:2 * E], b[E:2 * E], False)
         v = forward_gemm(xv, W[2 * E:], b[2 * E:], False)
+        if same_qk:
+            if ctx.needs_input_grad[0]:
+                expect_input_grad(W[:2 * E])
+        else:
+            if ctx.needs_input_grad[0]:
+                expect_input_grad(W[:E])
+            if ctx.needs_input_grad[1]:
+                expect_input_grad(W[E:2 * E])
+        if ctx.needs_input_grad[2]:
+            expect_input_grad(W[2 * E:])
         ctx.save_for_backward(xq, xk, xv, W)
         ctx.same_qk = same_qk
         return q, k, v
@@ -465,6 +546,8 @@ class _LinearCat(Function):
         y = torch.empty(x2d.shape[0], n1 + n2, device=x2d.device, dtype=torch.float32)
         forward_gemm(x2d, w1, b1, False, out=y[:, :n1])
         forward_gemm(x2d, w2, b2, False, out=y[:, n1:])
+        if ctx.needs_input_grad[0]:
+            expect_input_grad(w1, w2)
         ctx.save_for_backward(x2d, w1, w2)
         return y
 
@@ -474,10 +557,9 @@ class _LinearCat(Function):
         x2d, w1, w2 = ctx.saved_tensors
         n1 = w1.shape[0]
         dy = dy.contiguous()
-        W = torch.cat([w1, w2], 0)
-        dx = input_grad_gemm(dy, W) if ctx.needs_input_grad[0] else None
-        dW = torch.empty_like(W)
-        db = torch.empty(W.shape[0], device=W.device, dtype=W.dtype)
+        dx = input_grad_gemm(dy, (w1, w2)) if ctx.needs_input_grad[0] else None
+        dW = torch.empty(n1 + w2.shape[0], w1.shape[1], device=w1.device, dtype=w1.dtype)
+        db = torch.empty(dW.shape[0], device=w1.device, dtype=w1.dtype)
         _dw_into(dy, x2d, dW, db, defer=ctx.defer)
         return dx, dW[:n1], db[:n1], dW[n1:], db[n1:], None
 

@@ -37,23 +37,35 @@ def gemm_nt_batched(a, img, out):
     return out
 
 
+class PackedMask:
+    """The attention mask of one decoder layer in the two forms csrc/attention.hip reads: `bytes` uint8 [BT,Q,pitch]
+    (1 = masked out, the backward kernels) and `bits` int32 [BT,Q,wpitch] (bit k of word j = key 32 j + k, the forward
+    kernel: one word per query and 32-key tile)."""
+
+    def __init__(self, bytes_, bits):
+        self.bytes, self.bits = bytes_, bits
+
+
 def attn_mask_padded(logits, target_size, reset_full_rows=True):
-    """logits [BT,Q,H,W] fp32 -> blocked uint8 [BT,Q,pitch] (1 = masked out; pitch = h*w rounded up to 4, padding cells
-    blocked), row reset of :458 applied.  This is the form csrc/attention.hip reads."""
+    """logits [BT,Q,H,W] fp32 -> PackedMask: blocked bytes [BT,Q,pitch] (pitch = h*w rounded up to 4, padding cells blocked)
+    and the same rows bit-packed, row reset of :458 applied; one launch."""
     _lib.require_cuda(logits)
     bt, Q, H, W = logits.shape
     h, w = target_size
     pitch = (h * w + 3) // 4 * 4
+    wpitch = (h * w + 63) // 64 * 2
     out = torch.empty((bt, Q, pitch), dtype=torch.uint8, device=logits.device)
-    _lib.check(_lib.lib().combo_attn_mask_pitched_f32(logits.data_ptr(), bt * Q, H, W, h, w, 1 if reset_full_rows else 0, pitch,
-                                                      out.data_ptr(), _lib.current_stream()), "combo_attn_mask_pitched_f32")
-    return out
+    bits = torch.empty((bt, Q, wpitch), dtype=torch.int32, device=logits.device)
+    _lib.check(_lib.lib().combo_attn_mask_bits_f32(logits.data_ptr(), bt * Q, H, W, h, w, 1 if reset_full_rows else 0, pitch,
+                                                   out.data_ptr(), wpitch, bits.data_ptr(), _lib.current_stream()),
+               "combo_attn_mask_bits_f32")
+    return PackedMask(out, bits)
 
 
 def attn_mask(logits, target_size, reset_full_rows=True):
     """logits [BT,Q,H,W] fp32 -> blocked bool [BT,Q,h*w] (True = masked out), row reset of :458 applied."""
     h, w = target_size
-    return attn_mask_padded(logits, target_size, reset_full_rows)[:, :, :h * w].view(torch.bool)
+    return attn_mask_padded(logits, target_size, reset_full_rows).bytes[:, :, :h * w].view(torch.bool)
 
 
 class _MaskLogitsAll(torch.autograd.Function):

@@ -164,11 +164,13 @@ def poly_lr_factor(it, max_iter, power=0.9, constant_ending=0.0):
 
 def train_step(model, optimizer, batched_inputs):
     """forward -> 39-term loss -> backward -> one all-reduce -> clip + AdamW.  Returns the loss dict (device tensors)."""
-    loss_dict = model(batched_inputs)
-    total = getattr(loss_dict, "total", None)  # family-wise sum from the meta-arch (modeling.criterion.LossDict)
-    if total is None:
-        total = torch.stack(list(loss_dict.values())).sum()
-    optimizer.backward(total)
+    from .ops.linear import grouped_presplit
+    with grouped_presplit():  # one grouped weight pre-split for all input-gradient GEMMs of the step
+        loss_dict = model(batched_inputs)
+        total = getattr(loss_dict, "total", None)  # family-wise sum from the meta-arch (modeling.criterion.LossDict)
+        if total is None:
+            total = torch.stack(list(loss_dict.values())).sum()
+        optimizer.backward(total)
     optimizer.all_reduce_grads()
     optimizer.step()
     # detached: a caller holding the losses must not keep this step's autograd graph (and the parameters'
@@ -248,11 +250,13 @@ class GraphedTrainStep:
         return torch.clamp(num / world, min=1)
 
     def _fwd_bwd(self, batch):
-        loss_dict = self.model(batch)
-        total = getattr(loss_dict, "total", None)
-        if total is None:
-            total = torch.stack(list(loss_dict.values())).sum()
-        self.opt.backward(total)
+        from .ops.linear import grouped_presplit
+        with grouped_presplit():
+            loss_dict = self.model(batch)
+            total = getattr(loss_dict, "total", None)
+            if total is None:
+                total = torch.stack(list(loss_dict.values())).sum()
+            self.opt.backward(total)
         return {k: v.detach() for k, v in loss_dict.items()}
 
     def _capture(self, batched_inputs, num_masks):

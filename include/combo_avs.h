@@ -37,16 +37,18 @@ typedef void* combo_stream_t;
 int combo_abi_version(void);
 
 /* Measurement aid (bench.py): device-side timing of the instrumented kernels.  HIP refuses event records inside a
- * captured hipGraph on ROCm 7, so the kernels take wall-clock timestamps themselves: `buf` = slots x 4 uint64 on the
- * device, initialised to {~0, 0, 0, 0} per slot; every following instrumented launch takes the next slot (a graph node
- * keeps its slot over all replays) and adds (last workgroup end - first workgroup start) in ticks to slot[2] and 1 to
- * slot[3].  combo_timing_slot_info returns what the host recorded for a slot: kind (0 MSDeformAttn forward core,
+ * captured hipGraph on ROCm 7, so the kernels take wall-clock timestamps themselves: `buf` = slots x 256 uint64 on the
+ * device (16 sub-slots of 16 words: word 0 = earliest workgroup start, initialised to ~0, word 1 = latest end, initialised
+ * to 0; everything else 0); every following instrumented launch takes the next slot (a graph node keeps its slot over all
+ * replays); combo_timing_fold (call it once after every step / graph replay, on the stream of the launches) adds
+ * end - start in ticks to slot[2] and 1 to slot[3] for every slot that ran and re-arms it.  combo_timing_slot_info returns what the host recorded for a slot: kind (0 MSDeformAttn forward core,
  * 1 fp32-MFMA GEMM, 2 3xbf16 forward/dX GEMM, 3 weight-gradient GEMM, 4/5 decoder attention forward/backward,
  * 6 MSDeformAttn backward) and its algorithmic work per launch (bytes for the HBM-bound kinds 0 and 6, flops
  * 2*M*N*K for the others).  buf == NULL switches timing off.  The reference has no counterpart (it times whole
  * iterations with detectron2's IterationTimer, models/evaluation/evaluator.py:149-228). */
 int combo_timing_set_buffer(void* buf, int slots);
 int combo_timing_slots_used(void);
+int combo_timing_fold(combo_stream_t stream);
 int combo_timing_slot_info(int slot, int* kind, double* work);
 int combo_wall_clock_khz(void);
 const char* combo_build_arch(void); /* "gfx950" */
@@ -263,6 +265,15 @@ int combo_gemm_nt_x3_pre_masked_f32(const float* A, long long lda, const float* 
  *   frame, made by the batched pre-split from a strided view).  img of the pre-split: [batch][N][K] floats. */
 int combo_presplit_bf16x2_batched_f32(const float* src, long long ld_row, long long ld_col, long long batch_stride, int N,
                                       int K, int batch, float* img, combo_stream_t stream);
+/*   Grouped pre-split: element (n, k) of problem i = src[n*ld_row + k*ld_col] lands in image row n (img_ld floats per row,
+ *   >= K, a multiple of 8; img 32-byte aligned - an offset of k0 floats into a wider image concatenates sources along k).
+ *   One launch per 64 problems: all weights whose input-gradient GEMMs the backward pass of a step runs. */
+typedef struct {
+  const float* src; float* img;
+  long long ld_row, ld_col, img_ld;
+  int N, K;
+} combo_presplit_problem;
+int combo_presplit_bf16x2_grouped_f32(const combo_presplit_problem* problems, int count, combo_stream_t stream);
 int combo_gemm_nt_x3_pre_batched_f32(const float* A, long long lda, long long sA, const float* Bimg, long long sB, float* C,
                                      long long ldc, long long sC, int M, int N, int K, int batch, int relu,
                                      combo_stream_t stream);
@@ -349,6 +360,10 @@ int combo_attn_mask_f32(const float* logits, int N, int H, int W, int h, int w, 
  *   multiple of 4 the attention kernels below read the 4 keys of a register group with one dword load. */
 int combo_attn_mask_pitched_f32(const float* logits, int N, int H, int W, int h, int w, int reset_full_rows, int pitch,
                                 unsigned char* blocked, combo_stream_t stream);
+/*   _bits: additionally (blocked may be NULL: only) the same rows bit-packed, bits [N, wpitch] words with bit k of word j =
+ *   cell 32 j + k and every cell >= h*w set (blocked); wpitch >= ceil(h*w / 32).  The form the attention forward reads. */
+int combo_attn_mask_bits_f32(const float* logits, int N, int H, int W, int h, int w, int reset_full_rows, int pitch,
+                             unsigned char* blocked, int wpitch, unsigned* bits, combo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a12  masked multi-head attention of the decoder layers, head_dim = 32 (csrc/attention.hip)
@@ -356,17 +371,19 @@ int combo_attn_mask_pitched_f32(const float* logits, int N, int H, int W, int h,
  *   (transformer_decoder/transformer_decoder.py:99-118, 50-58; the packed in_proj / out_proj GEMMs are combo_gemm_nt_f32).
  *   q [B, Lq, >= H*32] (row stride ldq), k / v [B, Lk, .] (ldk / ldv), head h at column h*32; blocked: bytes [B, Lq, pitch]
  *   (1 = masked out, shared by the H heads; NULL = no mask), pitch % 4 == 0; scale = head_dim^-0.5 is applied to q.
+ *   Both also take the mask bit-packed (blocked_bits [B, Lq, wpitch] words from combo_attn_mask_bits_f32, NULL = use the
+ *   bytes): one word per (query, 32-key tile) instead of 32 byte reads.
  *   forward:  out [B, Lq, H*32], lse [B, H, Lq] (log-sum-exp of the scaled masked scores, saved for backward), exact fp32 MFMA.
  *   backward: dq [B, Lq, H*32], dk / dv [B, Lk, H*32] from dout; delta_ws: [B, H, Lq] workspace.  A query whose keys are all
  *   blocked yields zeros (the reference would produce NaN; the decoder never passes such a row: :458 resets it).
  * ---------------------------------------------------------------------------------------------- */
 int combo_attention_forward_f32(const float* q, long long ldq, const float* k, long long ldk, const float* v, long long ldv,
-                                const unsigned char* blocked, int pitch, int B, int H, int Lq, int Lk, float scale, float* out,
-                                float* lse, combo_stream_t stream);
+                                const unsigned char* blocked, int pitch, const unsigned* blocked_bits, int wpitch, int B, int H,
+                                int Lq, int Lk, float scale, float* out, float* lse, combo_stream_t stream);
 int combo_attention_backward_f32(const float* q, long long ldq, const float* k, long long ldk, const float* v, long long ldv,
-                                 const unsigned char* blocked, int pitch, int B, int H, int Lq, int Lk, float scale,
-                                 const float* out, const float* lse, const float* dout, float* delta_ws, float* dq, float* dk,
-                                 float* dv, combo_stream_t stream);
+                                 const unsigned char* blocked, int pitch, const unsigned* blocked_bits, int wpitch, int B, int H,
+                                 int Lq, int Lk, float scale, const float* out, const float* lse, const float* dout,
+                                 float* delta_ws, float* dq, float* dk, float* dv, combo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a14  Hungarian-matcher cost matrices, all (decoder output x frame) problems at once

@@ -26,13 +26,15 @@ def reference(q, k, v, blocked, B, H):
     return (p @ vh).permute(0, 2, 1, 3).reshape(B * Lq, E)
 
 
-@pytest.mark.parametrize("Lq,Lk,masked", [(100, 49, True), (100, 196, True), (100, 784, True), (100, 100, False), (37, 65, True)])
-def test_attention_forward_backward_vs_oracle(Lq, Lk, masked):
+@pytest.mark.parametrize("Lq,Lk,masked,H", [(100, 49, True, 8), (100, 196, True, 8), (100, 784, True, 8), (100, 100, False, 8),
+                                            (37, 65, True, 8), (4, 70, True, 8), (36, 130, True, 3), (64, 33, False, 3),
+                                            (3, 31, True, 5), (100, 2, False, 8)])
+def test_attention_forward_backward_vs_oracle(Lq, Lk, masked, H):
     import combo_avs_amd  # noqa: F401
     from combo_avs_amd.ops.attention import attention
     from oracle import combo_oracle as O
     torch.manual_seed(Lq * 1000 + Lk)
-    B, H, E = 3, 8, 256
+    B, E = 3, 32 * H
     # q and k as column blocks of one fused projection buffer (row stride 512), v contiguous
     qk = torch.randn(B * max(Lq, Lk), 2 * E, device="cuda")
     q = (qk[:B * Lq, :E] * 1.5).detach()
@@ -46,13 +48,21 @@ def test_attention_forward_backward_vs_oracle(Lq, Lk, masked):
     blocked_u8 = None
     if masked:
         blocked_b = torch.rand(B, Lq, Lk, device="cuda") < 0.6
-        blocked_b[0, 3] = True            # a fully blocked row: reset to unblocked (transformer_decoder.py:458)
-        blocked_b[0, 5, :Lk - 1] = True   # a row with a single open key
+        blocked_b[0, min(3, Lq - 1)] = True            # a fully blocked row: reset to unblocked (transformer_decoder.py:458)
+        blocked_b[0, min(5, Lq - 2), :Lk - 1] = True   # a row with a single open key
         blocked_b[blocked_b.all(-1)] = False
         pitch = (Lk + 3) // 4 * 4
         blocked_u8 = torch.ones(B, Lq, pitch, dtype=torch.uint8, device="cuda")
         blocked_u8[:, :, :Lk] = blocked_b.to(torch.uint8)
     out = attention(qv, kv, v, blocked_u8, B, H)
+    if masked:  # the bit-packed form of the same mask (what the mask kernel hands the decoder) gives the same bits
+        from combo_avs_amd.ops.masklogit import PackedMask
+        wpitch = (Lk + 63) // 64 * 2
+        cells = torch.ones(B, Lq, wpitch * 32, dtype=torch.int64, device="cuda")
+        cells[:, :, :Lk] = blocked_b.long()
+        words = (cells.view(B, Lq, wpitch, 32) << torch.arange(32, device="cuda")).sum(-1)
+        bits = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).contiguous()
+        assert torch.equal(attention(qv, kv, v, PackedMask(blocked_u8, bits), B, H), out)
     g = torch.randn_like(out)
     gq, gk, gv = torch.autograd.grad(out, (qv, kv, v), g)
     qd, kd, vd = (t.detach().double().contiguous().requires_grad_(True) for t in (qv, kv, v))
@@ -63,7 +73,7 @@ def test_attention_forward_backward_vs_oracle(Lq, Lk, masked):
     assert rel_err(gk, rk) < 5e-6, rel_err(gk, rk)
     assert rel_err(gv, rv) < 5e-6, rel_err(gv, rv)
     # the same numbers through the oracle's own module-level restatement (packed in_proj / out_proj set to identity)
-    if Lq == 100 and Lk in (49, 100):
+    if Lq == 100 and Lk in (49, 100) and H == 8:
         P = {"a.in_proj_weight": torch.eye(E).repeat(3, 1), "a.in_proj_bias": torch.zeros(3 * E),
              "a.out_proj.weight": torch.eye(E), "a.out_proj.bias": torch.zeros(E)}
         am = None if blocked_b is None else blocked_b.cpu()[:, None].expand(B, H, Lq, Lk).reshape(B * H, Lq, Lk)

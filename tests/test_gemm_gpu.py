@@ -300,3 +300,38 @@ def test_gemm_smallm_weight_streaming(M, K, N, relu, capsys):
         with capsys.disabled():
             print(f"\n[smallm {M}x{K}->{N}] {us:.1f} us = {K * N * 4 / us / 1e6:.2f} TB/s of weights "
                   f"(library: {_t(lambda: torch.nn.functional.linear(a, w, b), 20):.1f} us)")
+
+
+def test_grouped_weight_presplit_gives_bitwise_the_same_input_gradients():
+    """Inside grouped_presplit() the images of all announced weights are split by one grouped launch (ops.linear.expect_input_grad,
+    csrc/gemm_nt2.hip presplit_grouped_kernel): packed q/k/v slices, a column-concatenated pair and plain layers, compared
+    with the per-weight route outside the context - same split, same GEMM, so bit-identical."""
+    from combo_avs_amd.ops import linear as L
+    torch.manual_seed(3)
+    dev, E = "cuda", 256
+    x = torch.randn(4000, E, device=dev, requires_grad=True)
+    mem = torch.randn(6272, E, device=dev, requires_grad=True)
+    W = torch.randn(3 * E, E, device=dev, requires_grad=True) * 0.05
+    b = torch.randn(3 * E, device=dev)
+    w1, b1 = torch.randn(192, E, device=dev) * 0.05, torch.randn(192, device=dev)
+    w2, b2 = torch.randn(96, E, device=dev) * 0.05, torch.randn(96, device=dev)
+    wf1, bf1 = torch.randn(1024, E, device=dev) * 0.05, torch.randn(1024, device=dev)
+    wf2, bf2 = torch.randn(E, 1024, device=dev) * 0.05, torch.randn(E, device=dev)
+    for t in (w1, w2, wf1, wf2):
+        t.requires_grad_(True)
+
+    def run():
+        q, k, v = L.in_proj(x, x, x, W, b, same_qk=True, defer=True)
+        q2, k2, v2 = L.in_proj(x, mem, mem, W, b, same_qk=False, defer=True)
+        c = L.linear_cat(x, w1, b1, w2, b2, defer=True)
+        f = L.ffn(x, wf1, bf1, wf2, bf2)
+        loss = (q * k).sum() + v.square().sum() + q2.sum() * 0.3 + (k2 * v2).sum() + c.square().sum() + f.square().sum()
+        return torch.autograd.grad(loss, [x, mem])
+
+    ref = run()
+    with L.grouped_presplit(), L.deferred_dw():
+        got = run()
+        assert not L._split_pending and len(L._split_images) == 7  # W[:2E], W[:E], W[E:2E], W[2E:], (w1,w2), wf1, wf2
+    assert L._split_images is None
+    for r, g in zip(ref, got):
+        assert torch.equal(r, g)

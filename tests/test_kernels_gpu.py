@@ -26,6 +26,13 @@ def test_attn_mask_matches_interpolate_sigmoid(H, W, h, w):
     got = masklogit.attn_mask(logits, (h, w), reset_full_rows=True)
     assert ((got != ref_reset) & ~near0).sum().item() == 0
     assert not got[0, 5].any() and ref[0, 5].all()
+    # the bit-packed rows of the same launch: bit k of word j = cell 32 j + k, cells beyond h*w read as blocked
+    pm = masklogit.attn_mask_padded(logits, (h, w), True)
+    n = h * w
+    words = pm.bits.long() & 0xffffffff
+    cells = ((words[..., None] >> torch.arange(32, device="cuda")) & 1).flatten(2).bool()
+    assert torch.equal(cells[:, :, :n], pm.bytes[:, :, :n].bool()) and torch.equal(pm.bytes[:, :, :n].bool(), got)
+    assert cells[:, :, n:].all() and pm.bytes[:, :, n:].all()
 
 
 def test_fused_adamw_matches_torch_optimizer():
