@@ -633,82 +633,111 @@ attn_bwd_dq_kernel(const AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ backward, pass B: dK, dV
-__global__ void __launch_bounds__(256, 1)
+// One workgroup = 4 waves = 4 key tiles of one (frame, head) pair; a wave owns 32 keys (K / V rows in registers as B
+// operands) and walks the query tiles.  The Q and dO tiles of up to 128 queries (all of them for the decoder's 100) are
+// staged ONCE per workgroup by LDS-DMA (same swizzle as the forward tiles) and read by all four waves, by rows (S = Q . K^T,
+// dP = dO . V^T) and by columns (dV^T += dO^T . P, dK^T += Q^T . dS); lse / delta and the mask words of the 4 key tiles sit
+// next to them, laid out so that the 4 query rows of a register group come with one 16-byte read.
+constexpr int kQChunk = 128;  // queries per LDS fill
+__global__ void __launch_bounds__(256, 2)
 attn_bwd_dkv_kernel(const AttnArgs a) {
   combo_ts_begin(a.ts);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int pair = blockIdx.x, b = pair / a.H, h = pair - b * a.H;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane & 31, g = lane >> 5;  // here the column index is the KEY
-  const int n_qt = (a.Lq + 31) / 32, n_kt = (a.Lk + 31) / 32;
-  const int kt = blockIdx.y * 4 + wave;
-  if (kt < n_kt) {
-    const int ki = kt * 32 + c;
-    const bool k_ok = ki < a.Lk;
-    const int kc = min(ki, a.Lk - 1);
-    const float* kb = a.k + (long long)b * a.Lk * a.ldk + h * kD;
-    const float* vb = a.v + (long long)b * a.Lk * a.ldv + h * kD;
-    float kcol[16], vcol[16];
-    load_row16(kb + (long long)kc * a.ldk, g, kcol);
-    load_row16(vb + (long long)kc * a.ldv, g, vcol);
-    const float* qb = a.q + (long long)b * a.Lq * a.ldq + h * kD;
-    const float* dob = a.dout + (long long)b * a.Lq * (a.H * kD) + h * kD;
-    const float* lseb = a.lse + ((long long)b * a.H + h) * a.Lq;
-    const float* dlb = a.delta + ((long long)b * a.H + h) * a.Lq;
-    const unsigned char* mbase = a.mask ? a.mask + (long long)b * a.Lq * a.pitch : g_no_mask;
-    const long long mpitch = a.mask ? a.pitch : 0;
-    const int mcol = a.mask ? kc : 0;
-    f32x16 dk, dv;
+  const int n_kt = (a.Lk + 31) / 32;
+  const int kt = min((int)blockIdx.y * 4 + wave, n_kt - 1);  // (a surplus wave repeats the last tile and does not store)
+  const bool tile_ok = (int)blockIdx.y * 4 + wave < n_kt;
+  char* qt_lds = smem;                       // [4 tiles][4 KB]
+  char* do_lds = smem + 4 * kTileBytes;      // [4 tiles][4 KB]
+  float* lse_lds = reinterpret_cast<float*>(smem + 8 * kTileBytes);  // [128] log2-scaled
+  float* dl_lds = lse_lds + kQChunk;                                  // [128]
+  unsigned* mw_lds = reinterpret_cast<unsigned*>(dl_lds + kQChunk);   // [4 key tiles][128 queries]
+  const int ki = kt * 32 + c;
+  const bool k_ok = tile_ok && ki < a.Lk;
+  const int kc = min(ki, a.Lk - 1);
+  float kcol[16], vcol[16];
+  load_row16(a.k + ((long long)b * a.Lk + kc) * a.ldk + h * kD, g, kcol);
+  load_row16(a.v + ((long long)b * a.Lk + kc) * a.ldv + h * kD, g, vcol);
+  const float* qb = a.q + (long long)b * a.Lq * a.ldq + h * kD;
+  const float* dob = a.dout + (long long)b * a.Lq * (a.H * kD) + h * kD;
+  const float* lseb = a.lse + ((long long)b * a.H + h) * a.Lq;
+  const float* dlb = a.delta + ((long long)b * a.H + h) * a.Lq;
+  const float sc2 = a.scale * kLog2e;
+  f32x16 dk, dv;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { dk[e] = 0.f; dv[e] = 0.f; }
-    // lse / delta rows are padded reads: the buffers hold Lq floats per (b, h); indices are clamped per group of 4
-    float qrow[16], dorow[16], qtf[16], dotf[16], lse[16], dl[16];
-    unsigned char mb[16];
-    auto load_qtile = [&](int qt) __attribute__((always_inline)) {
-      const int qr = min(qt * 32 + c, a.Lq - 1);  // this lane's row of the A operands (a query)
-      load_row16(qb + (long long)qr * a.ldq, g, qrow, a.scale);
-      load_row16(dob + (long long)qr * (a.H * kD), g, dorow);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int q = min(qt * 32 + row_of(e, g), a.Lq - 1);
-        qtf[e] = qb[(long long)q * a.ldq + c] * a.scale;
-        dotf[e] = dob[(long long)q * (a.H * kD) + c];
-        lse[e] = lseb[q];
-        dl[e] = dlb[q];
-        mb[e] = mbase[(long long)q * mpitch + mcol];
-      }
-    };
-    load_qtile(0);
+  for (int e = 0; e < 16; ++e) { dk[e] = 0.f; dv[e] = 0.f; }
+  for (int qbase = 0; qbase < a.Lq; qbase += kQChunk) {
+    if (qbase) __syncthreads();  // everyone is done with the previous fill
+    // wave w stages query tile w of the chunk (Q and dO); rows beyond Lq repeat the last row (their mask words are all ones)
+    stage_tile(qb, a.ldq, qbase + wave * 32, a.Lq, qt_lds + wave * kTileBytes, lane);
+    stage_tile(dob, (long long)a.H * kD, qbase + wave * 32, a.Lq, do_lds + wave * kTileBytes, lane);
+    if (threadIdx.x < kQChunk) {
+      const int q = qbase + threadIdx.x;
+      lse_lds[threadIdx.x] = q < a.Lq ? lseb[q] * kLog2e : 0.f;
+      dl_lds[threadIdx.x] = q < a.Lq ? dlb[q] : 0.f;
+    }
+    for (int idx = threadIdx.x; idx < 4 * kQChunk; idx += 256) {
+      const int t = idx >> 7, ql = idx & (kQChunk - 1);
+      const int q = qbase + ql, ktw = min((int)blockIdx.y * 4 + t, n_kt - 1);
+      unsigned w = 0;
+      if (q >= a.Lq) w = ~0u;
+      else if (a.mbits) w = a.mbits[((long long)b * a.Lq + q) * a.wpitch + ktw];
+      else if (a.mask) w = pack_mask_word(a.mask + ((long long)b * a.Lq + q) * a.pitch, a.pitch, ktw * 32);
+      mw_lds[idx] = w;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int n_qt = min(4, (a.Lq - qbase + 31) / 32);
     for (int qt = 0; qt < n_qt; ++qt) {
+      const char* qtile = qt_lds + qt * kTileBytes;
+      const char* dtile = do_lds + qt * kTileBytes;
+      float qrow[16], dorow[16], qcol[16], docol[16];
+      lds_row16(qtile, c, g, qrow);
+      lds_row16(dtile, c, g, dorow);
+      lds_col16(qtile, c, g, qcol);
+      lds_col16(dtile, c, g, docol);
+      f4v lse4[4], dl4[4];
+      uint4 mw4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {  // rows 8 j + 4 g + {0..3} of the tile: one register group
+        lse4[j] = *reinterpret_cast<const f4v*>(lse_lds + qt * 32 + 8 * j + 4 * g);
+        dl4[j] = *reinterpret_cast<const f4v*>(dl_lds + qt * 32 + 8 * j + 4 * g);
+        mw4[j] = *reinterpret_cast<const uint4*>(mw_lds + wave * kQChunk + qt * 32 + 8 * j + 4 * g);
+      }
       f32x16 s, dp;
 #pragma unroll
       for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
 #pragma unroll
-      for (int t = 0; t < 16; ++t) s = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[t], kcol[t], s, 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < 16; ++t) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dorow[t], vcol[t], dp, 0, 0, 0);
-      float p[16], ds[16], qtc[16], dotc[16];
+      for (int t = 0; t < 16; ++t) {
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[t], kcol[t], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dorow[t], vcol[t], dp, 0, 0, 0);
+      }
+      float p[16], ds[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const unsigned bit = (unsigned)(mb[e] & 1) | (unsigned)(qt * 32 + row_of(e, g) >= a.Lq) | (unsigned)(!k_ok);
-        p[e] = bit ? 0.f : __expf(s[e] - lse[e]);
-        ds[e] = p[e] * (dp[e] - dl[e]);
-        qtc[e] = qtf[e];
-        dotc[e] = dotf[e];
+        const unsigned w = (e & 3) == 0 ? mw4[e >> 2].x : (e & 3) == 1 ? mw4[e >> 2].y : (e & 3) == 2 ? mw4[e >> 2].z : mw4[e >> 2].w;
+        const unsigned sel = 0u - ((w >> c) & 1u);  // ~0 for a blocked cell
+        const float pe = __builtin_amdgcn_exp2f(fmaf(s[e], sc2, -lse4[e >> 2][e & 3]));
+        p[e] = __uint_as_float(__float_as_uint(pe) & ~sel);
+        ds[e] = p[e] * (dp[e] - dl4[e >> 2][e & 3]);
       }
-      if (qt + 1 < n_qt) load_qtile(qt + 1);  // in flight during the dV / dK MFMAs below
 #pragma unroll
-      for (int e = 0; e < 16; ++e) dv = __builtin_amdgcn_mfma_f32_32x32x2f32(dotc[e], p[e], dv, 0, 0, 0);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) dk = __builtin_amdgcn_mfma_f32_32x32x2f32(qtc[e], ds[e], dk, 0, 0, 0);
+      for (int e = 0; e < 16; ++e) {
+        dv = __builtin_amdgcn_mfma_f32_32x32x2f32(docol[e], p[e], dv, 0, 0, 0);
+        dk = __builtin_amdgcn_mfma_f32_32x32x2f32(qcol[e], ds[e], dk, 0, 0, 0);
+      }
     }
-    if (k_ok) {
-      float* rk = a.dk + ((long long)b * a.Lk + ki) * (a.H * kD) + h * kD;
-      float* rv = a.dv + ((long long)b * a.Lk + ki) * (a.H * kD) + h * kD;
+  }
+  if (k_ok) {
+    float* rk = a.dk + ((long long)b * a.Lk + ki) * (a.H * kD) + h * kD;
+    float* rv = a.dv + ((long long)b * a.Lk + ki) * (a.H * kD) + h * kD;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        *reinterpret_cast<f4v*>(rk + 8 * j + 4 * g) = f4v{dk[4 * j], dk[4 * j + 1], dk[4 * j + 2], dk[4 * j + 3]};
-        *reinterpret_cast<f4v*>(rv + 8 * j + 4 * g) = f4v{dv[4 * j], dv[4 * j + 1], dv[4 * j + 2], dv[4 * j + 3]};
-      }
+    for (int j = 0; j < 4; ++j) {
+      *reinterpret_cast<f4v*>(rk + 8 * j + 4 * g) = f4v{dk[4 * j] * a.scale, dk[4 * j + 1] * a.scale, dk[4 * j + 2] * a.scale, dk[4 * j + 3] * a.scale};
+      *reinterpret_cast<f4v*>(rv + 8 * j + 4 * g) = f4v{dv[4 * j], dv[4 * j + 1], dv[4 * j + 2], dv[4 * j + 3]};
     }
   }
   combo_ts_end(a.ts);
@@ -782,6 +811,7 @@ extern "C" int combo_attention_backward_f32(const float* q, long long ldq, const
   }
   a.ts = combo_timing_next_slot(COMBO_TS_ATTN_BWD, 8.0 * B * H * (double)Lq * Lk * kD);
   const int n_kt = (Lk + 31) / 32;
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(B * H, (n_kt + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+  const int lds_kv = 8 * kTileBytes + 2 * kQChunk * 4 + 4 * kQChunk * 4;
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(B * H, (n_kt + 3) / 4), dim3(256), lds_kv, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
