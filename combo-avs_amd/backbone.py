@@ -55,7 +55,20 @@ class _FoldAll(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
+        out = [None] * len(grads)
         idx = [i for i, g in enumerate(grads) if g is not None]
+        if idx and grads[idx[0]].is_cuda and grads[idx[0]].dtype == torch.float32:
+            # weight gradients that are problems of the deferred grouped launch (ops/convwrw.py) do not exist yet: they pass
+            # through as they are and take their FrozenBN scale in place once the launch has written them
+            from .ops import linear as L
+            from .ops.foldcast import fold_cast
+            late = [i for i in idx if L.is_deferred_dest(grads[i])]
+            if late:
+                tensors, scales = [grads[i] for i in late], [ctx.scales[i] for i in late]
+                L.after_flush(lambda: fold_cast(tensors, tensors, scales))
+                for i in late:
+                    out[i] = grads[i]
+                idx = [i for i in idx if i not in set(late)]
         g32 = [torch.empty(grads[i].shape, dtype=torch.float32, device=grads[i].device) for i in idx]
         if idx and grads[idx[0]].is_cuda:
             from .ops.foldcast import fold_cast
@@ -63,7 +76,6 @@ class _FoldAll(torch.autograd.Function):
         elif idx:
             torch._foreach_copy_(g32, [grads[i] for i in idx])
             torch._foreach_mul_(g32, [ctx.scales[i] for i in idx])
-        out = [None] * len(grads)
         for i, g in zip(idx, g32):
             out[i] = g
         return (None, None) + tuple(out)
@@ -79,6 +91,9 @@ class ConvBN(nn.Conv2d):
 
     def forward(self, x, folded=None, bias=True):
         if folded is not None:  # (w * scale, shift) prepared for the whole backbone by ResNet.forward
+            if not bias:
+                from .ops.convwrw import conv2d  # fp32 recipe: weight gradient on the head's kernels where they apply
+                return conv2d(x, folded[0], self.stride, self.padding)
             return F.conv2d(x, folded[0], folded[1] if bias else None, self.stride, self.padding)
         scale, shift = self.norm.scale_shift()
         w = self.weight * scale[:, None, None, None]

@@ -1,0 +1,78 @@
+"""Weight gradients of the ResNet backbones' stride-1 convolutions on the head's gradient GEMM kernels (fp32 recipe).
+
+The reference's S4 / MS3 recipe trains two ResNet-50 encoders in fp32 (SOLVER.AMP.ENABLED False; detectron2's ResNet is not
+part of /root/reference - backbones are SURVEY section 8 row f2).  The library's fp32 weight-gradient kernels (split-K with
+atomics + a zero-fill launch per convolution) were 8.0 ms of a 59 ms step: 352 launches at ~80 TFLOP/s.  Policy of this
+package (ops/linear.py): FORWARD values exact fp32, GRADIENTS with the 3-product bf16 split.  So forward and input gradient
+stay the library's kernels and only dW moves:
+  * 1x1 / stride 1: dW = dY^T . X over the channels_last token views - one PROBLEM of the grouped, deferred weight-gradient
+    launch (ops.linear.weight_grad, csrc/gemm_tn.hip): all of them and the head's own run as one launch + one reduce;
+  * 3x3 / stride 1 / pad 1 with >= 128 channels: the implicit-GEMM kernel of ops/conv3x3.py (no im2col buffer).
+Everything else (7x7 stem, stride-2 layers, the 64-channel 3x3) keeps autograd's library backward."""
+import os
+
+import torch
+import torch.nn.functional as F
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import conv3x3 as C3
+from . import linear as L
+
+ENABLED = os.environ.get("COMBO_BACKBONE_WRW", "1") == "1"  # 0: the library's weight-gradient kernels (A/B)
+
+
+def kind(x, w, stride, padding):
+    """0: not handled; 1: 1x1 stride 1; 3: 3x3 stride 1 pad 1"""
+    if not (ENABLED and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and not torch.is_autocast_enabled()
+            and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and torch.is_grad_enabled() and w.requires_grad):
+        return 0
+    cout, cin, kh, kw = w.shape
+    s = tuple(stride) if isinstance(stride, (tuple, list)) else (stride, stride)
+    p = tuple(padding) if isinstance(padding, (tuple, list)) else (padding, padding)
+    if (kh, kw) == (1, 1) and s == (1, 1) and p == (0, 0) and cin % 16 == 0 and cout % 16 == 0 and cin >= 64 and cout >= 64:
+        return 1
+    if (kh, kw) == (3, 3) and s == (1, 1) and p == (1, 1) and cin % 128 == 0 and cout % 128 == 0 and x.shape[2] >= 2 and x.shape[3] >= 2 \
+            and x.shape[0] * x.shape[2] * x.shape[3] * max(x.shape[2], x.shape[3]) < 2 ** 31:
+        return 3
+    return 0
+
+
+class _ConvWrw(Function):
+    @staticmethod
+    def forward(ctx, x, w, k):
+        ctx.k = k
+        ctx.save_for_backward(x, w)
+        return F.conv2d(x, w, None, 1, 1 if k == 3 else 0)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        B, cin, H, W = x.shape
+        cout = w.shape[0]
+        pad = 1 if ctx.k == 3 else 0
+        if not dy.is_contiguous(memory_format=torch.channels_last):
+            dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:  # input gradient: the library's kernel
+            dx = torch.ops.aten.convolution_backward(dy, x, w, None, (1, 1), (pad, pad), (1, 1), False, (0, 0), 1,
+                                                     (True, False, False))[0]
+        if ctx.needs_input_grad[1]:
+            dy_tok, x_tok = C3._tokens(dy), C3._tokens(x)
+            if ctx.k == 1:
+                g, _ = L.weight_grad(w.view(cout, cin), dy_tok, x_tok, False, True)  # joins the grouped launch when it can
+                dw = g.view(cout, cin, 1, 1)
+            else:
+                dw = C3._wgrad_tokens(dy_tok, x_tok, B, H, W, cin, cout).permute(0, 3, 1, 2)
+                if not dw.is_contiguous():
+                    dw = dw.contiguous()
+        return dx, dw, None
+
+
+def conv2d(x, w, stride, padding):
+    """F.conv2d(x, w, None, stride, padding) whose weight gradient runs on the head's kernels where they apply"""
+    k = kind(x, w, stride, padding)
+    if k:
+        return _ConvWrw.apply(x, w, k)
+    return F.conv2d(x, w, None, stride, padding)

@@ -259,6 +259,20 @@ _GROUP_TOKENS_PER_SPLIT = int(_os.environ.get("COMBO_DW_TOKENS_PER_SPLIT", "1024
 _dw_queue = None  # [[uses, dw_out, db_out, extras]] while a deferred_dw() context is open (uses = [(dy, x2d), ...])
 _dw_index = {}    # ("w" | "ln", parameter address) -> queue entry: repeated uses of one parameter join its entry
 _ln_queue = None  # [[uses, out[2,C]]]: LayerNorm parameter gradients, same idea (ops/layernorm.py)
+_after_flush = []  # callables run once the deferred gradients exist (e.g. the FrozenBN fold of the backbone weight gradients)
+
+
+def is_deferred_dest(t):
+    """t is (a view of) the not-yet-written destination of a deferred weight gradient"""
+    return _dw_queue is not None and any(e[1].data_ptr() == t.data_ptr() for e in _dw_queue)
+
+
+def after_flush(fn):
+    """run fn() when the open deferred_dw() context has written its gradients (at once without a context)"""
+    if _dw_queue is None:
+        fn()
+    else:
+        _after_flush.append(fn)
 
 
 def _flush_ln(q):
@@ -307,6 +321,10 @@ class deferred_dw:
             _flush_dw(q)
         if exc[0] is None and ql:
             _flush_ln(ql)
+        post, _after_flush[:] = _after_flush[:], []
+        if exc[0] is None:
+            for fn in post:
+                fn()
         return False
 
 

@@ -432,3 +432,60 @@ def test_add_layernorm_forward_backward_vs_torch(rows, C, with_res):
         assert ((y.double() - ref).abs().max() / ref.abs().max()).item() < 1e-6
         for a, b in zip(got, ref_g):
             assert ((a.double() - b).norm() / b.norm()).item() < 2e-6
+
+
+def test_backbone_fp32_weight_gradients_on_the_grouped_kernels():
+    """fp32 ResNet: the weight gradients of the stride-1 convolutions as problems of the deferred grouped launch / the
+    implicit-GEMM 3x3 kernel (ops/convwrw.py, FrozenBN scale applied after the flush) against the library's backward."""
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.backbone import ResNet
+    from combo_avs_amd.ops import convwrw
+    from combo_avs_amd.ops import linear as L
+    torch.manual_seed(0)
+    m = ResNet(50).cuda().train()
+    for mod in m.modules():
+        if hasattr(mod, "running_var"):
+            mod.running_var.uniform_(0.5, 1.5); mod.running_mean.normal_(0, 0.1); mod.weight.uniform_(0.8, 1.2); mod.bias.normal_(0, 0.1)
+    m._bn_cache.clear()
+    x = torch.randn(6, 3, 128, 128, device="cuda")
+    params = [p for p in m.parameters()]
+
+    def grads(enabled):
+        convwrw.ENABLED = enabled
+        try:
+            with L.deferred_dw():
+                out = m(x)
+                g = torch.autograd.grad(sum(v.pow(2).mean() for v in out.values()), params)
+            return [t.clone() for t in g]
+        finally:
+            convwrw.ENABLED = True
+    # judge both against float64 (the library itself moves by ~1e-3 on the stem weight between algorithms it picks)
+    import copy
+    m64 = copy.deepcopy(m).double()
+
+    def unfused(mm, xx):  # per-convolution torch path (conv + FrozenBN affine + relu), no folded weights
+        xx = torch.nn.functional.max_pool2d(torch.relu(mm.stem.conv1(xx)), 3, 2, 1)
+        res = {}
+        for name in ("res2", "res3", "res4", "res5"):
+            for blk in getattr(mm, name):
+                xx = blk(xx)
+            res[name] = xx
+        return res
+    out64 = unfused(m64, x.double())
+    true = torch.autograd.grad(sum(v.pow(2).mean() for v in out64.values()), [p for p in m64.parameters()])
+    # (measured: two runs of the LIBRARY path differ from float64 by 1.2e-3 .. 2.9e-3 on the stem weight - atomics order in
+    # its weight-gradient kernels + ReLU gates next to 0 - so per-parameter bounds are loose and the whole-vector error decides)
+    tn = torch.sqrt(sum(b.pow(2).sum() for b in true))
+
+    def err(gs):
+        worst = max(float((a.double() - b).norm() / b.norm().clamp_min(1e-30)) for a, b in zip(gs, true))
+        return worst, float(torch.sqrt(sum((a.double() - b).pow(2).sum() for a, b in zip(gs, true))) / tn)
+    (w_lib, e_lib), (w_own, e_own) = err(grads(False)), err(grads(True))
+    assert len(L._after_flush) == 0
+    assert e_own < max(3 * e_lib, 2e-4) and w_own < max(3 * w_lib, 1e-2), (e_own, e_lib, w_own, w_lib)
+    # without a deferred_dw() context the same path computes every gradient at once
+    convwrw.ENABLED = True
+    out = m(x)
+    g2 = torch.autograd.grad(sum(v.pow(2).mean() for v in out.values()), params)
+    w2, e2 = err(g2)
+    assert e2 < max(3 * e_lib, 2e-4) and w2 < max(3 * w_lib, 1e-2), (e2, e_lib, w2, w_lib)
