@@ -13,12 +13,20 @@ Forward + loss + backward are replayed from ONE captured hipGraph (trainer.Graph
 launches; a failed capture falls back to eager and says so on stderr).  The first warm-up step is eager (MIOpen's
 exhaustive find for the backbone convolutions, ~2 min on a box with an empty MIOpen user db; COMBO_MIOPEN_BENCHMARK=0
 skips it), the capture happens in the second.
-Extra objects: `roofline` for the MSDeformAttn forward core (HBM-bound; duration by HIP events around its launches in two
-EAGER runs of the same step right after the timed region - HIP cannot record events inside a captured graph on ROCm 7),
-`other_kernels` (the 3xbf16 GEMM kernels against the bf16 MFMA peak, the MSDeformAttn backward against HBM, same event
-pass) and `cpu_baseline` (the CPU oracle's full training step on the host cores, bounded sample, rank 0 at N=1 only).
-Other modes (not the BASELINE metric): `--mode infer` (eval forward + fused inference tail), `--backbone pvt`
-(COMBO-PVTv2-B5), `--grad-comm bf16` (bf16 gradient all-reduce), `--dtype fp32`.
+Default precision: fp32 (the reference's S4 recipe has SOLVER.AMP.ENABLED False); `--dtype bf16` runs the backbones under
+bf16 autocast (secondary number, not `value`).  `--config {r50_s4, pvt_s4, pvt_avss_512, pvt_ms3_t10}` selects the workload.
+Extra objects: `roofline` = the instrumented kernel family with the largest time per step (the exact-fp32 MFMA GEMM
+`gemm_nt_f32_kernel`), `other_kernels` = the other instrumented families (3xbf16 gradient GEMMs, grouped weight-gradient
+GEMM, decoder attention forward / backward, MSDeformAttn forward / backward).  Durations are measured LIVE inside the timed
+graph replays: every instrumented launch records its first workgroup start / last workgroup end (wall-clock ticks) in a slot
+of a device buffer - two fire-and-forget atomics per workgroup, spread over 16 lines per slot - and one tiny fold launch per
+step adds end - start to the slot's sum (csrc/combo_common.h, csrc/timing.hip; HIP refuses event records inside a captured
+graph on ROCm 7).  `achieved` = algorithmic flops (2 M N K; bytes for the HBM-bound kinds) / that time; `large_launches`
+restricts the same ratio to launches of >= 2 GFLOP (the layers that can fill 256 CUs); `traffic` = HBM bytes per launch from
+the rocprofv3 PMC pass of the same commit (profiles/r02_pmc.json, tools/pmc_bench.sh).  `ms_per_step_median` is the median
+over the timed steps (events between graph launches).  `cpu_baseline`: the CPU oracle's full training step on the host cores
+(bounded sample, rank 0 at N=1, r50_s4 only).
+Other modes (not the BASELINE metric): `--mode infer` (eval forward + fused inference tail), `--grad-comm bf16`.
 """
 import argparse
 import json

@@ -60,6 +60,9 @@ _SIGNATURES = {
     "combo_timing_slot_info": [c_int, c_void_p, c_void_p],
     "combo_gemm_smallm_splits": [c_int, c_int, c_int],
     "combo_gemm_smallm_f32": [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_void_p] + [c_int] * 5 + [c_void_p],
+    "combo_gemm_smallk_f32": [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_longlong, c_longlong, c_int, c_int, c_void_p],
+    "combo_gemm_tn_smalln_slices": [c_longlong],
+    "combo_gemm_tn_smalln_f32": [c_void_p, c_longlong, c_void_p, c_longlong, c_longlong, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "combo_gemm_nt_f32": [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_void_p],
     "combo_gemm_nt_batched_f32": [c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_longlong,
                                   c_int, c_int, c_int, c_int, c_int, c_void_p],

@@ -143,3 +143,89 @@ extern "C" int combo_gemm_smallm_f32(const float* X, long long ldx, const float*
     hipLaunchKernelGGL(smallm_finish_kernel, dim3((M * N + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, splits, bias, Y, ldy, M, N, relu);
   return (int)hipGetLastError();
 }
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// C[M,N] = A[M,K] . W[K,N] for a tiny reduction length K <= 16 (the input gradient of class_embed: dY [BT*Q, K+1 classes] .
+// W [K+1, 256], transformer_decoder.py:495): an outer-product sum per output, exact fp32 FMAs.  The BLAS library ran this
+// as a 32x16x32 tile GEMM at 65 us per call (10 calls per step); a thread here computes 4 consecutive n of one row.
+namespace {
+__global__ void __launch_bounds__(256)
+gemm_smallk_kernel(const float* __restrict__ A, long long lda, const float* __restrict__ W, long long ldw, float* __restrict__ C,
+                   long long ldc, long long M, int N4, int K) {
+  const long long t = blockIdx.x * 256LL + threadIdx.x;
+  if (t >= M * N4) return;
+  const long long m = t / N4;
+  const int n4 = (int)(t - m * N4);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < K; ++k) {
+    const float a = A[m * lda + k];
+    const float4 w = *reinterpret_cast<const float4*>(W + (long long)k * ldw + 4 * n4);
+    acc.x = fmaf(a, w.x, acc.x); acc.y = fmaf(a, w.y, acc.y); acc.z = fmaf(a, w.z, acc.z); acc.w = fmaf(a, w.w, acc.w);
+  }
+  *reinterpret_cast<float4*>(C + m * ldc + 4 * n4) = acc;
+}
+}  // namespace
+
+extern "C" int combo_gemm_smallk_f32(const float* A, long long lda, const float* W, long long ldw, float* C, long long ldc,
+                                     long long M, int N, int K, combo_stream_t stream) {
+  if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || K > 16 || N % 4 != 0 || ldw % 4 != 0 || ldc % 4 != 0 ||
+      (((uintptr_t)W | (uintptr_t)C) & 15))
+    return COMBO_EINVAL;
+  const long long n = M * (N / 4);
+  hipLaunchKernelGGL(gemm_smallk_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A, lda, W, ldw, C, ldc,
+                     M, N / 4, K);
+  return (int)hipGetLastError();
+}
+
+
+// dW[N,K] = dY[M,N]^T . X[M,K] (+ db[N] = sum_m dY) for a tiny output-row count N <= 16 (class_embed's weight gradient: N =
+// classes + 1, M = BT*Q tokens, K = 256): one wave per token slice accumulates N x 4 outputs per lane in exact fp32 FMAs and
+// writes a split-K partial; combo_splitk_reduce_f32 sums the slices.  (BLAS: a 32x16x32 tile GEMM, 65 us per call.)
+namespace {
+__global__ void __launch_bounds__(64)
+gemm_tn_smalln_kernel(const float* __restrict__ dY, long long ldy, const float* __restrict__ X, long long ldx, long long M, int N,
+                      int K4, int rows_per_slice, float* __restrict__ partials, float* __restrict__ db_partials) {
+  const int slice = blockIdx.y, t = blockIdx.x * 64 + threadIdx.x;
+  const long long m0 = (long long)slice * rows_per_slice, m1 = m0 + rows_per_slice < M ? m0 + rows_per_slice : M;
+  const bool live = t < K4;
+  float4 acc[16];
+  float accb[16];
+#pragma unroll
+  for (int n = 0; n < 16; ++n) { acc[n] = make_float4(0.f, 0.f, 0.f, 0.f); accb[n] = 0.f; }
+  for (long long m = m0; m < m1; ++m) {
+    const float4 x = live ? *reinterpret_cast<const float4*>(X + m * ldx + 4 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int n = 0; n < 16; ++n)
+      if (n < N) {
+        const float d = dY[m * ldy + n];  // wave-uniform address
+        acc[n].x = fmaf(d, x.x, acc[n].x); acc[n].y = fmaf(d, x.y, acc[n].y);
+        acc[n].z = fmaf(d, x.z, acc[n].z); acc[n].w = fmaf(d, x.w, acc[n].w);
+        accb[n] += d;
+      }
+  }
+  if (live) {
+#pragma unroll
+    for (int n = 0; n < 16; ++n)
+      if (n < N) *reinterpret_cast<float4*>(partials + ((long long)slice * N + n) * (4LL * K4) + 4 * t) = acc[n];
+  }
+  if (db_partials && t == 0) {
+#pragma unroll
+    for (int n = 0; n < 16; ++n)
+      if (n < N) db_partials[(long long)slice * N + n] = accb[n];
+  }
+}
+}  // namespace
+
+extern "C" int combo_gemm_tn_smalln_slices(long long M) { return (int)((M + 127) / 128); }
+
+extern "C" int combo_gemm_tn_smalln_f32(const float* dY, long long ldy, const float* X, long long ldx, long long M, int N, int K,
+                                        float* partials, float* db_partials, combo_stream_t stream) {
+  if (!dY || !X || !partials || M <= 0 || N <= 0 || N > 16 || K <= 0 || K % 4 != 0 || ldx % 4 != 0 ||
+      (((uintptr_t)X | (uintptr_t)partials) & 15))
+    return COMBO_EINVAL;
+  const int slices = combo_gemm_tn_smalln_slices(M);
+  hipLaunchKernelGGL(gemm_tn_smalln_kernel, dim3((unsigned)((K / 4 + 63) / 64), (unsigned)slices), dim3(64), 0, (hipStream_t)stream,
+                     dY, ldy, X, ldx, M, N, K / 4, 128, partials, db_partials);
+  return (int)hipGetLastError();
+}

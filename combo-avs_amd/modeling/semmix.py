@@ -1,9 +1,10 @@
 """Siam-Encoder-Module mix: `channel_weighted_block` (models/utils/misc.py:112-131) and the
 per-level mix `f <- f + gate(p) * p` (models/maskformer_model.py:345-352).  The global average pool and the mix run on
-csrc/semmix.hip (channels-last, bf16 or fp32 in, fp32 out); the two tiny gate GEMVs stay library calls."""
+csrc/semmix.hip (channels-last, bf16 or fp32 in, fp32 out); the two tiny gate GEMVs run on the head's dense-layer kernels (ops/linear.py)."""
 import torch
 from torch import nn
 
+from ..ops import linear as L
 from ..ops import semmix as K
 
 
@@ -16,7 +17,8 @@ class channel_weighted_block(nn.Module):
     def forward(self, x):
         b, c, _, _ = x.size()
         y = K.global_avg_pool(x)  # [B,C] fp32
-        y = torch.sigmoid(self.fc2(torch.relu(self.fc1(y))))
+        # the two gate GEMVs ([BT, C] rows): the head's exact-fp32 kernels (a BLAS tile GEMM takes 65 us for these shapes)
+        y = torch.sigmoid(L.linear(L.linear(y, self.fc1.weight, self.fc1.bias, relu=True), self.fc2.weight, self.fc2.bias))
         return y.view(b, c, 1, 1)
 
 

@@ -20,6 +20,8 @@ from . import conv3x3 as C3
 from . import linear as L
 
 ENABLED = os.environ.get("COMBO_BACKBONE_WRW", "1") == "1"  # 0: the library's weight-gradient kernels (A/B)
+# input gradients on the head's 3-product kernels as well (A/B): bit 0 the 3x3 convolutions, bit 1 the 1x1 with >= 256 channels
+DX_OWN = int(os.environ.get("COMBO_BACKBONE_DX", "0"))
 
 
 def kind(x, w, stride, padding):
@@ -55,7 +57,12 @@ class _ConvWrw(Function):
         if not dy.is_contiguous(memory_format=torch.channels_last):
             dy = dy.contiguous(memory_format=torch.channels_last)
         dx = dw = None
-        if ctx.needs_input_grad[0]:  # input gradient: the library's kernel
+        if ctx.needs_input_grad[0] and ctx.k == 3 and (DX_OWN & 1):
+            wt = w.flip(2, 3).permute(1, 2, 3, 0).reshape(cin, 9 * cout)
+            dx = C3._conv_tokens(C3._tokens(dy), wt, None, B, H, W, cout, cin, exact=False).view(B, H, W, cin).permute(0, 3, 1, 2)
+        elif ctx.needs_input_grad[0] and ctx.k == 1 and (DX_OWN & 2) and min(cin, cout) >= 256:
+            dx = L.input_grad_gemm(C3._tokens(dy), w.view(cout, cin)).view(B, H, W, cin).permute(0, 3, 1, 2)
+        elif ctx.needs_input_grad[0]:  # input gradient: the library's kernel
             dx = torch.ops.aten.convolution_backward(dy, x, w, None, (1, 1), (pad, pad), (1, 1), False, (0, 0), 1,
                                                      (True, False, False))[0]
         if ctx.needs_input_grad[1]:

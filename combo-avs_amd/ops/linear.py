@@ -234,7 +234,15 @@ def input_grad_gemm(dy, weight, relu_mask=None):
         if img is not None:
             return gemm_nt_x3(dyc, img, relu_mask=relu_mask, img=img)  # img [K, N] has the shape of the operand view
         return gemm_nt_x3(dyc, (ws[0] if len(ws) == 1 else torch.cat(ws, 0)).t(), relu_mask=relu_mask)
-    dx = dy @ (ws[0] if len(ws) == 1 else torch.cat(ws, 0))
+    w = ws[0] if len(ws) == 1 else torch.cat(ws, 0)
+    if (dy.is_cuda and dy.dtype == torch.float32 and w.dtype == torch.float32 and dy.dim() == 2 and dy.shape[1] <= 16 and dy.stride(1) == 1
+            and w.shape[1] % 4 == 0 and w.is_contiguous() and w.data_ptr() % 16 == 0 and relu_mask is None):
+        # a tiny reduction length (class_embed: K + 1 classes): outer-product kernel instead of a BLAS tile GEMM
+        dx = torch.empty(dy.shape[0], w.shape[1], device=dy.device, dtype=torch.float32)
+        _lib.check(_lib.lib().combo_gemm_smallk_f32(dy.data_ptr(), dy.stride(0), w.data_ptr(), w.stride(0), dx.data_ptr(), dx.stride(0),
+                                                    dy.shape[0], w.shape[1], dy.shape[1], _lib.current_stream()), "combo_gemm_smallk_f32")
+        return dx
+    dx = dy @ w
     return relu_grad(dx, relu_mask) if relu_mask is not None else dx
 
 
@@ -401,6 +409,22 @@ def _dw_now(dy, x2d, want_db):
             and dy.data_ptr() % 16 == 0 and x2d.data_ptr() % 16 == 0:
         r = gemm_tn_x3(dy, x2d, with_bias_grad=want_db)  # long-reduction / small-output shape; db rides along
         return r if want_db else (r, None)
+    if (dy.is_cuda and dy.dtype == torch.float32 and x2d.dtype == torch.float32 and dy.shape[1] <= 16 and dy.stride(1) == 1
+            and x2d.stride(1) == 1 and x2d.shape[1] % 4 == 0 and x2d.stride(0) % 4 == 0 and x2d.data_ptr() % 16 == 0
+            and dy.shape[0] >= 256):
+        # a tiny output-row count (class_embed: K + 1 classes): FMA kernel + the split-K reduce instead of a BLAS tile GEMM
+        lib, st = _lib.lib(), _lib.current_stream()
+        M, N, K = dy.shape[0], dy.shape[1], x2d.shape[1]
+        slices = lib.combo_gemm_tn_smalln_slices(M)
+        part = torch.empty(slices, N, K, device=dy.device, dtype=torch.float32)
+        dbp = torch.empty(slices, N, device=dy.device, dtype=torch.float32) if want_db else None
+        _lib.check(lib.combo_gemm_tn_smalln_f32(dy.data_ptr(), dy.stride(0), x2d.data_ptr(), x2d.stride(0), M, N, K, part.data_ptr(),
+                                                _lib.ptr(dbp), st), "combo_gemm_tn_smalln_f32")
+        dw = torch.empty(N, K, device=dy.device, dtype=torch.float32)
+        db = torch.empty(N, device=dy.device, dtype=torch.float32) if want_db else None
+        _lib.check(lib.combo_splitk_reduce_f32(part.data_ptr(), slices, N * K, dw.data_ptr(), _lib.ptr(dbp), N if want_db else 0,
+                                               _lib.ptr(db), st), "combo_splitk_reduce_f32")
+        return dw, db
     dw = dy.t() @ x2d
     return dw, (dy.sum(0) if want_db else None)
 

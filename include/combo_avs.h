@@ -241,6 +241,16 @@ int combo_conv3x3_nhwc_f32(const float* X, long long ldx, const float* Wm, const
 int combo_gemm_smallm_splits(int M, int N, int K);
 int combo_gemm_smallm_f32(const float* X, long long ldx, const float* W, long long ldw, const float* bias, float* Y, long long ldy,
                           float* partial_ws, int splits, int M, int N, int K, int relu, combo_stream_t stream);
+/*   C[M,N] = A[M,K] . W[K,N] for K <= 16, N % 4 == 0 (rows of W and C 16-byte aligned): the input gradient of class_embed
+ *   (transformer_decoder.py:495, K = classes + 1), exact fp32. */
+int combo_gemm_smallk_f32(const float* A, long long lda, const float* W, long long ldw, float* C, long long ldc, long long M,
+                          int N, int K, combo_stream_t stream);
+/*   dW[N,K] = dY[M,N]^T . X[M,K] for N <= 16 (class_embed's weight gradient), exact fp32: split-K partials
+ *   [combo_gemm_tn_smalln_slices(M)][N][K] (+ db_partials [slices][N] = per-slice column sums of dY, or NULL), to be summed by
+ *   combo_splitk_reduce_f32. */
+int combo_gemm_tn_smalln_slices(long long M);
+int combo_gemm_tn_smalln_f32(const float* dY, long long ldy, const float* X, long long ldx, long long M, int N, int K,
+                             float* partials, float* db_partials, combo_stream_t stream);
 
 /*   Input-gradient GEMM C[M,N] = A[M,K] . B[N,K]^T (+ bias[N]) (+ ReLU) with the 3-product bf16 split (x.w ~ hi.hi +
  *   hi.lo + lo.hi, hi = rne_bf16, ~2^-17 relative per product) on the bf16 matrix cores (csrc/gemm_nt2.hip): persistent

@@ -480,12 +480,39 @@ def test_backbone_fp32_weight_gradients_on_the_grouped_kernels():
     def err(gs):
         worst = max(float((a.double() - b).norm() / b.norm().clamp_min(1e-30)) for a, b in zip(gs, true))
         return worst, float(torch.sqrt(sum((a.double() - b).pow(2).sum() for a, b in zip(gs, true))) / tn)
+    # (the library's FIRST call of a configuration returns the result of another, more accurate algorithm than the one its
+    # find pass settles on for later calls: compare steady states)
+    grads(False), grads(True)
     (w_lib, e_lib), (w_own, e_own) = err(grads(False)), err(grads(True))
     assert len(L._after_flush) == 0
-    assert e_own < max(3 * e_lib, 2e-4) and w_own < max(3 * w_lib, 1e-2), (e_own, e_lib, w_own, w_lib)
+    # plumbing check (a missing / doubled FrozenBN scale, an unwritten deferred gradient would be O(0.1 .. 1)); the kernels'
+    # own accuracy is pinned per layer by test_backbone_conv_weight_gradient_kernels_vs_fp64
+    assert e_own < max(3 * e_lib, 2e-3) and w_own < max(3 * w_lib, 3e-2), (e_own, e_lib, w_own, w_lib)
     # without a deferred_dw() context the same path computes every gradient at once
     convwrw.ENABLED = True
     out = m(x)
     g2 = torch.autograd.grad(sum(v.pow(2).mean() for v in out.values()), params)
     w2, e2 = err(g2)
-    assert e2 < max(3 * e_lib, 2e-4) and w2 < max(3 * w_lib, 1e-2), (e2, e_lib, w2, w_lib)
+    assert e2 < max(3 * e_lib, 2e-3) and w2 < max(3 * w_lib, 3e-2), (e2, e_lib, w2, w_lib)
+
+
+@pytest.mark.parametrize("B,C,Co,H,k", [(6, 256, 64, 32, 1), (6, 64, 256, 32, 1), (6, 1024, 256, 8, 1), (6, 512, 2048, 4, 1),
+                                        (6, 128, 128, 16, 3), (6, 256, 256, 8, 3), (6, 512, 512, 4, 3)])
+def test_backbone_conv_weight_gradient_kernels_vs_fp64(B, C, Co, H, k):
+    """one convolution through ops.convwrw.conv2d: dW on the head's kernels (immediately, and as a problem of the deferred
+    grouped launch), dX by the library - both against float64"""
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.ops import convwrw
+    from combo_avs_amd.ops import linear as L
+    torch.manual_seed(B * C + Co + H + k)
+    x = torch.randn(B, C, H, H, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = (torch.randn(Co, C, k, k, device="cuda") * 0.05).requires_grad_(True)
+    g = torch.randn(B, Co, H, H, device="cuda").contiguous(memory_format=torch.channels_last)
+    assert convwrw.kind(x, w, 1, k // 2) == k
+    rx, rw = torch.autograd.grad(torch.nn.functional.conv2d(x.double(), w.double(), None, 1, k // 2), (x, w), g.double())
+    rel = lambda a, b: float((a.double() - b).norm() / b.norm())
+    dx, dw = torch.autograd.grad(convwrw.conv2d(x, w, 1, k // 2), (x, w), g)
+    assert rel(dx, rx) < 2e-6 and rel(dw, rw) < 2e-5, (rel(dx, rx), rel(dw, rw))
+    with L.deferred_dw():
+        dx2, dw2 = torch.autograd.grad(convwrw.conv2d(x, w, 1, k // 2), (x, w), g)
+    assert rel(dx2, rx) < 2e-6 and rel(dw2, rw) < 2e-5, (rel(dx2, rx), rel(dw2, rw))
