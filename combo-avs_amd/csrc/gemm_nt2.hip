@@ -392,6 +392,7 @@ presplit_grouped_kernel(const SplitGroupArgs args) {
   const combo_presplit_problem& pr = args.p[pi];
   const long long t = t0 - args.thread_start[pi];
   const int kg = pr.K >> 3;
+  if (t >= (long long)pr.N * kg) return;  // (a problem's threads are rounded up to whole workgroups)
   int n, g8;
   if (pr.ld_col == 1) { n = (int)(t / kg); g8 = (int)(t - (long long)n * kg); }
   else { g8 = (int)(t / pr.N); n = (int)(t - (long long)g8 * pr.N); }

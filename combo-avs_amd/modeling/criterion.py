@@ -230,6 +230,13 @@ class SetCriterion(nn.Module):
             masks = None
         else:
             masks = torch.stack([lo["pred_masks"] for lo in layers])  # [L,F,Q,h,w]
+            if frame_ids is not None and logits.shape[1] != F_:
+                # the caller passed all BT frames for the fused path, which does not apply (layout / dtype / head count):
+                # pick the ground-truth frames here - never fold 5 frames into the class dimension
+                if len(frame_ids) != F_:
+                    raise ValueError(f"{len(frame_ids)} ground-truth frame ids for {F_} targets")
+                sel = torch.tensor(list(frame_ids), dtype=torch.int64, device=dev)
+                logits, masks = logits.index_select(1, sel), masks.index_select(1, sel)
         Q = logits.shape[2]
         G = [int(t["labels"].shape[0]) for t in targets]
         Gmax, Nm = max(G), sum(G)

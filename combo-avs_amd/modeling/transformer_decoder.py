@@ -156,7 +156,7 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
                 self.input_proj.append(conv)
             else:
                 self.input_proj.append(nn.Sequential())
-        self.class_embed = nn.Linear(hidden_dim, num_classes + 1)
+        self.class_embed = Linear(hidden_dim, num_classes + 1)  # own kernels incl. the 3-wide gradients (csrc/gemm_smallm.hip)
         self.mask_embed = MLP(hidden_dim, hidden_dim, mask_dim, 3)
         self.dataset_name = dataset_name
         self.use_cosine_loss = use_cosine_loss

@@ -51,7 +51,9 @@ class FlatAdamW:
                  betas=(0.9, 0.999), eps=1e-8, weight_decay_norm=0.0, weight_decay_embed=0.0, grad_dtype=torch.float32,
                  grad_comm_dtype=torch.float32):
         entries = param_groups(model, base_lr, weight_decay, backbone_multiplier, weight_decay_norm, weight_decay_embed)
+        ref_index = {id(e[0]): i for i, e in enumerate(entries)}  # position in the reference's optimizer (train_net.py:170-194)
         entries.sort(key=lambda e: (e[2], e[3]))  # stable: contiguous (lr, wd) segments
+        self.ref_order = [ref_index[id(e[0])] for e in entries]
         self.entries = entries
         # every (lr, wd) segment starts on a 16-byte boundary (vectorised fused AdamW kernel)
         # ... and so does every parameter (the dense-layer kernels read weights with 16-byte loads)
@@ -85,6 +87,7 @@ class FlatAdamW:
         self.step_count = 0
         self.lr_scale = 1.0  # WarmupPolyLR factor, set by the caller each iteration
         self.numel = total
+        self.unused = ()  # indices (into self.params) of parameters the last backward pass produced no gradient for
 
     def zero_grad(self):
         self.flat_grad.zero_()
@@ -96,6 +99,9 @@ class FlatAdamW:
         from .ops.linear import deferred_dw
         with deferred_dw():  # latency-bound decoder weight gradients: one grouped launch when the context closes
             grads = torch.autograd.grad(loss, self.params, allow_unused=True)
+        # torch.optim.AdamW (the reference's optimizer) skips parameters whose gradient is None - no decay, no moment update:
+        # `step` leaves them out (a static property of the model / recipe, so it is safe inside a captured graph)
+        self.unused = tuple(i for i, g in enumerate(grads) if g is None)
         if self.flat_grad.dtype != torch.float32 or any(g is not None and g.dtype != torch.float32 for g in grads):
             dst = [v for v, g in zip(self.grad_views, grads) if g is not None]
             src = [g for g in grads if g is not None]
@@ -148,12 +154,71 @@ class FlatAdamW:
         b1, b2 = self.betas
         bc1 = 1 - b1 ** self.step_count
         bc2 = 1 - b2 ** self.step_count
-        for s, e, lr, wd in self.segments:
+        for s, e, lr, wd in self._active_segments():
             optim.adamw_segment(self.flat_param[s:e], g[s:e], self.exp_avg[s:e], self.exp_avg_sq[s:e], clip_coef,
                                 lr * self.lr_scale, wd, b1, b2, self.eps, bc1, bc2)
 
+    def _active_segments(self):
+        """the (lr, wd) segments with the ranges of the unused parameters cut out (every parameter starts 16-byte aligned)"""
+        if not self.unused:
+            return self.segments
+        cache = self.__dict__.setdefault("_active_cache", {})
+        if self.unused not in cache:
+            holes = sorted((self.offsets[i], self.offsets[i] + self.params[i].numel()) for i in self.unused)
+            out = []
+            for s, e, lr, wd in self.segments:
+                cur = s
+                for hs, he in holes:
+                    if he <= cur or hs >= e:
+                        continue
+                    if hs > cur:
+                        out.append([cur, hs, lr, wd])
+                    cur = max(cur, (he + 3) // 4 * 4)
+                if cur < e:
+                    out.append([cur, e, lr, wd])
+            cache[self.unused] = out
+        return cache[self.unused]
+
     def state_dict(self):
-        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq}
+        """torch.optim.AdamW's layout over the reference's parameter order (one group per parameter, train_net.py:170-194):
+        what detectron2's checkpointer stores as "optimizer"; plus the flat buffers under "flat"."""
+        state, groups = {}, [None] * len(self.params)
+        for j, (p, off) in enumerate(zip(self.params, self.offsets)):
+            i, n = self.ref_order[j], p.numel()
+            _, name, lr, wd = self.entries[j]
+            groups[i] = {"lr": lr * self.lr_scale, "initial_lr": lr, "betas": self.betas, "eps": self.eps, "weight_decay": wd,
+                         "amsgrad": False, "params": [i]}
+            if self.step_count > 0 and j not in self.unused:
+                state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": self.exp_avg[off:off + n].view_as(p).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[off:off + n].view_as(p).clone()}
+        return {"state": state, "param_groups": groups,
+                "flat": {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq}}
+
+    def load_state_dict(self, sd):
+        """accepts torch.optim.AdamW.state_dict() of the reference's optimizer (same parameter order) or this class's own"""
+        if "flat" in sd and sd["flat"]["exp_avg"].numel() == self.numel:
+            self.exp_avg.copy_(sd["flat"]["exp_avg"])
+            self.exp_avg_sq.copy_(sd["flat"]["exp_avg_sq"])
+            self.step_count = int(sd["flat"]["step"])
+            return
+        if len(sd["param_groups"]) != len(self.params):
+            raise ValueError(f"optimizer state for {len(sd['param_groups'])} parameter groups, this model has {len(self.params)}")
+        steps = set()
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        for j, (p, off) in enumerate(zip(self.params, self.offsets)):
+            st = sd["state"].get(self.ref_order[j])
+            if st is None:
+                continue
+            n = p.numel()
+            if st["exp_avg"].numel() != n:
+                raise ValueError(f"optimizer state of parameter {self.entries[j][1]}: {tuple(st['exp_avg'].shape)} vs {tuple(p.shape)}")
+            self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(st["step"]))
+        if len(steps) > 1:
+            raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): not representable in the flat optimizer")
+        self.step_count = steps.pop() if steps else 0
 
 
 def poly_lr_factor(it, max_iter, power=0.9, constant_ending=0.0):

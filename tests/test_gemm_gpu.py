@@ -316,6 +316,8 @@ def test_grouped_weight_presplit_gives_bitwise_the_same_input_gradients():
     w1, b1 = torch.randn(192, E, device=dev) * 0.05, torch.randn(192, device=dev)
     w2, b2 = torch.randn(96, E, device=dev) * 0.05, torch.randn(96, device=dev)
     wf1, bf1 = torch.randn(1024, E, device=dev) * 0.05, torch.randn(1024, device=dev)
+    ws, bs = (torch.randn(E, 32, device=dev) * 0.05).requires_grad_(True), torch.randn(E, device=dev)  # 32 x 256 image: < one workgroup
+    xs = torch.randn(4000, 32, device=dev, requires_grad=True)
     wf2, bf2 = torch.randn(E, 1024, device=dev) * 0.05, torch.randn(E, device=dev)
     for t in (w1, w2, wf1, wf2):
         t.requires_grad_(True)
@@ -325,13 +327,14 @@ def test_grouped_weight_presplit_gives_bitwise_the_same_input_gradients():
         q2, k2, v2 = L.in_proj(x, mem, mem, W, b, same_qk=False, defer=True)
         c = L.linear_cat(x, w1, b1, w2, b2, defer=True)
         f = L.ffn(x, wf1, bf1, wf2, bf2)
-        loss = (q * k).sum() + v.square().sum() + q2.sum() * 0.3 + (k2 * v2).sum() + c.square().sum() + f.square().sum()
-        return torch.autograd.grad(loss, [x, mem])
+        sm = L.linear(xs, ws, bs, defer=True)  # a weight whose image is smaller than one workgroup of the grouped split
+        loss = (q * k).sum() + v.square().sum() + q2.sum() * 0.3 + (k2 * v2).sum() + c.square().sum() + f.square().sum() + sm.square().sum()
+        return torch.autograd.grad(loss, [x, mem, xs])
 
     ref = run()
     with L.grouped_presplit(), L.deferred_dw():
         got = run()
-        assert not L._split_pending and len(L._split_images) == 7  # W[:2E], W[:E], W[E:2E], W[2E:], (w1,w2), wf1, wf2
+        assert not L._split_pending and len(L._split_images) == 8  # W[:2E], W[:E], W[E:2E], W[2E:], (w1,w2), wf1, wf2, ws
     assert L._split_images is None
     for r, g in zip(ref, got):
         assert torch.equal(r, g)

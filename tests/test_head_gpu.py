@@ -308,18 +308,24 @@ def test_fused_criterion_path_equals_unfused(head_run, mode):
     probe = [named[n] for n in ("predictor.mask_embed.layers.2.weight", "predictor.query_feat.weight",
                                 "pixel_decoder.mask_features.weight", "predictor.transformer_ffn_layers.4.linear1.weight")]
     res = []
-    for fused in (True, False):
+    for fused in (True, False, "declined"):
         crit, wd = make_criterion(mode)
         o = {"pred_logits": out["pred_logits"], "pred_masks": out["pred_masks"], "aux_outputs": [dict(a) for a in out["aux_outputs"]],
              "middles_attn_mask": list(out["middles_attn_mask"])}
-        if fused:
+        if fused is True:
             o["_logits_all"] = out["_logits_all"]
+        elif fused == "declined":
+            # a buffer the fused path does not take (one head short): forward() still hands _losses all BT frames + the
+            # ground-truth frame ids, and the unfused branch has to pick those frames itself
+            o["_logits_all"] = out["_logits_all"][:-1]
         torch.manual_seed(11)
         losses = crit(o, targets)
         total = sum(losses[k] * wd[k] for k in losses)
         grads = torch.autograd.grad(total, probe, retain_graph=True)
         res.append(({k: float(v) for k, v in losses.items()}, grads))
-    (la, ga), (lb, gb) = res
+    (la, ga), (lb, gb), (lc, gc) = res
+    # the declined-fused call is the unfused computation (the cosine term may take another summation order)
+    assert sorted(lc) == sorted(lb) and all(abs(lc[k] - lb[k]) <= 1e-6 * abs(lb[k]) + 1e-7 for k in lb), (lc, lb)
     assert sorted(la) == sorted(lb) and len(la) == 39
     for k in la:
         assert abs(la[k] - lb[k]) <= 1e-5 * abs(lb[k]) + 1e-6, (k, la[k], lb[k])
