@@ -112,7 +112,9 @@ class Bottleneck(nn.Module):
         """the order `forward` consumes the folded weights in"""
         return [self.conv1, self.conv2, self.conv3] + ([self.shortcut] if self.shortcut is not None else [])
 
-    def forward(self, x, folded=None):
+    def forward(self, x, folded=None, x_res=None, fanout=False):
+        """x_res: the same values as x as a second autograd output of the producing block (its identity / shortcut consumer);
+        fanout: hand the output over in that form (-> a pair)."""
         if folded is None:
             out = F.relu_(self.conv1(x))
             out = F.relu_(self.conv2(out))
@@ -121,14 +123,15 @@ class Bottleneck(nn.Module):
             return F.relu_(out + sc)
         # folded path: convolutions run WITHOUT bias, bias (+ residual) + ReLU is one fused pass (csrc/biasact.hip)
         from .ops.biasact import bias_act
+        xr = x if x_res is None else x_res
         f1, f2, f3 = next(folded), next(folded), next(folded)
         out = bias_act(self.conv1(x, f1, bias=False), f1[2])
         out = bias_act(self.conv2(out, f2, bias=False), f2[2])
         out = self.conv3(out, f3, bias=False)
         if self.shortcut is not None:
             fs = next(folded)
-            return bias_act(out, f3[2] + fs[2], self.shortcut(x, fs, bias=False))
-        return bias_act(out, f3[2], x)
+            return bias_act(out, f3[2] + fs[2], self.shortcut(xr, fs, bias=False), fanout=fanout)
+        return bias_act(out, f3[2], xr, fanout=fanout)
 
 
 class BasicStem(nn.Module):
@@ -195,10 +198,15 @@ class ResNet(nn.Module):
         with torch.autocast("cuda", enabled=False):
             x = self.stem(x.to(dtype).contiguous(memory_format=torch.channels_last), folded)
             out = {}
-            for name in ("res2", "res3", "res4", "res5"):
-                for blk in getattr(self, name):
-                    x = blk(x, folded)
-                if name in self._out_features:
+            # fp32: a block output goes to the next block twice (first convolution, identity / shortcut branch); handed over as
+            # two autograd outputs, the two gradients are added inside the block's ReLU-gradient pass (ops/biasact.py)
+            blocks = [(name, blk) for name in ("res2", "res3", "res4", "res5") for blk in getattr(self, name)]
+            x_res = None
+            for i, (name, blk) in enumerate(blocks):
+                fan = dtype == torch.float32 and i + 1 < len(blocks) and torch.is_grad_enabled()
+                y = blk(x, folded, x_res, fan)
+                x, x_res = y if fan else (y, None)
+                if name in self._out_features and (i + 1 == len(blocks) or blocks[i + 1][0] != name):
                     out[name] = x
         return out
 

@@ -68,6 +68,21 @@ relu_grad_f32_kernel(const float* __restrict__ dy, const float* __restrict__ y, 
   reinterpret_cast<float4*>(dx)[i] = make_float4(v.x > 0.f ? g.x : 0.f, v.y > 0.f ? g.y : 0.f, v.z > 0.f ? g.z : 0.f, v.w > 0.f ? g.w : 0.f);
 }
 
+// fp32: dx = (dy1 + dy2) * (y > 0): the ReLU backward of a bottleneck block's output whose two consumers (next block's first
+// convolution, next block's identity / shortcut branch) hand their gradients over separately - one pass instead of autograd's
+// accumulation kernel (read 2, write 1) followed by the ReLU gradient (read 2, write 1)
+__global__ void __launch_bounds__(256)
+relu_grad2_f32_kernel(const float* __restrict__ dy1, const float* __restrict__ dy2, const float* __restrict__ y, long long n4,
+                      float* __restrict__ dx) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4 a = reinterpret_cast<const float4*>(dy1)[i];
+  const float4 b = reinterpret_cast<const float4*>(dy2)[i];
+  const float4 v = reinterpret_cast<const float4*>(y)[i];
+  reinterpret_cast<float4*>(dx)[i] = make_float4(v.x > 0.f ? a.x + b.x : 0.f, v.y > 0.f ? a.y + b.y : 0.f, v.z > 0.f ? a.z + b.z : 0.f,
+                                                 v.w > 0.f ? a.w + b.w : 0.f);
+}
+
 // fp32 variant of bias_act_kernel (the reference's S4 recipe runs the backbones in fp32: SOLVER.AMP.ENABLED False); 4 channels per thread
 __global__ void __launch_bounds__(256)
 bias_act_f32_kernel(float* __restrict__ y, const float* __restrict__ bias, const float* __restrict__ res, long long n4, int C4, int relu) {
@@ -102,6 +117,14 @@ int combo_relu_grad_f32(const float* dy, const float* y, long long n, float* dx,
     return COMBO_EINVAL;
   const long long n4 = n / 4;
   hipLaunchKernelGGL(relu_grad_f32_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, y, n4, dx);
+  return (int)hipGetLastError();
+}
+
+int combo_relu_grad2_f32(const float* dy1, const float* dy2, const float* y, long long n, float* dx, combo_stream_t stream) {
+  if (!dy1 || !dy2 || !y || !dx || n <= 0 || n % 4 != 0 || (((uintptr_t)dy1 | (uintptr_t)dy2 | (uintptr_t)y | (uintptr_t)dx) & 15))
+    return COMBO_EINVAL;
+  const long long n4 = n / 4;
+  hipLaunchKernelGGL(relu_grad2_f32_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy1, dy2, y, n4, dx);
   return (int)hipGetLastError();
 }
 

@@ -193,16 +193,24 @@ gemm_tn_smalln_kernel(const float* __restrict__ dY, long long ldy, const float* 
   float accb[16];
 #pragma unroll
   for (int n = 0; n < 16; ++n) { acc[n] = make_float4(0.f, 0.f, 0.f, 0.f); accb[n] = 0.f; }
-  for (long long m = m0; m < m1; ++m) {
-    const float4 x = live ? *reinterpret_cast<const float4*>(X + m * ldx + 4 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (long long mb = m0; mb < m1; mb += 8) {  // 8 rows per trip: their loads are in flight together (the loop is latency-bound)
+    float4 x[8];
 #pragma unroll
-    for (int n = 0; n < 16; ++n)
-      if (n < N) {
-        const float d = dY[m * ldy + n];  // wave-uniform address
-        acc[n].x = fmaf(d, x.x, acc[n].x); acc[n].y = fmaf(d, x.y, acc[n].y);
-        acc[n].z = fmaf(d, x.z, acc[n].z); acc[n].w = fmaf(d, x.w, acc[n].w);
-        accb[n] += d;
-      }
+    for (int r = 0; r < 8; ++r)
+      x[r] = (live && mb + r < m1) ? *reinterpret_cast<const float4*>(X + (mb + r) * ldx + 4 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const long long m = mb + r < m1 ? mb + r : m1 - 1;
+      const float keep = mb + r < m1 ? 1.f : 0.f;
+#pragma unroll
+      for (int n = 0; n < 16; ++n)
+        if (n < N) {
+          const float d = dY[m * ldy + n] * keep;  // wave-uniform address
+          acc[n].x = fmaf(d, x[r].x, acc[n].x); acc[n].y = fmaf(d, x[r].y, acc[n].y);
+          acc[n].z = fmaf(d, x[r].z, acc[n].z); acc[n].w = fmaf(d, x[r].w, acc[n].w);
+          accb[n] += d;
+        }
+    }
   }
   if (live) {
 #pragma unroll
@@ -217,7 +225,7 @@ gemm_tn_smalln_kernel(const float* __restrict__ dY, long long ldy, const float* 
 }
 }  // namespace
 
-extern "C" int combo_gemm_tn_smalln_slices(long long M) { return (int)((M + 127) / 128); }
+extern "C" int combo_gemm_tn_smalln_slices(long long M) { return (int)((M + 31) / 32); }
 
 extern "C" int combo_gemm_tn_smalln_f32(const float* dY, long long ldy, const float* X, long long ldx, long long M, int N, int K,
                                         float* partials, float* db_partials, combo_stream_t stream) {
@@ -226,6 +234,6 @@ extern "C" int combo_gemm_tn_smalln_f32(const float* dY, long long ldy, const fl
     return COMBO_EINVAL;
   const int slices = combo_gemm_tn_smalln_slices(M);
   hipLaunchKernelGGL(gemm_tn_smalln_kernel, dim3((unsigned)((K / 4 + 63) / 64), (unsigned)slices), dim3(64), 0, (hipStream_t)stream,
-                     dY, ldy, X, ldx, M, N, K / 4, 128, partials, db_partials);
+                     dY, ldy, X, ldx, M, N, K / 4, 32, partials, db_partials);
   return (int)hipGetLastError();
 }

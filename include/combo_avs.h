@@ -86,6 +86,8 @@ int combo_relu_grad_bf16(const void* dy, const void* y, long long n, void* dx, c
 int combo_bias_act_f32(float* y, const float* bias, const float* residual, long long tokens, int C, int relu, combo_stream_t stream);
 /* fp32 variant for the head's Linear+ReLU layers (MLP.forward transformer_decoder.py:216-219, FFN :178-182, encoder FFN). */
 int combo_relu_grad_f32(const float* dy, const float* y, long long n, float* dx, combo_stream_t stream);
+/*   dx = (dy1 + dy2) * (y > 0): a block output with two consumers that hand their gradients over separately (backbone.py) */
+int combo_relu_grad2_f32(const float* dy1, const float* dy2, const float* y, long long n, float* dx, combo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * PVTv2 depth-wise 3x3 convolution on token-major bf16 activations (models/modeling/backbone/pvtv2.py:377-388, DWConv:
