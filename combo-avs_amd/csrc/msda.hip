@@ -105,7 +105,7 @@ __device__ __forceinline__ void atomic_add_relaxed(T* p, T v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <typename T, int G>
+template <typename T, int G, bool VALUE = true>
 __global__ void __launch_bounds__(256)
 msda_bwd_generic(const T* __restrict__ gout, const T* __restrict__ value, const int64_t* __restrict__ shapes,
                  const int64_t* __restrict__ lsi, const T* __restrict__ loc, const T* __restrict__ aw, int B, int S,
@@ -154,7 +154,7 @@ msda_bwd_generic(const T* __restrict__ gout, const T* __restrict__ value, const 
                 g_w += tg[c] * wt[k] * v[c];
                 g_y += tg[c] * dh[k] * v[c];
                 g_x += tg[c] * dw[k] * v[c];
-                atomic_add_relaxed(gvalue + o + c, wt[k] * tg[c] * a);
+                if constexpr (VALUE) atomic_add_relaxed(gvalue + o + c, wt[k] * tg[c] * a);
               }
             }
           }
@@ -434,7 +434,10 @@ __device__ __forceinline__ void bwd_value_pass(const float* __restrict__ gout, c
                                                const float* __restrict__ aw, int b, int m, int half, int S, int M,
                                                int L, int Lq, int P, int mult, int wave, int lane, float wscale,
                                                const float (&inv_mx)[4], int* __restrict__ acc,
-                                               int* __restrict__ wsum) {
+                                               int* __restrict__ wsum, int row0 = 0, int lvl_lo = 0, int lvl_hi = 1 << 30) {
+  // S: number of value rows this workgroup accumulates = index of its dummy sink row; row0: first of them in the flattened
+  // pyramid (a window of a pyramid that does not fit the LDS, e.g. 64^2 + 32^2 + 16^2 cells at 512 x 512 inputs); only the
+  // points of the levels lvl_lo .. lvl_hi - 1 can touch the window
   constexpr int D = 32, HD = 16, NW = kBwdVThreads / 64;
   const int LP = L * P;
   const int cg = lane & 3, slot = lane >> 2, rot = slot & 3;
@@ -472,11 +475,11 @@ __device__ __forceinline__ void bwd_value_pass(const float* __restrict__ gout, c
       my_ok[j] = 0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) { my_r[j][k] = S; my_v[j][k] = 0.f; }
-      if (pt < LP && live) {
+      if (pt < LP && live && pt / P >= lvl_lo && pt / P < lvl_hi) {
         const float2 xy = *reinterpret_cast<const float2*>(loc + (qm * LP + pt) * 2);
         const float a = aw[qm * LP + pt];
         const int l = pt / P;
-        const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)lsi[l];
+        const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)lsi[l] - row0;
         const float h_im = xy.y * H - 0.5f, w_im = xy.x * W - 0.5f;
         if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
           const float hf = floorf(h_im), wf = floorf(w_im);
@@ -484,8 +487,10 @@ __device__ __forceinline__ void bwd_value_pass(const float* __restrict__ gout, c
           const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
           const bool t_ok = h0 >= 0, b_ok = h0 + 1 <= H - 1, l_ok = w0 >= 0, r_ok = w0 + 1 <= W - 1;
           const int base = st + h0 * W + w0;
-          const int r[4] = {(t_ok && l_ok) ? base : S, (t_ok && r_ok) ? base + 1 : S, (b_ok && l_ok) ? base + W : S,
-                            (b_ok && r_ok) ? base + W + 1 : S};  // row S is a dummy sink for out-of-range taps
+          int r[4] = {(t_ok && l_ok) ? base : S, (t_ok && r_ok) ? base + 1 : S, (b_ok && l_ok) ? base + W : S,
+                      (b_ok && r_ok) ? base + W + 1 : S};  // row S is a dummy sink for out-of-range taps
+#pragma unroll
+          for (int k = 0; k < 4; ++k) r[k] = (r[k] < 0 || r[k] > S) ? S : r[k];  // ... and for taps outside this window
           const float wt[4] = {hh * hw * a, hh * lw * a, lh * hw * a, lh * lw * a};
           my_ok[j] = 1;
 #pragma unroll
@@ -547,9 +552,19 @@ __device__ __forceinline__ void bwd_value_pass(const float* __restrict__ gout, c
 __global__ void __launch_bounds__(kBwdVThreads)
 msda_bwd_value_lds_d32(const float* __restrict__ gout, const int64_t* __restrict__ shapes,
                        const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ aw,
-                       int B, int S, int M, int L, int Lq, int P, int mult, float* __restrict__ gvalue) {
+                       int B, int S_all, int M, int L, int Lq, int P, int mult, float* __restrict__ gvalue, int n_parts,
+                       int rows_per_part) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int D = 32, HD = 16, NW = kBwdVThreads / 64;
+  // window of the flattened pyramid this workgroup accumulates (n_parts == 1: all of it)
+  const int part = xcd_remap(blockIdx.x, gridDim.x) / 2 % n_parts;
+  const int row0 = part * rows_per_part;
+  const int S = min(rows_per_part, S_all - row0);
+  int lvl_lo = L, lvl_hi = 0;
+  for (int l = 0; l < L; ++l) {
+    const int st = (int)lsi[l], en = st + (int)(shapes[2 * l] * shapes[2 * l + 1]);
+    if (st < row0 + S && en > row0) { lvl_lo = min(lvl_lo, l); lvl_hi = max(lvl_hi, l + 1); }
+  }
   int* acc = reinterpret_cast<int*>(smem);                         // [S+1][16] fixed point
   int* wsum = acc + (S + 1) * HD;                                  // [S+1] weight bound -> row scale
   float* red = reinterpret_cast<float*>(wsum + ((S + 1 + 3) & ~3));  // [NW][20] block-reduction scratch
@@ -558,7 +573,7 @@ msda_bwd_value_lds_d32(const float* __restrict__ gout, const int64_t* __restrict
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int half = logical & 1;
-  const int bm = logical >> 1;
+  const int bm = (logical >> 1) / n_parts;
   const int m = bm % M, b = bm / M;
   const int cg = tid & 3;  // this lane's 4 channels: half*16 + cg*4 ..
 
@@ -578,7 +593,7 @@ msda_bwd_value_lds_d32(const float* __restrict__ gout, const int64_t* __restrict
   }
   for (int i = tid; i < Lq * LP; i += kBwdVThreads) {
     const int q = i / LP, pt = i - q * LP;
-    sa += fabsf(aw[(((long long)b * Lq + q) * M + m) * LP + pt]);
+    if (pt / P >= lvl_lo && pt / P < lvl_hi) sa += fabsf(aw[(((long long)b * Lq + q) * M + m) * LP + pt]);
   }
 #pragma unroll
   for (int s = 4; s < 64; s <<= 1)  // lanes with equal cg
@@ -609,7 +624,8 @@ msda_bwd_value_lds_d32(const float* __restrict__ gout, const int64_t* __restrict
   const float inv_wscale = tot > 0.f ? tot * (1.f / 1073741824.f) : 0.f;
 
   float dummy[4] = {0.f, 0.f, 0.f, 0.f};
-  bwd_value_pass<0>(gout, shapes, lsi, loc, aw, b, m, half, S, M, L, Lq, P, mult, wave, lane, wscale, dummy, acc, wsum);
+  bwd_value_pass<0>(gout, shapes, lsi, loc, aw, b, m, half, S, M, L, Lq, P, mult, wave, lane, wscale, dummy, acc, wsum, row0,
+                    lvl_lo, lvl_hi);
   __syncthreads();
   // W_r (upper bound, rounded up) -> per-row fixed-point scale 2^30 / W_r, stored in place as float
   for (int r = tid; r <= S; r += kBwdVThreads) {
@@ -617,10 +633,11 @@ msda_bwd_value_lds_d32(const float* __restrict__ gout, const int64_t* __restrict
     reinterpret_cast<float*>(wsum)[r] = wr > 0.f ? 1073741824.f / wr : 0.f;
   }
   __syncthreads();
-  bwd_value_pass<1>(gout, shapes, lsi, loc, aw, b, m, half, S, M, L, Lq, P, mult, wave, lane, wscale, inv_mx, acc, wsum);
+  bwd_value_pass<1>(gout, shapes, lsi, loc, aw, b, m, half, S, M, L, Lq, P, mult, wave, lane, wscale, inv_mx, acc, wsum, row0,
+                    lvl_lo, lvl_hi);
   __syncthreads();
   {
-    float* gb = gvalue + ((long long)b * S * M + m) * D + half * HD + cg * 4;
+    float* gb = gvalue + (((long long)b * S_all + row0) * M + m) * D + half * HD + cg * 4;
     const float* rowscale = reinterpret_cast<const float*>(wsum);
     for (int r = tid >> 2; r < S; r += kBwdVThreads / 4) {
       const int4 v = *reinterpret_cast<const int4*>(acc + r * HD + cg * 4);
@@ -1082,14 +1099,23 @@ int msda_forward(const T* value, const int64_t* shapes, const int64_t* lsi, cons
   return (int)hipGetLastError();
 }
 
-template <typename T, int G>
+template <typename T, int G, bool VALUE = true>
 void launch_bwd_generic(const T* gout, const T* value, const int64_t* shapes, const int64_t* lsi, const T* loc,
                         const T* aw, int B, int S, int M, int D, int L, int Lq, int P, T* gv, T* gl, T* gw,
                         hipStream_t stream) {
   long long total = (long long)B * Lq * M * G;
   total = (total + 255) / 256 * 256;
-  hipLaunchKernelGGL((msda_bwd_generic<T, G>), dim3(grid_for(total, 256)), dim3(256), 0, stream, gout, value, shapes,
+  hipLaunchKernelGGL((msda_bwd_generic<T, G, VALUE>), dim3(grid_for(total, 256)), dim3(256), 0, stream, gout, value, shapes,
                      lsi, loc, aw, B, S, M, D, L, Lq, P, gv, gl, gw, total);
+}
+
+// A pyramid whose value slab does not fit the LDS (S = 5376 at 512 x 512 inputs, BASELINE configs[3]): grad_value on the
+// fixed-point LDS kernel over WINDOWS of <= kBwdWindowRows rows (two workgroups per CU), grad_loc / grad_w on the generic
+// gather kernel with its value-gradient atomics compiled out.  (The all-in-one generic kernel, global float atomics for
+// grad_value, took 62 ms per layer at BT = 80.)
+constexpr int kBwdWindowRows = 1100;
+inline bool bwd_windowed_ok(int S, int D, int L, int P, int elem_bytes) {
+  return elem_bytes == 4 && D == 32 && S < 65535 && L * P <= kMaxLP && L <= kMaxLevels;
 }
 
 template <typename T>
@@ -1119,7 +1145,7 @@ int msda_backward(const T* gout, const T* value, const int64_t* shapes, const in
       auto gcd = [](int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; };
       while (gcd(mult, Lq) != 1) ++mult;
       hipLaunchKernelGGL(msda_bwd_value_lds_d32, dim3(B * M * 2), dim3(kBwdVThreads), bwd_value_lds_bytes(S), stream,
-                         gout, shapes, lsi, loc, aw, B, S, M, L, Lq, P, mult, gv);
+                         gout, shapes, lsi, loc, aw, B, S, M, L, Lq, P, mult, gv, 1, S);
       hipError_t e1 = hipGetLastError();
       if (e1 != hipSuccess) return (int)e1;
       const int nw = fwd_lds_bytes(S, L, P, 12) <= kLdsLimit ? 12 : 8;
@@ -1127,6 +1153,28 @@ int msda_backward(const T* gout, const T* value, const int64_t* shapes, const in
       while ((long long)B * M * QT < 1024 && QT < 8 && Lq / (QT * 2) >= nw * kQW) QT *= 2;
       hipLaunchKernelGGL(msda_bwd_locw_lds_d32, dim3(B * M * QT), dim3(nw * 64), fwd_lds_bytes(S, L, P, nw), stream,
                          gout, value, shapes, lsi, loc, aw, B, S, M, L, Lq, P, QT, gl, gw);
+      return (int)hipGetLastError();
+    }
+  }
+  if constexpr (sizeof(T) == 4) {
+    if (bwd_windowed_ok(S, D, L, P, 4) && algo != 1) {
+      static bool attr_w = false;
+      if (!attr_w) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_value_lds_d32),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
+        if (e != hipSuccess) return (int)e;
+        attr_w = true;
+      }
+      const int n_parts = (S + kBwdWindowRows - 1) / kBwdWindowRows;
+      const int rows = (S + n_parts - 1) / n_parts;
+      int mult = Lq / 16 + 1;
+      auto gcd = [](int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; };
+      while (gcd(mult, Lq) != 1) ++mult;
+      hipLaunchKernelGGL(msda_bwd_value_lds_d32, dim3(B * M * 2 * n_parts), dim3(kBwdVThreads), bwd_value_lds_bytes(rows), stream,
+                         gout, shapes, lsi, loc, aw, B, S, M, L, Lq, P, mult, gv, n_parts, rows);
+      hipError_t e1 = hipGetLastError();
+      if (e1 != hipSuccess) return (int)e1;
+      launch_bwd_generic<T, 8, false>(gout, value, shapes, lsi, loc, aw, B, S, M, D, L, Lq, P, gv, gl, gw, stream);
       return (int)hipGetLastError();
     }
   }
@@ -1157,7 +1205,7 @@ extern "C" {
 int combo_msda_backward_needs_zero(int S, int D, int L, int P, int elem_bytes, int algo) {
   const bool lds_ok = elem_bytes == 4 && D == 32 && S < 65535 && L * P <= kMaxLP && fwd_lds_bytes(S, L, P, 8) <= kLdsLimit &&
                       bwd_value_lds_bytes(S) <= kLdsLimit;
-  return (lds_ok && algo != 1) ? 0 : 1;
+  return ((lds_ok || bwd_windowed_ok(S, D, L, P, elem_bytes)) && algo != 1) ? 0 : 1;
 }
 
 int combo_msda_forward_f32(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
