@@ -374,7 +374,8 @@ def _flush_dw(q):
             M = dy.shape[0]
             # a problem of a grouped launch does not have to fill the chip alone: long token chunks per workgroup keep the
             # split-K partial traffic (and the reduce) small; the group as a whole still has thousands of workgroups
-            splits = min(lib.combo_gemm_tn_splits(M, N, K), max(1, -(-M // _GROUP_TOKENS_PER_SPLIT)))
+            # (very long token axes - 1.3 M tokens at 512 x 512 inputs - get proportionally longer chunks: at most ~128 partials)
+            splits = min(lib.combo_gemm_tn_splits(M, N, K), max(1, -(-M // max(_GROUP_TOKENS_PER_SPLIT, M // 128))))
             mchunk = (-(-M // splits) + 15) // 16 * 16
             plan.append(-(-M // mchunk))
         total = sum(plan)

@@ -1,7 +1,9 @@
 #!/bin/bash
-# rocprofv3 kernel stats of `bench.py --config $1` (output to files, never through a pipe); prints the top kernels
+# rocprofv3 kernel trace of `bench.py --config $1` (output to files, never through a pipe) -> steady-state per-kernel summary of
+# the graph-replayed steps (tools/prof_graph_steps.py) in gpurun_out/steady_$1.csv
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 rm -rf /tmp/pc
-rocprofv3 --kernel-trace --stats -d /tmp/pc -o c --output-format csv -- python3 bench.py --config $1 --steps ${2:-3} --warmup 2 --no-cpu-baseline > gpurun_out/prof_$1.log 2>&1 < /dev/null
-f=$(find /tmp/pc -name 'c_kernel_stats.csv' | head -1); cp "$f" gpurun_out/kstats_$1.csv
-head -25 gpurun_out/kstats_$1.csv | awk -F'","' '{printf "%-90s calls %s total_ms %.1f avg_us %.1f pct %s\n", substr($1,2,90), $2, $3/1e6, $4/1e3, $5}'
+rocprofv3 --kernel-trace --stats -d /tmp/pc -o c --output-format csv -- python3 bench.py --config $1 --steps ${2:-4} --warmup 2 --no-cpu-baseline > gpurun_out/prof_$1.log 2>&1 < /dev/null
+t=$(find /tmp/pc -name 'c_kernel_trace.csv' | head -1)
+python tools/prof_graph_steps.py "$t" ${3:-3} 0 > gpurun_out/steady_$1.csv
+head -32 gpurun_out/steady_$1.csv | cut -c1-150

@@ -18,6 +18,8 @@ with open(path) as f:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
 marks = [i for i, r in enumerate(rows) if "msda_fwd_tap_d32" in r[2]]
+if not marks:  # pyramids that run the generic forward kernel (512 x 512 inputs)
+    marks = [i for i, r in enumerate(rows) if "msda_fwd_generic" in r[2]]
 per = 6
 first, last = marks[len(marks) - per * tail - per * (steps + 1)], marks[len(marks) - per * tail - per * 1]
 agg = defaultdict(lambda: [0, 0])
