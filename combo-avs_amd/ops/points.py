@@ -1,5 +1,7 @@
-"""Point sampling (detectron2 `point_sample` == grid_sample(x, 2c-1, bilinear, zeros, align_corners=False)).
-HIP kernel: csrc/points.hip (planned: fused with the BCE/dice reductions)."""
+"""Point sampling (detectron2 `point_sample` == grid_sample(x, 2c-1, bilinear, zeros, align_corners=False)) for the
+reference-shaped single-call methods kept for API parity (`SetCriterion.loss_masks`, `HungarianMatcher.forward` on one decoder
+output: criterion.py:137-186, matcher.py:84-136).  The training step does not come through here: `SetCriterion._losses` samples
+inside the fused kernels (csrc/matcher.hip: cost matrices; csrc/maskloss.hip: importance sampling + BCE / dice)."""
 import torch
 import torch.nn.functional as F
 
