@@ -428,7 +428,7 @@ constexpr int kBwdVThreads = 512;
 // wave iteration, `mult` apart.  PASS 0: scatter |a * tapweight| (rounded UP, fixed point) into wsum[row]
 // -> an upper bound W_r of everything that can ever be added to a row.  PASS 1: scatter the gradient itself
 // in fixed point with the per-row scale 2^30 / W_r (and grad_out normalised per channel to [-1, 1]).
-template <int PASS>
+template <int PASS, bool WIN = false>
 __device__ __forceinline__ void bwd_value_pass(const float* __restrict__ gout, const int64_t* __restrict__ shapes,
                                                const int64_t* __restrict__ lsi, const float* __restrict__ loc,
                                                const float* __restrict__ aw, int b, int m, int half, int S, int M,
@@ -475,7 +475,7 @@ __device__ __forceinline__ void bwd_value_pass(const float* __restrict__ gout, c
       my_ok[j] = 0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) { my_r[j][k] = S; my_v[j][k] = 0.f; }
-      if (pt < LP && live && pt / P >= lvl_lo && pt / P < lvl_hi) {
+      if (pt < LP && live && (!WIN || (pt / P >= lvl_lo && pt / P < lvl_hi))) {
         const float2 xy = *reinterpret_cast<const float2*>(loc + (qm * LP + pt) * 2);
         const float a = aw[qm * LP + pt];
         const int l = pt / P;
@@ -489,8 +489,10 @@ __device__ __forceinline__ void bwd_value_pass(const float* __restrict__ gout, c
           const int base = st + h0 * W + w0;
           int r[4] = {(t_ok && l_ok) ? base : S, (t_ok && r_ok) ? base + 1 : S, (b_ok && l_ok) ? base + W : S,
                       (b_ok && r_ok) ? base + W + 1 : S};  // row S is a dummy sink for out-of-range taps
+          if constexpr (WIN) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) r[k] = (r[k] < 0 || r[k] > S) ? S : r[k];  // ... and for taps outside this window
+            for (int k = 0; k < 4; ++k) r[k] = (r[k] < 0 || r[k] > S) ? S : r[k];  // ... and for taps outside this window
+          }
           const float wt[4] = {hh * hw * a, hh * lw * a, lh * hw * a, lh * lw * a};
           my_ok[j] = 1;
 #pragma unroll
@@ -549,6 +551,7 @@ __device__ __forceinline__ void bwd_value_pass(const float* __restrict__ gout, c
   }
 }
 
+template <bool WIN>
 __global__ void __launch_bounds__(kBwdVThreads)
 msda_bwd_value_lds_d32(const float* __restrict__ gout, const int64_t* __restrict__ shapes,
                        const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ aw,
@@ -557,13 +560,15 @@ msda_bwd_value_lds_d32(const float* __restrict__ gout, const int64_t* __restrict
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int D = 32, HD = 16, NW = kBwdVThreads / 64;
   // window of the flattened pyramid this workgroup accumulates (n_parts == 1: all of it)
-  const int part = xcd_remap(blockIdx.x, gridDim.x) / 2 % n_parts;
+  const int part = WIN ? xcd_remap(blockIdx.x, gridDim.x) / 2 % n_parts : 0;
   const int row0 = part * rows_per_part;
-  const int S = min(rows_per_part, S_all - row0);
-  int lvl_lo = L, lvl_hi = 0;
-  for (int l = 0; l < L; ++l) {
-    const int st = (int)lsi[l], en = st + (int)(shapes[2 * l] * shapes[2 * l + 1]);
-    if (st < row0 + S && en > row0) { lvl_lo = min(lvl_lo, l); lvl_hi = max(lvl_hi, l + 1); }
+  const int S = WIN ? min(rows_per_part, S_all - row0) : S_all;
+  int lvl_lo = WIN ? L : 0, lvl_hi = WIN ? 0 : L;
+  if constexpr (WIN) {
+    for (int l = 0; l < L; ++l) {
+      const int st = (int)lsi[l], en = st + (int)(shapes[2 * l] * shapes[2 * l + 1]);
+      if (st < row0 + S && en > row0) { lvl_lo = min(lvl_lo, l); lvl_hi = max(lvl_hi, l + 1); }
+    }
   }
   int* acc = reinterpret_cast<int*>(smem);                         // [S+1][16] fixed point
   int* wsum = acc + (S + 1) * HD;                                  // [S+1] weight bound -> row scale
@@ -593,7 +598,7 @@ msda_bwd_value_lds_d32(const float* __restrict__ gout, const int64_t* __restrict
   }
   for (int i = tid; i < Lq * LP; i += kBwdVThreads) {
     const int q = i / LP, pt = i - q * LP;
-    if (pt / P >= lvl_lo && pt / P < lvl_hi) sa += fabsf(aw[(((long long)b * Lq + q) * M + m) * LP + pt]);
+    if (!WIN || (pt / P >= lvl_lo && pt / P < lvl_hi)) sa += fabsf(aw[(((long long)b * Lq + q) * M + m) * LP + pt]);
   }
 #pragma unroll
   for (int s = 4; s < 64; s <<= 1)  // lanes with equal cg
@@ -624,7 +629,7 @@ msda_bwd_value_lds_d32(const float* __restrict__ gout, const int64_t* __restrict
   const float inv_wscale = tot > 0.f ? tot * (1.f / 1073741824.f) : 0.f;
 
   float dummy[4] = {0.f, 0.f, 0.f, 0.f};
-  bwd_value_pass<0>(gout, shapes, lsi, loc, aw, b, m, half, S, M, L, Lq, P, mult, wave, lane, wscale, dummy, acc, wsum, row0,
+  bwd_value_pass<0, WIN>(gout, shapes, lsi, loc, aw, b, m, half, S, M, L, Lq, P, mult, wave, lane, wscale, dummy, acc, wsum, row0,
                     lvl_lo, lvl_hi);
   __syncthreads();
   // W_r (upper bound, rounded up) -> per-row fixed-point scale 2^30 / W_r, stored in place as float
@@ -633,7 +638,7 @@ msda_bwd_value_lds_d32(const float* __restrict__ gout, const int64_t* __restrict
     reinterpret_cast<float*>(wsum)[r] = wr > 0.f ? 1073741824.f / wr : 0.f;
   }
   __syncthreads();
-  bwd_value_pass<1>(gout, shapes, lsi, loc, aw, b, m, half, S, M, L, Lq, P, mult, wave, lane, wscale, inv_mx, acc, wsum, row0,
+  bwd_value_pass<1, WIN>(gout, shapes, lsi, loc, aw, b, m, half, S, M, L, Lq, P, mult, wave, lane, wscale, inv_mx, acc, wsum, row0,
                     lvl_lo, lvl_hi);
   __syncthreads();
   {
@@ -1132,7 +1137,7 @@ int msda_backward(const T* gout, const T* value, const int64_t* shapes, const in
     if (lds_ok && algo != 1) {
       static bool attr_set = false;
       if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_value_lds_d32),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_value_lds_d32<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
         if (e != hipSuccess) return (int)e;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_locw_lds_d32),
@@ -1144,7 +1149,7 @@ int msda_backward(const T* gout, const T* value, const int64_t* shapes, const in
       int mult = Lq / 16 + 1;
       auto gcd = [](int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; };
       while (gcd(mult, Lq) != 1) ++mult;
-      hipLaunchKernelGGL(msda_bwd_value_lds_d32, dim3(B * M * 2), dim3(kBwdVThreads), bwd_value_lds_bytes(S), stream,
+      hipLaunchKernelGGL(msda_bwd_value_lds_d32<false>, dim3(B * M * 2), dim3(kBwdVThreads), bwd_value_lds_bytes(S), stream,
                          gout, shapes, lsi, loc, aw, B, S, M, L, Lq, P, mult, gv, 1, S);
       hipError_t e1 = hipGetLastError();
       if (e1 != hipSuccess) return (int)e1;
@@ -1160,7 +1165,7 @@ int msda_backward(const T* gout, const T* value, const int64_t* shapes, const in
     if (bwd_windowed_ok(S, D, L, P, 4) && algo != 1) {
       static bool attr_w = false;
       if (!attr_w) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_value_lds_d32),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_value_lds_d32<true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
         if (e != hipSuccess) return (int)e;
         attr_w = true;
@@ -1170,7 +1175,7 @@ int msda_backward(const T* gout, const T* value, const int64_t* shapes, const in
       int mult = Lq / 16 + 1;
       auto gcd = [](int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; };
       while (gcd(mult, Lq) != 1) ++mult;
-      hipLaunchKernelGGL(msda_bwd_value_lds_d32, dim3(B * M * 2 * n_parts), dim3(kBwdVThreads), bwd_value_lds_bytes(rows), stream,
+      hipLaunchKernelGGL(msda_bwd_value_lds_d32<true>, dim3(B * M * 2 * n_parts), dim3(kBwdVThreads), bwd_value_lds_bytes(rows), stream,
                          gout, shapes, lsi, loc, aw, B, S, M, L, Lq, P, mult, gv, n_parts, rows);
       hipError_t e1 = hipGetLastError();
       if (e1 != hipSuccess) return (int)e1;
