@@ -639,7 +639,7 @@ attn_bwd_dq_kernel(const AttnArgs a) {
 // dP = dO . V^T) and by columns (dV^T += dO^T . P, dK^T += Q^T . dS); lse / delta and the mask words of the 4 key tiles sit
 // next to them, laid out so that the 4 query rows of a register group come with one 16-byte read.
 constexpr int kQChunk = 128;  // queries per LDS fill
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, 3)
 attn_bwd_dkv_kernel(const AttnArgs a) {
   combo_ts_begin(a.ts);
   extern __shared__ __attribute__((aligned(16))) char smem[];
