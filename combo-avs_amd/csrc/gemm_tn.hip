@@ -459,7 +459,15 @@ splitk_reduce_grouped_kernel(const ReduceGroupArgs args) {
   const long long n4 = pr.n >> 2;
   if (i < n4) {
     float4 a = reinterpret_cast<const float4*>(pr.partials)[i];
-    for (int z = 1; z < pr.splits; ++z) {
+    int z = 1;
+    for (; z + 8 <= pr.splits; z += 8) {  // 8 slices in flight (the loop is latency-bound), added in the same fixed order
+      float4 b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) b[u] = reinterpret_cast<const float4*>(pr.partials + (long long)(z + u) * pr.n)[i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a.x += b[u].x; a.y += b[u].y; a.z += b[u].z; a.w += b[u].w; }
+    }
+    for (; z < pr.splits; ++z) {
       const float4 b = reinterpret_cast<const float4*>(pr.partials + (long long)z * pr.n)[i];
       a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
