@@ -10,15 +10,16 @@
 //     query column (lane & 31) and 16 of the 32 keys, so the online-softmax statistics are per-lane scalars plus one exchange
 //     with lane ^ 32 - no 32-lane row reductions;
 //   * P^T in D layout IS the B operand of O^T[32 d x 32 q] += V^T . P^T when the contraction index is enumerated as
-//     k-slot (step e, half g) <-> key (e & 3) + 8 (e >> 2) + 4 g; the A operand V^T is loaded with the same enumeration
-//     (lane (d, g) reads V[key(e, g)][d]: two coalesced 128-byte rows per load).  No transpose, no LDS;
-//   * one wave = 32 queries of one (frame, head) pair, operands straight from L2 (K / V of a pair are 100 KB and are read by
-//     its 4 query waves), next tile prefetched into registers during the MFMAs of the current one;
-//   * the mask is ONE byte per (frame, query, key), shared by the heads (the reference materialises 8 copies), rows padded to
-//     a multiple of 4 bytes so a lane reads the 4 keys of a register group with one dword load.
+//     k-slot (step e, half g) <-> key (e & 3) + 8 (e >> 2) + 4 g; the A operand V^T is read with the same enumeration
+//     (lane (d, g) reads V[key(e, g)][d]) - no transpose;
+//   * operand tiles (32 rows x 32 channels) are staged by LDS-DMA with the 16-byte chunks of a row XOR-swizzled on the source
+//     side: the row-per-lane reads (ds_read_b128) and the column reads (ds_read_b32) of one tile are both conflict free;
+//   * the mask is ONE bit (or byte) per (frame, query, key), shared by the heads (the reference materialises 8 byte copies):
+//     bit-packed rows come from the mask kernel (attnmask.hip), byte rows (pitch % 4 == 0) are packed per wave.
 // Backward, two passes that each recompute the scores in the orientation they need (no atomics, no dQ round trip):
 //   pass A (a wave owns 32 queries, walks the key tiles): S^T, dP^T = V . dO^T, dS^T, dQ^T += K^T . dS^T;
 //   pass B (a wave owns 32 keys, walks the query tiles):   S, dP = dO . V^T, dS, dV^T += dO^T . P, dK^T += Q^T . dS.
+// Work decomposition and staging of each kernel: see the comments above attn_fwd_kernel / attn_bwd_dq_kernel / attn_bwd_dkv_kernel.
 #include <math.h>
 #include <cstdlib>
 
