@@ -31,8 +31,6 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef float f4v __attribute__((ext_vector_type(4)));
 
 constexpr int kD = 32;          // head_dim
-constexpr float kNeg = -1e30f;  // "minus infinity" that stays finite under subtraction
-__device__ __attribute__((aligned(16))) unsigned char g_no_mask[16];  // zero-initialised: the "mask" of unmasked attention (pitch 4)
 
 __device__ __forceinline__ float xor32(float v) {  // value of lane ^ 32
   return __shfl_xor(v, 32, 64);
@@ -66,15 +64,6 @@ __device__ __forceinline__ void load_row16(const float* row, int g, float (&f)[1
   for (int j = 0; j < 4; ++j) {
     const f4v t = *reinterpret_cast<const f4v*>(row + 16 * g + 4 * j);
     f[4 * j] = t.x * mul; f[4 * j + 1] = t.y * mul; f[4 * j + 2] = t.z * mul; f[4 * j + 3] = t.w * mul;
-  }
-}
-
-// blocked flags of the 16 (query, key) cells a lane holds: register group j = e >> 2 covers 4 consecutive columns
-__device__ __forceinline__ void load_mask_t(const unsigned char* mrow, int pitch, int col0, int g, unsigned (&mw)[4]) {
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int off = min(col0 + 8 * j + 4 * g, pitch - 4);
-    mw[j] = *reinterpret_cast<const unsigned*>(mrow + off);
   }
 }
 
