@@ -89,11 +89,11 @@ class ConvBN(nn.Conv2d):
         self.norm = FrozenBatchNorm2d(cout)
         nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")
 
-    def forward(self, x, folded=None, bias=True):
+    def forward(self, x, folded=None, bias=True, mask_dx=False):
         if folded is not None:  # (w * scale, shift) prepared for the whole backbone by ResNet.forward
             if not bias:
                 from .ops.convwrw import conv2d  # fp32 recipe: weight gradient on the head's kernels where they apply
-                return conv2d(x, folded[0], self.stride, self.padding)
+                return conv2d(x, folded[0], self.stride, self.padding, mask_dx)
             return F.conv2d(x, folded[0], folded[1] if bias else None, self.stride, self.padding)
         scale, shift = self.norm.scale_shift()
         w = self.weight * scale[:, None, None, None]
@@ -126,8 +126,12 @@ class Bottleneck(nn.Module):
         xr = x if x_res is None else x_res
         f1, f2, f3 = next(folded), next(folded), next(folded)
         out = bias_act(self.conv1(x, f1, bias=False), f1[2])
-        out = bias_act(self.conv2(out, f2, bias=False), f2[2])
-        out = self.conv3(out, f3, bias=False)
+        c2 = self.conv2(out, f2, bias=False)
+        # conv2's ReLU feeds only conv3: its gradient mask rides in the epilogue of conv3's input-gradient GEMM
+        from .ops import convwrw
+        fold_relu = c2.dtype == torch.float32 and convwrw.kind(c2, f3[0], 1, 0) == 1
+        out = bias_act(c2, f2[2], grad_masked=fold_relu)
+        out = self.conv3(out, f3, bias=False, mask_dx=fold_relu)
         if self.shortcut is not None:
             fs = next(folded)
             return bias_act(out, f3[2] + fs[2], self.shortcut(xr, fs, bias=False), fanout=fanout)

@@ -20,8 +20,10 @@ from . import conv3x3 as C3
 from . import linear as L
 
 ENABLED = os.environ.get("COMBO_BACKBONE_WRW", "1") == "1"  # 0: the library's weight-gradient kernels (A/B)
-# input gradients on the head's 3-product kernels as well (A/B): bit 0 the 3x3 convolutions, bit 1 the 1x1 with >= 256 channels
-DX_OWN = int(os.environ.get("COMBO_BACKBONE_DX", "0"))
+# input gradients on the head's 3-product kernels as well: bit 0 the 3x3 convolutions (measured: +1.3 ms per step, off), bit 1 the
+# 1x1 convolutions with >= DX_MIN_C channels (measured: -0.85 ms per step with all of them, on)
+DX_OWN = int(os.environ.get("COMBO_BACKBONE_DX", "2"))
+DX_MIN_C = int(os.environ.get("COMBO_BACKBONE_DX_MINC", "64"))
 
 
 def kind(x, w, stride, padding):
@@ -42,8 +44,11 @@ def kind(x, w, stride, padding):
 
 class _ConvWrw(Function):
     @staticmethod
-    def forward(ctx, x, w, k):
-        ctx.k = k
+    def forward(ctx, x, w, k, mask_dx=False):
+        """mask_dx: x is the ReLU output of the producing layer and feeds nothing else - the input gradient is returned already
+        multiplied by [x > 0] (folded into the dX GEMM's epilogue); the producer then skips its ReLU-gradient pass
+        (ops.biasact.bias_act(grad_masked=True)).  Set in pairs by backbone.Bottleneck."""
+        ctx.k, ctx.mask_dx = k, mask_dx
         ctx.save_for_backward(x, w)
         return F.conv2d(x, w, None, 1, 1 if k == 3 else 0)
 
@@ -60,11 +65,14 @@ class _ConvWrw(Function):
         if ctx.needs_input_grad[0] and ctx.k == 3 and (DX_OWN & 1):
             wt = w.flip(2, 3).permute(1, 2, 3, 0).reshape(cin, 9 * cout)
             dx = C3._conv_tokens(C3._tokens(dy), wt, None, B, H, W, cout, cin, exact=False).view(B, H, W, cin).permute(0, 3, 1, 2)
-        elif ctx.needs_input_grad[0] and ctx.k == 1 and (DX_OWN & 2) and min(cin, cout) >= 256:
-            dx = L.input_grad_gemm(C3._tokens(dy), w.view(cout, cin)).view(B, H, W, cin).permute(0, 3, 1, 2)
+        elif ctx.needs_input_grad[0] and ctx.k == 1 and (DX_OWN & 2) and min(cin, cout) >= DX_MIN_C:
+            dx = L.input_grad_gemm(C3._tokens(dy), w.view(cout, cin), relu_mask=C3._tokens(x) if ctx.mask_dx else None)
+            dx = dx.view(B, H, W, cin).permute(0, 3, 1, 2)
         elif ctx.needs_input_grad[0]:  # input gradient: the library's kernel
             dx = torch.ops.aten.convolution_backward(dy, x, w, None, (1, 1), (pad, pad), (1, 1), False, (0, 0), 1,
                                                      (True, False, False))[0]
+            if ctx.mask_dx:
+                dx = L.relu_grad(C3._tokens(dx.contiguous(memory_format=torch.channels_last)), C3._tokens(x)).view(B, H, W, cin).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
             dy_tok, x_tok = C3._tokens(dy), C3._tokens(x)
             if ctx.k == 1:
@@ -74,12 +82,14 @@ class _ConvWrw(Function):
                 dw = C3._wgrad_tokens(dy_tok, x_tok, B, H, W, cin, cout).permute(0, 3, 1, 2)
                 if not dw.is_contiguous():
                     dw = dw.contiguous()
-        return dx, dw, None
+        return dx, dw, None, None
 
 
-def conv2d(x, w, stride, padding):
-    """F.conv2d(x, w, None, stride, padding) whose weight gradient runs on the head's kernels where they apply"""
+def conv2d(x, w, stride, padding, mask_dx=False):
+    """F.conv2d(x, w, None, stride, padding) whose weight gradient (and, for the 1x1 layers, input gradient) runs on the head's
+    kernels where they apply.  mask_dx (only with kind(...) != 0): see _ConvWrw.forward."""
     k = kind(x, w, stride, padding)
     if k:
-        return _ConvWrw.apply(x, w, k)
+        return _ConvWrw.apply(x, w, k, mask_dx)
+    assert not mask_dx
     return F.conv2d(x, w, None, stride, padding)

@@ -500,7 +500,7 @@ def test_backbone_fp32_weight_gradients_on_the_grouped_kernels():
                                         (6, 128, 128, 16, 3), (6, 256, 256, 8, 3), (6, 512, 512, 4, 3)])
 def test_backbone_conv_weight_gradient_kernels_vs_fp64(B, C, Co, H, k):
     """one convolution through ops.convwrw.conv2d: dW on the head's kernels (immediately, and as a problem of the deferred
-    grouped launch), dX by the library - both against float64"""
+    grouped launch), dX by the library (3x3) / the 3-product GEMM (1x1) - both against float64"""
     import combo_avs_amd  # noqa: F401
     from combo_avs_amd.ops import convwrw
     from combo_avs_amd.ops import linear as L
@@ -512,7 +512,8 @@ def test_backbone_conv_weight_gradient_kernels_vs_fp64(B, C, Co, H, k):
     rx, rw = torch.autograd.grad(torch.nn.functional.conv2d(x.double(), w.double(), None, 1, k // 2), (x, w), g.double())
     rel = lambda a, b: float((a.double() - b).norm() / b.norm())
     dx, dw = torch.autograd.grad(convwrw.conv2d(x, w, 1, k // 2), (x, w), g)
-    assert rel(dx, rx) < 2e-6 and rel(dw, rw) < 2e-5, (rel(dx, rx), rel(dw, rw))
+    # (dX of the 1x1 layers also runs on the 3-product kernels since ops.convwrw.DX_OWN = 2; the 3x3 dX is the library's)
+    assert rel(dx, rx) < 2e-5 and rel(dw, rw) < 2e-5, (rel(dx, rx), rel(dw, rw))
     with L.deferred_dw():
         dx2, dw2 = torch.autograd.grad(convwrw.conv2d(x, w, 1, k // 2), (x, w), g)
-    assert rel(dx2, rx) < 2e-6 and rel(dw2, rw) < 2e-5, (rel(dx2, rx), rel(dw2, rw))
+    assert rel(dx2, rx) < 2e-5 and rel(dw2, rw) < 2e-5, (rel(dx2, rx), rel(dw2, rw))
