@@ -23,6 +23,7 @@ ENABLED = os.environ.get("COMBO_BACKBONE_WRW", "1") == "1"  # 0: the library's w
 # input gradients on the head's 3-product kernels as well: bit 0 the 3x3 convolutions (measured: +1.3 ms per step, off), bit 1 the
 # 1x1 convolutions with >= DX_MIN_C channels (measured: -0.85 ms per step with all of them, on)
 DX_OWN = int(os.environ.get("COMBO_BACKBONE_DX", "2"))
+FWD_OWN = os.environ.get("COMBO_BACKBONE_FWD", "0") == "1"  # forward of the 1x1 layers on the exact-fp32 GEMM (A/B)
 DX_MIN_C = int(os.environ.get("COMBO_BACKBONE_DX_MINC", "64"))
 
 
@@ -50,6 +51,11 @@ class _ConvWrw(Function):
         (ops.biasact.bias_act(grad_masked=True)).  Set in pairs by backbone.Bottleneck."""
         ctx.k, ctx.mask_dx = k, mask_dx
         ctx.save_for_backward(x, w)
+        if k == 1 and FWD_OWN and L.f32_ok(C3._tokens(x), w.view(w.shape[0], w.shape[1])):
+            B, cin, H, W = x.shape
+            y = torch.empty((B, w.shape[0], H, W), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+            L.gemm_nt_f32(C3._tokens(x), w.view(w.shape[0], cin), out=C3._tokens(y))  # exact fp32 MFMA (csrc/gemm_f32.hip)
+            return y
         return F.conv2d(x, w, None, 1, 1 if k == 3 else 0)
 
     @staticmethod
