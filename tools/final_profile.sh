@@ -12,3 +12,4 @@ f=$(find /tmp/prof -name 'b_kernel_stats.csv' | head -1); cp "$f" gpurun_out/kst
 t=$(find /tmp/prof -name 'b_kernel_trace.csv' | head -1)
 python tools/prof_graph_steps.py "$t" 5 0 > gpurun_out/steady_graph.csv
 head -60 gpurun_out/steady_graph.csv | cut -c1-170
+if [ -n "$COMBO_PROF_HIST" ]; then python tools/prof_hist.py "$t" "$COMBO_PROF_HIST" 5 > gpurun_out/prof_hist.txt; fi
