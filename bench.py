@@ -209,6 +209,34 @@ def infer_bench(args, model, batch, world, rank, dev):
                        "parallelism": f"dp{world}"}}), flush=True)
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: this parent - which has made NO GPU call (device_count() does not
+    initialise HIP on this image) - starts the N ranks as a child process group through torch.distributed.run, the same
+    command line the driver uses, relays their output (rank 0's JSON line included) and returns their status.  Never an
+    exec: a child, so a profiler's preloaded runtime in the parent is harmless too."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if have < n and env.get("COMBO_SINGLE_DEVICE") != "1":
+        print(f"[bench] --gpus {n} but only {have} device(s) visible; set COMBO_SINGLE_DEVICE=1 (+ COMBO_DIST_BACKEND=gloo) "
+              "for a functional N-rank run on one device", file=sys.stderr, flush=True)
+        return 2
+    port = env.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -236,6 +264,11 @@ def main():
     if args.cpu_baseline_child:
         cpu_baseline_child()
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: the launcher's world size is what runs "
+              "and what `n_gpus` reports", file=sys.stderr, flush=True)
     if args.backbone == "pvt" and args.config == "r50_s4":
         args.config = "pvt_s4"
     wl = WORKLOADS[args.config]

@@ -1,0 +1,46 @@
+"""CPU: `python bench.py --gpus N` (N > 1, no launcher around it) must hand the run to N child ranks through
+torch.distributed.run BEFORE the parent touches the GPU, with the command line the driver itself uses, and must refuse loudly
+when the box has fewer devices than ranks (instead of silently running one rank and printing `n_gpus: 1`)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_spawn_builds_the_drivers_command_line(monkeypatch):
+    import bench
+    seen = {}
+
+    class FakeProc:
+        stdout = iter(['{"metric": "x"}\n'])
+
+        def wait(self):
+            return 0
+
+    def fake_popen(cmd, **kw):
+        seen["cmd"], seen["env"] = cmd, kw["env"]
+        return FakeProc()
+    monkeypatch.setattr(subprocess, "Popen", fake_popen)
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 8)
+    monkeypatch.delenv("MASTER_PORT", raising=False)
+    rc = bench.spawn_ranks(4, ["--gpus", "4", "--steps", "3", "--warmup", "1"])
+    assert rc == 0
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-7:] == [os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_refuses_more_ranks_than_devices():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("box has >= 2 devices")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "COMBO_SINGLE_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 2 and "--gpus 2 but only" in r.stderr
+    assert '"metric"' not in r.stdout

@@ -28,3 +28,40 @@ def test_two_ranks_sharing_the_gpu_run_the_bench_flow():
     assert len(lines) == 1, r.stdout[-1000:]  # rank 0 only
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and out["config"]["global_batch_clips"] == 4
+
+
+def _json_line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, stdout[-1000:]  # rank 0 only
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_spawns_two_ranks_by_itself():
+    """`python bench.py --gpus 2` - the form the driver uses at N = 1, no launcher - must start two ranks itself
+    (bench.spawn_ranks: a child process group created before the parent touches the GPU) and relay rank 0's line."""
+    env = dict(os.environ, COMBO_SINGLE_DEVICE="1", COMBO_DIST_BACKEND="gloo", COMBO_MIOPEN_BENCHMARK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--clips", "2",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _json_line(r.stdout)
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["config"]["global_batch_clips"] == 4
+    assert out["value"] > 0
+
+
+def test_bench_gpus_2_over_rccl_when_two_devices_exist():
+    """The same form on the `nccl` (= RCCL) backend, one rank per device: runs the first time a box has >= 2 GPUs."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL over xGMI)")
+    env = dict(os.environ, COMBO_MIOPEN_BENCHMARK="0", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "COMBO_SINGLE_DEVICE", "COMBO_DIST_BACKEND"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _json_line(r.stdout)
+    assert out["n_gpus"] == 2 and out["config"]["global_batch_clips"] == 16 and out["value"] > 0
