@@ -209,6 +209,29 @@ def infer_bench(args, model, batch, world, rank, dev):
                        "parallelism": f"dp{world}"}}), flush=True)
 
 
+def _pmc_stale(pmc):
+    """None when the PMC file's commit still describes the kernels being run (no change under combo-avs_amd/csrc since), else
+    the reason `traffic` is withheld.  On the GPU box there is no .git: the build records the tree's kernel digest instead."""
+    want = pmc.get("csrc_sha256")
+    if not want:
+        return f"PMC file of commit {pmc.get('commit')} carries no kernel-source digest: traffic withheld"
+    if csrc_digest() != want:
+        return f"kernel sources changed since the PMC passes of commit {pmc.get('commit')}: traffic withheld"
+    return None
+
+
+def csrc_digest():
+    """sha256 over the kernel sources (combo-avs_amd/csrc/*.hip, *.h): what tools/pmc_bench.sh stamps its counters with"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "combo-avs_amd", "csrc", "*"))):
+        if path.endswith((".hip", ".h")):
+            with open(path, "rb") as f:
+                h.update(os.path.basename(path).encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` (N > 1) outside a launcher: this parent - which has made NO GPU call (device_count() does not
     initialise HIP on this image) - starts the N ranks as a child process group through torch.distributed.run, the same
@@ -249,7 +272,6 @@ def main():
                     help="host-PyTorch backbone compute dtype.  fp32 = the reference's S4 recipe (SOLVER.AMP.ENABLED False, "
                          "configs/avs_s4/R50-AVSS4-SemanticSegmentation.yaml:44-45) and the BASELINE metric; bf16 = backbones "
                          "under bf16 autocast, a throughput mode that is NOT the quoted metric")
-    ap.add_argument("--head-dtype", default="fp32", choices=["bf16", "fp32"], help="dense layers of the head")
     ap.add_argument("--grad-comm", default="fp32", choices=["fp32", "bf16"],
                     help="dtype of the gradient all-reduce (fp32 = the reference's DDP semantics; bf16 halves the xGMI bytes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -309,8 +331,6 @@ def main():
     model = build_model(cfg).to(dev).train()
     if args.dtype == "bf16":
         model.backbone_dtype = torch.bfloat16
-    if args.head_dtype == "bf16":
-        model.head_dtype = torch.bfloat16
     opt = FlatAdamW(model, base_lr=cfg.SOLVER.BASE_LR, weight_decay=cfg.SOLVER.WEIGHT_DECAY,
                     backbone_multiplier=cfg.SOLVER.BACKBONE_MULTIPLIER, clip_value=cfg.SOLVER.CLIP_GRADIENTS.CLIP_VALUE,
                     grad_comm_dtype=torch.bfloat16 if args.grad_comm == "bf16" else torch.float32)
@@ -345,6 +365,8 @@ def main():
     n_slots = 4096
     ts_buf = torch.zeros(n_slots, 256, dtype=torch.int64, device=dev)  # csrc/combo_common.h: 16 sub-slots of 16 words
     ts_buf[:, 0::16] = -1  # ~0ull: earliest-start words
+    slot_timing = not args.no_graph  # the instrumented kernels time themselves into ts_buf (graph replays or eager launches)
+    graphed = None
     if args.no_graph:
         def step(b):
             return train_step(model, opt, b)
@@ -368,11 +390,17 @@ def main():
             step = graphed
         except Exception as exc:  # noqa: BLE001 - a failed capture must not cost the run: fall back to eager launches
             print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eager", file=sys.stderr, flush=True)
-            args.no_graph = True
+            graphed.graphs.clear()
+            _clib.lib().combo_timing_set_buffer(ts_buf.data_ptr(), n_slots)  # slots handed out to the failed capture: start over
 
             def step(b):
                 return train_step(model, opt, b)
+        # timing buffer set but the steps launch eagerly (AVSS batches, a failed capture): the step's i-th instrumented launch
+        # takes slot i in EVERY step (combo_timing_rewind), as a graph node does by construction
+        eager_slots = not graphed.graphs
         for i in range(max(args.warmup - 1, 0)):
+            if eager_slots:
+                _clib.lib().combo_timing_rewind()
             step(batches[i % len(batches)])
             trace("warm-up step done")
         _clib.lib().combo_timing_fold(_clib.current_stream())
@@ -382,44 +410,55 @@ def main():
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     marks[0].record()
+    eager_slots = slot_timing and not graphed.graphs
     for i in range(args.steps):
+        if eager_slots:
+            _clib.lib().combo_timing_rewind()
         step(batches[i % len(batches)])
-        if not args.no_graph:
+        if slot_timing:
             _clib.lib().combo_timing_fold(_clib.current_stream())  # one tiny launch: slot sums += last end - first start
         marks[i + 1].record()  # (an event on the stream between graph launches: no host sync inside the timed region)
         trace("timed step done")
     sync()
     elapsed = time.perf_counter() - t0
     trace("timed region done")
+    model.criterion.matcher.check_status()  # a diverged step (non-finite matching cost) is an error, not a number
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     median_ms = step_ms[len(step_ms) // 2] if step_ms else None
     per_kind = {}
-    if not args.no_graph:
+    timing_truncated = False
+    if slot_timing:
         torch.cuda.synchronize()
         tsv = ts_buf.cpu()
         lib = _clib.lib()
         used = lib.combo_timing_slots_used()
+        timing_truncated = bool(lib.combo_timing_truncated())
         khz = lib.combo_wall_clock_khz()
         import ctypes
         lib.combo_timing_slot_info.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]
+        lib.combo_timing_slot_bytes.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
         for sl in range(min(used, n_slots)):
-            kind, work = ctypes.c_int(0), ctypes.c_double(0.0)
+            kind, work, nbytes = ctypes.c_int(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
             lib.combo_timing_slot_info(sl, ctypes.byref(kind), ctypes.byref(work))
+            lib.combo_timing_slot_bytes(sl, ctypes.byref(nbytes))
             n_l = int(tsv[sl, 3])
             if khz > 0 and n_l > 0 and os.environ.get("COMBO_BENCH_DUMP_SLOTS") and str(kind.value) in os.environ["COMBO_BENCH_DUMP_SLOTS"].split(","):
                 print(f"[slot {sl}] kind {kind.value} work {work.value:.4g} avg_us {float(tsv[sl, 2]) / khz * 1e3 / n_l:.1f}", file=sys.stderr)
             if khz > 0 and n_l > 0:
-                d = per_kind.setdefault(kind.value, {"us": 0.0, "launches": 0, "work": 0.0, "nodes": 0, "big_us": 0.0, "big_work": 0.0,
-                                                     "big_launches": 0})
+                d = per_kind.setdefault(kind.value, {"us": 0.0, "launches": 0, "work": 0.0, "bytes": 0.0, "nodes": 0, "big_us": 0.0,
+                                                     "big_work": 0.0, "big_launches": 0})
                 us = float(tsv[sl, 2]) / khz * 1e3
                 d["us"] += us
                 d["launches"] += n_l
                 d["work"] += work.value * n_l
+                d["bytes"] += nbytes.value * n_l
                 d["nodes"] += 1
                 if work.value >= 2e9:  # launches of >= 2 GFLOP (GB for the HBM-bound kinds): the layers that can fill the chip
                     d["big_us"] += us
                     d["big_work"] += work.value * n_l
                     d["big_launches"] += n_l
+        # the graph's kernel nodes keep raw pointers into ts_buf: the buffer lives as long as the graphs do
+        graphed._timing_buffer = ts_buf
         lib.combo_timing_set_buffer(None, 0)
     kt = {"fwd_us": [], "bwd_us": [], "kernels": {}}
     if args.no_graph:
@@ -437,34 +476,55 @@ def main():
     #   core; flops: 2*M*N*K for the GEMMs) / their summed duration.  Peaks from MI355X_MICROARCH.md: HBM 8 TB/s, fp32 MFMA
     #   157.3 TFLOP/s (the forward GEMMs compute in exact fp32), bf16 MFMA 2.5 PFLOP/s (the gradient GEMMs issue 3 bf16
     #   products per fp32 MAC: `achieved` counts the USEFUL 2*M*N*K, `issued` the 3x).
+    X3 = 2500.0 / 3  # ceiling of USEFUL flops of the 3-product kernels: 3 bf16 MFMA products per fp32 multiply-add
     KINDS = {0: ("msda_fwd_tap_d32", "hbm", 8000.0, "GB/s", 1e9), 1: ("gemm_nt_f32_kernel", "mfma", 157.3, "TFLOP/s", 1e12),
-             2: ("gemm_nt2_kernel", "mfma", 2500.0, "TFLOP/s", 1e12), 3: ("gemm_tn_grouped_kernel", "mfma", 2500.0, "TFLOP/s", 1e12),
+             2: ("gemm_nt2_kernel", "mfma", X3, "TFLOP/s", 1e12), 3: ("gemm_tn_grouped_kernel", "hbm", 8000.0, "GB/s", 1e9),
              4: ("attn_fwd_kernel", "mfma", 157.3, "TFLOP/s", 1e12), 5: ("attn_bwd_dq/dkv_kernel", "mfma", 157.3, "TFLOP/s", 1e12),
-             6: ("msda_bwd", "hbm", 8000.0, "GB/s", 1e9)}
-    pmc = {}
-    pmc_path = os.path.join(ROOT, "profiles", "r02_pmc.json")
+             6: ("msda_bwd", "hbm", 8000.0, "GB/s", 1e9), 7: ("bifuse", "hbm", 8000.0, "GB/s", 1e9)}
+    # HBM traffic per launch: PMC passes of tools/pmc_bench.sh, valid only for the kernels of the commit they were taken at
+    pmc, pmc_note = {}, None
+    pmc_path = os.path.join(ROOT, "profiles", os.environ.get("COMBO_PMC_FILE", "r03_pmc.json"))
+    if not os.path.exists(pmc_path):
+        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc.json")
     if os.path.exists(pmc_path):
         with open(pmc_path) as f:
             pmc = json.load(f)
+        pmc_note = _pmc_stale(pmc)
+        if pmc_note:
+            pmc = {}
     rooflines = []
     for kind, d in per_kind.items():
-        name, bound, peak, unit, scale = KINDS.get(kind, (f"kind{kind}", "mfma", 2500.0, "TFLOP/s", 1e12))
-        ach = d["work"] / (d["us"] * 1e-6) / scale
+        name, bound, peak, unit, scale = KINDS.get(kind, (f"kind{kind}", "mfma", X3, "TFLOP/s", 1e12))
+        secs = d["us"] * 1e-6
+        if kind == 3:  # weight-gradient GEMM: a long-M reduction that streams dY and X once - HBM-bound (`work` holds flops)
+            ach = d["bytes"] / secs / scale
+        else:
+            ach = d["work"] / secs / scale
         rec = pmc.get(name, {}) if pmc.get("frames_per_launch") == bt else {}
-        r = {"kernel": name, "bound": bound, "achieved": round(ach, 1), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
+        r = {"kernel": name, "bound": bound, "achieved": round(ach, 1), "peak": round(peak, 1), "unit": unit, "frac": round(ach / peak, 4),
              "traffic": rec.get("hbm_bytes_per_launch"), "traffic_commit": pmc.get("commit") if rec else None,
              "avg_launch_us": round(d["us"] / d["launches"], 2), "launches": d["launches"],
              "launches_per_step": d["launches"] // max(args.steps, 1), "ms_per_step": round(d["us"] / max(args.steps, 1) / 1e3, 3),
-             "algorithmic_work_per_step": d["work"] / max(args.steps, 1),
-             "timing": "device-side wall-clock timestamps of the kernel over the launches of the timed graph replays"}
-        if d["big_launches"] and kind not in (0, 6):
+             "algorithmic_work_per_step": (d["bytes"] if kind == 3 else d["work"]) / max(args.steps, 1),
+             "timing": "device-side wall-clock timestamps of the kernel over the launches of the timed "
+                       + ("eager steps" if eager_slots else "graph replays")}
+        if pmc_note and r["traffic"] is None:
+            r["traffic_note"] = pmc_note
+        if timing_truncated:
+            r["timing_truncated"] = True  # the slot buffer ran out: figures cover the slotted launches only
+        if d["big_launches"] and kind in (1, 2, 4, 5):
             big = d["big_work"] / (d["big_us"] * 1e-6) / scale
             r["large_launches"] = {"min_gflop": 2, "launches_per_step": d["big_launches"] // max(args.steps, 1),
                                    "ms_per_step": round(d["big_us"] / max(args.steps, 1) / 1e3, 3), "achieved": round(big, 1),
                                    "frac": round(big / peak, 4)}
-        if kind in (2, 3):
-            r["issued_tflops_bf16"] = round(3 * ach, 1)
-            r["note"] = "useful 2*M*N*K flops over the dense bf16 peak; the kernel issues 3 bf16 products per fp32 MAC"
+        if kind in (1, 2, 3) and d["bytes"] > 0:  # the GEMM families also report the other side of their roofline
+            useful = d["work"] / secs / 1e12
+            r["hbm"] = {"algorithmic_bytes_per_step": d["bytes"] / max(args.steps, 1), "achieved_gbs": round(d["bytes"] / secs / 1e9, 1),
+                        "frac_of_8tbs": round(d["bytes"] / secs / 8e12, 4)}
+            if kind in (2, 3):
+                r["mfma"] = {"useful_tflops": round(useful, 1), "ceiling_useful_tflops": round(X3, 1), "frac": round(useful / X3, 4),
+                             "issued_tflops_bf16": round(3 * useful, 1),
+                             "note": "3 bf16 MFMA products per fp32 multiply-add: the ceiling of useful flops is 2500 / 3 TFLOP/s"}
         rooflines.append(r)
     rooflines.sort(key=lambda r: -r["ms_per_step"])
     roof = rooflines[0] if rooflines else None
@@ -487,7 +547,13 @@ def main():
             "config": {"workload": f"{wl['name']}: bs={args.clips} clips x {T} frames x {H}x{W} per GPU, K={wl['K']}, full train step "
                                    "(fwd + 39-term loss + bwd + all-reduce + clip + AdamW), random-init weights",
                        "name": args.config,
-                       "launch": "eager" if args.no_graph else "hipGraph (fwd+loss+bwd captured; all-reduce + AdamW eager)",
+                       "launch": "eager" if (args.no_graph or eager_slots) else "hipGraph (fwd+loss+bwd captured; all-reduce + AdamW eager)",
+                       "instrumentation": "the instrumented kernels' timing atomics (2 per workgroup) and one fold launch per step run "
+                                          "inside the timed region" if slot_timing else "HIP events around the MSDeformAttn core",
+                       "arithmetic": "forward GEMMs / convolutions / attention of the head in exact fp32 on v_mfma_f32_* (peak 157.3 "
+                                     "TFLOP/s): the north-star's 1e-3 bound on the mask logits rules bf16 products out (DESIGN section 2), so "
+                                     "its '>= 40 % of the bf16 MFMA peak' target does not apply to this line; gradient GEMMs issue 3 bf16 "
+                                     "products per fp32 multiply-add (ceiling 833 TFLOP/s useful)",
                        "grad_all_reduce": args.grad_comm,
                        "global_batch_clips": args.clips * world, "frames_per_clip": T, "parallelism": f"dp{world}",
                        "precision": "bf16 backbones (host PyTorch), fp32 head + HIP kernels" if args.dtype == "bf16" else "fp32"},

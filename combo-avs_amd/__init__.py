@@ -15,5 +15,4 @@ from .registry import (BACKBONE_REGISTRY, META_ARCH_REGISTRY, SEM_SEG_HEADS_REGI
                        TRANSFORMER_DECODER_REGISTRY)
 from . import backbone, backbone_pvt  # noqa: E402,F401  (populate BACKBONE_REGISTRY: build_resnet_backbone, build_pvtv2_b5_backbone)
 
-from . import d2_register  # noqa: E402
-d2_register.install_if_detectron2()  # no-op without detectron2; never replaces names that are already registered
+from . import d2_register  # noqa: E402,F401  (explicit: d2_register.install(); importing this package never touches detectron2's registries)

@@ -57,8 +57,11 @@ _SIGNATURES = {
     "combo_gemm_nt_x3_pre_masked_f32": [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_void_p],
     "combo_timing_set_buffer": [c_void_p, c_int],
     "combo_timing_slots_used": [],
+    "combo_timing_rewind": [],
+    "combo_timing_truncated": [],
     "combo_timing_fold": [c_void_p],
     "combo_timing_slot_info": [c_int, c_void_p, c_void_p],
+    "combo_timing_slot_bytes": [c_int, c_void_p],
     "combo_gemm_smallm_splits": [c_int, c_int, c_int],
     "combo_gemm_smallm_f32": [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_void_p] + [c_int] * 5 + [c_void_p],
     "combo_gemm_smallk_f32": [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_longlong, c_longlong, c_int, c_int, c_void_p],
@@ -84,7 +87,7 @@ _SIGNATURES = {
     "combo_mask_loss_backward_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int] + [c_void_p] * 4 + [c_int, c_void_p],
     "combo_cosine_stats_f32": [c_void_p, c_longlong, c_longlong, c_int, c_void_p, c_void_p, c_void_p],
     "combo_cosine_grad_f32": [c_void_p, c_longlong, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
-    "combo_lsap_small_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
+    "combo_lsap_small_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "combo_attn_mask_f32": [c_void_p] + [c_int] * 6 + [c_void_p, c_void_p],
     "combo_attn_mask_pitched_f32": [c_void_p] + [c_int] * 7 + [c_void_p, c_void_p],
     "combo_attention_forward_f32": [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_int, c_void_p] + [c_int] * 5 + [c_float, c_void_p, c_void_p, c_void_p],

@@ -26,7 +26,9 @@ __device__ __forceinline__ int xcd_contiguous(int id, int n) {
 enum { COMBO_TS_MSDA_FWD = 0, COMBO_TS_GEMM_F32 = 1, COMBO_TS_GEMM_X3 = 2, COMBO_TS_GEMM_TN = 3, COMBO_TS_ATTN_FWD = 4,
        COMBO_TS_ATTN_BWD = 5, COMBO_TS_MSDA_BWD = 6, COMBO_TS_KINDS = 8 };
 enum { COMBO_TS_SUBS = 16, COMBO_TS_SUB_U64 = 16, COMBO_TS_SLOT_U64 = 256 };
-unsigned long long* combo_timing_next_slot(int kind, double work);  // host; nullptr when timing is off (timing.hip)
+// host; nullptr when timing is off (timing.hip).  work: flops (bytes for the HBM-bound kinds); bytes: algorithmic HBM bytes
+// of the launch (operands read once + result written once) for the kinds that report a second, HBM-side fraction
+unsigned long long* combo_timing_next_slot(int kind, double work, double bytes = 0.0);
 
 __device__ __forceinline__ unsigned long long* combo_ts_sub(unsigned long long* ts) {
   return ts + ((blockIdx.x + 5u * blockIdx.y) & (COMBO_TS_SUBS - 1)) * COMBO_TS_SUB_U64;

@@ -458,7 +458,8 @@ int launch_cfg(F32Args a, hipStream_t stream) {
   if (tiles > 0x7fffffffLL) return COMBO_EINVAL;
   const long long slots = n_cu_cached();  // one persistent workgroup per CU
   const int grid = (int)(tiles < slots ? tiles : slots);
-  a.ts = combo_timing_next_slot(COMBO_TS_GEMM_F32, 2.0 * a.M * a.N * a.K * a.batch);
+  a.ts = combo_timing_next_slot(COMBO_TS_GEMM_F32, 2.0 * a.M * a.N * a.K * a.batch,
+                                4.0 * a.batch * ((double)a.M * (CONV ? a.K / 9 : a.K) + (double)a.N * a.K + (double)a.M * a.N));
   hipLaunchKernelGGL((gemm_nt_f32_kernel<CONV, Cfg>), dim3((unsigned)grid), dim3(256), Cfg::LDS, stream, a);
   return (int)hipGetLastError();
 }

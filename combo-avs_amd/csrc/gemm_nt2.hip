@@ -443,7 +443,8 @@ int launch_nt2_cfg(const float* A, long long lda, const float* Bimg, const float
   if (c_bytes >= 0x7fffffffLL) return COMBO_EINVAL;
   hipLaunchKernelGGL((gemm_nt2_kernel<CONV, Cfg>), dim3((unsigned)grid), dim3(256), Cfg::LDS, (hipStream_t)stream, A, lda, Bimg,
                      (long long)K, bias, C, ldc, (int)M, N, K, relu, stagger, cg, (int)c_bytes, nb.batch, nb.sA, nb.sB, nb.sC, mask,
-                     combo_timing_next_slot(COMBO_TS_GEMM_X3, 2.0 * M * N * K * nb.batch));
+                     combo_timing_next_slot(COMBO_TS_GEMM_X3, 2.0 * M * N * K * nb.batch,
+                                            4.0 * nb.batch * ((double)M * (CONV ? K / 9 : K) + (double)N * K + (double)M * N)));
   return (int)hipGetLastError();
 }
 

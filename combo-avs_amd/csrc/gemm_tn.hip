@@ -625,9 +625,12 @@ int combo_gemm_tn_x3_grouped_f32(const combo_gemm_tn_problem* problems, int coun
     }
     a.remap = remap;
     a.block_start[a.count] = blocks;
-    double flops = 0.0;
-    for (int i = 0; i < a.count; ++i) flops += 2.0 * a.p[i].M * a.p[i].N * a.p[i].K;
-    a.ts = combo_timing_next_slot(COMBO_TS_GEMM_TN, flops);
+    double flops = 0.0, bytes = 0.0;
+    for (int i = 0; i < a.count; ++i) {
+      flops += 2.0 * a.p[i].M * a.p[i].N * a.p[i].K;
+      bytes += 4.0 * ((double)a.p[i].M * (a.p[i].N + a.p[i].K) + (double)a.p[i].N * a.p[i].K);  // dY, X once; dW once
+    }
+    a.ts = combo_timing_next_slot(COMBO_TS_GEMM_TN, flops, bytes);
     hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, a);
   }
   return (int)hipGetLastError();

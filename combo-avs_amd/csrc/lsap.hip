@@ -10,6 +10,9 @@
 // distinct query indices - scipy raises ValueError there (matcher.py:133); here the NaN simply reaches the loss, and the
 // downstream gathers (criterion mask_index) can never be driven out of bounds (round 1: a NaN cost left the arg-min at its
 // 0x7fffffff sentinel, which the mask-loss kernels then used as a row index - a hardware exception, not an error message).
+// The condition is SURFACED, not hidden: `status` (nullable device word) gets bit 0 when a non-finite cost was read and bit 1
+// when a frame's target count exceeds what this kernel solves (it then solves the first min(Gpad, 6) targets); the host side
+// (HungarianMatcher.check_status) turns either into the ValueError scipy would have raised, without a per-step sync.
 #include <math.h>
 
 #include "combo_common.h"
@@ -20,9 +23,11 @@ constexpr int GMAX = 6;
 
 __global__ void __launch_bounds__(64)
 lsap_small_kernel(const float* __restrict__ cost, const int* __restrict__ gcount, int N, int Q, int Gpad,
-                  long long* __restrict__ row_for_col) {
+                  long long* __restrict__ row_for_col, int* __restrict__ status) {
   const int n = blockIdx.x, lane = threadIdx.x;
   const int G = min(max(gcount[n], 0), min(Gpad, GMAX));
+  bool bad = false;
+  if (status && lane == 0 && gcount[n] > min(Gpad, GMAX)) atomicOr(status, COMBO_LSAP_TOO_MANY_TARGETS);
   const float* C = cost + (long long)n * Q * Gpad;
   __shared__ int cand[GMAX][GMAX];
   __shared__ float candc[GMAX][GMAX];
@@ -35,7 +40,9 @@ lsap_small_kernel(const float* __restrict__ cost, const int* __restrict__ gcount
         bool used = false;
         for (int p = 0; p < r; ++p) used |= (cand[g][p] == q);
         float c = C[q * Gpad + g];
-        c = (c == c && fabsf(c) < 3.0e38f) ? c : 3.0e38f;  // NaN / Inf -> the largest finite cost
+        const bool fin = (c == c && fabsf(c) < 3.0e38f);
+        bad |= !fin;
+        c = fin ? c : 3.0e38f;  // NaN / Inf -> the largest finite cost
         if (!used && (c < best || (c == best && q < bi))) { best = c; bi = q; }
       }
 #pragma unroll
@@ -48,6 +55,7 @@ lsap_small_kernel(const float* __restrict__ cost, const int* __restrict__ gcount
       __syncthreads();
     }
   }
+  if (status && __any(bad) && lane == 0) atomicOr(status, COMBO_LSAP_NONFINITE_COST);
   // ---- enumerate the G^G tuples ----
   int total = 1;
   for (int g = 0; g < G; ++g) total *= G;
@@ -87,8 +95,8 @@ lsap_small_kernel(const float* __restrict__ cost, const int* __restrict__ gcount
 }  // namespace
 
 extern "C" int combo_lsap_small_f32(const float* cost, const int* gcount, int N, int Q, int Gpad, long long* row_for_col,
-                                    combo_stream_t stream) {
+                                    int* status, combo_stream_t stream) {
   if (!cost || !gcount || !row_for_col || N <= 0 || Q <= 0 || Gpad <= 0 || Gpad > GMAX || Q < Gpad) return COMBO_EINVAL;
-  hipLaunchKernelGGL(lsap_small_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, cost, gcount, N, Q, Gpad, row_for_col);
+  hipLaunchKernelGGL(lsap_small_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, cost, gcount, N, Q, Gpad, row_for_col, status);
   return (int)hipGetLastError();
 }

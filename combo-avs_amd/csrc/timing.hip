@@ -5,8 +5,9 @@
 
 namespace {
 unsigned long long* g_base = nullptr;
-int g_slots = 0, g_next = 0;
-struct SlotInfo { int kind; double work; };
+int g_slots = 0, g_next = 0, g_high = 0;  // g_high: slots handed out so far (g_next rewinds in eager runs)
+bool g_truncated = false;
+struct SlotInfo { int kind; double work; double bytes; };
 std::vector<SlotInfo> g_info;
 
 __global__ void timing_fold_kernel(unsigned long long* base, int slots) {
@@ -28,10 +29,13 @@ __global__ void timing_fold_kernel(unsigned long long* base, int slots) {
 }
 }  // namespace
 
-unsigned long long* combo_timing_next_slot(int kind, double work) {
-  if (!g_base || g_next >= g_slots) return nullptr;  // out of slots: later launches run untimed
-  g_info[g_next] = SlotInfo{kind, work};
-  return g_base + (long long)COMBO_TS_SLOT_U64 * g_next++;
+unsigned long long* combo_timing_next_slot(int kind, double work, double bytes) {
+  if (!g_base) return nullptr;
+  if (g_next >= g_slots) { g_truncated = true; return nullptr; }  // out of slots: later launches run untimed (reported)
+  g_info[g_next] = SlotInfo{kind, work, bytes};
+  unsigned long long* p = g_base + (long long)COMBO_TS_SLOT_U64 * g_next++;
+  if (g_next > g_high) g_high = g_next;
+  return p;
 }
 
 extern "C" {
@@ -39,23 +43,37 @@ extern "C" {
 int combo_timing_set_buffer(void* buf, int slots) {
   g_base = reinterpret_cast<unsigned long long*>(buf);
   g_slots = buf ? slots : 0;
-  g_next = 0;
-  g_info.assign(g_slots > 0 ? g_slots : 0, SlotInfo{-1, 0.0});
+  g_next = g_high = 0;
+  g_truncated = false;
+  g_info.assign(g_slots > 0 ? g_slots : 0, SlotInfo{-1, 0.0, 0.0});
   return 0;
 }
 
-int combo_timing_slots_used(void) { return g_next; }
+int combo_timing_slots_used(void) { return g_high; }
+
+// Eager (un-captured) steps: call before every step so that the step's i-th instrumented launch takes slot i again (a graph
+// node keeps its slot by construction; without the rewind an eager run takes fresh slots every step and runs out).
+int combo_timing_rewind(void) { g_next = 0; return 0; }
+
+// 1 when a launch asked for a slot after the buffer ran out: the per-kind figures then cover only the slotted launches.
+int combo_timing_truncated(void) { return g_truncated ? 1 : 0; }
 
 int combo_timing_fold(combo_stream_t stream) {
-  if (!g_base || g_next <= 0) return 0;
-  hipLaunchKernelGGL(timing_fold_kernel, dim3((g_next + 255) / 256), dim3(256), 0, (hipStream_t)stream, g_base, g_next);
+  if (!g_base || g_high <= 0) return 0;
+  hipLaunchKernelGGL(timing_fold_kernel, dim3((g_high + 255) / 256), dim3(256), 0, (hipStream_t)stream, g_base, g_high);
   return (int)hipGetLastError();
 }
 
 int combo_timing_slot_info(int slot, int* kind, double* work) {
-  if (slot < 0 || slot >= g_next) return COMBO_EINVAL;
+  if (slot < 0 || slot >= g_high) return COMBO_EINVAL;
   if (kind) *kind = g_info[slot].kind;
   if (work) *work = g_info[slot].work;
+  return 0;
+}
+
+int combo_timing_slot_bytes(int slot, double* bytes) {
+  if (slot < 0 || slot >= g_high || !bytes) return COMBO_EINVAL;
+  *bytes = g_info[slot].bytes;
   return 0;
 }
 

@@ -5,9 +5,11 @@ BACKBONE_REGISTRY["build_pvtv2_b5_backbone"] (pvtv2.py:391) - so that detectron2
 MI355X implementation.  detectron2 calls a registry entry as `entry(cfg[, input_shape])`; the entries installed here are
 factories doing `cls(**cls.from_config(cfg, ...))` (what d2's @configurable does for the reference's classes).
 
-`install()` is called on import of the package when detectron2 is importable (names already taken are left alone);
-`install(override=True)` replaces entries the reference's own `models` package registered - that is what the alias package
-compat/models does, so `from models import ...` in the unchanged drivers picks this implementation for the hot path.
+Registration is EXPLICIT: importing combo_avs_amd never writes into detectron2's global registries (a side-by-side run
+with the reference's own `models` package would otherwise depend on import order - fvcore's Registry asserts on a second
+registration of a name).  `install()` leaves names already taken alone; `install(override=True)` replaces entries the
+reference's own `models` package registered - that is what the alias package compat/models does, so `from models import ...`
+in the unchanged drivers picks this implementation for the hot path.
 The registries are passed in by tests as detectron2-shaped stubs (detectron2 is not installed in the build image)."""
 
 
@@ -59,11 +61,3 @@ def install(registries=None, override=False):
                 reg.register(obj)
             done.append(f"{reg_name}[{name}]")
     return done
-
-
-def install_if_detectron2():
-    try:
-        import detectron2  # noqa: F401,PLC0415
-    except ImportError:
-        return []
-    return install(override=False)

@@ -67,7 +67,6 @@ class MaskFormer(nn.Module):
         self.semantic_on, self.instance_on, self.panoptic_on = semantic_on, instance_on, panoptic_on
         self.test_topk_per_image = test_topk_per_image
         self.backbone_dtype = torch.float32  # bench/trainer may switch the host-PyTorch backbones to bf16
-        self.head_dtype = torch.float32  # bf16 = autocast the head's dense layers (MFMA bf16), fp32 accumulate
         if not self.semantic_on:
             assert self.sem_seg_postprocess_before_inference
 
@@ -187,8 +186,7 @@ class MaskFormer(nn.Module):
         else:
             with amp:
                 features = self.backbone(images)
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.head_dtype == torch.bfloat16):
-            outputs = self.sem_seg_head(features, audio_feature)
+        outputs = self.sem_seg_head(features, audio_feature)
         if self.training:
             if "instances" not in batched_inputs[0]:
                 raise ValueError("MaskFormer requires `instances` in training!")

@@ -69,6 +69,10 @@ class SetCriterion(nn.Module):
         self.importance_sample_ratio = importance_sample_ratio
         self.n_frame = n_frame  # hard-coded 5 in the reference (criterion.py:243,284)
         self.point_source = None  # test hook
+        # test hook: {"match_src", "match_tgt": int64 [L, Nm], "topk": bool [L, Nm, oversampled points]} - the reference's own
+        # Hungarian pairs and importance-sampling top-k sets (tests/golden `*/match_all_*`, `*/topk_bits`) used INSTEAD of the
+        # device LSAP's / the selection kernel's, so that a gradient comparison does not hinge on a near-tie
+        self.frozen_choices = None
         # True: SciPy on the host like the reference (always used when a frame has > 6 instances)
         import os
         self.host_lsap = os.environ.get("COMBO_HOST_LSAP", "0") == "1"
@@ -278,7 +282,13 @@ class SetCriterion(nn.Module):
                 C = self.matcher.batched_cost(logits.view(L * F_, Q, -1), masks.view(L * F_, Q, *masks.shape[-2:]).float(),
                                               lab.repeat(L, 1), gt.repeat(L, 1, 1, 1), mpts)  # [L*F,Q,Gmax]
         frame = torch.cat([torch.full((g,), f, dtype=torch.int64) for f, g in enumerate(G)])
-        if Gmax <= self.matcher.LSAP_DEVICE_MAX_G and self.host_lsap is False:
+        if self.frozen_choices is not None:
+            src_q = self.frozen_choices["match_src"].to(dev)
+            tgt_g = self.frozen_choices["match_tgt"].to(dev)
+            frame = frame.to(dev)
+            assert src_q.shape == (L, Nm) and tgt_g.shape == (L, Nm)
+            self.last_indices = (src_q, tgt_g, frame)
+        elif Gmax <= self.matcher.LSAP_DEVICE_MAX_G and self.host_lsap is False:
             # exact assignment on the device: the step has no device->host synchronisation
             gcount, valid, frame = self._static_match_index(tuple(G), L, Gmax, dev)
             rfc = self.matcher.solve_device(C, gcount).view(L, F_, Gmax)  # query matched to (frame, target)
@@ -316,7 +326,9 @@ class SetCriterion(nn.Module):
         gt_index = (frame_b * Gmax + tgt_g).reshape(-1).contiguous()
         if fused:
             mask_index = ((head_of_layer[lidx] * BT + gframe[frame_b]) * Q + src_q).reshape(-1).contiguous()
-            coords = maskloss.uncertain_points(xall.view(-1, *xall.shape[-2:]), mask_index, over, extra, n_unc)
+            coords = self._frozen_coords(over, extra, n_unc)
+            if coords is None:
+                coords = maskloss.uncertain_points(xall.view(-1, *xall.shape[-2:]), mask_index, over, extra, n_unc)
             n_mid = len(outputs.get("middles_attn_mask", []))
             bce, dice, dot, nrm = maskloss.mask_and_cosine(xall, n_mid, self.n_frame, mask_index, gt, gt_index, coords)
             bce, dice = bce.view(L, Nm), dice.view(L, Nm)
@@ -329,12 +341,23 @@ class SetCriterion(nn.Module):
             return self._assemble(loss_ce, bce.sum(1) / num_masks, dice.sum(1) / num_masks, outputs, lc)
         masks32 = masks.float().contiguous()  # [L,F,Q,h,w]; pairs address their maps by flat index, no gather copies
         mask_index = ((lidx * F_ + frame_b) * Q + src_q).reshape(-1).contiguous()
-        coords = maskloss.uncertain_points(masks32, mask_index, over, extra, n_unc)  # importance sampling, no sort
+        coords = self._frozen_coords(over, extra, n_unc)
+        if coords is None:
+            coords = maskloss.uncertain_points(masks32, mask_index, over, extra, n_unc)  # importance sampling, no sort
         bce, dice = maskloss.mask_losses(masks32, mask_index, gt, gt_index, coords)
         bce, dice = bce.view(L, Nm), dice.view(L, Nm)
         loss_mask = bce.sum(1) / num_masks
         loss_dice = dice.sum(1) / num_masks
         return self._assemble(loss_ce, loss_mask, loss_dice, outputs)
+
+    def _frozen_coords(self, over, extra, n_unc):
+        """test hook (frozen_choices): the injected top-k SETS applied to this step's oversampled points -> [L*Nm, P, 2]"""
+        if self.frozen_choices is None:
+            return None
+        keep = self.frozen_choices["topk"].to(over.device).reshape(over.shape[0], over.shape[1])
+        assert bool((keep.sum(1) == n_unc).all())
+        coords = over[keep].view(over.shape[0], n_unc, 2)
+        return (torch.cat([coords, extra], 1) if extra is not None else coords).contiguous()
 
     def forward(self, outputs, targets):
         bt = len(outputs["pred_logits"])

@@ -41,6 +41,7 @@ class HungarianMatcher(nn.Module):
         self.cost_class, self.cost_mask, self.cost_dice = cost_class, cost_mask, cost_dice
         assert cost_class != 0 or cost_mask != 0 or cost_dice != 0, "all costs cant be 0"
         self.num_points = num_points
+        self._lsap_status = None  # device word the LSAP kernel ORs its condition bits into (see check_status)
 
     @torch.no_grad()
     def cost_matrices(self, outputs, targets, point_source=None):
@@ -92,9 +93,26 @@ class HungarianMatcher(nn.Module):
         _lib.require_cuda(cost, gcount)
         N, Q, Gpad = cost.shape
         out = torch.empty(N, Gpad, device=cost.device, dtype=torch.int64)
+        if self._lsap_status is None or self._lsap_status.device != cost.device:
+            self._lsap_status = torch.zeros(1, device=cost.device, dtype=torch.int32)
         _lib.check(_lib.lib().combo_lsap_small_f32(cost.data_ptr(), gcount.data_ptr(), N, Q, Gpad, out.data_ptr(),
-                                                   _lib.current_stream()), "combo_lsap_small_f32")
+                                                   self._lsap_status.data_ptr(), _lib.current_stream()), "combo_lsap_small_f32")
         return out
+
+    def check_status(self):
+        """Raises what scipy.optimize.linear_sum_assignment raises at matcher.py:133 when a cost matrix was not finite (a
+        diverged step), or when a frame had more targets than the device solver takes.  The device solver only sets bits in a
+        status word (no sync on the hot path); call this where a host sync is acceptable - trainer.train_loop does every
+        `check_every` steps, bench.py after its timed region."""
+        if self._lsap_status is None:
+            return
+        bits = int(self._lsap_status.item())
+        if bits:
+            self._lsap_status.zero_()
+        if bits & 1:
+            raise ValueError("matrix contains invalid numeric entries (non-finite Hungarian matching cost: the step diverged)")
+        if bits & 2:
+            raise ValueError(f"a frame has more than {self.LSAP_DEVICE_MAX_G} targets: not solvable by the device LSAP")
 
     @staticmethod
     def solve(costs_host):

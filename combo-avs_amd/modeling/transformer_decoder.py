@@ -160,6 +160,9 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         self.mask_embed = MLP(hidden_dim, hidden_dim, mask_dim, 3)
         self.dataset_name = dataset_name
         self.use_cosine_loss = use_cosine_loss
+        # test hook: list of ops.masklogit.PackedMask, one per prediction head #0.., used INSTEAD of the masks computed from the
+        # logits (tests inject the reference's own masks so that a gradient comparison does not hinge on a near-zero cell)
+        self.attn_mask_override = None
 
     @classmethod
     def from_config(cls, cfg, in_channels, mask_classification):
@@ -214,6 +217,7 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         # one buffer for the mask logits of all prediction heads; head i fills slice i (values, no grad) ...
         logit_buf = torch.empty(nheads_pred, bt, self.num_queries, h_m * w_m, device=mf_tok.device, dtype=torch.float32)
         predictions_class, mask_embeds = [], []
+        self._head_no = 0
         outputs_class, mask_embed, blocked = self.forward_prediction_heads(output, mf_tok, (h_m, w_m), size_list[0], logit_buf[0])
         predictions_class.append(outputs_class)
         mask_embeds.append(mask_embed)
@@ -251,4 +255,7 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         mask_embed = self.mask_embed(dec)
         masklogit.mask_logits_into(mask_embed, mf_tok, logits_out)
         blocked = masklogit.attn_mask_padded(logits_out.view(output.shape[0], self.num_queries, hw[0], hw[1]), attn_mask_target_size, True)
+        if self.attn_mask_override is not None and self._head_no < len(self.attn_mask_override):
+            blocked = self.attn_mask_override[self._head_no]
+        self._head_no += 1
         return outputs_class, mask_embed, blocked

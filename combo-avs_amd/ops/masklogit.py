@@ -62,6 +62,23 @@ def attn_mask_padded(logits, target_size, reset_full_rows=True):
     return PackedMask(out, bits)
 
 
+def pack_mask(blocked, reset_full_rows=True):
+    """bool [BT,Q,n] (True = masked out; as produced by a prediction head) -> PackedMask in the layout attn_mask_padded
+    writes, row reset of :458 applied.  Host-side torch ops: for tests that inject masks, not on the step's path."""
+    bt, Q, n = blocked.shape
+    b = blocked.clone()
+    if reset_full_rows:
+        b[b.all(-1)] = False
+    pitch, wpitch = (n + 3) // 4 * 4, (n + 63) // 64 * 2
+    by = torch.ones(bt, Q, pitch, dtype=torch.uint8, device=b.device)
+    by[:, :, :n] = b.to(torch.uint8)
+    full = torch.ones(bt, Q, wpitch * 32, dtype=torch.int64, device=b.device)
+    full[:, :, :n] = b.to(torch.int64)
+    words = (full.view(bt, Q, wpitch, 32) << torch.arange(32, device=b.device)).sum(-1)  # bit k of word j = key 32 j + k
+    words = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32)
+    return PackedMask(by.contiguous(), words.contiguous())
+
+
 def attn_mask(logits, target_size, reset_full_rows=True):
     """logits [BT,Q,H,W] fp32 -> blocked bool [BT,Q,h*w] (True = masked out), row reset of :458 applied."""
     h, w = target_size

@@ -31,6 +31,9 @@ extern "C" {
 #endif
 
 #define COMBO_EINVAL 1
+/* bits of the device LSAP's status word (combo_lsap_small_f32) */
+#define COMBO_LSAP_NONFINITE_COST 1
+#define COMBO_LSAP_TOO_MANY_TARGETS 2
 typedef void* combo_stream_t;
 
 /* Library / device introspection (host only, no GPU needed). */
@@ -48,8 +51,11 @@ int combo_abi_version(void);
  * iterations with detectron2's IterationTimer, models/evaluation/evaluator.py:149-228). */
 int combo_timing_set_buffer(void* buf, int slots);
 int combo_timing_slots_used(void);
+int combo_timing_rewind(void);    /* eager (un-captured) steps: before every step, so its i-th launch takes slot i again */
+int combo_timing_truncated(void); /* 1: a launch found no free slot - the figures cover the slotted launches only */
 int combo_timing_fold(combo_stream_t stream);
 int combo_timing_slot_info(int slot, int* kind, double* work);
+int combo_timing_slot_bytes(int slot, double* bytes); /* algorithmic HBM bytes per launch of the slot (GEMM kinds; else 0) */
 int combo_wall_clock_khz(void);
 const char* combo_build_arch(void); /* "gfx950" */
 
@@ -434,9 +440,12 @@ int combo_semantic_inference_f32(const float* cls_prob, const float* masks, int 
 
 /*   Exact linear sum assignment on the device for G <= 6 targets per problem (replaces the per-frame
  *   scipy.optimize.linear_sum_assignment host call + .cpu() sync, matcher.py:132-134).
- *   cost [N,Q,Gpad], gcount [N] int32 (real number of targets, <= Gpad <= 6) -> row_for_col [N,Gpad] int64 (-1 = padding). */
+ *   cost [N,Q,Gpad], gcount [N] int32 (real number of targets, <= Gpad <= 6) -> row_for_col [N,Gpad] int64 (-1 = padding).
+ *   status (nullable device int): bits are OR-ed in, never cleared - COMBO_LSAP_NONFINITE_COST when a NaN / Inf cost was read
+ *   (scipy raises ValueError there, matcher.py:133; the kernel reads it as the largest finite cost and still returns valid,
+ *   distinct rows), COMBO_LSAP_TOO_MANY_TARGETS when gcount[n] > min(Gpad, 6).  Gpad > 6 returns COMBO_EINVAL. */
 int combo_lsap_small_f32(const float* cost, const int* gcount, int N, int Q, int Gpad, long long* row_for_col,
-                         combo_stream_t stream);
+                         int* status, combo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a15  mask losses of the criterion (models/modeling/criterion.py:137-186, :19-62, :70-84)

@@ -322,10 +322,18 @@ def scramble_audio(audio, num_queries):
     return audio.repeat(1, num_queries, 1).reshape(num_queries, -1, audio.shape[-1])
 
 
-def transformer_decoder(P, pre, x, audio, mask_features, num_layers=9, num_heads=8):
+def transformer_decoder(P, pre, x, audio, mask_features, num_layers=9, num_heads=8, attn_override=None):
     """MultiScaleMaskedTransformerDecoder.forward (transformer_decoder.py:405-491); `pre` = '...predictor.'.
     x: 3 maps (7^2,14^2,28^2 at 224 input), audio [BT,1,256], mask_features [BT,256,H,W].
-    Returns dict(pred_logits, pred_masks, aux_outputs, middles_attn_mask) + 'attn_masks' (the 10 bool masks)."""
+    Returns dict(pred_logits, pred_masks, aux_outputs, middles_attn_mask) + 'attn_masks' (the 10 bool masks).
+    attn_override: list of bool [BT,Q,hw] masks AS PRODUCED by heads #0.. (before the row reset of :458) that replace the
+    computed ones - test hook that freezes the decoder's discrete choices (golden `dec/attn_bits*`)."""
+    def frozen(k, am):
+        if attn_override is None or k >= len(attn_override):
+            return am
+        o = attn_override[k].unsqueeze(1).repeat(1, num_heads, 1, 1).flatten(0, 1)
+        assert o.shape == am.shape
+        return o
     bt = mask_features.shape[0]
     Q = P[pre + "query_feat.weight"].shape[0]
     src, pos, sizes = [], [], []
@@ -338,6 +346,7 @@ def transformer_decoder(P, pre, x, audio, mask_features, num_layers=9, num_heads
     output = output + scramble_audio(audio, Q)  # QUERIES_FUSE_TYPE == "add", :437-440
     classes, masks, attn_masks, attn_used, middles = [], [], [], [], []
     c, m, am = forward_prediction_heads(P, pre, output, mask_features, sizes[0], num_heads)  # :451
+    am = frozen(0, am)
     classes.append(c); masks.append(m); attn_masks.append(am)
     middles.append(m.reshape(bt, Q, -1))  # :455  (raw mask LOGITS, despite the name)
     for i in range(num_layers):
@@ -357,6 +366,7 @@ def transformer_decoder(P, pre, x, audio, mask_features, num_layers=9, num_heads
                       P[ff + "linear2.weight"], P[ff + "linear2.bias"])
         output = layer_norm(P, ff + "norm.", output + t2)  # :178-182
         c, m, am = forward_prediction_heads(P, pre, output, mask_features, sizes[(i + 1) % 3], num_heads)  # :474
+        am = frozen(i + 1, am)
         classes.append(c); masks.append(m); attn_masks.append(am)
         if i != num_layers - 1:  # :479-482
             middles.append(m.reshape(bt, Q, -1))
@@ -368,11 +378,11 @@ def transformer_decoder(P, pre, x, audio, mask_features, num_layers=9, num_heads
 
 
 # MaskFormerHead.layers                               meta_arch/mask_former_head.py:141-159
-def head_forward(P, pre, features, audio, enc_layers=6, dec_layers=9, return_intermediates=False):
+def head_forward(P, pre, features, audio, enc_layers=6, dec_layers=9, return_intermediates=False, attn_override=None):
     mf, _, ms = pixel_decoder_forward_features(P, pre + "pixel_decoder.", features, enc_layers)
     fv, fa = avfuse(P, pre + "fusion_module.", mf, audio)
     a256 = audio_mlp(P, pre + "audio_transformation.", fa)
-    out = transformer_decoder(P, pre + "predictor.", ms, a256, fv, dec_layers)
+    out = transformer_decoder(P, pre + "predictor.", ms, a256, fv, dec_layers, attn_override=attn_override)
     if return_intermediates:
         out["_inter"] = {"mask_features": mf, "multi_scale": ms, "fused_visual": fv, "fused_audio": fa, "audio256": a256}
     return out
@@ -436,18 +446,25 @@ def hungarian_matcher(pred_logits, pred_masks, targets, num_points=12544, rand=t
 # a15-a16  SetCriterion / SetCriterion_SS             modeling/criterion.py:121-287, criterion_ss.py:238-289
 # =====================================================================================================
 
-def uncertain_point_coords(src_masks, num_points, oversample_ratio, importance_sample_ratio, rand=torch.rand):
-    """detectron2 get_uncertain_point_coords_with_randomness with uncertainty = -|logit| (criterion.py:70-84,159-165)."""
+def uncertain_point_coords(src_masks, num_points, oversample_ratio, importance_sample_ratio, rand=torch.rand, topk_mask=None):
+    """detectron2 get_uncertain_point_coords_with_randomness with uncertainty = -|logit| (criterion.py:70-84,159-165).
+    topk_mask: bool [n, oversampled points] - test hook: the frozen top-k SETS of the reference (golden `*/topk_bits`) instead
+    of this function's own selection (the random stream is consumed identically; the order inside a set only changes the
+    summation order of the point losses)."""
     n = src_masks.shape[0]
     ns = int(num_points * oversample_ratio)
     pc = rand(n, ns, 2)
-    logits = point_sample(src_masks, pc)
-    unc = -logits.abs()
     nu = int(importance_sample_ratio * num_points)
     nr = num_points - nu
-    idx = torch.topk(unc[:, 0, :], k=nu, dim=1)[1]
-    idx = idx + ns * torch.arange(n, dtype=torch.long)[:, None]
-    pc = pc.view(-1, 2)[idx.view(-1)].view(n, nu, 2)
+    if topk_mask is not None:
+        assert topk_mask.shape == (n, ns) and bool((topk_mask.sum(1) == nu).all())
+        pc = pc[topk_mask].view(n, nu, 2)
+    else:
+        logits = point_sample(src_masks, pc)
+        unc = -logits.abs()
+        idx = torch.topk(unc[:, 0, :], k=nu, dim=1)[1]
+        idx = idx + ns * torch.arange(n, dtype=torch.long)[:, None]
+        pc = pc.view(-1, 2)[idx.view(-1)].view(n, nu, 2)
     if nr > 0:
         pc = torch.cat([pc, rand(n, nr, 2)], 1)
     return pc
@@ -465,13 +482,13 @@ def loss_labels(pred_logits, targets, indices, num_classes, eos_coef=0.1):
 
 
 def loss_masks(pred_masks, targets, indices, num_masks, num_points=12544, oversample=3.0, importance=0.75,
-               rand=torch.rand):
+               rand=torch.rand, topk_mask=None):
     """criterion.py:137-186 -> (loss_mask, loss_dice)"""
     src = torch.cat([pred_masks[b, s] for b, (s, _) in enumerate(indices)])  # [Nm,h,w]
     tgt = torch.cat([targets[b]["masks"][t] for b, (_, t) in enumerate(indices)]).to(src.dtype)
     src, tgt = src[:, None], tgt[:, None]
     with torch.no_grad():
-        pc = uncertain_point_coords(src, num_points, oversample, importance, rand)
+        pc = uncertain_point_coords(src, num_points, oversample, importance, rand, topk_mask)
         labels = point_sample(tgt, pc).squeeze(1)
     logits = point_sample(src, pc).squeeze(1)
     l_mask = F.binary_cross_entropy_with_logits(logits, labels, reduction="none").mean(1).sum() / num_masks  # :44-62
@@ -495,10 +512,13 @@ def similarity_loss(middle, n_frame=5):
 
 
 def set_criterion(outputs, targets, num_classes=2, gt_frame_index=None, world_size=1, rand=torch.rand,
-                  num_points=12544, n_frame=5):
+                  num_points=12544, n_frame=5, frozen=None):
     """SetCriterion.forward (criterion.py:233-287).  `gt_frame_index`: None -> S4 rule (frames 0,5,10,... when
     len(outputs) != len(targets), :241-254); a LongTensor -> AVSS rule (criterion_ss.py:246-257).
-    Returns the 39 un-weighted losses keyed like the reference."""
+    Returns the 39 un-weighted losses keyed like the reference.
+    frozen: test hook - {"match_src", "match_tgt": int64 [10, Nm], "topk": bool [10, Nm, oversampled points]}: the reference's
+    own discrete choices (golden `*/match_all_*`, `*/topk_bits`) replace the matcher's / the importance sampling's, so that a
+    gradient comparison is not at the mercy of a near-tie falling the other way."""
     def select(t):
         if gt_frame_index is not None:
             return t.index_select(0, gt_frame_index)
@@ -511,9 +531,16 @@ def set_criterion(outputs, targets, num_classes=2, gt_frame_index=None, world_si
     losses = {}
     for li, (lg, mk) in enumerate(layers):  # final first, then aux 0..8  (:259, :268-277)
         ind = hungarian_matcher(lg, mk, targets, num_points, rand)
+        topk_mask = None
+        if frozen is not None:
+            src, tgt = frozen["match_src"][li], frozen["match_tgt"][li]
+            sizes = [len(t["labels"]) for t in targets]
+            ind = list(zip(torch.split(torch.as_tensor(src, dtype=torch.int64), sizes),
+                           torch.split(torch.as_tensor(tgt, dtype=torch.int64), sizes)))
+            topk_mask = frozen["topk"][li]
         sfx = "" if li == 0 else f"_{li - 1}"
         losses["loss_ce" + sfx] = loss_labels(lg, targets, ind, num_classes)
-        lm, ld = loss_masks(mk, targets, ind, num_masks, num_points, rand=rand)
+        lm, ld = loss_masks(mk, targets, ind, num_masks, num_points, rand=rand, topk_mask=topk_mask)
         losses["loss_mask" + sfx] = lm
         losses["loss_dice" + sfx] = ld
     for i, mid in enumerate(outputs["middles_attn_mask"]):  # :282-286

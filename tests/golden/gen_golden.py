@@ -207,6 +207,10 @@ def gen_head_and_criterion(R):
     out["dec/attn_used_true_count"] = np.array([int(a.sum()) for a in rec["attn_live"]], dtype=np.int64)
     # packed bits of head#0's mask for frame 0, head 0  [100, 49]
     out["dec/attn0_bits"] = np.packbits(rec["attn"][0][0].numpy().astype(np.uint8))
+    # round 3: the masks of heads #0..#8 AS PRODUCED (before the row reset of :458), one copy of the 8 identical head
+    # replicas [BT,Q,hw], bit-packed - tests inject them to freeze the decoder's discrete choices
+    for i in range(9):
+        out[f"dec/attn_bits{i}"] = np.packbits(rec["attn"][i][::8].numpy().astype(np.uint8))
     assert len(pred["middles_attn_mask"]) == 9
     save("head.npz", out)
 
@@ -244,10 +248,15 @@ def gen_head_and_criterion(R):
     ]
     named = dict(head.named_parameters())
 
+    match_rec = []
+    matcher.register_forward_hook(lambda m, i, o: match_rec.append(o))
+
     for mode, cls in (("s4", R.SetCriterion), ("all", R.SetCriterion), ("ss", R.SetCriterion_SS)):
         criterion = mk(cls)
         torch.manual_seed(11)
         o = clone_outputs(pred)
+        del match_rec[:]
+        refshim.TOPK_RECORD = []
         if mode == "ss":
             gt_flag = torch.tensor([1, 0, 1, 1, 0])
             vid_flag = torch.ones(5)
@@ -258,6 +267,21 @@ def gen_head_and_criterion(R):
         else:
             targets = make_targets(mode)
             losses = criterion(o, targets)
+        # round 3: the discrete choices inside the criterion - Hungarian pairs of all 10 outputs (final first, then aux
+        # 0..8: the order of criterion.py:259-277; pairs frame by frame as _get_src_permutation_idx concatenates them) and
+        # the top-k sets of the importance sampling as bit masks over the 37 632 oversampled points of every matched mask
+        assert len(match_rec) == 10 and len(refshim.TOPK_RECORD) == 10
+        crit[f"{mode}/match_all_src"] = np.stack([np.concatenate([i.numpy() for i, _ in m]) for m in match_rec])
+        crit[f"{mode}/match_all_tgt"] = np.stack([np.concatenate([j.numpy() for _, j in m]) for m in match_rec])
+        n_over = int(12544 * 3.0)
+        bits = []
+        for idx in refshim.TOPK_RECORD:
+            chosen = torch.zeros(idx.shape[0], n_over, dtype=torch.bool)
+            chosen.scatter_(1, idx, True)
+            assert int(chosen.sum()) == idx.numel()
+            bits.append(np.packbits(chosen.numpy(), axis=1))
+        crit[f"{mode}/topk_bits"] = np.stack(bits)  # [10, Nm, 4704] uint8
+        refshim.TOPK_RECORD = None
         keys = sorted(losses.keys())
         assert len(keys) == 39, len(keys)
         crit[f"{mode}/keys"] = np.array(json.dumps(keys))

@@ -123,6 +123,9 @@ def point_sample(input, point_coords, **kwargs):
     return output
 
 
+TOPK_RECORD = None  # gen_golden.py sets this to a list: every call appends its chosen top-k indices [num_boxes, k]
+
+
 def get_uncertain_point_coords_with_randomness(coarse_logits, uncertainty_func, num_points, oversample_ratio, importance_sample_ratio):
     assert oversample_ratio >= 1
     assert 0 <= importance_sample_ratio <= 1
@@ -134,6 +137,8 @@ def get_uncertain_point_coords_with_randomness(coarse_logits, uncertainty_func, 
     num_uncertain_points = int(importance_sample_ratio * num_points)
     num_random_points = num_points - num_uncertain_points
     idx = torch.topk(point_uncertainties[:, 0, :], k=num_uncertain_points, dim=1)[1]
+    if TOPK_RECORD is not None:
+        TOPK_RECORD.append(idx.clone())
     shift = num_sampled * torch.arange(num_boxes, dtype=torch.long, device=coarse_logits.device)
     idx = idx + shift[:, None]
     point_coords = point_coords.view(-1, 2)[idx.view(-1), :].view(num_boxes, num_uncertain_points, 2)

@@ -148,6 +148,13 @@ def test_criterion_matches_reference(head_run, mode):
         losses = crit(o, targets)
     keys = json.loads(str(zc[f"{mode}/keys"]))
     assert sorted(losses.keys()) == keys
+    # index work, bit-exact: the device LSAP's Hungarian pairs of ALL 10 outputs (final first, then aux 0..8) equal the pairs
+    # scipy returned inside the reference's criterion (matcher.py:132-134), and the final layer's equal `match_src/_tgt`
+    src_q, tgt_g, _ = crit.last_indices
+    assert np.array_equal(src_q.cpu().numpy(), zc[f"{mode}/match_all_src"]), (src_q.cpu().numpy(), zc[f"{mode}/match_all_src"])
+    assert np.array_equal(tgt_g.cpu().numpy(), zc[f"{mode}/match_all_tgt"])
+    assert np.array_equal(src_q[0].cpu().numpy(), zc[f"{mode}/match_src"].reshape(-1))
+    assert np.array_equal(tgt_g[0].cpu().numpy(), zc[f"{mode}/match_tgt"].reshape(-1))
     got = np.array([float(losses[k]) for k in keys])
     np.testing.assert_allclose(got, zc[f"{mode}/values"], rtol=2e-3, atol=2e-4)
     total = sum(losses[k] * wd[k] for k in keys)
@@ -159,30 +166,99 @@ def test_criterion_matches_reference(head_run, mode):
     gi = list(feats.values()) + [audio] + [named[n] for n in grad_params]
     grads = torch.autograd.grad(total, gi, retain_graph=True, allow_unused=True)
     names = [f"feat.{k}" for k in feats] + ["feat.audio"] + grad_params
-    # Gradients pass through the 3-product bf16 backward GEMMs (2^-17 per product): every sampled entry within 2e-3 of the
-    # tensor's RMS + 2e-3 relative, for at most 0.2 % of the samples in S4 mode.  In the modes with ground truth on EVERY frame
-    # the comparison itself has a noise floor: the fp32 CPU oracle - which differs from the reference by re-association only -
-    # measured at THIS tolerance moves 1.2 % / 2.1 % (all / ss) of the sampled entries of sampling_offsets.weight and 8.6 % /
-    # 15.5 % of input_proj.0.0.weight (a bilinear tap that crosses a pixel boundary, a near-zero attention-mask cell or a top-k
-    # tie of the importance sampling that falls the other way changes a gradient row wholesale).  Which side of such an event
-    # an implementation lands on depends on its summation order: the HIP path measured 3.4 % / 0.07 % on sampling_offsets.weight
-    # with ATen's LayerNorm, 4.6 % with its own (two-pass variance), and then 7.7 % / 15.0 % on input_proj.0.0.weight - the
-    # oracle's numbers.
-    # Budget per entry: 1.25 x the oracle's measured floor (ORACLE_FLOOR, generated by running tests/test_oracle_golden.py's
-    # gradient check at rtol = atol/RMS = 2e-3), at least 6 %.
-    ORACLE_FLOOR = {"all/grad/feat.res3": 0.0034, "all/grad/feat.res4": 0.0071, "all/grad/feat.res5": 0.0095,
-                    "all/grad/pixel_decoder.transformer.encoder.layers.0.self_attn.sampling_offsets.weight": 0.012,
-                    "all/grad/pixel_decoder.input_proj.0.0.weight": 0.0862,
-                    "ss/grad/feat.res3": 0.0042, "ss/grad/feat.res4": 0.0088, "ss/grad/feat.res5": 0.0144,
-                    "ss/grad/pixel_decoder.transformer.encoder.layers.0.self_attn.sampling_offsets.weight": 0.0208,
-                    "ss/grad/pixel_decoder.input_proj.0.0.weight": 0.1548}
+    # Un-frozen run: the product makes ALL its own discrete choices (attention-mask bits, Hungarian pairs, top-k point sets).
+    # S4 mode: every gradient within 2e-3 of the tensor's RMS + 2e-3 relative for >= 99.8 % of the samples.  In the modes with
+    # ground truth on every frame a single near-tie that falls the other way moves a whole gradient row, so here only the
+    # energy of the error is bounded (relative L2 <= 5e-2, no entry beyond 1 RMS); the TIGHT comparison of those modes is
+    # test_criterion_gradients_with_the_references_choices_frozen below.
     worst = []
     for n, g in zip(names, grads):
         d = synth.unpack(f"{mode}/grad/{n}", zc)
         scale = float(d["l2"]) / max(np.sqrt(float(d["numel"])), 1.0)
-        budget = 0.002 if mode == "s4" else max(0.06, 1.25 * ORACLE_FLOOR.get(f"{mode}/grad/{n}", 0.0))
         try:
-            synth.check_digest(g.cpu(), d, f"{mode}/grad/{n}", rtol=2e-3, atol=2e-3 * scale + 1e-9, frac_bad=budget)
+            if mode == "s4":
+                synth.check_digest(g.cpu(), d, f"{mode}/grad/{n}", rtol=2e-3, atol=2e-3 * scale + 1e-9, frac_bad=0.002)
+            else:
+                synth.check_digest_l2(g.cpu(), d, f"{mode}/grad/{n}", rel_l2=5e-2, cap_rms=1.0)
+        except AssertionError as e:
+            worst.append(str(e))
+    assert not worst, worst
+
+
+# gradients downstream of MSDeformAttn's bilinear taps (encoder layer 0's offsets, the 7x7 level's projection, the inputs)
+PIXEL_BOUNDARY = ("feat.res3", "feat.res4", "feat.res5", "pixel_decoder.input_proj.0.0.weight",
+                  "pixel_decoder.transformer.encoder.layers.0.self_attn.sampling_offsets.weight")
+
+
+@pytest.fixture(scope="module")
+def head_run_frozen(head_run):
+    """The same forward with the reference's own 9 attention masks injected (head.npz `dec/attn_bits*`)."""
+    from combo_avs_amd.ops import masklogit
+    z, head, feats, audio, _ = head_run
+    head.predictor.attn_mask_override = [masklogit.pack_mask(m.cuda()) for m in synth.frozen_attn_masks(z)]
+    try:
+        out = head(dict(feats), audio)
+        torch.cuda.synchronize()
+    finally:
+        head.predictor.attn_mask_override = None
+    return z, head, feats, audio, out
+
+
+def test_pack_mask_equals_the_mask_kernel(head_run):
+    """ops.masklogit.pack_mask (the injection helper) writes what csrc/attnmask.hip writes for the same decisions"""
+    from combo_avs_amd.ops import masklogit
+    z, head, feats, audio, out = head_run
+    m = out["aux_outputs"][3]["pred_masks"].detach().contiguous()
+    for tgt in ((7, 7), (14, 14), (28, 28)):
+        ker = masklogit.attn_mask_padded(m, tgt, True)
+        raw = masklogit.attn_mask_padded(m, tgt, False)
+        n = tgt[0] * tgt[1]
+        inj = masklogit.pack_mask(raw.bytes[:, :, :n].view(torch.bool), True)
+        assert torch.equal(inj.bytes, ker.bytes) and torch.equal(inj.bits, ker.bits)
+
+
+@pytest.mark.parametrize("mode", ["s4", "all", "ss"])
+def test_criterion_gradients_with_the_references_choices_frozen(head_run_frozen, mode):
+    """Gradients of the weighted 39-term loss against the reference's with the reference's own discrete choices injected on
+    the HIP path: the 9 attention masks (decoder.attn_mask_override), the Hungarian pairs of all 10 outputs and the top-k sets
+    of the importance sampling (criterion.frozen_choices).  What is left is arithmetic: NO outlier budget beyond 0.2 % at
+    2e-3 for every gradient that does not pass through the deformable encoder's bilinear taps, and an energy bound for the
+    five that do (synth.check_digest_l2; the CPU oracle measures rel. L2 <= 2.7e-3, worst entry 0.11 RMS on the same vectors -
+    tests/test_oracle_golden.py - the bound here leaves 4x for the 3-product bf16 gradient GEMMs)."""
+    z, head, feats, audio, out = head_run_frozen
+    zc = np.load(os.path.join(G, "criterion.npz"))
+    crit, wd = make_criterion(mode)
+    crit.frozen_choices = synth.frozen_criterion_choices(zc, mode)
+    o = {"pred_logits": out["pred_logits"], "pred_masks": out["pred_masks"], "_logits_all": out["_logits_all"],
+         "aux_outputs": [dict(a) for a in out["aux_outputs"]], "middles_attn_mask": list(out["middles_attn_mask"])}
+    torch.manual_seed(11)
+    if mode == "ss":
+        gt_flag = torch.from_numpy(zc["ss/gt_flag"])
+        t_all = gen_inputs.make_targets("all")
+        targets = [{k: v.cuda() for k, v in t_all[i].items()} for i in range(5) if gt_flag[i] == 1]
+        o.pop("_logits_all")
+        losses = crit(o, targets, torch.ones(5).cuda(), gt_flag.cuda())
+    else:
+        targets = [{k: v.cuda() for k, v in t.items()} for t in gen_inputs.make_targets(mode)]
+        losses = crit(o, targets)
+    keys = json.loads(str(zc[f"{mode}/keys"]))
+    got = np.array([float(losses[k]) for k in keys])
+    np.testing.assert_allclose(got, zc[f"{mode}/values"], rtol=1e-3, atol=1e-4)
+    total = sum(losses[k] * wd[k] for k in keys)
+    grad_params = json.loads(str(zc["grad_params"]))
+    named = dict(head.named_parameters())
+    gi = list(feats.values()) + [audio] + [named[n] for n in grad_params]
+    grads = torch.autograd.grad(total, gi, retain_graph=True, allow_unused=True)
+    names = [f"feat.{k}" for k in feats] + ["feat.audio"] + grad_params
+    worst = []
+    for n, g in zip(names, grads):
+        d = synth.unpack(f"{mode}/grad/{n}", zc)
+        scale = float(d["l2"]) / max(np.sqrt(float(d["numel"])), 1.0)
+        try:
+            if n in PIXEL_BOUNDARY:
+                synth.check_digest_l2(g.cpu(), d, f"{mode}/grad/{n}", rel_l2=1e-2, cap_rms=0.3)
+            else:
+                synth.check_digest(g.cpu(), d, f"{mode}/grad/{n}", rtol=2e-3, atol=2e-3 * scale + 1e-9, frac_bad=0.002)
         except AssertionError as e:
             worst.append(str(e))
     assert not worst, worst

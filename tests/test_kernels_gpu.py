@@ -239,6 +239,32 @@ def test_device_lsap_equals_scipy(G):
             assert dict(zip(c.tolist(), r.tolist())) == dict(zip(range(g), rows.tolist()))
 
 
+def test_device_lsap_surfaces_non_finite_costs_and_too_many_targets():
+    """scipy.optimize.linear_sum_assignment raises ValueError on NaN / Inf costs (matcher.py:133).  The device solver keeps
+    returning valid, distinct rows (no out-of-range index can reach the mask-loss gathers) AND sets a status bit that
+    HungarianMatcher.check_status turns into that ValueError."""
+    import numpy as np
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.modeling.matcher import HungarianMatcher
+    m = HungarianMatcher(1, 1, 1, 16)
+    rng = np.random.default_rng(0)
+    cost = rng.standard_normal((4, 100, 3)).astype(np.float32)
+    gcount = torch.full((4,), 3, dtype=torch.int32).cuda()
+    got = m.solve_device(torch.from_numpy(cost).cuda(), gcount)
+    m.check_status()  # clean
+    cost[2, 17, 1] = np.nan
+    cost[3, :, 0] = np.inf
+    got = m.solve_device(torch.from_numpy(cost).cuda(), gcount).cpu().numpy()
+    assert ((got >= 0) & (got < 100)).all() and all(len(set(r.tolist())) == 3 for r in got)
+    with pytest.raises(ValueError, match="invalid numeric entries"):
+        m.check_status()
+    m.check_status()  # the word is cleared once reported
+    gcount[1] = 5  # more targets than the padded width
+    m.solve_device(torch.from_numpy(np.nan_to_num(cost, posinf=1.0)).cuda(), gcount)
+    with pytest.raises(ValueError, match="more than"):
+        m.check_status()
+
+
 def test_backbone_fused_epilogue_matches_unfused_bf16():
     """ResNet forward/backward with the folded weights + fused bias/residual/ReLU epilogue (csrc/biasact.hip) against
     the per-convolution torch path (conv + FrozenBN affine + relu) under the same bf16 autocast."""

@@ -195,9 +195,66 @@ def test_criterion_losses_and_grads(head_run, mode):
         # with ground truth on every frame up to 1.6 % of the sampled gradient entries of the 7x7-level parameters move by more
         # than 5e-3 of the tensor's RMS (s4: none) - a near-zero attention-mask cell or a top-k tie of the importance
         # sampling that falls the other way changes one query's gradient wholesale.  The GPU tests inherit this floor.
-        synth.check_digest(g, d, f"{mode}/grad/{n}", rtol=5e-3, atol=5e-3 * scale + 1e-9, frac_bad=0.01 if mode == "s4" else 0.03)
+        # The 3 % allowance applies ONLY to the tensor where that noise was measured (input_proj.0.0.weight: 0.56 % / 1.56 %);
+        # everything else stays at 1 % (measured <= 0.46 %).  The frozen-choices test below removes the noise altogether.
+        noisy = mode != "s4" and n == "pixel_decoder.input_proj.0.0.weight"
+        synth.check_digest(g, d, f"{mode}/grad/{n}", rtol=5e-3, atol=5e-3 * scale + 1e-9, frac_bad=0.03 if noisy else 0.01)
     for p in grad_params:
         P[p].requires_grad_(False)
+
+
+# gradients downstream of MSDeformAttn's bilinear taps (encoder layer 0's offsets, the 7x7 level's projection, the inputs)
+PIXEL_BOUNDARY = ("feat.res3", "feat.res4", "feat.res5", "pixel_decoder.input_proj.0.0.weight",
+                  "pixel_decoder.transformer.encoder.layers.0.self_attn.sampling_offsets.weight")
+
+
+@pytest.mark.parametrize("mode", ["s4", "all", "ss"])
+def test_criterion_grads_with_the_references_discrete_choices_frozen(head_run, mode):
+    """The same gradient comparison with the reference's own discrete choices injected - the 9 attention masks
+    (`dec/attn_bits*`), the Hungarian pairs of all 10 outputs (`*/match_all_*`) and the top-k sets of the importance sampling
+    (`*/topk_bits`).  What remains is floating-point re-association: NO outlier budget at 2e-3 for the gradients that do not
+    pass through the deformable encoder's bilinear sampling, and an energy bound (synth.check_digest_l2: relative L2 error
+    <= 1e-2, no entry beyond 0.3 RMS) for the four that do - a tap within round-off of a pixel boundary is the one discrete
+    event that cannot be injected (measured with everything else frozen: the 8.6 % / 15.5 % "outliers" of
+    input_proj.0.0.weight are 2-3 such taps, each moving thousands of entries by ~1e-3 of the RMS; relative L2 error 1.9e-3)."""
+    import gen_inputs
+    z, P, feats, audio, out = head_run
+    zc = load("criterion.npz")
+    grad_params = json.loads(str(zc["grad_params"]))
+    for p in grad_params:
+        P[p].requires_grad_(True)
+    try:
+        out2 = O.head_forward(P, "", feats, audio, attn_override=synth.frozen_attn_masks(z))
+        fr = synth.frozen_criterion_choices(zc, mode)
+        torch.manual_seed(11)
+        if mode == "ss":
+            gt_flag = torch.from_numpy(zc["ss/gt_flag"])
+            t_all = gen_inputs.make_targets("all")
+            targets = [t_all[i] for i in range(5) if gt_flag[i] == 1]
+            losses = O.set_criterion(out2, targets, 2, gt_frame_index=torch.where(gt_flag == 1)[0], frozen=fr)
+        else:
+            targets = gen_inputs.make_targets(mode)
+            losses = O.set_criterion(out2, targets, 2, frozen=fr)
+        keys = json.loads(str(zc[f"{mode}/keys"]))
+        got = np.array([float(losses[k]) for k in keys])
+        np.testing.assert_allclose(got, zc[f"{mode}/values"], rtol=5e-4, atol=2e-5)
+        wd = O.loss_weights()
+        total = sum(losses[k] * wd[k] for k in keys)
+        gi = list(feats.values()) + [audio] + [P[p] for p in grad_params]
+        grads = torch.autograd.grad(total, gi, allow_unused=True)
+        names = [f"feat.{k}" for k in feats] + ["feat.audio"] + grad_params
+        for n, g in zip(names, grads):
+            d = synth.unpack(f"{mode}/grad/{n}", zc)
+            scale = float(d["l2"]) / max(np.sqrt(float(d["numel"])), 1.0)
+            # measured (oracle vs reference): 0.000 % outliers for every tensor that is not downstream of the deformable
+            # encoder's sampling; relative L2 error <= 2.7e-3 and worst entry <= 0.11 RMS for those that are (PIXEL_BOUNDARY)
+            if n in PIXEL_BOUNDARY:
+                synth.check_digest_l2(g, d, f"{mode}/grad/{n}", rel_l2=1e-2, cap_rms=0.3)
+            else:
+                synth.check_digest(g, d, f"{mode}/grad/{n}", rtol=2e-3, atol=2e-3 * scale + 1e-9, frac_bad=0.002)
+    finally:
+        for p in grad_params:
+            P[p].requires_grad_(False)
 
 
 # ---------------------------------------------------------------------------------------- plain-C core-op oracle

@@ -2,7 +2,7 @@
 # HBM traffic (and MFMA / LDS counters) of the head's instrumented kernels inside the BENCH step, per launch, as
 # MI355X_MICROARCH.md prescribes: separate rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit together), kernel trace
 # only; FETCH_SIZE is doubled (gfx950 counts 128-B requests of wide coalesced reads at 64 B).  The step runs eagerly
-# (--no-graph) so that every launch is its own dispatch record.  Writes gpurun_out/r02_pmc.json, stamped with $COMBO_COMMIT;
+# (--no-graph) so that every launch is its own dispatch record.  Writes gpurun_out/r03_pmc.json, stamped with $COMBO_COMMIT;
 # copy it to profiles/ - bench.py reports its numbers in `roofline.traffic`.
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_bench.txt
@@ -16,7 +16,7 @@ agg=collections.defaultdict(lambda: collections.defaultdict(list))
 if fs:
     for r in csv.DictReader(open(fs[0])):
         n=r["Kernel_Name"]
-        m=re.search(r"(gemm_nt_f32_kernel|gemm_smallm_kernel|gemm_nt2_kernel|gemm_tn_grouped_kernel|gemm_tn_glds_kernel|conv3x3_wgrad_kernel|attn_fwd_kernel|attn_bwd_dq_kernel|attn_bwd_dkv_kernel|msda_fwd_tap_d32|msda_bwd_value_lds_d32|msda_bwd_locw_lds_d32|bifuse_\w+|add_ln_fwd_kernel|ln_bwd_kernel|presplit_kernel)", n)
+        m=re.search(r"(gemm_nt_f32_kernel|gemm_smallm_kernel|gemm_nt2_kernel|gemm_tn_grouped_kernel|gemm_tn_glds_kernel|conv3x3_wgrad_kernel|attn_fwd_kernel|attn_bwd_dq_kernel|attn_bwd_dkv_kernel|msda_fwd_tap_d32|msda_bwd_\w+|bifuse_\w+|add_ln_fwd_kernel|ln_bwd_kernel|presplit_kernel)", n)
         if m: agg[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k,v in sorted(agg.items()):
     print("PMC", k, {c: [round(sum(x)/len(x),1), len(x)] for c,x in v.items()})
@@ -24,8 +24,10 @@ PY
   rm -rf /tmp/pmc
 done
 python3 - <<PY
-import ast, json, os
-out={"commit": os.environ.get("COMBO_COMMIT","unknown"), "frames_per_launch": 40,
+import ast, json, os, sys
+sys.path.insert(0, "$GRAFT_REPO_ROOT")
+import bench
+out={"commit": os.environ.get("COMBO_COMMIT","unknown"), "csrc_sha256": bench.csrc_digest(), "frames_per_launch": 40,
      "command": "rocprofv3 --pmc <set> --kernel-trace -- python3 bench.py --no-graph --steps 2 --warmup 1 (tools/pmc_bench.sh); FETCH_SIZE x 2 (gfx950), KiB"}
 for line in open("$OUT"):
     if not line.startswith("PMC "): continue
@@ -37,6 +39,6 @@ for line in open("$OUT"):
 for name,rec in out.items():
     if isinstance(rec, dict) and "FETCH_SIZE" in rec and "WRITE_SIZE" in rec:
         rec["hbm_bytes_per_launch"]=int((2.0*rec["FETCH_SIZE"]+rec["WRITE_SIZE"])*1024)
-json.dump(out, open(os.path.join("$GRAFT_REPO_ROOT","gpurun_out","r02_pmc.json"),"w"), indent=1)
+json.dump(out, open(os.path.join("$GRAFT_REPO_ROOT","gpurun_out","r03_pmc.json"),"w"), indent=1)
 print(json.dumps({k:(v.get("hbm_bytes_per_launch") if isinstance(v,dict) else v) for k,v in out.items()}))
 PY
