@@ -50,6 +50,41 @@ def test_training_forward_matches_cpu_oracle(setup):
     model.criterion.point_source = None
 
 
+def test_training_forward_bs8_matches_cpu_oracle(setup):
+    """BASELINE configs[1] at its size: 8 clips x 5 frames (BT = 40) through the whole model - every LDS-path kernel at the
+    benchmarked batch, and the audio scramble `(q * BT + b) // Q` of transformer_decoder.py:437 at BT = 40 (it depends on the
+    per-GPU batch; the golden vectors pin it at BT = 5) - against the CPU oracle's forward on the same weights / inputs with
+    the random points replayed: all 39 losses."""
+    from bench import synth_batch
+    from oracle import combo_oracle as O
+    cfg, model, P, _ = setup
+    batch = synth_batch(8, 5, 224, 224, "cpu", seed=13)
+    model.train()
+    model.sem_seg_head.fusion_module.b_attn.attn_list[0].dropout = 0.0  # oracle has no dropout stream (SURVEY fact 5)
+    model.criterion.point_source = lambda n, p: torch.rand(n, p, 2).cuda()
+    try:
+        torch.manual_seed(22)
+        gpu_batch = [{k: (v.cuda() if torch.is_tensor(v) else [{kk: vv.cuda() for kk, vv in i.items()} for i in v])
+                      for k, v in b.items()} for b in batch]
+        with torch.no_grad():
+            losses = model(gpu_batch)
+        torch.manual_seed(22)
+        with torch.no_grad():
+            ref = O.maskformer_forward(P, batch, num_classes=2, training=True)
+    finally:
+        model.criterion.point_source = None
+    assert sorted(losses) == sorted(ref) and len(losses) == 39
+    for k in sorted(ref):
+        a, b = float(losses[k]), float(ref[k])
+        assert abs(a - b) <= 5e-3 * abs(b) + 5e-3, (k, a, b)
+    # the scramble rule itself at BT = 40: query q of frame b carries the audio of frame (q * 40 + b) // 100
+    dec = model.sem_seg_head.predictor
+    a = torch.arange(40, dtype=torch.float32, device="cuda").view(40, 1, 1).expand(40, 1, 4).contiguous()
+    got = dec.scramble_audio(a, 40)[..., 0].cpu()
+    q, b = torch.arange(100)[None, :], torch.arange(40)[:, None]
+    assert torch.equal(got, torch.div(q * 40 + b, 100, rounding_mode="floor").float())
+
+
 def test_eval_output_contract(setup):
     cfg, model, P, batch = setup
     model.eval()
@@ -168,3 +203,57 @@ def test_ms3_ten_frame_clips_train_graphed():
         losses = step(batch)
     torch.cuda.synchronize()
     assert all(torch.isfinite(v) for v in losses.values()) and torch.isfinite(opt.flat_param).all()
+
+
+def _full_size_steps(yaml, clips, T, HW, K, avss, opts=(), graphed=True):
+    sys.path.insert(0, ROOT)
+    import combo_avs_amd  # noqa: F401
+    from bench import synth_batch
+    from combo_avs_amd import combo_cfg
+    from combo_avs_amd.meta_arch import build_model
+    from combo_avs_amd.trainer import FlatAdamW, GraphedTrainStep, train_step
+    cfg = combo_cfg(os.path.join(ROOT, "configs", yaml), opts=opts)
+    torch.manual_seed(0)
+    model = build_model(cfg).cuda().train()
+    model.backbone_dtype = torch.bfloat16
+    opt = FlatAdamW(model, base_lr=1e-4, weight_decay=0.05, backbone_multiplier=0.1, clip_value=0.01)
+    batch = synth_batch(clips, T, HW, HW, "cuda", seed=8, K=K, gt="all", avss=avss)
+    before = opt.flat_param.clone()
+    losses = train_step(model, opt, batch)
+    torch.cuda.synchronize()
+    assert len(losses) == 39 and all(torch.isfinite(v) for v in losses.values()), losses
+    moved = (opt.flat_param - before).abs().max().item()
+    assert 0 < moved <= 1.2e-4 and bool(torch.isfinite(opt.flat_param).all())  # |AdamW step| <= lr at step 1
+    first = {k: float(v) for k, v in losses.items()}
+    if graphed:
+        step = GraphedTrainStep(model, opt)
+        for _ in range(2):
+            losses = step(batch)
+        torch.cuda.synchronize()
+        assert step.graphs, "the step was not captured"
+    else:
+        losses = train_step(model, opt, batch)
+        torch.cuda.synchronize()
+    assert all(torch.isfinite(v) for v in losses.values()) and bool(torch.isfinite(opt.flat_param).all())
+    # same batch, three optimiser steps later: the weighted total must not have exploded (lr 1e-4, clip 0.01)
+    tot0, tot1 = sum(first.values()), sum(float(v) for v in losses.values())
+    assert tot1 <= 1.5 * tot0 + 1.0, (tot0, tot1)
+    model.criterion.matcher.check_status()
+    return model
+
+
+def test_configs3_avss_512_full_size_step():
+    """BASELINE configs[3] AT ITS SIZE: COMBO-PVTv2-B5 AVSS, 8 clips x 10 frames x 512 x 512, K = 71, 1-4 instances per frame
+    (BT = 80, encoder S = 5376: MSDeformAttn on the windowed / generic kernels, 128 x 128 mask maps, 64 x 64 attention level):
+    two eager training steps (AVSS batches select frames by flag VALUES: not graph material) - 39 finite losses, every
+    parameter moves by at most the learning rate, no non-finite matching cost.  The core op's adjoint identities at this
+    size are in test_msda_gpu.py::test_512_shape_bt80_full_size_properties_all_three_gradients."""
+    model = _full_size_steps("avs_ss/COMBO_PVTV2B5_bs8_90k.yaml", clips=8, T=10, HW=512, K=71, avss=True, graphed=False)
+    assert model.is_avss_data and type(model.criterion).__name__ == "SetCriterion_SS"
+
+
+def test_configs4_ms3_ten_frames_four_clips_full_size_steps():
+    """BASELINE configs[4] per-GPU share AT ITS SIZE: COMBO-PVTv2-B5 MS3, 4 clips x 10 frames x 224 x 224 (32 clips over 8
+    GPUs), every frame annotated: one eager step, then two replays of the captured hipGraph."""
+    _full_size_steps("avs_ms3/COMBO_PVTV2B5_bs8_20k.yaml", clips=4, T=10, HW=224, K=2, avss=False,
+                     opts=("MODEL.FUSE_CONFIG.NUM_FRAMES", 10))

@@ -157,6 +157,18 @@ def test_large_level_generic_path_512():
     torch.testing.assert_close(out, ref.detach(), rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(gv, rg[0], rtol=1e-4, atol=2e-5)
     torch.testing.assert_close(gw, rg[2], rtol=1e-4, atol=2e-5)
+    assert_grad_loc_close(gl, rg[1], loc.detach(), shapes)  # the gather-only loc / w kernel of the windowed backward
+
+
+def assert_grad_loc_close(gl, ref, loc, shapes, rtol=1e-3, atol=2e-4, border=1e-4):
+    """grad_sampling_loc against the oracle's; d/dloc jumps where a sample sits on a pixel border, so samples within
+    `border` pixels of one are left out (counted: they must stay a negligible fraction)."""
+    wh = torch.tensor([[w, h] for h, w in shapes], dtype=loc.dtype)[None, None, None, :, None, :]
+    px = loc * wh - 0.5
+    near = ((px - px.round()).abs() < border).any(-1, keepdim=True).expand_as(gl)
+    assert near.float().mean().item() < 1e-2
+    bad = ((gl - ref).abs() > atol + rtol * ref.abs()) & ~near
+    assert not bool(bad.any()), (int(bad.sum()), float(((gl - ref).abs() * (~near)).max()))
 
 
 def test_512_shape_bs8_oracle_at_b2_and_properties_at_full_size():
@@ -174,6 +186,7 @@ def test_512_shape_bs8_oracle_at_b2_and_properties_at_full_size():
     torch.testing.assert_close(out[:2], ref.detach(), rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(gv[:2], rg[0], rtol=1e-4, atol=2e-5)
     torch.testing.assert_close(gw[:2], rg[2], rtol=1e-4, atol=2e-5)
+    assert_grad_loc_close(gl[:2], rg[1], loc[:2], shapes)
     vb = synth.synth_tensor("big8.v2", tuple(v.shape), 0)
     o2 = run_hip(vb, shapes, loc, w)[0]
     o12 = run_hip(2.0 * v + 3.0 * vb, shapes, loc, w)[0]
@@ -181,6 +194,44 @@ def test_512_shape_bs8_oracle_at_b2_and_properties_at_full_size():
     lhs = (out.double() * g.double()).sum().item()
     rhs = (v.double() * gv.double()).sum().item()
     assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0) + 1e-2
+
+
+def test_512_shape_bt80_full_size_properties_all_three_gradients():
+    """BASELINE configs[3] at its size: 8 clips x 10 frames = BT 80, S = 5376 (the windowed fixed-point grad_value kernel +
+    the gather-only loc / w kernel).  The op is bilinear in (value, attention weight), so for ANY second weight tensor w2 and
+    value v2:   <out(v, loc, w2), g> == <w2, grad_w>   and   <out(v2, loc, w), g> == <v2, grad_value>   (exact adjoint
+    identities of grad_w / grad_value at full size); grad_loc: central difference of <out, g> along a random direction of the
+    sampling locations; frames 0 and 79 against the CPU oracle (forward + all three gradients)."""
+    shapes = ((16, 16), (32, 32), (64, 64))
+    B = 80
+    v, shapes, loc, w = prod_inputs(B=B, shapes=shapes, seed_tag="big80")
+    g = synth.synth_tensor("big80.g", (B, 5376, 256), 0)
+    out, gv, gl, gw = run_hip(v, shapes, loc, w, g)
+    assert all(bool(torch.isfinite(t).all()) for t in (out, gv, gl, gw))
+    for f in (0, 79):
+        v1, l1, w1 = (t[f:f + 1].clone().requires_grad_(True) for t in (v, loc, w))
+        ref = O.ms_deform_attn_core(v1, shapes, l1, w1)
+        rg = torch.autograd.grad(ref, (v1, l1, w1), g[f:f + 1])
+        torch.testing.assert_close(out[f:f + 1], ref.detach(), rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(gv[f:f + 1], rg[0], rtol=1e-4, atol=2e-5)
+        torch.testing.assert_close(gw[f:f + 1], rg[2], rtol=1e-4, atol=2e-5)
+        assert_grad_loc_close(gl[f:f + 1], rg[1], loc[f:f + 1], shapes)
+    gd = g.double()
+    v2 = synth.synth_tensor("big80.v2", tuple(v.shape), 0)
+    w2 = synth.synth_tensor("big80.w2", tuple(w.shape), 0)
+    lhs = (run_hip(v2, shapes, loc, w)[0].double() * gd).sum().item()
+    rhs = (v2.double() * gv.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), 1.0) + 1e-2, (lhs, rhs)
+    lhs = (run_hip(v, shapes, loc, w2)[0].double() * gd).sum().item()
+    rhs = (w2.double() * gw.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), 1.0) + 1e-2, (lhs, rhs)
+    # grad_loc: directional derivative, step 2e-3 pixels of the finest level (second-order error; border crossings are rare)
+    d = synth.synth_tensor("big80.dir", tuple(loc.shape), 0)
+    eps = 2e-3 / 64
+    fp = (run_hip(v, shapes, loc + eps * d, w)[0].double() * gd).sum().item()
+    fm = (run_hip(v, shapes, loc - eps * d, w)[0].double() * gd).sum().item()
+    fd, an = (fp - fm) / (2 * eps), (d.double() * gl.double()).sum().item()
+    assert abs(fd - an) <= 2e-2 * max(abs(fd), abs(an)) + 1.0, (fd, an)
 
 
 def test_error_behaviour():
