@@ -30,6 +30,8 @@ _SIGNATURES = {
     "combo_msda_forward_f64": [c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_int, c_void_p],
     "combo_msda_backward_f32": [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 3 + [c_int, c_void_p],
     "combo_msda_backward_f64": [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 3 + [c_int, c_void_p],
+    "combo_msda_backward_win_ok": [c_void_p, c_int, c_int, c_int, c_int],
+    "combo_msda_backward_win_f32": [c_void_p] * 6 + [c_int] * 7 + [c_void_p] * 3 + [c_void_p],
     "combo_event_create": [c_void_p],
     "combo_event_record": [c_void_p, c_void_p, c_int],
     "combo_event_elapsed_us": [c_void_p, c_void_p, c_void_p],

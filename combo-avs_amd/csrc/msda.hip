@@ -556,8 +556,9 @@ __global__ void __launch_bounds__(kBwdVThreads)
 msda_bwd_value_lds_d32(const float* __restrict__ gout, const int64_t* __restrict__ shapes,
                        const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ aw,
                        int B, int S_all, int M, int L, int Lq, int P, int mult, float* __restrict__ gvalue, int n_parts,
-                       int rows_per_part) {
+                       int rows_per_part, unsigned long long* __restrict__ ts) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  combo_ts_begin(ts);
   constexpr int D = 32, HD = 16, NW = kBwdVThreads / 64;
   // window of the flattened pyramid this workgroup accumulates (n_parts == 1: all of it)
   const int part = WIN ? xcd_remap(blockIdx.x, gridDim.x) / 2 % n_parts : 0;
@@ -652,14 +653,16 @@ msda_bwd_value_lds_d32(const float* __restrict__ gout, const int64_t* __restrict
           make_float4((float)v.x * f * mxc[0], (float)v.y * f * mxc[1], (float)v.z * f * mxc[2], (float)v.w * f * mxc[3]);
     }
   }
+  combo_ts_end(ts);
 }
 
 __global__ void __launch_bounds__(768)
 msda_bwd_locw_lds_d32(const float* __restrict__ gout, const float* __restrict__ value,
                       const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
                       const float* __restrict__ loc, const float* __restrict__ aw, int B, int S, int M, int L, int Lq,
-                      int P, int QT, float* __restrict__ gloc, float* __restrict__ gaw) {
+                      int P, int QT, float* __restrict__ gloc, float* __restrict__ gaw, unsigned long long* __restrict__ ts) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  combo_ts_begin(ts);
   constexpr int D = 32;
   float* slab = reinterpret_cast<float*>(smem);
   const int LP = L * P;
@@ -781,6 +784,7 @@ msda_bwd_locw_lds_d32(const float* __restrict__ gout, const float* __restrict__ 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
+  combo_ts_end(ts);
 }
 
 inline int grid_for(long long total, int block) {
@@ -1150,14 +1154,18 @@ int msda_backward(const T* gout, const T* value, const int64_t* shapes, const in
       auto gcd = [](int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; };
       while (gcd(mult, Lq) != 1) ++mult;
       hipLaunchKernelGGL(msda_bwd_value_lds_d32<false>, dim3(B * M * 2), dim3(kBwdVThreads), bwd_value_lds_bytes(S), stream,
-                         gout, shapes, lsi, loc, aw, B, S, M, L, Lq, P, mult, gv, 1, S);
+                         gout, shapes, lsi, loc, aw, B, S, M, L, Lq, P, mult, gv, 1, S,
+                         // algorithmic bytes of the PAIR of kernels (value, grad_out, loc, w once; three gradients once) on
+                         // the first slot, 0 on the second: the per-kind sums give the pair's rate
+                         combo_timing_next_slot(COMBO_TS_MSDA_BWD, 4.0 * B * (2.0 * ((double)S + Lq) * M * D + 6.0 * (double)Lq * M * L * P)));
       hipError_t e1 = hipGetLastError();
       if (e1 != hipSuccess) return (int)e1;
       const int nw = fwd_lds_bytes(S, L, P, 12) <= kLdsLimit ? 12 : 8;
       int QT = 1;
       while ((long long)B * M * QT < 1024 && QT < 8 && Lq / (QT * 2) >= nw * kQW) QT *= 2;
       hipLaunchKernelGGL(msda_bwd_locw_lds_d32, dim3(B * M * QT), dim3(nw * 64), fwd_lds_bytes(S, L, P, nw), stream,
-                         gout, value, shapes, lsi, loc, aw, B, S, M, L, Lq, P, QT, gl, gw);
+                         gout, value, shapes, lsi, loc, aw, B, S, M, L, Lq, P, QT, gl, gw,
+                         combo_timing_next_slot(COMBO_TS_MSDA_BWD, 0.0));
       return (int)hipGetLastError();
     }
   }
@@ -1176,7 +1184,7 @@ int msda_backward(const T* gout, const T* value, const int64_t* shapes, const in
       auto gcd = [](int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; };
       while (gcd(mult, Lq) != 1) ++mult;
       hipLaunchKernelGGL(msda_bwd_value_lds_d32<true>, dim3(B * M * 2 * n_parts), dim3(kBwdVThreads), bwd_value_lds_bytes(rows), stream,
-                         gout, shapes, lsi, loc, aw, B, S, M, L, Lq, P, mult, gv, n_parts, rows);
+                         gout, shapes, lsi, loc, aw, B, S, M, L, Lq, P, mult, gv, n_parts, rows, (unsigned long long*)nullptr);
       hipError_t e1 = hipGetLastError();
       if (e1 != hipSuccess) return (int)e1;
       launch_bwd_generic<T, 8, false>(gout, value, shapes, lsi, loc, aw, B, S, M, D, L, Lq, P, gv, gl, gw, stream);

@@ -177,6 +177,8 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
             normalizer = torch.tensor([[w, h] for h, w in shapes_list], dtype=torch.float32, device=device)
             g = (spatial_shapes, level_start_index, ref, normalizer)
             self._geom[key] = g
+            from .. import msda
+            msda.register_level_shapes(spatial_shapes, shapes_list)  # host copy for the fused backward (no sync)
         return g
 
     def forward(self, srcs, pos_embeds):

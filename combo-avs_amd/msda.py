@@ -17,6 +17,42 @@ from . import _lib
 ALGO_AUTO, ALGO_GENERIC, ALGO_LDS, ALGO_TAP = 0, 1, 2, 3  # 2: one tile per workgroup (v1), 3: persistent tap-parallel forward
 _algo = ALGO_AUTO
 
+# Host copies of the level geometry, keyed by the identity of the device tensor `spatial_shapes` (the reference's signature
+# passes the geometry as device tensors only, ms_deform_attn_func.py:36-41).  The fused backward (csrc/msda_bwd.hip) sizes its
+# window table and LDS from the level sizes ON THE HOST: the pixel decoder, which builds the tensors from python ints,
+# registers them (no synchronisation); for a tensor of unknown origin the geometry is fetched once with a device->host copy -
+# unless the stream is being captured, in which case the two-kernel path (no host geometry needed) runs.
+_host_geometry = {}
+# OFF by default: measured on MI355X (tools/bench_msda.py, bench.py) the one-launch windowed kernel reads every operand once
+# (HBM traffic ~1.1x algorithmic instead of 1.77x) but takes 341 us per layer inside the bench step against 303 us for the
+# two-kernel path ("MSDeformAttn backward").  COMBO_MSDA_BWD_WIN=1 selects it.
+WINDOWED_BACKWARD = __import__("os").environ.get("COMBO_MSDA_BWD_WIN", "0") == "1"
+
+
+def register_level_shapes(spatial_shapes, shapes_list):
+    """spatial_shapes: the int64 [L,2] device tensor handed to the op; shapes_list: the same (H, W) pairs as python ints"""
+    import ctypes
+    flat = [int(v) for hw in shapes_list for v in hw]
+    start, acc = [], 0
+    for h, w in shapes_list:
+        start.append(acc)
+        acc += int(h) * int(w)
+    L = len(shapes_list)
+    entry = ((ctypes.c_int * (2 * L))(*flat), (ctypes.c_int * L)(*start), tuple(flat), spatial_shapes)  # (keeps the tensor alive)
+    _host_geometry[(spatial_shapes.data_ptr(), L)] = entry
+    return entry
+
+
+def _geometry_of(spatial_shapes, level_start_index):
+    key = (spatial_shapes.data_ptr(), spatial_shapes.shape[0])
+    g = _host_geometry.get(key)
+    if g is None and not torch.cuda.is_current_stream_capturing():
+        hs, st = spatial_shapes.cpu().tolist(), level_start_index.cpu().tolist()  # once per shapes tensor
+        g = register_level_shapes(spatial_shapes, hs)
+        if list(g[1]) != [int(v) for v in st]:  # a level_start_index that is not the running sum of H*W: not this kernel's layout
+            _host_geometry[key] = g = (None, None, None, spatial_shapes)
+    return g
+
 
 def start_timing(graph=False):
     """Record HIP events around every instrumented launch (MSDeformAttn core, dense-layer GEMMs) until stop_timing()."""
@@ -82,6 +118,17 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     B, S, M, D, L, Lq, P = _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
     if tuple(grad_output.shape) != (B, Lq, M * D):
         raise RuntimeError("ms_deform_attn_backward: grad_output [B,Lq,M*D] expected")
+    if WINDOWED_BACKWARD and _algo == ALGO_AUTO and value.dtype == torch.float32:
+        g = _geometry_of(spatial_shapes, level_start_index)
+        lib = _lib.lib()
+        if g is not None and g[0] is not None and lib.combo_msda_backward_win_ok(g[0], L, P, D, 4):
+            grad_value, grad_loc, grad_w = torch.empty_like(value), torch.empty_like(sampling_loc), torch.empty_like(attn_weight)
+            with _Timed("bwd"):
+                rc = lib.combo_msda_backward_win_f32(grad_output.data_ptr(), value.data_ptr(), g[0], g[1], sampling_loc.data_ptr(),
+                                                     attn_weight.data_ptr(), B, S, M, D, L, Lq, P, grad_value.data_ptr(),
+                                                     grad_loc.data_ptr(), grad_w.data_ptr(), _lib.current_stream())
+            _lib.check(rc, "combo_msda_backward_win")
+            return grad_value, grad_loc, grad_w
     # the LDS kernels write every output element; only the generic (global-atomics) path accumulates into zeros
     need_zero = _lib.lib().combo_msda_backward_needs_zero(S, D, L, P, value.element_size(), _algo)
     alloc = torch.zeros_like if need_zero else torch.empty_like

@@ -147,6 +147,19 @@ int combo_msda_backward_f64(const double* grad_out, const double* value, const i
                             double* grad_value, double* grad_sampling_loc, double* grad_attn_weight,
                             int algo, combo_stream_t stream);
 
+/*   Fused, windowed backward (csrc/msda_bwd.hip; D == 32, P == 4, fp32): the three gradients of
+ *   ms_deform_attn_cuda_backward (ms_deform_attn_cuda.cu:88-157) from ONE launch that needs value, grad_out, sampling_loc
+ *   and attn_weight once; workgroup = (frame, head, band of image rows of one level), all 32 channels, grad_value in 2 x 32-bit
+ *   fixed point per 64-bit LDS word (bitwise deterministic), every output element written (no zero-fill).  The level
+ *   geometry is taken ON THE HOST (host_shapes [L,2] = (H,W) ints, host_start [L]): the band table and the LDS budget depend
+ *   on it, and the reference's launcher has it as device tensors only (ms_deform_attn_cuda.cu:72-73).
+ *   combo_msda_backward_win_ok: 1 when this geometry is taken (else use combo_msda_backward_f32). */
+int combo_msda_backward_win_ok(const int* host_shapes, int L, int P, int D, int elem_bytes);
+int combo_msda_backward_win_f32(const float* grad_out, const float* value, const int* host_shapes, const int* host_start,
+                                const float* sampling_loc, const float* attn_weight, int B, int S, int M, int D, int L, int Lq,
+                                int P, float* grad_value, float* grad_sampling_loc, float* grad_attn_weight,
+                                combo_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * a2  GroupNorm (+ ReLU) on channels_last / token-major fp32 maps [B, HW, C] (the norm + activation of detectron2's Conv2d
  *   wrapper [d2] as used at msdeformattn.py:215-224 (input_proj) and :271-286 (FPN lateral / output convolutions)).

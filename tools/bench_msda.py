@@ -49,3 +49,18 @@ for algo, name in ((1, "generic"), (2, "lds"), (3, "tap")):
     print(f"fwd {name:8s}: {t:8.1f} us   {fwd_bytes / t / 1e3:8.1f} GB/s algorithmic ({fwd_bytes/1e6:.1f} MB)")
     t = timeit(lambda: msda.ms_deform_attn_backward(value, sh, lsi, loc, w, go), a.iters)
     print(f"bwd {name:8s}: {t:8.1f} us   {bwd_bytes / t / 1e3:8.1f} GB/s algorithmic ({bwd_bytes/1e6:.1f} MB) (incl. 3 memsets)")
+
+# fused windowed backward (csrc/msda_bwd.hip) against the two-kernel LDS path, same inputs; max deviation between the two
+msda.set_algo(0)
+for flag, name in ((False, "two-kernel"), (True, "windowed")):
+    msda.WINDOWED_BACKWARD = flag
+    t = timeit(lambda: msda.ms_deform_attn_backward(value, sh, lsi, loc, w, go), a.iters)
+    print(f"bwd {name:10s}: {t:8.1f} us   {bwd_bytes / t / 1e3:8.1f} GB/s algorithmic ({bwd_bytes/1e6:.1f} MB)")
+msda.WINDOWED_BACKWARD = False
+r0 = msda.ms_deform_attn_backward(value, sh, lsi, loc, w, go)
+msda.WINDOWED_BACKWARD = True
+r1 = msda.ms_deform_attn_backward(value, sh, lsi, loc, w, go)
+r2 = msda.ms_deform_attn_backward(value, sh, lsi, loc, w, go)
+for nm, x, y, z in zip(("grad_value", "grad_loc", "grad_w"), r0, r1, r2):
+    print(f"{nm}: max |windowed - two-kernel| = {(x - y).abs().max().item():.3e} (max |x| {x.abs().max().item():.3e}); "
+          f"windowed run-to-run bitwise equal: {bool(torch.equal(y, z))}")
