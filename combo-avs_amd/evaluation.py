@@ -1,4 +1,5 @@
-"""S4 / MS3 evaluator metric of the reference (models/evaluation/sem_seg_evaluation.py:66-137, 219-281) as pure device-side
+"""Evaluator metrics of the reference - S4 / MS3 (models/evaluation/sem_seg_evaluation.py:66-137, 219-281) and AVSS
+(models/evaluation/sem_seg_evaluation_ss.py:66-118, 212-266) - as pure device-side
 functions - what `SemSegEvaluator.process` computes per batch from the model's eval output, so that mIoU / F-score can be
 checked on the GPU box without detectron2's evaluator plumbing.  All reductions stay on the device; one
 host read per metric."""
@@ -59,3 +60,59 @@ class AverageMeter:
 
     def mean(self, key):
         return self.sum[key] / max(self.n.get(key, 0), 1)
+
+
+# ---- AVSS (semantic) metric: per-class IoU / F-score histograms, sem_seg_evaluation_ss.py:66-118 ------------------------------
+def batch_miou_fscore(output, target, nclass, T=10, beta2=0.3):
+    """`_batch_miou_fscore` (:66-104) for all frames at once on the device: output [BF,C,H,W] scores, target [BF,H,W] class ids
+    -> (ious [C], fscores [C], cls_count [C], vid_miou [BF]): the per-frame IoU / F-score of every class summed over the
+    frames, the number of frames in which a class has a non-empty union, and the per-frame mean IoU over the classes with
+    IoU != 0.  The reference copies every frame to the host and calls torch.histc three times per frame (bins = classes,
+    range [1, C]: integer values 1..C fall in bin value - 1, zeros are out of range); here the three histograms of all
+    frames are ONE scatter-add each (exact integer counts) and nothing leaves the device."""
+    BF = target.shape[0]
+    predict = torch.argmax(output, 1) + 1
+    tgt = target.long() + 1
+    predict = predict * (tgt > 0)
+    inter = predict * (predict == tgt)
+
+    def hist(x):  # [BF, C] counts of the values 1..C (0 = not counted, as histc with min = 1)
+        h = torch.zeros(BF, nclass + 1, device=x.device, dtype=torch.float32)
+        h.scatter_add_(1, x.reshape(BF, -1).clamp(0, nclass), torch.ones(BF, x[0].numel(), device=x.device))
+        return h[:, 1:]
+    a_i, a_p, a_l = hist(inter), hist(predict), hist(tgt.clamp(min=0))
+    a_u = a_p + a_l - a_i
+    iou = a_i / (2.220446049250313e-16 + a_u)
+    prec, rec = a_i / a_p, a_i / a_l
+    f = torch.nan_to_num((1 + beta2) * prec * rec / (beta2 * prec + rec), nan=0.0, posinf=float("inf"), neginf=float("-inf"))
+    vid = iou.sum(1) / (iou != 0).float().sum(1)
+    return iou.sum(0), f.sum(0), (a_u != 0).float().sum(0), vid
+
+
+def calc_color_miou_fscore(pred, target, T=10):
+    """:107-118.  pred [BF,C,H,W] (the eval output's `sem_seg` maps stacked), target [BF,H,W]; the reference's softmax over C
+    does not move the arg-max and is skipped."""
+    return batch_miou_fscore(pred, target, pred.shape[1], T)
+
+
+class AVSSMeter:
+    """What SemSegEvaluator_SS accumulates over `process` calls (:212-230) and reports in `evaluate` (:254-266)."""
+
+    def __init__(self):
+        self.batches = []
+
+    def process(self, outputs, gts):
+        """outputs: list of {"sem_seg": [K,H,W]} (or a stacked tensor) of the frames of the batch; gts [BF,H,W] class ids"""
+        sem = outputs if torch.is_tensor(outputs) else torch.stack([o["sem_seg"] for o in outputs])
+        miou, f, cls, _ = calc_color_miou_fscore(sem.float(), gts)
+        self.batches.append((miou, f, cls))
+
+    def evaluate(self):
+        n = len(self.batches)
+        miou_pc = sum(b[0] for b in self.batches) / n
+        f_pc = sum(b[1] for b in self.batches) / n
+        cls_pc = sum(b[2] for b in self.batches) / n
+        miou_pc = torch.nan_to_num(miou_pc / cls_pc, nan=0.0)
+        f_pc = torch.nan_to_num(f_pc / cls_pc, nan=0.0)
+        return {"mIoU": round(miou_pc.mean().item(), 4), "f_score": round(f_pc.mean().item(), 4),
+                "mIoU_noBg": miou_pc[:-1].mean().item(), "f_score_noBg": f_pc[:-1].mean().item()}

@@ -693,3 +693,49 @@ def s4_clip_metrics(sem_seg, gts):
     (a SECOND softmax: the inference tail already mixed class probabilities, Appendix A) -> channel 1 -> (mIoU, F-score)."""
     probs = F.softmax(sem_seg, dim=1)[:, 1]
     return float(mask_iou(probs, gts)), eval_fmeasure(probs, gts)
+
+
+# ---------------------------------------------------------------------------------------- AVSS evaluator metric
+def avss_batch_miou_fscore(output, target, nclass, T=10, beta2=0.3):
+    """models/evaluation/sem_seg_evaluation_ss.py:66-104 `_batch_miou_fscore`, frame by frame with torch.histc like the
+    reference: output [BF,C,H,W] scores, target [BF,H,W] class ids -> (sum of per-frame IoU per class, sum of per-frame F
+    per class, number of frames in which a class has a non-empty union, per-frame mean IoU over the classes with IoU != 0)."""
+    predict = (torch.argmax(output, 1) + 1).float()
+    target = target.float() + 1
+    predict = predict * (target > 0).float()
+    inter = predict * (predict == target).float()
+    ious, fscores, cls_count, vid = torch.zeros(nclass), torch.zeros(nclass), torch.zeros(nclass), []
+    for i in range(target.shape[0]):
+        a_i = torch.histc(inter[i], bins=nclass, min=1, max=nclass)
+        a_p = torch.histc(predict[i], bins=nclass, min=1, max=nclass)
+        a_l = torch.histc(target[i], bins=nclass, min=1, max=nclass)
+        a_u = a_p + a_l - a_i
+        iou = a_i / (2.220446049250313e-16 + a_u)
+        ious += iou
+        cls_count[a_u != 0] += 1
+        prec, rec = a_i / a_p, a_i / a_l
+        f = (1 + beta2) * prec * rec / (beta2 * prec + rec)
+        f[torch.isnan(f)] = 0.0
+        fscores += f
+        vid.append(iou.sum() / (iou != 0).float().sum())
+    return ious, fscores, cls_count, vid
+
+
+def avss_calc_color_miou_fscore(pred, target, T=10):
+    """sem_seg_evaluation_ss.py:107-118: softmax over the class axis first (does not move the arg-max)"""
+    return avss_batch_miou_fscore(torch.softmax(pred, dim=1), target, pred.shape[1], T)
+
+
+def avss_evaluate(batches):
+    """SemSegEvaluator_SS.evaluate on one process (:254-266).  batches: list of (miou, fscore, cls_count) from `process`
+    -> {"mIoU", "f_score"} rounded to 4 digits like the reference, + the no-background means."""
+    n = len(batches)
+    miou_pc = sum(b[0] for b in batches) / n
+    f_pc = sum(b[1] for b in batches) / n
+    cls_pc = sum(b[2] for b in batches) / n
+    miou_pc = miou_pc / cls_pc
+    miou_pc[torch.isnan(miou_pc)] = 0
+    f_pc = f_pc / cls_pc
+    f_pc[torch.isnan(f_pc)] = 0
+    return {"mIoU": round(miou_pc.mean().item(), 4), "f_score": round(f_pc.mean().item(), 4),
+            "mIoU_noBg": miou_pc[:-1].mean().item(), "f_score_noBg": f_pc[:-1].mean().item()}

@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 REF = "/root/reference/models/evaluation/sem_seg_evaluation.py"
+REF_SS = "/root/reference/models/evaluation/sem_seg_evaluation_ss.py"
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
@@ -43,6 +44,54 @@ def load_reference():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
+
+
+def load_reference_ss():
+    """the AVSS evaluator module (same third-party stubs; none is touched by the metric functions)"""
+    spec = importlib.util.spec_from_file_location("ref_sem_seg_evaluation_ss", REF_SS)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def gen_avss(out_path):
+    """Round 3: the AVSS metric - `calc_color_miou_fscore` / `_batch_miou_fscore` (sem_seg_evaluation_ss.py:66-118) on two
+    seeded 10-frame clips with K = 8 classes (some never present, some predicted but absent, one frame all background), and
+    the aggregation of SemSegEvaluator_SS.evaluate (:254-266) over the two `process` calls."""
+    R = load_reference_ss()
+    g = torch.Generator().manual_seed(11)
+    K, T, H, W = 8, 10, 24, 32
+    out = {}
+    sums = [torch.zeros(K), torch.zeros(K), torch.zeros(K)]
+    for clip in range(2):
+        tgt = torch.randint(0, 5, (T, H, W), generator=g)  # classes 5..7 never in the ground truth
+        tgt[:, :, W // 2:] = torch.randint(0, 2, (T, H, W // 2), generator=g) * (3 + clip)
+        tgt[4] = 0  # one frame: background only
+        logits = torch.randn(T, K, H, W, generator=g)
+        logits.scatter_add_(1, tgt[:, None], torch.full((T, 1, H, W), 1.5))  # mostly right, often wrong
+        logits[:, 6] += 0.8 * (torch.rand(T, H, W, generator=g) > 0.8)     # a class that is predicted but never present
+        logits[:, 7] -= 100.0        # never predicted, never present: empty union in every frame (0 / 0 in `evaluate`)
+        logits[1::2, 5] -= 100.0     # predicted (wrongly) in the even frames only: cls_count 5
+        miou, fscore, cls, vid = R.calc_color_miou_fscore(logits, tgt, T=T)
+        out[f"ss{clip}/logits"] = logits.numpy().astype(np.float32)
+        out[f"ss{clip}/target"] = tgt.numpy().astype(np.int64)
+        out[f"ss{clip}/miou"] = miou.numpy().astype(np.float64)
+        out[f"ss{clip}/fscore"] = fscore.numpy().astype(np.float64)
+        out[f"ss{clip}/cls_count"] = cls.numpy().astype(np.float64)
+        out[f"ss{clip}/vid_miou"] = np.array([float(v) for v in vid], dtype=np.float64)
+        for acc, v in zip(sums, (miou, fscore, cls)):
+            acc += v
+    # SemSegEvaluator_SS.evaluate, single process (:254-266): the AverageMeter means of the per-batch vectors
+    miou_pc, f_pc, cls_pc = (v / 2 for v in sums)
+    miou_pc = miou_pc / cls_pc
+    miou_pc[torch.isnan(miou_pc)] = 0
+    f_pc = f_pc / cls_pc
+    f_pc[torch.isnan(f_pc)] = 0
+    out["ss/mIoU"] = np.float64(round(torch.mean(miou_pc).item(), 4))
+    out["ss/f_score"] = np.float64(round(torch.mean(f_pc).item(), 4))
+    out["ss/mIoU_noBg"] = np.float64(torch.mean(miou_pc[:-1]).item())
+    np.savez_compressed(out_path, **out)
+    print({k: (float(v) if v.ndim == 0 else v.shape) for k, v in out.items() if "logits" not in k and "target" not in k})
 
 
 def main():
@@ -75,6 +124,7 @@ def main():
     out["c/fscore"] = np.float64(R.Eval_Fmeasure(probs[:, 1], gt))
     np.savez_compressed(os.path.join(HERE, "eval_metric.npz"), **out)
     print({k: float(v) for k, v in out.items() if v.ndim == 0})
+    gen_avss(os.path.join(HERE, "eval_metric_ss.npz"))
 
 
 if __name__ == "__main__":

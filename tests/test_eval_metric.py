@@ -53,3 +53,62 @@ def test_device_metric_matches_reference_and_scores_the_fused_inference_tail():
     sem_cpu = O.semantic_inference(cls, masks, (224, 224))
     m_cpu, f_cpu = O.s4_clip_metrics(sem_cpu, gts)
     assert abs(m_gpu - m_cpu) < 1e-4 and abs(f_gpu - f_cpu) < 1e-4
+
+
+# ---- AVSS metric (sem_seg_evaluation_ss.py:66-118, 254-266), vectors from the reference's own functions ------------------------
+G_SS = os.path.join(os.path.dirname(__file__), "golden", "eval_metric_ss.npz")
+
+
+def _check_ss(calc, evaluate, dev):
+    z = np.load(G_SS)
+    batches = []
+    for clip in range(2):
+        logits = torch.from_numpy(z[f"ss{clip}/logits"]).to(dev)
+        tgt = torch.from_numpy(z[f"ss{clip}/target"]).to(dev)
+        miou, f, cls, vid = calc(logits, tgt)
+        np.testing.assert_allclose(miou.cpu().numpy(), z[f"ss{clip}/miou"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(f.cpu().numpy(), z[f"ss{clip}/fscore"], rtol=1e-6, atol=1e-7)
+        assert np.array_equal(cls.cpu().numpy(), z[f"ss{clip}/cls_count"])  # integer counts: exact
+        np.testing.assert_allclose(np.array([float(v) for v in vid]), z[f"ss{clip}/vid_miou"], rtol=1e-6)
+        batches.append((miou, f, cls))
+        assert (z[f"ss{clip}/cls_count"] == 0).any() and (z[f"ss{clip}/cls_count"] == 10).any()  # absent and always-present classes
+    res = evaluate(batches)
+    assert res["mIoU"] == float(z["ss/mIoU"]) and res["f_score"] == float(z["ss/f_score"])
+    assert abs(res["mIoU_noBg"] - float(z["ss/mIoU_noBg"])) < 1e-6
+
+
+def test_oracle_avss_metric_matches_reference():
+    from oracle import combo_oracle as O
+    _check_ss(O.avss_calc_color_miou_fscore, O.avss_evaluate, "cpu")
+
+
+def test_product_avss_metric_host_logic_matches_reference():
+    """the product's device-side formulation (one scatter-add per histogram) is plain torch: checked on the CPU here, on the
+    GPU below"""
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd import evaluation as E
+
+    def evaluate(batches):
+        m = E.AVSSMeter()
+        m.batches = batches
+        return m.evaluate()
+    _check_ss(E.calc_color_miou_fscore, evaluate, "cpu")
+
+
+@pytest.mark.gpu
+def test_device_avss_metric_matches_reference():
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd import evaluation as E
+    z = np.load(G_SS)
+    m = E.AVSSMeter()
+    for clip in range(2):
+        sem = torch.from_numpy(z[f"ss{clip}/logits"]).cuda()
+        m.process([{"sem_seg": s} for s in sem], torch.from_numpy(z[f"ss{clip}/target"]).cuda())
+    res = m.evaluate()
+    assert res["mIoU"] == float(z["ss/mIoU"]) and res["f_score"] == float(z["ss/f_score"])
+
+    def evaluate(batches):
+        mm = E.AVSSMeter()
+        mm.batches = batches
+        return mm.evaluate()
+    _check_ss(E.calc_color_miou_fscore, evaluate, "cuda")
