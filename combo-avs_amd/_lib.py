@@ -81,14 +81,14 @@ _SIGNATURES = {
     "combo_gemm_tn_x3_grouped_f32": [c_void_p, c_int, c_void_p],
     "combo_splitk_reduce_grouped_f32": [c_void_p, c_int, c_void_p],
     "combo_ln_param_grad_grouped_f32": [c_void_p, c_int, c_void_p],
-    "combo_add_layernorm_forward_f32": [c_void_p] * 4 + [c_float, c_longlong, c_int] + [c_void_p] * 5,
-    "combo_layernorm_backward_f32": [c_void_p] * 5 + [c_longlong, c_int, c_void_p, c_void_p],
+    "combo_add_layernorm_forward_f32": [c_void_p] * 4 + [c_float, c_longlong, c_int] + [c_void_p] * 5 + [c_longlong, c_void_p, c_void_p],
+    "combo_layernorm_backward_f32": [c_void_p] * 5 + [c_longlong, c_int] + [c_void_p] * 6,
     "combo_splitk_reduce_f32": [c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "combo_uncertain_points_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p],
     "combo_mask_loss_forward_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p],
-    "combo_mask_loss_backward_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int] + [c_void_p] * 4 + [c_int, c_void_p],
+    "combo_mask_loss_backward_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int] + [c_void_p] * 4 + [c_int, c_void_p, c_void_p],
     "combo_cosine_stats_f32": [c_void_p, c_longlong, c_longlong, c_int, c_void_p, c_void_p, c_void_p],
-    "combo_cosine_grad_f32": [c_void_p, c_longlong, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "combo_cosine_grad_f32": [c_void_p, c_longlong, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_longlong, c_longlong, c_void_p],
     "combo_lsap_small_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "combo_attn_mask_f32": [c_void_p] + [c_int] * 6 + [c_void_p, c_void_p],
     "combo_attn_mask_pitched_f32": [c_void_p] + [c_int] * 7 + [c_void_p, c_void_p],

@@ -39,7 +39,7 @@ cosine_stats_kernel(const float* __restrict__ x, long long E, int n_frame, float
 
 __global__ void __launch_bounds__(THREADS)
 cosine_grad_kernel(const float* __restrict__ x, long long E, int n_frame, const float* __restrict__ gdot,
-                   const float* __restrict__ gnrm, float* __restrict__ grad) {
+                   const float* __restrict__ gnrm, float* __restrict__ grad, long long perm_inner, long long perm_outer) {
   const long long row = blockIdx.y;
   const int t = (int)(row % n_frame);
   const float cs = 2.f * gnrm[row];
@@ -48,7 +48,9 @@ cosine_grad_kernel(const float* __restrict__ x, long long E, int n_frame, const 
   const float4* xs = reinterpret_cast<const float4*>(x + row * E);
   const float4* xn = reinterpret_cast<const float4*>(x + (row + (t + 1 < n_frame ? 1 : 0)) * E);
   const float4* xp = reinterpret_cast<const float4*>(x + (row - (t > 0 ? 1 : 0)) * E);
-  float4* g = reinterpret_cast<float4*>(grad + row * E);
+  // output row: `row` itself, or - rows = [outer', inner] (head, frame) - the row of the transposed [inner, outer] stack
+  const long long orow = perm_outer > 0 ? (row % perm_inner) * perm_outer + row / perm_inner : row;
+  float4* g = reinterpret_cast<float4*>(grad + orow * E);
   const long long n4 = E >> 2;
   for (long long i = blockIdx.x * (long long)THREADS + threadIdx.x; i < n4; i += (long long)gridDim.x * THREADS) {
     const float4 s = xs[i], n = xn[i], p = xp[i];
@@ -69,10 +71,11 @@ int combo_cosine_stats_f32(const float* x, long long rows, long long E, int n_fr
 }
 
 int combo_cosine_grad_f32(const float* x, long long rows, long long E, int n_frame, const float* gdot, const float* gnrm,
-                          float* grad, combo_stream_t stream) {
+                          float* grad, long long perm_inner, long long perm_outer, combo_stream_t stream) {
   if (!x || !gdot || !gnrm || !grad || rows <= 0 || E <= 0 || (E & 3) || n_frame <= 0 || rows % n_frame) return COMBO_EINVAL;
+  if (perm_outer > 0 && (perm_inner <= 0 || rows % perm_inner || rows / perm_inner > perm_outer)) return COMBO_EINVAL;
   hipLaunchKernelGGL(cosine_grad_kernel, dim3(16, (unsigned)rows), dim3(THREADS), 0, (hipStream_t)stream, x, E, n_frame, gdot, gnrm,
-                     grad);
+                     grad, perm_inner, perm_outer);
   return (int)hipGetLastError();
 }
 

@@ -6,6 +6,11 @@
 // layer_norm_grad_input kernel + the accumulation add of the two branches.  Here: ONE pass forward (reads x and r, writes
 // z = x + r once - it is what the backward needs - and y), ONE pass backward (dz serves both branches: the caller returns the
 // same tensor for x and r).  The parameter gradients stay in the deferred grouped launch (csrc/lngrad.hip).
+// Round 3: fan-out.  The LN output of a post-norm layer feeds 2-3 consumers (the next block's value / FFN input, its residual,
+// and - plus the position embedding - its query): autograd then sums their gradients with one accumulation kernel per extra
+// consumer (read 2, write 1 of the full activation each) before it calls this backward, and the forward needs an `y + pos`
+// kernel.  The forward kernel now also writes yp = y + pos (pos broadcast over the frames), and the backward kernel takes up
+// to FOUR output gradients (the autograd node hands its consumers aliases of y) and sums them on the fly.
 // HBM-bound: 16 B per lane per tensor, one wave per row (C = 64 * VEC channels), statistics by DPP/shuffle inside the wave,
 // two-pass variance on the registers (no E[x^2] - E[x]^2 cancellation).
 #include "combo_common.h"
@@ -22,7 +27,7 @@ template <int VEC>  // channels per lane: C = 64 * VEC, VEC in {1, 2, 4, 5, 8} (
 __global__ void __launch_bounds__(256)
 add_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ w, const float* __restrict__ b,
                   float eps, long long rows, float* __restrict__ z, float* __restrict__ y, float* __restrict__ mean,
-                  float* __restrict__ rstd) {
+                  float* __restrict__ rstd, const float* __restrict__ pos, long long pos_rows, float* __restrict__ yp) {
   constexpr int C = 64 * VEC;
   const long long row = blockIdx.x * 4LL + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -46,7 +51,9 @@ add_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ r, cons
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
     if (z) z[off + i] = v[i];
-    y[off + i] = (v[i] - mu) * rs * w[lane * VEC + i] + b[lane * VEC + i];
+    const float o = (v[i] - mu) * rs * w[lane * VEC + i] + b[lane * VEC + i];
+    y[off + i] = o;
+    if (yp) yp[off + i] = o + pos[(row % pos_rows) * C + lane * VEC + i];
   }
   if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
@@ -55,7 +62,8 @@ add_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ r, cons
 template <int VEC>
 __global__ void __launch_bounds__(256)
 ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ rstd,
-              const float* __restrict__ w, long long rows, float* __restrict__ dz) {
+              const float* __restrict__ w, long long rows, float* __restrict__ dz, const float* __restrict__ dy2,
+              const float* __restrict__ dy3, const float* __restrict__ dy4, float* __restrict__ dy_sum) {
   constexpr int C = 64 * VEC;
   const long long row = blockIdx.x * 4LL + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -66,7 +74,12 @@ ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z, const f
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
-    g[i] = dy[off + i] * w[lane * VEC + i];
+    float d = dy[off + i];
+    if (dy2) d += dy2[off + i];
+    if (dy3) d += dy3[off + i];
+    if (dy4) d += dy4[off + i];
+    if (dy_sum) dy_sum[off + i] = d;  // the summed output gradient, for the deferred parameter-gradient launch
+    g[i] = d * w[lane * VEC + i];
     xh[i] = (z[off + i] - mu) * rs;
     s1 += g[i];
     s2 += g[i] * xh[i];
@@ -82,33 +95,37 @@ inline bool c_ok(int C) { return C == 64 || C == 128 || C == 256 || C == 320 || 
 }  // namespace
 
 extern "C" int combo_add_layernorm_forward_f32(const float* x, const float* r, const float* w, const float* b, float eps, long long rows,
-                                               int C, float* z, float* y, float* mean, float* rstd, combo_stream_t stream) {
+                                               int C, float* z, float* y, float* mean, float* rstd, const float* pos,
+                                               long long pos_rows, float* yp, combo_stream_t stream) {
   if (!x || !w || !b || !y || !mean || !rstd || rows <= 0 || !c_ok(C) ||
-      (((uintptr_t)x | (uintptr_t)r | (uintptr_t)z | (uintptr_t)y | (uintptr_t)w | (uintptr_t)b) & 15))
+      (((uintptr_t)x | (uintptr_t)r | (uintptr_t)z | (uintptr_t)y | (uintptr_t)w | (uintptr_t)b | (uintptr_t)pos | (uintptr_t)yp) & 15) ||
+      ((pos != nullptr) != (yp != nullptr)) || (pos && pos_rows <= 0))
     return COMBO_EINVAL;
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   switch (C / 64) {
-    case 1: hipLaunchKernelGGL(add_ln_fwd_kernel<1>, grid, block, 0, (hipStream_t)stream, x, r, w, b, eps, rows, z, y, mean, rstd); break;
-    case 2: hipLaunchKernelGGL(add_ln_fwd_kernel<2>, grid, block, 0, (hipStream_t)stream, x, r, w, b, eps, rows, z, y, mean, rstd); break;
-    case 4: hipLaunchKernelGGL(add_ln_fwd_kernel<4>, grid, block, 0, (hipStream_t)stream, x, r, w, b, eps, rows, z, y, mean, rstd); break;
-    case 5: hipLaunchKernelGGL(add_ln_fwd_kernel<5>, grid, block, 0, (hipStream_t)stream, x, r, w, b, eps, rows, z, y, mean, rstd); break;
-    default: hipLaunchKernelGGL(add_ln_fwd_kernel<8>, grid, block, 0, (hipStream_t)stream, x, r, w, b, eps, rows, z, y, mean, rstd); break;
+    case 1: hipLaunchKernelGGL(add_ln_fwd_kernel<1>, grid, block, 0, (hipStream_t)stream, x, r, w, b, eps, rows, z, y, mean, rstd, pos, pos_rows, yp); break;
+    case 2: hipLaunchKernelGGL(add_ln_fwd_kernel<2>, grid, block, 0, (hipStream_t)stream, x, r, w, b, eps, rows, z, y, mean, rstd, pos, pos_rows, yp); break;
+    case 4: hipLaunchKernelGGL(add_ln_fwd_kernel<4>, grid, block, 0, (hipStream_t)stream, x, r, w, b, eps, rows, z, y, mean, rstd, pos, pos_rows, yp); break;
+    case 5: hipLaunchKernelGGL(add_ln_fwd_kernel<5>, grid, block, 0, (hipStream_t)stream, x, r, w, b, eps, rows, z, y, mean, rstd, pos, pos_rows, yp); break;
+    default: hipLaunchKernelGGL(add_ln_fwd_kernel<8>, grid, block, 0, (hipStream_t)stream, x, r, w, b, eps, rows, z, y, mean, rstd, pos, pos_rows, yp); break;
   }
   return (int)hipGetLastError();
 }
 
 extern "C" int combo_layernorm_backward_f32(const float* dy, const float* z, const float* mean, const float* rstd, const float* w,
-                                            long long rows, int C, float* dz, combo_stream_t stream) {
+                                            long long rows, int C, float* dz, const float* dy2, const float* dy3, const float* dy4,
+                                            float* dy_sum, combo_stream_t stream) {
   if (!dy || !z || !mean || !rstd || !w || !dz || rows <= 0 || !c_ok(C) ||
-      (((uintptr_t)dy | (uintptr_t)z | (uintptr_t)dz | (uintptr_t)w) & 15))
+      (((uintptr_t)dy | (uintptr_t)z | (uintptr_t)dz | (uintptr_t)w | (uintptr_t)dy2 | (uintptr_t)dy3 | (uintptr_t)dy4 |
+        (uintptr_t)dy_sum) & 15))
     return COMBO_EINVAL;
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   switch (C / 64) {
-    case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, (hipStream_t)stream, dy, z, mean, rstd, w, rows, dz); break;
-    case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, (hipStream_t)stream, dy, z, mean, rstd, w, rows, dz); break;
-    case 4: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, (hipStream_t)stream, dy, z, mean, rstd, w, rows, dz); break;
-    case 5: hipLaunchKernelGGL(ln_bwd_kernel<5>, grid, block, 0, (hipStream_t)stream, dy, z, mean, rstd, w, rows, dz); break;
-    default: hipLaunchKernelGGL(ln_bwd_kernel<8>, grid, block, 0, (hipStream_t)stream, dy, z, mean, rstd, w, rows, dz); break;
+    case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, (hipStream_t)stream, dy, z, mean, rstd, w, rows, dz, dy2, dy3, dy4, dy_sum); break;
+    case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, (hipStream_t)stream, dy, z, mean, rstd, w, rows, dz, dy2, dy3, dy4, dy_sum); break;
+    case 4: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, (hipStream_t)stream, dy, z, mean, rstd, w, rows, dz, dy2, dy3, dy4, dy_sum); break;
+    case 5: hipLaunchKernelGGL(ln_bwd_kernel<5>, grid, block, 0, (hipStream_t)stream, dy, z, mean, rstd, w, rows, dz, dy2, dy3, dy4, dy_sum); break;
+    default: hipLaunchKernelGGL(ln_bwd_kernel<8>, grid, block, 0, (hipStream_t)stream, dy, z, mean, rstd, w, rows, dz, dy2, dy3, dy4, dy_sum); break;
   }
   return (int)hipGetLastError();
 }

@@ -201,7 +201,7 @@ mask_loss_bwd_kernel(const float* __restrict__ masks, const long long* __restric
                      const float* __restrict__ gt, const long long* __restrict__ gidx, int H, int W,
                      const float* __restrict__ coords, int P, const float* __restrict__ stats,
                      const float* __restrict__ g_bce, const float* __restrict__ g_dice, float* __restrict__ grad_masks,
-                     int accumulate) {
+                     int accumulate, const long long* __restrict__ grad_index) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* img = smem;
   float* gimg = smem + h * w;
@@ -235,7 +235,7 @@ mask_loss_bwd_kernel(const float* __restrict__ masks, const long long* __restric
     if (xr && yb) atomicAdd(&gimg[(y0 + 1) * w + x0 + 1], dx * ly * lx);
   }
   __syncthreads();
-  float* dst = grad_masks + midx[n] * h * w;
+  float* dst = grad_masks + (grad_index ? grad_index[n] : midx[n]) * h * w;
   // accumulate: the map already holds another term's gradient (cosine loss written by combo_cosine_grad_f32); a map is
   // matched at most once per frame and output, so the read-modify-write needs no atomics
   if (accumulate) { for (int i = tid; i < h * w; i += THREADS) dst[i] += gimg[i]; }
@@ -279,13 +279,13 @@ int combo_mask_loss_forward_f32(const float* masks, const long long* mask_index,
 int combo_mask_loss_backward_f32(const float* masks, const long long* mask_index, int NM, int h, int w, const float* gt,
                                  const long long* gt_index, int H, int W, const float* coords, int P, const float* stats,
                                  const float* g_bce, const float* g_dice, float* grad_masks, int accumulate,
-                                 combo_stream_t stream) {
+                                 const long long* grad_index, combo_stream_t stream) {
   if (!masks || !mask_index || !gt || !gt_index || !coords || !stats || !g_bce || !g_dice || !grad_masks || NM <= 0 ||
       P <= 0 || (size_t)h * w * 8 > kMaxLds)
     return COMBO_EINVAL;
   if (int e = big_lds(reinterpret_cast<const void*>(mask_loss_bwd_kernel))) return e;
   hipLaunchKernelGGL(mask_loss_bwd_kernel, dim3(NM), dim3(THREADS), (size_t)h * w * 8, (hipStream_t)stream, masks, mask_index,
-                     h, w, gt, gt_index, H, W, coords, P, stats, g_bce, g_dice, grad_masks, accumulate);
+                     h, w, gt, gt_index, H, W, coords, P, stats, g_bce, g_dice, grad_masks, accumulate, grad_index);
   return (int)hipGetLastError();
 }
 

@@ -153,7 +153,9 @@ class MaskFormer(nn.Module):
         images = torch.cat([b["images"].to(dev, non_blocking=True) for b in batched_inputs], dim=0)
         image_size = tuple(images.shape[-2:])
         audio_log_mels = torch.cat([b["audio_log_mel"].to(dev, non_blocking=True) for b in batched_inputs], dim=0)
-        images = self._pad((images.float() - self.pixel_mean) / self.pixel_std)  # maskformer_model.py:324-325
+        # (x - mean) / std as in maskformer_model.py:324-325; uint8 - fp32 promotes inside ONE kernel, the division is in place
+        images = self._pad(images.sub(self.pixel_mean).div_(self.pixel_std) if images.dtype == torch.uint8
+                           else (images.float() - self.pixel_mean) / self.pixel_std)
         amp = torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.backbone_dtype == torch.bfloat16)
         with torch.no_grad(), amp:
             audio_feature = self.audio_backbone(audio_log_mels).float()  # :327-328
@@ -162,7 +164,8 @@ class MaskFormer(nn.Module):
             audio_feature = audio_feature[vid_flag.bool()]
         if self.use_pre_sam:
             pre = torch.cat([b["pre_masks"].to(dev, non_blocking=True) for b in batched_inputs], dim=0)
-            pre = self._pad((pre.float() - self.pixel_mean) / self.pixel_std)
+            pre = self._pad(pre.sub(self.pixel_mean).div_(self.pixel_std) if pre.dtype == torch.uint8
+                            else (pre.float() - self.pixel_mean) / self.pixel_std)
             if images.is_cuda and self.parallel_backbones:
                 # the Siam pair is independent until the SEM mix: run the second encoder on its own HIP stream (fork/join
                 # with events, also inside a captured hipGraph).  Autograd replays each backward on its forward stream, so

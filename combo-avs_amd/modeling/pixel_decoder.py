@@ -114,14 +114,21 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         self.dropout3 = nn.Dropout(dropout)
         self.norm2 = _deferred_layer_norm(d_model)
 
-    def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None, normalizer=None):
-        src2 = self.self_attn(src + pos, reference_points, src, spatial_shapes, level_start_index, padding_mask, normalizer)
-        src = self.norm1(src, self.dropout1(src2))  # LN(src + src2) in one pass (csrc/layernorm.hip)
+    def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None, normalizer=None,
+                fan=None, last=True):
+        """fan = (residual, value input, query = src + pos): three autograd handles on the previous layer's output (aliases of
+        one buffer + the `+ pos` variant written by its LayerNorm kernel, ops/layernorm.py) - their gradients are summed inside
+        the LayerNorm backward kernel instead of by autograd's accumulation kernels.  last = False: returns such a triple."""
+        src_res, src_val, src_q = fan if fan is not None else (src, src, src + pos)
+        src2 = self.self_attn(src_q, reference_points, src_val, spatial_shapes, level_start_index, padding_mask, normalizer)
+        x_ffn, x_res = self.norm1(src_res, self.dropout1(src2), fanout=2)  # LN(src + src2) in one pass (csrc/layernorm.hip)
         if self.dropout2.p == 0.0:  # (every shipped config) FFN with the ReLU backward folded into linear2's dX GEMM
-            src2 = ffn(src, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias)
+            src2 = ffn(x_ffn, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias)
         else:
-            src2 = self.linear2(self.dropout2(linear(src, self.linear1.weight, self.linear1.bias, relu=True, defer=True)))
-        return self.norm2(src, self.dropout3(src2))
+            src2 = self.linear2(self.dropout2(linear(x_ffn, self.linear1.weight, self.linear1.bias, relu=True, defer=True)))
+        if last:
+            return self.norm2(x_res, self.dropout3(src2))
+        return self.norm2(x_res, self.dropout3(src2), fanout=2, pos=pos)
 
 
 class MSDeformAttnTransformerEncoder(nn.Module):
@@ -189,9 +196,12 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
         pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[l].view(1, 1, -1)
                          for l, p in enumerate(pos_embeds)], 1)
         ref = ref.expand(src.shape[0], -1, -1, -1)
-        out = src
-        for layer in self.encoder.layers:
-            out = layer(out, pos, ref, spatial_shapes, level_start_index, None, normalizer)
+        out, fan = src, None
+        n = len(self.encoder.layers)
+        for i, layer in enumerate(self.encoder.layers):
+            out = layer(out, pos, ref, spatial_shapes, level_start_index, None, normalizer, fan=fan, last=i == n - 1)
+            if i < n - 1:
+                fan, out = out, None
         return out, spatial_shapes, level_start_index, shapes_list
 
 

@@ -67,9 +67,12 @@ class SelfAttentionLayer(nn.Module):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
 
-    def forward(self, tgt, query_pos):
-        qk = tgt + query_pos
-        return self.norm(tgt, self.self_attn(qk, qk, tgt))  # LN(tgt + attn), transformer_decoder.py:50-58
+    def forward(self, tgt, query_pos, fan=None):
+        """fan = (residual, value, query-key = tgt + query_pos) handles on the cross-attention layer's output (see
+        ops/layernorm.py: aliases whose gradients are summed inside the LayerNorm backward kernel); returns
+        (FFN input, residual) handles on this layer's output."""
+        t_res, t_val, qk = fan if fan is not None else (tgt, tgt, tgt + query_pos)
+        return self.norm(t_res, self.self_attn(qk, qk, t_val), fanout=2)  # LN(tgt + attn), transformer_decoder.py:50-58
 
 
 class CrossAttentionLayer(nn.Module):
@@ -85,9 +88,15 @@ class CrossAttentionLayer(nn.Module):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
 
-    def forward(self, tgt, memory, blocked, pos, query_pos):
-        tgt2 = self.multihead_attn(tgt + query_pos, memory + pos, memory, blocked)  # :99-118
-        return self.norm(tgt, tgt2)  # LN(tgt + tgt2) in one pass (csrc/layernorm.hip)
+    def forward(self, tgt, memory, blocked, pos, query_pos, memory_k=None, fan=None):
+        """memory_k: `memory + pos`, computed once per level by the caller (three layers share a level's memory);
+        fan = (residual, query = tgt + query_pos) handles on the previous FFN layer's output; returns
+        (residual, value, query-key = out + query_pos) handles on this layer's output for the self-attention layer."""
+        if memory_k is None:
+            memory_k = memory + pos
+        t_res, t_q = fan if fan is not None else (tgt, tgt + query_pos)
+        tgt2 = self.multihead_attn(t_q, memory_k, memory, blocked)  # :99-118
+        return self.norm(t_res, tgt2, fanout=2, pos=query_pos)  # LN(tgt + tgt2) in one pass (csrc/layernorm.hip)
 
 
 class FFNLayer(nn.Module):
@@ -105,8 +114,14 @@ class FFNLayer(nn.Module):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
 
-    def forward(self, tgt):
-        return self.norm(tgt, ffn(tgt, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias))  # :178-182
+    def forward(self, tgt, fan=None, query_pos=None, last=False):
+        """fan = (FFN input, residual) handles on the self-attention layer's output; returns (prediction-head input, residual,
+        query = out + query_pos) handles for the prediction head and the next cross-attention layer (last: only the first)."""
+        t_in, t_res = fan if fan is not None else (tgt, tgt)
+        y = ffn(t_in, self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias)
+        if last or query_pos is None:
+            return self.norm(t_res, y)  # :178-182
+        return self.norm(t_res, y, fanout=2, pos=query_pos)
 
 
 @TRANSFORMER_DECODER_REGISTRY.register()
@@ -204,6 +219,7 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
             pos.append(p.flatten(2).transpose(1, 2))  # [1,hw,C]
             s = self.input_proj[i](x[i]).flatten(2) + self.level_embed.weight[i][None, :, None]
             src.append(s.transpose(1, 2))  # [BT,hw,C]
+        src_k = [s_ + p_ for s_, p_ in zip(src, pos)]  # key input of the cross-attention layers of a level: once, not per layer
         query_embed = self.query_embed.weight.unsqueeze(0)  # [1,Q,C]
         output = self.query_feat.weight.unsqueeze(0).expand(bt, -1, -1)
         if self.queries_fuse_type == "add":
@@ -221,12 +237,18 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         outputs_class, mask_embed, blocked = self.forward_prediction_heads(output, mf_tok, (h_m, w_m), size_list[0], logit_buf[0])
         predictions_class.append(outputs_class)
         mask_embeds.append(mask_embed)
+        fan = None  # handles on the previous layer's output (aliases: gradients are summed inside the LayerNorm backward kernel)
         for i in range(self.num_layers):
             lvl = i % self.num_feature_levels
+            last = i == self.num_layers - 1
             # `blocked` already has the fully-blocked-row reset of :458 applied (fused in the mask kernel)
-            output = self.transformer_cross_attention_layers[i](output, src[lvl], blocked, pos[lvl], query_embed)
-            output = self.transformer_self_attention_layers[i](output, query_embed)
-            output = self.transformer_ffn_layers[i](output)
+            fan = self.transformer_cross_attention_layers[i](output, src[lvl], blocked, pos[lvl], query_embed, src_k[lvl], fan=fan)
+            fan = self.transformer_self_attention_layers[i](None, query_embed, fan=fan)
+            out = self.transformer_ffn_layers[i](None, fan=fan, query_pos=query_embed, last=last)
+            if last:
+                output, fan = out, None
+            else:
+                output, fan = out[0], (out[1], out[2])
             outputs_class, mask_embed, blocked = self.forward_prediction_heads(
                 output, mf_tok, (h_m, w_m), size_list[(i + 1) % self.num_feature_levels], logit_buf[i + 1])
             predictions_class.append(outputs_class)

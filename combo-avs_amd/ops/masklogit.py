@@ -102,7 +102,9 @@ class _MaskLogitsAll(torch.autograd.Function):
     def backward(ctx, dL):
         mf_tok, *mes = ctx.saved_tensors
         nh, bt, Q, HW = dL.shape
-        dL2 = dL.permute(1, 0, 2, 3).reshape(bt, nh * Q, HW)  # one 50 MB re-layout instead of 9 x 128 MB accumulations
+        # [BT, heads * Q, HW]: a free view when the criterion hands the stack over transposed (ops/maskloss.py builds its
+        # gradient as [BT, heads, ...]); a 0.5 GB re-layout copy for a gradient in the forward layout
+        dL2 = dL.permute(1, 0, 2, 3).reshape(bt, nh * Q, HW)
         ME = torch.cat(mes, dim=1)  # [BT, nh*Q, C]
         C = mf_tok.shape[2]
         if _hip_ok(dL2, mf_tok, ME) and HW % 16 == 0 and C % 4 == 0 and HW % 4 == 0 and nh * Q >= 256 and C >= 64:

@@ -49,7 +49,7 @@ class _MaskLoss(Function):
         _lib.check(_lib.lib().combo_mask_loss_backward_f32(
             masks.data_ptr(), mask_index.data_ptr(), NM, h, w, gt.data_ptr(), gt_index.data_ptr(), H, W, coords.data_ptr(), P,
             stats.data_ptr(), g_bce.contiguous().float().data_ptr(), g_dice.contiguous().float().data_ptr(), grad.data_ptr(), 0,
-            _lib.current_stream()), "combo_mask_loss_backward_f32")
+            None, _lib.current_stream()), "combo_mask_loss_backward_f32")
         return grad, None, None, None, None
 
 
@@ -96,17 +96,22 @@ class _MaskAndCosine(Function):
         NM, P = coords.shape[:2]
         H, W = gt.shape[-2:]
         rows, E = cos_heads * BT, Q * h * w
-        grad = torch.empty_like(x)
+        # the gradient stack is built TRANSPOSED, [BT, heads, Q, h, w], and handed to autograd as the permuted view: that is the
+        # layout the mask-logit gradient GEMMs contract over (heads * Q rows per frame, ops/masklogit.py) - without it they
+        # start with a 0.5 GB re-layout copy of this very buffer
+        grad = torch.empty(BT, heads, Q, h, w, device=x.device, dtype=torch.float32)
         if rows > 0:
             _lib.check(lib.combo_cosine_grad_f32(x.data_ptr(), rows, E, n_frame, gdot.contiguous().float().data_ptr(),
-                                                 gnrm.contiguous().float().data_ptr(), grad.data_ptr(), st), "combo_cosine_grad_f32")
+                                                 gnrm.contiguous().float().data_ptr(), grad.data_ptr(), BT, heads, st),
+                       "combo_cosine_grad_f32")
         if cos_heads < heads:
-            grad.view(heads, -1)[cos_heads:].zero_()  # heads without a cosine term (the final prediction)
+            grad[:, cos_heads:].zero_()  # heads without a cosine term (the final prediction)
+        grad_index = (mask_index // Q % BT * heads + mask_index // (Q * BT)) * Q + mask_index % Q  # (h, f, q) -> (f, h, q)
         _lib.check(lib.combo_mask_loss_backward_f32(
             x.data_ptr(), mask_index.data_ptr(), NM, h, w, gt.data_ptr(), gt_index.data_ptr(), H, W, coords.data_ptr(), P,
-            stats.data_ptr(), g_bce.contiguous().float().data_ptr(), g_dice.contiguous().float().data_ptr(), grad.data_ptr(), 1, st),
-            "combo_mask_loss_backward_f32")
-        return grad, None, None, None, None, None, None
+            stats.data_ptr(), g_bce.contiguous().float().data_ptr(), g_dice.contiguous().float().data_ptr(), grad.data_ptr(), 1,
+            grad_index.data_ptr(), st), "combo_mask_loss_backward_f32")
+        return grad.permute(1, 0, 2, 3, 4), None, None, None, None, None, None
 
 
 def mask_and_cosine(x, cos_heads, n_frame, mask_index, gt, gt_index, coords):
@@ -137,7 +142,7 @@ class _CosineStats(Function):
         rows, E = x.shape
         grad = torch.empty_like(x)
         _lib.check(_lib.lib().combo_cosine_grad_f32(x.data_ptr(), rows, E, ctx.n_frame, gdot.contiguous().float().data_ptr(),
-                                                    gnrm.contiguous().float().data_ptr(), grad.data_ptr(), _lib.current_stream()),
+                                                    gnrm.contiguous().float().data_ptr(), grad.data_ptr(), 0, 0, _lib.current_stream()),
                    "combo_cosine_grad_f32")
         return grad, None
 

@@ -366,11 +366,16 @@ int combo_ln_param_grad_grouped_f32(const combo_ln_grad_problem* problems, int c
  *   y = (z - mean) * rstd * w + b over the last dimension C in {64, 128, 256, 320, 512}; mean / rstd [rows] are saved for the backward
  *   pass, which returns dz = d(loss)/dz (the gradient of BOTH x and r).  Replaces `self.norm(tgt + tgt2)` of the post-norm
  *   layers (transformer_decoder/transformer_decoder.py:99-118, 50-58, 178-182; pixel_decoder/msdeformattn.py:119-134) and
- *   decoder_norm (:494).  All tensors contiguous [rows, C], 16-byte aligned. */
+ *   decoder_norm (:494).  All tensors contiguous [rows, C], 16-byte aligned.
+ *   Fan-out (round 3): pos [pos_rows, C] + yp (both or neither): yp = y + pos[row % pos_rows] is written as well (the next
+ *   block's query `src + pos` / `tgt + query_pos`); backward: dy2 / dy3 / dy4 (nullable) are further gradients of the SAME
+ *   output (its consumers hold aliases), summed on the fly; dy_sum (nullable) receives the sum (for the parameter gradients). */
 int combo_add_layernorm_forward_f32(const float* x, const float* r, const float* w, const float* b, float eps, long long rows,
-                                    int C, float* z, float* y, float* mean, float* rstd, combo_stream_t stream);
+                                    int C, float* z, float* y, float* mean, float* rstd, const float* pos, long long pos_rows,
+                                    float* yp, combo_stream_t stream);
 int combo_layernorm_backward_f32(const float* dy, const float* z, const float* mean, const float* rstd, const float* w,
-                                 long long rows, int C, float* dz, combo_stream_t stream);
+                                 long long rows, int C, float* dz, const float* dy2, const float* dy3, const float* dy4,
+                                 float* dy_sum, combo_stream_t stream);
 
 /*   Finishes a split-K result in ONE launch: out[i] = sum_z partials[z*n + i] (n % 4 == 0, 16-byte aligned) and, when
  *   nb > 0, db[j] = sum_z db_partials[z*nb + j]; fixed summation order.  `out` may be a row block of a larger matrix
@@ -480,14 +485,18 @@ int combo_mask_loss_forward_f32(const float* masks, const long long* mask_index,
 int combo_mask_loss_backward_f32(const float* masks, const long long* mask_index, int NM, int h, int w, const float* gt,
                                  const long long* gt_index, int H, int W, const float* coords, int P, const float* stats,
                                  const float* g_bce, const float* g_dice, float* grad_masks, int accumulate,
-                                 combo_stream_t stream); /* accumulate != 0: grad_masks[...] += (another term is already there) */
+                                 const long long* grad_index, combo_stream_t stream);
+/* accumulate != 0: grad_masks[...] += (another term is already there); grad_index (nullable): the gradient of pair n is
+ * written at grad_masks + grad_index[n]*h*w instead of + mask_index[n]*h*w (a gradient stack in another layout) */
 
 /*   Frame-to-frame cosine loss (criterion.py:208-231): x [rows,E], rows = heads*BT, clips = n_frame consecutive rows.
  *   stats: nrm[r] += |x_r|^2, dot[r] += x_r . x_{r+1} (same clip; both zero-filled by the caller);
- *   grad : grad[r] = 2 gnrm[r] x_r + gdot[r] x_{r+1} + gdot[r-1] x_{r-1} (neighbours inside the clip). */
+ *   grad : grad[r] = 2 gnrm[r] x_r + gdot[r] x_{r+1} + gdot[r-1] x_{r-1} (neighbours inside the clip); perm_outer > 0: row
+ *          r = (head, frame) of [rows / perm_inner, perm_inner] is written at row frame * perm_outer + head (the gradient stack
+ *          transposed to [BT, heads, E]: the layout the mask-logit gradient GEMMs read, no 0.5 GB re-layout copy). */
 int combo_cosine_stats_f32(const float* x, long long rows, long long E, int n_frame, float* dot, float* nrm, combo_stream_t stream);
 int combo_cosine_grad_f32(const float* x, long long rows, long long E, int n_frame, const float* gdot, const float* gnrm,
-                          float* grad, combo_stream_t stream);
+                          float* grad, long long perm_inner, long long perm_outer, combo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (f)1  optimiser: fused gradient clip + AdamW on a flat fp32 segment

@@ -543,3 +543,40 @@ def test_backbone_conv_weight_gradient_kernels_vs_fp64(B, C, Co, H, k):
     with L.deferred_dw():
         dx2, dw2 = torch.autograd.grad(convwrw.conv2d(x, w, 1, k // 2), (x, w), g)
     assert rel(dx2, rx) < 2e-5 and rel(dw2, rw) < 2e-5, (rel(dx2, rx), rel(dw2, rw))
+
+
+def test_layernorm_fanout_aliases_and_pos_output_match_torch():
+    """ops/layernorm.py fan-out: LN(x + r) handed out as aliases (one autograd output per consumer) plus `+ pos`; the consumers'
+    gradients are summed inside the backward kernel - against nn.LayerNorm with autograd's own accumulation."""
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.ops.layernorm import LayerNorm
+    torch.manual_seed(0)
+    B, S, C = 3, 37, 256
+    ln = LayerNorm(C).cuda()
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5)
+        ln.bias.normal_()
+    ref = torch.nn.LayerNorm(C).cuda()
+    ref.load_state_dict(ln.state_dict())
+    x = torch.randn(B, S, C, device="cuda", requires_grad=True)
+    r = torch.randn(B, S, C, device="cuda", requires_grad=True)
+    pos = torch.randn(1, S, C, device="cuda")
+    w1, w2, w3 = (torch.randn(B, S, C, device="cuda") for _ in range(3))
+    a, b, q = ln(x, r, fanout=2, pos=pos)
+    assert a.data_ptr() == b.data_ptr() and q.data_ptr() != a.data_ptr()
+    loss = (a * w1).sum() + (b * w2).sum() + (q * w3).sum()
+    got = torch.autograd.grad(loss, [x, r, ln.weight, ln.bias])
+    x2, r2 = x.detach().clone().requires_grad_(True), r.detach().clone().requires_grad_(True)
+    y = ref(x2 + r2)
+    loss2 = (y * w1).sum() + (y * w2).sum() + ((y + pos) * w3).sum()
+    want = torch.autograd.grad(loss2, [x2, r2, ref.weight, ref.bias])
+    torch.testing.assert_close(a, y, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(q, y + pos, rtol=1e-5, atol=1e-5)
+    for g, wnt in zip(got, want):
+        torch.testing.assert_close(g, wnt, rtol=2e-4, atol=2e-4)
+    # one consumer unused: its gradient arrives as None
+    a, b, q = ln(x, r, fanout=2, pos=pos)
+    got = torch.autograd.grad((a * w1).sum() + (q * w3).sum(), [x])
+    y = ref(x2 + r2)
+    want = torch.autograd.grad((y * w1).sum() + ((y + pos) * w3).sum(), [x2])
+    torch.testing.assert_close(got[0], want[0], rtol=2e-4, atol=2e-4)
