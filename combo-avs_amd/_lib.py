@@ -57,6 +57,9 @@ _SIGNATURES = {
     "combo_gemm_nt_x3_pre_batched_f32": [c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_void_p, c_longlong, c_longlong,
                                          c_int, c_int, c_int, c_int, c_int, c_void_p],
     "combo_gemm_nt_x3_pre_masked_f32": [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_void_p],
+    "combo_downsample_tokens_f32": [c_void_p] + [c_int] * 6 + [c_void_p, c_void_p],
+    "combo_mask_bits_f32": [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p, c_int, c_void_p, c_void_p],
+    "combo_mask_logits_all_f32": [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p],
     "combo_timing_set_buffer": [c_void_p, c_int],
     "combo_timing_slots_used": [],
     "combo_timing_rewind": [],

@@ -86,7 +86,9 @@ struct F32Args {
   const float* bias;      // [N] or nullptr
   float* C; long long ldc;
   int M, N, K, relu, c_bytes, batch, vec_store, dbg;  // dbg: ablation bits (COMBO_F32_DBG, tools/bench_f32.py): 1 no DMA, 2 no LDS reads, 4 no barrier, 8 no stores
-  long long sA, sB, sC;   // batch strides (elements)
+  long long sA, sB, sC;   // batch strides (elements) of the INNER batch index bi % bdiv ...
+  int bdiv;               // ... and of the outer index bi / bdiv (0: one-level batch, the outer strides are unused)
+  long long sA2, sB2, sC2;
   ConvGeomF cg;
   unsigned long long* ts; // device-side timing slot (combo_common.h) or nullptr
 };
@@ -137,8 +139,9 @@ gemm_nt_f32_kernel(const F32Args p) {
   const float* pb[PPW - APW];
   auto open_tile = [&]() __attribute__((always_inline)) {
     const int bi = i_tile / tpb, rem = i_tile - bi * tpb;
-    const float* i_A = A + bi * p.sA;
-    const float* i_B = Bm + bi * p.sB;
+    const int b_in = p.bdiv ? bi % p.bdiv : bi, b_out = p.bdiv ? bi / p.bdiv : 0;
+    const float* i_A = A + b_in * p.sA + b_out * p.sA2;
+    const float* i_B = Bm + b_in * p.sB + b_out * p.sB2;
     const int i_m_blk = (rem / n_tiles) * BM;
     const int i_n_blk = (rem % n_tiles) * BN;
     i_s = 0; i_tap = 0; i_cin0 = 0;
@@ -404,7 +407,8 @@ gemm_nt_f32_kernel(const F32Args p) {
     const int tile = w + t * G;
     const int bi = tile / tpb, rem = tile - bi * tpb;
     const EpiCtx ec{(rem / n_tiles) * BM, (rem % n_tiles) * BN};
-    const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.C + bi * p.sC, 0, p.c_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        p.C + (p.bdiv ? (bi % p.bdiv) * p.sC + (bi / p.bdiv) * p.sC2 : bi * p.sC), 0, p.c_bytes, 0x00020000);
     // ---- stage 0 (peeled: its first k-step starts the accumulators from zero)
     read_half(std::integral_constant<int, 1>{}, (unsigned)(c_slot * STAGE));
     mfma_half(std::integral_constant<int, 0>{}, std::true_type{}, std::true_type{});
@@ -550,7 +554,7 @@ extern "C" int combo_gemm_nt_f32(const float* A, long long lda, const float* B, 
                                  long long ldc, int M, int N, int K, int relu, combo_stream_t stream) {
   if (!args_ok(A, lda, B, ldb, C, ldc, M, N, K, 1) || (bias && N > kMaxBiasN)) return COMBO_EINVAL;
   F32Args a{A, lda, B, ldb, bias, C, ldc, M, N, K, relu, (int)(((M - 1LL) * ldc + N) * 4), 1, vec_ok(C, ldc, 0, N, bias), dbg_bits(), 0, 0, 0,
-            ConvGeomF{1, 1, K}, nullptr};
+            0, 0, 0, 0, ConvGeomF{1, 1, K}, nullptr};
   return launch_f32<false>(a, (hipStream_t)stream);
 }
 
@@ -559,7 +563,24 @@ extern "C" int combo_gemm_nt_batched_f32(const float* A, long long lda, long lon
                                          combo_stream_t stream) {
   if (!args_ok(A, lda, B, ldb, C, ldc, M, N, K, batch) || sA % 4 != 0 || sB % 4 != 0) return COMBO_EINVAL;
   F32Args a{A, lda, B, ldb, nullptr, C, ldc, M, N, K, relu, (int)(((M - 1LL) * ldc + N) * 4), batch, vec_ok(C, ldc, sC, N, nullptr),
-            dbg_bits(), sA, sB, sC, ConvGeomF{1, 1, K}, nullptr};
+            dbg_bits(), sA, sB, sC, 0, 0, 0, 0, ConvGeomF{1, 1, K}, nullptr};
+  return launch_f32<false>(a, (hipStream_t)stream);
+}
+
+/* The full-resolution mask logits of ALL prediction heads in one launch (transformer_decoder.py:498-500, x 10):
+ * out[h, b] = mask_embed[h, b] [Q, C] . mask_features[b] [HW, C]^T, exact fp32.  mask_embed [heads, B, Q, C], mask_features
+ * [B, HW, C] token-major, out [heads, B, Q, HW].  The problems are enumerated frame-major (the `heads` problems of a frame are
+ * neighbours: they share the frame's mask features in the L2 of one XCD).  The decoder's attention masks do not need these
+ * logits (csrc/maskbits.hip), so they are computed after the layer loop, for the losses. */
+extern "C" int combo_mask_logits_all_f32(const float* mask_embed, const float* mask_features, float* out, int heads, int B, int Q,
+                                         int HW, int C, combo_stream_t stream) {
+  if (heads <= 0 || B <= 0 || !args_ok(mask_embed, C, mask_features, C, out, HW, Q, HW, C, heads * B) ||
+      (long long)heads * B > 0x7fffffffLL)
+    return COMBO_EINVAL;
+  F32Args a{mask_embed, C, mask_features, C, nullptr, out, HW, Q, HW, C, 0, (int)(((Q - 1LL) * HW + HW) * 4), heads * B,
+            vec_ok(out, HW, (long long)Q * HW, HW, nullptr), dbg_bits(),
+            (long long)B * Q * C, 0, (long long)B * Q * HW, heads, (long long)Q * C, (long long)HW * C, (long long)Q * HW,
+            ConvGeomF{1, 1, C}, nullptr};
   return launch_f32<false>(a, (hipStream_t)stream);
 }
 
@@ -570,6 +591,6 @@ extern "C" int combo_conv3x3_nhwc_f32(const float* X, long long ldx, const float
       !args_ok(X, ldx, Wm, 9LL * Cin, Y, ldy, M, Cout, 9 * Cin, 1) || (bias && Cout > kMaxBiasN))
     return COMBO_EINVAL;
   F32Args a{X, ldx, Wm, 9LL * Cin, bias, Y, ldy, (int)M, Cout, 9 * Cin, relu, (int)(((M - 1) * ldy + Cout) * 4), 1,
-            vec_ok(Y, ldy, 0, Cout, bias), dbg_bits(), 0, 0, 0, ConvGeomF{H, W, Cin}, nullptr};
+            vec_ok(Y, ldy, 0, Cout, bias), dbg_bits(), 0, 0, 0, 0, 0, 0, 0, ConvGeomF{H, W, Cin}, nullptr};
   return launch_f32<true>(a, (hipStream_t)stream);
 }

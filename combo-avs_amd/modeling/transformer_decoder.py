@@ -20,6 +20,10 @@ from ..ops.linear import Linear, ffn, in_proj, linear
 from .layers import MLP, position_embedding_sine
 
 
+import os as _os
+FUSED_MASKS = _os.environ.get("COMBO_FUSED_MASKS", "1") == "1"  # 0: per-head full logits + csrc/attnmask.hip (A/B)
+
+
 def _deferred_layer_norm(dim):
     """per-layer post-norm: applied once per forward, so its parameter gradients may join the grouped launch"""
     from ..ops.layernorm import LayerNorm
@@ -230,8 +234,18 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
             output = self.scramble_audio(audio_features, bt)
         from ..ops import masklogit
         nheads_pred = self.num_layers + 1
-        # one buffer for the mask logits of all prediction heads; head i fills slice i (values, no grad) ...
+        # one buffer for the mask logits of all prediction heads ...
         logit_buf = torch.empty(nheads_pred, bt, self.num_queries, h_m * w_m, device=mf_tok.device, dtype=torch.float32)
+        # Fused mask path (csrc/maskbits.hip): a layer's attention mask comes from the mask embedding and the pixel embedding
+        # DOWNSAMPLED to the layer's memory size (interpolation and contraction commute), in one kernel whose MFMA result tile
+        # is balloted into the bit-packed mask - the full-resolution logits are not needed inside the layer loop and are
+        # computed for all heads by ONE launch after it.
+        self._fused_masks = (mf_tok.is_cuda and mf_tok.dtype == torch.float32 and c_m == 256 and mf_tok.is_contiguous()
+                             and max(h * w for h, w in size_list) <= 4096 and FUSED_MASKS)
+        self._mfd = {}
+        if self._fused_masks:
+            for sz in set(size_list):
+                self._mfd[sz] = masklogit.downsample_tokens(mf_tok, (h_m, w_m), sz)
         predictions_class, mask_embeds = [], []
         self._head_no = 0
         outputs_class, mask_embed, blocked = self.forward_prediction_heads(output, mf_tok, (h_m, w_m), size_list[0], logit_buf[0])
@@ -254,6 +268,9 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
             predictions_class.append(outputs_class)
             mask_embeds.append(mask_embed)
         assert len(predictions_class) == self.num_layers + 1
+        if self._fused_masks:
+            masklogit.mask_logits_all_into(mask_embeds, mf_tok, logit_buf)  # all heads' full-resolution logits: one launch
+        self._mfd = {}
         # ... and ONE autograd node carries the gradient of all heads back to mask_features / the mask embeddings
         logits_all = masklogit.attach_mask_logit_grads(mf_tok, logit_buf, mask_embeds)
         parts = logits_all.unbind(0)  # ONE backward node (a stack of the 10 head gradients), not 19 zero-padded slices
@@ -275,8 +292,12 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         dec = self.decoder_norm(output)
         outputs_class = self.class_embed(dec)
         mask_embed = self.mask_embed(dec)
-        masklogit.mask_logits_into(mask_embed, mf_tok, logits_out)
-        blocked = masklogit.attn_mask_padded(logits_out.view(output.shape[0], self.num_queries, hw[0], hw[1]), attn_mask_target_size, True)
+        if self._fused_masks:
+            # (the mask of the LAST head is never used - the reference computes it anyway, transformer_decoder.py:474-478)
+            blocked = masklogit.mask_bits(mask_embed, self._mfd[tuple(attn_mask_target_size)]) if self._head_no < self.num_layers else None
+        else:
+            masklogit.mask_logits_into(mask_embed, mf_tok, logits_out)
+            blocked = masklogit.attn_mask_padded(logits_out.view(output.shape[0], self.num_queries, hw[0], hw[1]), attn_mask_target_size, True)
         if self.attn_mask_override is not None and self._head_no < len(self.attn_mask_override):
             blocked = self.attn_mask_override[self._head_no]
         self._head_no += 1

@@ -430,6 +430,34 @@ def _dw_now(dy, x2d, want_db):
     return dw, (dy.sum(0) if want_db else None)
 
 
+_grad_targets = None  # {parameter address: view of the optimiser's flat gradient buffer} while grad_targets() is open
+
+
+class grad_targets:
+    """trainer.FlatAdamW.backward: the weight gradients computed by this module's kernels are written STRAIGHT into the flat
+    gradient buffer (the views registered here) instead of into fresh tensors that one 350 MB concatenation then copies there."""
+
+    def __init__(self, mapping):
+        self.mapping = mapping
+
+    def __enter__(self):
+        global _grad_targets
+        self.prev, _grad_targets = _grad_targets, self.mapping
+
+    def __exit__(self, *exc):
+        global _grad_targets
+        _grad_targets = self.prev
+
+
+def grad_buffer_like(weight):
+    """destination of a full weight gradient: the registered flat-buffer view of `weight`, else a fresh tensor"""
+    if _grad_targets is not None:
+        v = _grad_targets.get(weight.data_ptr())
+        if v is not None and v.shape == weight.shape and v.dtype == weight.dtype:
+            return v
+    return torch.empty_like(weight)
+
+
 def weight_grad(weight, dy, x2d, want_db, defer):
     """-> (dw, db) to hand to autograd for this use of `weight` (None, None when the use joined a deferred entry).
     Inside deferred_dw() a weight whose gradient the grouped reduce can write is entry-managed from its FIRST use on: that
@@ -442,7 +470,7 @@ def weight_grad(weight, dy, x2d, want_db, defer):
         ent = _dw_index.get(key)
         first = ent is None
         if first:
-            dw_t = torch.empty_like(weight)
+            dw_t = grad_buffer_like(weight)
             if _dest_ok(dw_t):
                 db_t = torch.empty(weight.shape[0], device=weight.device, dtype=weight.dtype) if want_db else None
                 ent = [[], dw_t, db_t, []]
@@ -559,7 +587,7 @@ class _InProj(Function):
             dxv = input_grad_gemm(dv, W[2 * E:])
         dW = db = None
         if ctx.needs_input_grad[3]:
-            dW = torch.empty_like(W)
+            dW = grad_buffer_like(W)
             db = torch.empty(3 * E, device=W.device, dtype=W.dtype)
             for i, (dy, x) in enumerate(((dq, xq), (dk, xk), (dv, xv))):
                 _dw_into(dy, x, dW[i * E:(i + 1) * E], db[i * E:(i + 1) * E], defer=ctx.defer)

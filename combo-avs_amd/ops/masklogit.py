@@ -46,6 +46,54 @@ class PackedMask:
         self.bytes, self.bits = bytes_, bits
 
 
+def downsample_tokens(mf_tok, hw_in, hw_out):
+    """mf_tok [BT, H*W, C] (token-major mask features) -> [BT, h*w, C]: F.interpolate(..., mode="bilinear",
+    align_corners=False) of transformer_decoder.py:502 applied to the pixel embedding (it commutes with the contraction)."""
+    x = mf_tok.detach()
+    _lib.require_cuda(x)
+    BT, HW, C = x.shape
+    (H, W), (h, w) = hw_in, hw_out
+    assert H * W == HW and x.is_contiguous() and x.dtype == torch.float32
+    out = torch.empty(BT, h * w, C, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().combo_downsample_tokens_f32(x.data_ptr(), BT, H, W, h, w, C, out.data_ptr(), _lib.current_stream()),
+               "combo_downsample_tokens_f32")
+    return out
+
+
+def mask_bits(mask_embed, mfd, reset_full_rows=True, with_bytes=False):
+    """The attention mask of a decoder layer, fused (csrc/maskbits.hip): mask_embed [BT, Q, 256] x downsampled pixel embedding
+    mfd [BT, hw, 256] -> PackedMask (bit-packed rows; byte rows only on request).  No score tensor is written."""
+    me, mfd = mask_embed.detach(), mfd.detach()
+    _lib.require_cuda(me, mfd)
+    BT, Q, C = me.shape
+    hw = mfd.shape[1]
+    if not (_hip_ok(me, mfd) and C == 256 and mfd.shape[2] == C and hw <= 4096):
+        raise RuntimeError("mask_bits: fp32 contiguous CUDA tensors [BT, Q, 256] / [BT, hw <= 4096, 256] expected")
+    wpitch = (hw + 63) // 64 * 2
+    pitch = (hw + 3) // 4 * 4
+    bits = torch.empty(BT, Q, wpitch, dtype=torch.int32, device=me.device)
+    by = torch.empty(BT, Q, pitch, dtype=torch.uint8, device=me.device) if with_bytes else None
+    _lib.check(_lib.lib().combo_mask_bits_f32(me.data_ptr(), mfd.data_ptr(), BT, Q, hw, C, 1 if reset_full_rows else 0, wpitch,
+                                              bits.data_ptr(), pitch, _lib.ptr(by), _lib.current_stream()), "combo_mask_bits_f32")
+    return PackedMask(by, bits)
+
+
+def mask_logits_all_into(mask_embeds, mf_tok, out):
+    """no-grad: out[h] = mask_embeds[h] @ mf_tok^T for ALL prediction heads in one launch (exact fp32, csrc/gemm_f32.hip);
+    mask_embeds: list of [BT, Q, C]; out [heads, BT, Q, HW]"""
+    me = torch.stack([m.detach() for m in mask_embeds])  # [heads, BT, Q, C]
+    mf = mf_tok.detach()
+    heads, BT, Q, C = me.shape
+    HW = mf.shape[1]
+    if not (_hip_ok(me, mf, out) and C % 16 == 0 and Q * HW * 4 < 2 ** 31 - 1):
+        raise RuntimeError("mask_logits_all_into: fp32 contiguous 16-byte aligned CUDA tensors with C % 16 == 0 expected")
+    with _lib.timed("gemm_nt_f32", (heads * BT * Q, HW, C)):
+        rc = _lib.lib().combo_mask_logits_all_f32(me.data_ptr(), mf.data_ptr(), out.data_ptr(), heads, BT, Q, HW, C,
+                                                  _lib.current_stream())
+    _lib.check(rc, "combo_mask_logits_all_f32")
+    return out
+
+
 def attn_mask_padded(logits, target_size, reset_full_rows=True):
     """logits [BT,Q,H,W] fp32 -> PackedMask: blocked bytes [BT,Q,pitch] (pitch = h*w rounded up to 4, padding cells blocked)
     and the same rows bit-packed, row reset of :458 applied; one launch."""

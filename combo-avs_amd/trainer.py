@@ -52,7 +52,10 @@ class FlatAdamW:
                  grad_comm_dtype=torch.float32):
         entries = param_groups(model, base_lr, weight_decay, backbone_multiplier, weight_decay_norm, weight_decay_embed)
         ref_index = {id(e[0]): i for i, e in enumerate(entries)}  # position in the reference's optimizer (train_net.py:170-194)
-        entries.sort(key=lambda e: (e[2], e[3]))  # stable: contiguous (lr, wd) segments
+        # stable: contiguous (lr, wd) segments; inside a segment the head's matrix weights come first - their gradients are
+        # written in place by the grouped weight-gradient launches (ops.linear.grad_targets), the rest forms few long runs
+        # for the concatenation that fills the flat gradient buffer
+        entries.sort(key=lambda e: (e[2], e[3], 0 if (e[0].dim() == 2 and "sem_seg_head" in e[1]) else 1))
         self.ref_order = [ref_index[id(e[0])] for e in entries]
         self.entries = entries
         # every (lr, wd) segment starts on a 16-byte boundary (vectorised fused AdamW kernel)
@@ -96,8 +99,10 @@ class FlatAdamW:
         """d loss / d params straight into the flat gradient buffer: `autograd.grad` (no per-parameter AccumulateGrad
         add kernels - 530 launches/step for this model) followed by ONE batched concatenation into the flat buffer
         (`torch.cat(out=)`: ~5 launches; a `_foreach_copy_` decays into one D2D memcpy per parameter here)."""
-        from .ops.linear import deferred_dw
-        with deferred_dw():  # latency-bound decoder weight gradients: one grouped launch when the context closes
+        from .ops.linear import deferred_dw, grad_targets
+        in_place = self.flat_grad.dtype == torch.float32 and self.flat_grad.is_cuda
+        targets = {p.data_ptr(): v for p, v in zip(self.params, self.grad_views) if p.dim() == 2} if in_place else {}
+        with grad_targets(targets), deferred_dw():  # latency-bound decoder weight gradients: one grouped launch when the context closes
             grads = torch.autograd.grad(loss, self.params, allow_unused=True)
         # torch.optim.AdamW (the reference's optimizer) skips parameters whose gradient is None - no decay, no moment update:
         # `step` leaves them out (a static property of the model / recipe, so it is safe inside a captured graph)
@@ -109,16 +114,30 @@ class FlatAdamW:
                 self.flat_grad.zero_()
             torch._foreach_copy_(dst, src)
             return
-        pieces, cursor = [], 0
-        for g, p, off in zip(grads, self.params, self.offsets):
-            if off > cursor:
-                pieces.append(self._zeros(off - cursor))
+        # gradients that were written in place (they ARE their flat-buffer views) stay; every maximal run of the others is
+        # filled by one concatenation (alignment gaps and parameters without a gradient: cached zeros)
+        pieces, run_start, cursor = [], 0, 0
+
+        def flush(end):
+            nonlocal pieces, run_start
+            if pieces:
+                torch.cat(pieces, out=self.flat_grad[run_start:end])
+            pieces, run_start = [], end
+        for g, p, off, view in zip(grads, self.params, self.offsets, self.grad_views):
             n = p.numel()
-            pieces.append(g.reshape(-1) if g is not None else self._zeros(n))
+            if g is not None and g.data_ptr() == view.data_ptr() and g.is_contiguous():
+                if off > cursor:
+                    pieces.append(self._zeros(off - cursor))
+                flush(off)
+                run_start = off + n
+            else:
+                if off > cursor:
+                    pieces.append(self._zeros(off - cursor))
+                pieces.append(g.reshape(-1) if g is not None else self._zeros(n))
             cursor = off + n
         if self.numel > cursor:
             pieces.append(self._zeros(self.numel - cursor))
-        torch.cat(pieces, out=self.flat_grad)
+        flush(self.numel)
 
     def _zeros(self, n):
         """cached zero filler (alignment gaps of the flat layout, parameters without a gradient)"""

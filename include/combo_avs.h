@@ -255,6 +255,25 @@ int combo_gemm_nt_batched_f32(const float* A, long long lda, long long sA, const
 int combo_conv3x3_nhwc_f32(const float* X, long long ldx, const float* Wm, const float* bias, float* Y, long long ldy,
                            int B, int H, int W, int Cin, int Cout, int relu, combo_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * a13  prediction heads: `mask_embed @ pixel_embed` -> sigmoid < 0.5 -> attention mask, FUSED (csrc/maskbits.hip)
+ *   replaces, per prediction head (transformer_decoder.py:498-507 + the row reset at :458): the full-resolution einsum, its
+ *   bilinear down-interpolation to the next layer's memory size, sigmoid < 0.5, the 8x head replication and the
+ *   nonzero()/index_put row reset.  Interpolation and contraction commute: the mask is computed from the DOWNSAMPLED pixel
+ *   embedding (combo_downsample_tokens_f32, once per forward and level) by combo_mask_bits_f32, whose fp32-MFMA result tile
+ *   is turned into the bit-packed mask words by wave ballots - the scores are never written.  The full-resolution logits
+ *   (needed by the losses only) come from ONE launch for all heads, combo_mask_logits_all_f32.
+ *     x [B, H*W, C] tokens -> out [B, h*w, C] (bilinear, align_corners = False); C % 4 == 0
+ *     mask_embed [B, Q, 256], mfd [B, hw, 256] -> bits [B, Q, wpitch] (bit k of word j = cell 32 j + k blocked; cells >= hw
+ *       blocked; fully blocked rows un-blocked when reset_full_rows), bytes (nullable) [B, Q, pitch]
+ *     mask_embed [heads, B, Q, C], mask_features [B, HW, C] -> out [heads, B, Q, HW]
+ * ---------------------------------------------------------------------------------------------- */
+int combo_downsample_tokens_f32(const float* x, int B, int H, int W, int h, int w, int C, float* out, combo_stream_t stream);
+int combo_mask_bits_f32(const float* mask_embed, const float* mfd, int B, int Q, int hw, int C, int reset_full_rows, int wpitch,
+                        unsigned* bits, int pitch, unsigned char* bytes, combo_stream_t stream);
+int combo_mask_logits_all_f32(const float* mask_embed, const float* mask_features, float* out, int heads, int B, int Q, int HW,
+                              int C, combo_stream_t stream);
+
 /*   a10  audio_mlp (models/modeling/misc/audio_transformation.py:5-14: 128 -> 4096 -> 4096 -> 256 with ReLU on the BT fused
  *   audio tokens): weight-streaming forward GEMM for M <= 64 rows, exact fp32 (csrc/gemm_smallm.hip).  Y[M,N] = X[M,K] .
  *   W[N,K]^T (+ bias) (+ ReLU); splits = combo_gemm_smallm_splits(M, N, K) K-splits (partial_ws: [splits, M, N] floats when

@@ -580,3 +580,59 @@ def test_layernorm_fanout_aliases_and_pos_output_match_torch():
     y = ref(x2 + r2)
     want = torch.autograd.grad((y * w1).sum() + ((y + pos) * w3).sum(), [x2])
     torch.testing.assert_close(got[0], want[0], rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("HW,hw,BT,Q", [((56, 56), (7, 7), 5, 100), ((56, 56), (14, 14), 5, 100), ((56, 56), (28, 28), 3, 100),
+                                         ((128, 128), (64, 64), 2, 100), ((40, 56), (9, 13), 2, 37)])
+def test_fused_mask_bits_equal_the_reference_rule(HW, hw, BT, Q):
+    """csrc/maskbits.hip: attention mask from mask_embed and the DOWNSAMPLED pixel embedding (one fp32-MFMA kernel, ballots ->
+    bit words, row reset) against the reference's formulation - full einsum, F.interpolate, sigmoid < 0.5, row reset
+    (transformer_decoder.py:458, 498-507) - in fp64 on the same operands: cells may differ only where the interpolated logit is
+    within 1e-5 x RMS of 0; and against csrc/attnmask.hip applied to the product's own full-resolution logits."""
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.ops import masklogit
+    torch.manual_seed(HW[0] + hw[0])
+    C = 256
+    me = torch.randn(BT, Q, C, device="cuda")
+    me[0, 3] = -me[0, 3].abs() * 0 - 1.0  # a query whose logits are all negative against positive features: fully blocked row
+    mf = torch.randn(BT, HW[0] * HW[1], C, device="cuda")
+    mf[0] = mf[0].abs()
+    mfd = masklogit.downsample_tokens(mf, HW, hw)
+    ref_d = torch.nn.functional.interpolate(mf.transpose(1, 2).reshape(BT, C, *HW), size=hw, mode="bilinear", align_corners=False)
+    torch.testing.assert_close(mfd, ref_d.flatten(2).transpose(1, 2), rtol=1e-6, atol=1e-6)
+    pm = masklogit.mask_bits(me, mfd, True, with_bytes=True)
+    n = hw[0] * hw[1]
+    got = pm.bytes[:, :, :n].bool()
+    logits = torch.einsum("bqc,bpc->bqp", me.double(), mf.double()).view(BT, Q, *HW)
+    down = torch.nn.functional.interpolate(logits, size=hw, mode="bilinear", align_corners=False).flatten(2)
+    want = down.float().sigmoid() < 0.5
+    full = want.all(-1)
+    assert bool(full[0, 3]) and int(full.sum()) >= 1
+    want[full] = False
+    near = down.abs() < 1e-5 * down.pow(2).mean().sqrt()
+    near = near | near.any(-1, keepdim=True) & full[..., None]  # (a row whose "fully blocked" verdict hinges on a near-zero cell)
+    assert bool(((got == want) | near).all()), int(((got != want) & ~near).sum())
+    assert bool((pm.bytes[:, :, n:] == 1).all())
+    # bit rows == byte rows, padding bits blocked
+    inj = masklogit.pack_mask(got, reset_full_rows=False)
+    assert torch.equal(inj.bits, pm.bits)
+    # the old two-step path on the product's own full-resolution logits agrees away from 0
+    out = torch.empty(BT, Q, HW[0] * HW[1], device="cuda")
+    masklogit.mask_logits_into(me, mf, out)
+    old = masklogit.attn_mask(out.view(BT, Q, *HW), hw, True)
+    assert bool(((old == got) | near).all())
+
+
+def test_mask_logits_of_all_heads_in_one_launch_equal_per_head_launches():
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.ops import masklogit
+    torch.manual_seed(1)
+    heads, BT, Q, HW, C = 10, 5, 100, 3136, 256
+    mes = [torch.randn(BT, Q, C, device="cuda") for _ in range(heads)]
+    mf = torch.randn(BT, HW, C, device="cuda")
+    allb = torch.empty(heads, BT, Q, HW, device="cuda")
+    masklogit.mask_logits_all_into(mes, mf, allb)
+    one = torch.empty(BT, Q, HW, device="cuda")
+    for h in range(heads):
+        masklogit.mask_logits_into(mes[h], mf, one)
+        assert torch.equal(one, allb[h])  # the same kernel, the same k order: bit for bit
