@@ -1,37 +1,40 @@
-// MSDeformAttn backward, fused and windowed (D == 32, fp32): grad_value, grad_sampling_loc and grad_attn_weight from ONE
-// launch in which value, grad_out, sampling_loc and attn_weight are each needed once.
+// MSDeformAttn backward, fused and windowed (D == 32, P == 4, fp32): grad_value, grad_sampling_loc and grad_attn_weight from
+// ONE launch in which value, grad_out, sampling_loc and attn_weight are each needed once.
 //
 // Replaces ms_deformable_col2im_cuda / ...col2im_gpu_kernel_shm_blocksize_aware_reduce_v1<32>
 // (models/modeling/pixel_decoder/ops/src/cuda/ms_deform_im2col_cuda.cuh:961-1331, :306-408; taps :92-164): one thread per
 // (b, q, m, c), 4 global float atomics per tap and channel into grad_value, a serial thread-0 reduction for d/dloc, d/dw.
 //
-// Work decomposition: a workgroup owns (frame b, head m, WINDOW) where a window is a band of image rows [y0, y1) of ONE
-// pyramid level - a whole level when its rows fit the LDS, otherwise equal bands (224 x 224: 7x7 | 14x14 | 28x28 rows 0-13 |
-// rows 14-27; 512 x 512: 16x16 | 3 bands of 32x32 | 11 bands of 64x64).  A window keeps, for ALL 32 channels of the head:
-//   * the value rows of its band plus one image row below it (the bottom taps of the band's last row)    - LDS, 128 B / row
-//   * a fixed-point accumulator of grad_value for the rows of its band                                   - LDS, 128 B / row
+// Work decomposition: a workgroup (8 waves, two resident per CU) owns (frame b, head m, WINDOW); a window is a band of image
+// rows [y0, y1) of ONE pyramid level - a whole level when its value rows AND its gradient accumulator fit the LDS budget
+// together (224 x 224: the 7x7 and the 14x14 level), otherwise equal bands (28x28: four bands of 7 rows; 512 x 512: every
+// level in bands, one workgroup per CU).  For ALL 32 channels of the head a window keeps
+//   * a fixed-point accumulator of grad_value for the rows of its band                            - LDS, 128 B / row
+//   * the value rows of the band + one image row below it, 16-byte chunks XOR-swizzled by row    - LDS, 128 B / row
 // and scans the sampling points of its level of every query (P of the L*P points):
-//   scatter  every tap that lands in the band adds  w_tap * a * grad_out[q, :]  to the accumulator row (LDS integer atomics:
-//            bitwise deterministic, no float atomics anywhere - the reference's atomicAdd is neither);
-//   gather   the window that OWNS a sample (the band holding its top tap row, clamped into the image) has the four tap rows in
-//            LDS, computes the four <value_tap, grad_out[q]> products over all 32 channels and with them d/dw and d/dloc of
-//            that sample - complete sums, written once with plain stores (the two-kernel design split the channels in halves,
-//            read value / grad_out / loc / w twice and still needed the slab of the whole pyramid).
+//   scatter  every tap that lands in the band adds  w_tap * a * grad_out[q, :]  to the accumulator row with LDS integer
+//            atomics (bitwise deterministic, no float atomics anywhere - the reference's atomicAdd is neither);
+//   gather   the window that OWNS a sample (the band holding its top tap row, clamped into the image) forms the four
+//            <value_tap, grad_out[q]> products over all 32 channels and with them d/dw and d/dloc of that sample - complete
+//            sums, written once with plain stores (feeding the band gathers from L2 instead of LDS was measured: 4x slower).
 // So every sample is scattered by the window(s) its taps touch (no duplicated atomics) and differentiated by exactly one.
 //
 // Fixed point: two channels share one 64-bit LDS word, X = (v1 << 32) + sext(v0); sum(X) = 2^32 sum(v1) + sum(v0), hence
 // low word = sum(v0) and high word = sum(v1) - [sum(v0) < 0], both exact as long as |sum| < 2^31.  A wave instruction
-// ds_add_u64 covers 4 taps x 16 channel pairs = 4 rows x 128 contiguous bytes: conflict-free (6.4 cycles, tools/ubench;
-// the 16-rows-x-4-lanes pattern of the previous kernel measured 9.5 cycles for a QUARTER of the channels).  Scales: per
-// channel 1 / max_q |grad_out[q, c]|, per row 2^30 / W_r with W_r an upper bound of the row's total tap weight from a first,
-// cheap pass over the same samples (geometry + one 4-byte LDS atomic per tap, no channel work).  A single window-wide scale
-// 2^30 / sum |a| was measured: 2.3e-5 absolute error on grad_value at Lq = 1029 (5x that at 5376) - rows of the 7x7 level
-// collect 300+ adds at a resolution set by a bound 50x above their real weight; with the row scales it is 6e-7.
+// ds_add_u64 covers 4 rows x 128 contiguous bytes: conflict-free (6.4 cycles, tools/ubench; the 16-rows-x-4-lanes pattern
+// of the two-kernel path measured 9.5 cycles for a QUARTER of the channels).  Scales: per channel 1 / max_q |grad_out[q, c]|,
+// per row 2^30 / W_r with W_r an upper bound of the row's total tap weight from a first, cheap pass over the same samples
+// (geometry + one 4-byte LDS atomic per tap).  (A single window-wide scale 2^30 / sum |a| was measured: 2.3e-5 absolute error
+// at Lq = 1029 - the 7x7 rows collect 300+ adds at a resolution set by a bound 50x above their weight; row scales: 6e-7.)
 //
-// A wave handles 64 samples per iteration in three phases over a per-wave LDS record array:
-//   A  lane = sample: tap geometry once -> record {(w_tap * scale, accumulator row) x 4 | lh, lw, a W, a H | slab rows}
-//   B  lane = (sample of 8, 4 channels of 32): the owner's gather, 8 samples per step, DPP reductions over the 8 lanes
-//   C  lane = (tap of 4, channel pair of 16): one ds_add_u64 per sample, skipped when no tap of the sample is in the band.
+// A wave handles 64 samples (16 queries x 4 points) per iteration:
+//   A  lane = sample: tap geometry, kept in REGISTERS; the 16 grad_out rows of the iteration arrive by LDS-DMA meanwhile
+//   B  gather, lane = (query of 16, tap of 4), one step per point: the lane's 32-channel dot product <value row, grad_out
+//      row>, quad DPP sums with per-tap coefficients -> d/dw, d/dloc of 16 samples per step, stored per (query, point)
+//   C  scatter, lane = (sample of the query's 4, channel pair of 16), one step per query and tap: one ds_add_u64 per
+//      (sample, tap); the {tap weight, accumulator row} records of 32 samples at a time pass through 1 KiB of LDS per wave
+// (v1 of this file - 12-wave workgroups, one per CU, 56-byte LDS records per sample, 8-lane gather - ran 320 us per layer
+//  against 303 us for the two-kernel path: ~33 issued instructions per sample, 25 us of un-overlapped prologue per workgroup.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -41,14 +44,18 @@
 namespace {
 
 constexpr int kD = 32;
+constexpr int kP = 4;
 constexpr int kMaxLv = 8;
-constexpr int kMaxWin = 48;
+constexpr int kMaxWin = 64;
 constexpr int kLds = 160 * 1024;
+constexpr int kNWmax = 16;
+constexpr int kWaveLds = 2048 + 1024;  // per wave: 16 grad_out rows (2 KiB) + the scatter records of 32 samples (1 KiB)
 
 struct WinArgs {
   int n_win;
   int H[kMaxLv], W[kMaxLv], start[kMaxLv];
   short lvl[kMaxWin], y0[kMaxWin], y1[kMaxWin];
+  unsigned char slab[kMaxWin];  // 1: the level's value rows are staged in LDS (whole-level windows only)
 };
 
 template <int CTRL>
@@ -68,18 +75,26 @@ __device__ __forceinline__ void lds_dma16(const float* g, float* l) {
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-// per-sample record arrays of one wave (64 samples): c0 {ws_k, accrow_k} x 4 (32 B), c1 {lh, lw, a*W, a*H} (16 B),
-// c2 {slab rows 0|1, 2|3 as u16 pairs} (8 B)
-constexpr int kRecBytes = 64 * (32 + 16 + 8);
+__device__ __forceinline__ float bperm(float v, int src_lane) {
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
+}
+__device__ __forceinline__ unsigned bperm_u(unsigned v, int src_lane) {
+  return (unsigned)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v);
+}
 
-template <int NW, int P>
-__global__ void __launch_bounds__(NW * 64)
+inline size_t win_lds_bytes(int R, int halo, int nw) {
+  return (size_t)(R + 1) * 128 + (size_t)(R + halo + 1) * 128 + (size_t)((R + 1 + 3) & ~3) * 4 + (size_t)(nw * 36 + 36) * 4 +
+         (size_t)nw * kWaveLds + 16;
+}
+
+template <int kNW>
+__global__ void __launch_bounds__(kNW * 64, 4)
 msda_bwd_win_d32(const float* __restrict__ gout, const float* __restrict__ value, const float* __restrict__ loc,
                  const float* __restrict__ aw, int B, int S, int M, int L, int Lq, float* __restrict__ gvalue,
                  float* __restrict__ gloc, float* __restrict__ gaw, WinArgs wa, unsigned long long* __restrict__ ts, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   combo_ts_begin(ts);
-  constexpr int NT = NW * 64;
+  constexpr int P = kP, NW = kNW, NT = kNW * 64;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int logical = xcd_contiguous(blockIdx.x, gridDim.x);
@@ -89,26 +104,26 @@ msda_bwd_win_d32(const float* __restrict__ gout, const float* __restrict__ value
   const int lv = wa.lvl[win], y0 = wa.y0[win], y1 = wa.y1[win];
   const int H = wa.H[lv], W = wa.W[lv];
   const int R = (y1 - y0) * W;                 // accumulator rows of the band (local row R = sink of foreign taps)
-  const int NR = R + (y1 < H ? W : 0);         // value rows in LDS: the band + one image row below (local row NR = zeros)
+  const int NR = R + (y1 < H ? W : 0);         // value rows in LDS: the band + one image row below it (local row NR = zeros)
   const int row0 = wa.start[lv] + y0 * W;      // first pyramid row of the band
   const int LP = L * P;
 
-  float* slab = reinterpret_cast<float*>(smem);                                       // [NR + 1][32] f32
-  unsigned long long* acc = reinterpret_cast<unsigned long long*>(slab + (NR + 1) * kD);  // [R + 1][16] u64
-  int* wsum = reinterpret_cast<int*>(acc + (R + 1) * 16);                             // [R + 1] -> row scales
-  float* red = reinterpret_cast<float*>(wsum + ((R + 1 + 3) & ~3));                   // [NW][36] + chmx[32] + misc[4]
+  unsigned long long* acc = reinterpret_cast<unsigned long long*>(smem);               // [R + 1][16] u64
+  float* slab = reinterpret_cast<float*>(acc + (R + 1) * 16);                          // [NR + 1][32] f32, chunk-swizzled
+  int* wsum = reinterpret_cast<int*>(slab + (NR + 1) * kD);                            // [R + 1] -> row scales
+  float* red = reinterpret_cast<float*>(wsum + ((R + 1 + 3) & ~3));                    // [NW][36] + chmx[36]
   float* chmx = red + NW * 36;
-  char* rec = reinterpret_cast<char*>(chmx + 36) + wave * kRecBytes;
-  float2* c0 = reinterpret_cast<float2*>(rec);                 // [64][4] {ws, accrow}
-  float4* c1 = reinterpret_cast<float4*>(rec + 64 * 32);       // [64]
-  uint2* c2 = reinterpret_cast<uint2*>(rec + 64 * 48);         // [64]
+  float* gbuf = chmx + 36 + wave * (kWaveLds / 4);                                     // [16 queries][32]: grad_out rows of the iteration
+  float4* rec = reinterpret_cast<float4*>(gbuf + 512);                                 // [32 samples][2]: {ws, row * 128} x 4 taps
 
-  // ---- stage the value rows of the band (+ halo) with LDS-DMA; clear the accumulators --------------------------------------
+  // ---- stage the level's value rows with LDS-DMA (whole-level windows); clear the accumulators --------------------------------
   {
-    const float* vb = value + (((long long)b * S + row0) * M + m) * kD + (lane & 7) * 4;
-    for (int r0 = wave * 8; r0 < NR; r0 += NW * 8) {
+    // position p of row r holds the 16-byte chunk p ^ (r & 7): the gather reads chunk c of 64 DIFFERENT rows at once - un-swizzled,
+    // all of them in the same 4 banks
+    const int p = lane & 7;
+    for (int r0 = wave * 8; r0 < NR && !(dbg & 128); r0 += NW * 8) {  // (ablation bit 128: no slab staging)
       const int r = r0 + (lane >> 3);
-      if (r < NR) lds_dma16(vb + (long long)r * M * kD, slab + r0 * kD);
+      if (r < NR) lds_dma16(value + (((long long)b * S + row0 + r) * M + m) * kD + ((p ^ (r & 7)) * 4), slab + r0 * kD);
     }
     if (tid < 8) *reinterpret_cast<float4*>(slab + NR * kD + tid * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
@@ -118,33 +133,34 @@ msda_bwd_win_d32(const float* __restrict__ gout, const float* __restrict__ value
   // ---- pre-pass: max_q |grad_out[q, c]| per channel, sum |a| over the level's samples ----------------------------------------
   {
     const int cg = tid & 7;
-    float mx[4] = {0.f, 0.f, 0.f, 0.f};
+    float mx[4] = {1.f, 1.f, 1.f, 1.f};
     bool nan = false;
-    for (int q0 = tid >> 3; q0 < Lq; q0 += 4 * (NT / 8)) {  // 4 independent 16-byte loads in flight per lane
-      float4 t[4];
+    if (!(dbg & 16)) { mx[0] = mx[1] = mx[2] = mx[3] = 0.f; }  // ablation bit 16: no grad_out scan (wrong scales, timing only)
+    for (int q0 = tid >> 3; q0 < Lq && !(dbg & 16); q0 += 8 * (NT / 8)) {  // 8 independent 16-byte loads in flight per lane (latency-bound)
+      float4 t[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 8; ++u) {
         const int q = q0 + u * (NT / 8);
         t[u] = q < Lq ? *reinterpret_cast<const float4*>(gout + (((long long)b * Lq + q) * M + m) * kD + cg * 4)
                       : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 8; ++u) {
         mx[0] = fmaxf(mx[0], fabsf(t[u].x)); mx[1] = fmaxf(mx[1], fabsf(t[u].y));
         mx[2] = fmaxf(mx[2], fabsf(t[u].z)); mx[3] = fmaxf(mx[3], fabsf(t[u].w));
         nan |= !(t[u].x == t[u].x) || !(t[u].y == t[u].y) || !(t[u].z == t[u].z) || !(t[u].w == t[u].w);  // fmaxf drops NaNs
       }
     }
     float sa = 0.f;
-    for (int i0 = tid; i0 < Lq * P; i0 += 4 * NT) {
-      float t[4];
+    for (int i0 = tid; i0 < Lq * P; i0 += 8 * NT) {
+      float t[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 8; ++u) {
         const int i = i0 + u * NT;
         const int q = i / P, p = i - q * P;
         t[u] = i < Lq * P ? aw[(((long long)b * Lq + q) * M + m) * LP + lv * P + p] : 0.f;
       }
-      sa += (fabsf(t[0]) + fabsf(t[1])) + (fabsf(t[2]) + fabsf(t[3]));
+      sa += ((fabsf(t[0]) + fabsf(t[1])) + (fabsf(t[2]) + fabsf(t[3]))) + ((fabsf(t[4]) + fabsf(t[5])) + (fabsf(t[6]) + fabsf(t[7])));
     }
 #pragma unroll
     for (int s = 8; s < 64; s <<= 1)
@@ -176,22 +192,21 @@ msda_bwd_win_d32(const float* __restrict__ gout, const float* __restrict__ value
   const int n_samples = Lq * P;
   const int n_iter = (n_samples + 63) / 64;
 
-  // tap geometry of sample i (reference .cuh:92-164): local rows of the four taps (slab / accumulator), weights
-  auto fetch = [&](int i, float2& xy, float& a) {  // sampling location + attention weight of sample i of this level
-    xy = make_float2(-4.f, -4.f);  // (outside every map)
-    a = 0.f;
-    if (i < n_samples) {
-      const int q = i / P, p = i - q * P;
-      const long long e = (((long long)b * Lq + q) * M + m) * LP + lv * P + p;
-      xy = *reinterpret_cast<const float2*>(loc + e * 2);
-      a = aw[e];
-    }
+  // sampling location + attention weight of sample i of this level; ALWAYS two memory instructions (counted waits below)
+  auto fetch = [&](int i, float2& xy, float& a) {
+    const int ic = i < n_samples ? i : n_samples - 1;
+    const int q = ic / P, p = ic - q * P;
+    const long long e = (((long long)b * Lq + q) * M + m) * LP + lv * P + p;
+    xy = *reinterpret_cast<const float2*>(loc + e * 2);
+    a = aw[e];
   };
-  auto geometry = [&](float2 xy, float a, bool live, int (&srow)[4], int (&arow)[4], float (&wt)[4], float4& par, bool& owner) {
+  // tap geometry of a sample (reference .cuh:92-164).  grow: slab rows of the four taps (NR = the zero row: outside the map /
+  // not needed here); arow: accumulator rows (R = not in this band); wt: w_tap * a
+  auto geometry = [&](float2 xy, float a, bool live, int (&grow)[4], int (&arow)[4], float (&wt)[4], float4& par, bool& owner) {
     owner = false;
     par = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { srow[k] = NR; arow[k] = R; wt[k] = 0.f; }
+    for (int k = 0; k < 4; ++k) { grow[k] = NR; arow[k] = R; wt[k] = 0.f; }
     if (!live) return;
     const float h_im = xy.y * H - 0.5f, w_im = xy.x * W - 0.5f;
     if (!(h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W)) {
@@ -204,7 +219,7 @@ msda_bwd_win_d32(const float* __restrict__ gout, const float* __restrict__ value
     const bool t_ok = h0 >= 0, b_ok = h0 + 1 <= H - 1, l_ok = w0 >= 0, r_ok = w0 + 1 <= W - 1;
     const int yo = h0 < 0 ? 0 : h0;
     owner = yo >= y0 && yo < y1;
-    const int base = (h0 - y0) * W + w0;  // local row of the top-left tap
+    const int base = (h0 - y0) * W + w0;  // band-local row of the top-left tap
     const bool ok[4] = {t_ok && l_ok, t_ok && r_ok, b_ok && l_ok, b_ok && r_ok};
     const int rr[4] = {base, base + 1, base + W, base + W + 1};
     const float w4[4] = {hh * hw * a, hh * lw * a, lh * hw * a, lh * lw * a};
@@ -212,24 +227,37 @@ msda_bwd_win_d32(const float* __restrict__ gout, const float* __restrict__ value
     for (int k = 0; k < 4; ++k) {
       const int y = h0 + (k >> 1);
       if (ok[k] && y >= y0 && y < y1) { arow[k] = rr[k]; wt[k] = w4[k]; }
-      if (ok[k] && owner) srow[k] = rr[k];  // y in [y0, y1]: the band or its halo row
+      if (ok[k] && owner) grow[k] = rr[k];  // y in [y0, y1]: the band or its halo row
     }
     par = make_float4(lh, lw, a * W, a * H);
   };
 
-  // ---- pass 0: W_r, an upper bound of the total tap weight a row can receive (two samples in flight per lane) ----------------------
-  for (int it = wave; it < n_iter; it += 2 * NW) {
-    float2 xy[2];
-    float a[2];
-    fetch(it * 64 + lane, xy[0], a[0]);
-    fetch((it + NW) * 64 + lane, xy[1], a[1]);
+  // Band windows: most iterations hold no sample near the band (queries come in raster order, offsets are local).  A cheap
+  // test on the vertical coordinate alone - can any tap of the sample touch rows [y0, y1), or is the sample owned here (rows
+  // clamp into the image; samples outside the map belong to the first band) - lets a wave drop such an iteration before the
+  // full geometry, the grad_out rows and the record traffic.
+  const bool full_level = y0 == 0 && y1 == H;
+  auto may_touch = [&](float2 xy, bool live) {
+    const float h_im = xy.y * H - 0.5f;
+    return live && ((h_im > (float)(y0 - 1) - 1e-3f && h_im < (float)y1 + 1e-3f) || (y0 == 0 && !(h_im > -1.f && h_im < (float)H)) ||
+                    (y0 == 0 && !(xy.x * W - 0.5f > -1.f && xy.x * W - 0.5f < (float)W)));
+  };
+
+  // ---- pass 0: W_r, an upper bound of the total tap weight a row can receive (eight samples in flight per lane) --------------------
+  for (int it = wave; it < n_iter && !(dbg & 32); it += 8 * NW) {  // (ablation bit 32: no pass 0)
+    float2 xy[8];
+    float a[8];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      int srow[4], arow[4];
+    for (int u = 0; u < 8; ++u) fetch((it + u * NW) * 64 + lane, xy[u], a[u]);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const bool live = (it + u * NW) * 64 + lane < n_samples;
+      if (!full_level && !__any(may_touch(xy[u], live))) continue;  // wave-uniform
+      int grow[4], arow[4];
       float wt[4];
       float4 par;
       bool owner;
-      geometry(xy[u], a[u], (it + u * NW) * 64 + lane < n_samples, srow, arow, wt, par, owner);
+      geometry(xy[u], a[u], live, grow, arow, wt, par, owner);
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (arow[k] < R)
@@ -245,125 +273,137 @@ msda_bwd_win_d32(const float* __restrict__ gout, const float* __restrict__ value
   __syncthreads();
 
   // ---- the pass over the samples --------------------------------------------------------------------------------------------------------
-  const int kk = lane >> 4, cp = lane & 15;    // phase C: tap, channel pair
-  const int g8 = lane >> 3, cg = lane & 7;     // phase B: sample of 8, 4 channels
+  const int cp = lane & 15, u4 = lane >> 4;   // phase C: channel pair, sample of the query's 4
+  const int qi = lane >> 2, kt = lane & 3;    // phase B: query of the iteration's 16, tap
   const float inv0 = [&] { const float mm = chmx[2 * cp]; return mm > 0.f ? 1.f / mm : (mm == mm ? 0.f : mm); }();
   const float inv1 = [&] { const float mm = chmx[2 * cp + 1]; return mm > 0.f ? 1.f / mm : (mm == mm ? 0.f : mm); }();
-  constexpr int QI = 64 / P;  // queries per wave iteration (64 % P == 0: an iteration starts on a query boundary)
-  const bool full_level = y0 == 0 && y1 == H;  // every sample inside the map touches the window: no per-sample skip test
-  float2 xy_next;
-  float a_next;
-  fetch(wave * 64 + lane, xy_next, a_next);
-  for (int it = wave; it < n_iter; it += NW) {
+  char* acc_lane = reinterpret_cast<char*>(acc) + cp * 8;
+  // (the next iteration's sample is in flight during the current one; the counted vmcnt waits for the grad_out rows retire
+  //  the loads in order, so a deeper prefetch would be drained by them anyway)
+  float2 xy_n0;
+  float a_n0;
+  fetch(wave * 64 + lane, xy_n0, a_n0);
+  for (int it = wave; it < n_iter && !(dbg & 64); it += NW) {  // (ablation bit 64: no main loop)
     const int ibase = it * 64;
-    const float2 xy_cur = xy_next;
-    const float a_cur = a_next;
-    fetch((it + NW) * 64 + lane, xy_next, a_next);  // the next iteration's sample: in flight during this one
     const int qbase = ibase / P;
-    // grad_out rows of the iteration's queries, requested first so that their latency hides behind phase A:
-    //   phase C: this lane's channel pair of every query;  phase B: this lane's 4 channels of the queries of its 8 samples
-    float2 gq[QI];
-    float4 tgB[8];
-    auto prefetch = [&]() {
-#pragma unroll
-      for (int u = 0; u < QI; ++u) {
-        const int q = qbase + u < Lq ? qbase + u : Lq - 1;
-        const float2 t = *reinterpret_cast<const float2*>(gout + (((long long)b * Lq + q) * M + m) * kD + 2 * cp);
-        gq[u] = make_float2(t.x * inv0, t.y * inv1);  // normalised to [-1, 1] per channel
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int qq = qbase + (j * 8 + g8) / P;
-        const int q = qq < Lq ? qq : Lq - 1;
-        tgB[j] = *reinterpret_cast<const float4*>(gout + (((long long)b * Lq + q) * M + m) * kD + cg * 4);
-      }
+    const float2 xy_cur = xy_n0;
+    const float a_cur = a_n0;
+    // the 16 grad_out rows of this iteration -> LDS (2 x 1 KiB LDS-DMA: lane -> (query lane >> 3, 16-byte chunk lane & 7)): a
+    // whole-level window needs them in every iteration and requests them first; a band only once it knows it has work
+    auto request_gout = [&]() {
+      const int q0 = min(qbase + (lane >> 3), Lq - 1), q1 = min(qbase + 8 + (lane >> 3), Lq - 1);
+      lds_dma16(gout + (((long long)b * Lq + q0) * M + m) * kD + (lane & 7) * 4, gbuf);
+      lds_dma16(gout + (((long long)b * Lq + q1) * M + m) * kD + (lane & 7) * 4, gbuf + 256);
     };
-    // a whole-level window works on every iteration: request the rows first, their latency hides behind phase A; a band sees
-    // most iterations pass by untouched (queries are in raster order, offsets are local) and requests them once it knows
-    if (full_level) prefetch();
-    // -- phase A: one lane per sample
-    unsigned long long own_mask, touch_mask;
-    {
-      const int i = ibase + lane;
-      int srow[4], arow[4];
-      float wt[4];
-      float4 par;
-      bool owner;
-      geometry(xy_cur, a_cur, i < n_samples, srow, arow, wt, par, owner);
-      own_mask = __ballot(owner);
-      touch_mask = __ballot(arow[0] < R || arow[1] < R || arow[2] < R || arow[3] < R);
-      if (dbg & 1) own_mask = 0;    // ablation (COMBO_MSDA_BWD_DBG): no gather phase
-      if (dbg & 2) touch_mask = 0;  // ablation: no scatter phase
-      if (!full_level && (own_mask | touch_mask) == 0ull) continue;  // nothing of this band in these 64 samples (wave-uniform)
-      float4 lo, hi;
-      lo.x = wt[0] * rowscale[arow[0]]; lo.y = __int_as_float(arow[0]);
-      lo.z = wt[1] * rowscale[arow[1]]; lo.w = __int_as_float(arow[1]);
-      hi.x = wt[2] * rowscale[arow[2]]; hi.y = __int_as_float(arow[2]);
-      hi.z = wt[3] * rowscale[arow[3]]; hi.w = __int_as_float(arow[3]);
-      reinterpret_cast<float4*>(c0)[lane * 2] = lo;
-      reinterpret_cast<float4*>(c0)[lane * 2 + 1] = hi;
-      c1[lane] = par;
-      c2[lane] = make_uint2((unsigned)srow[0] | ((unsigned)srow[1] << 16), (unsigned)srow[2] | ((unsigned)srow[3] << 16));
+    if (full_level) request_gout();
+    fetch((it + NW) * 64 + lane, xy_n0, a_n0);  // (2 loads) the next iteration's sample
+    const bool live = ibase + lane < n_samples;
+    if (!full_level && !__any(may_touch(xy_cur, live))) continue;  // wave-uniform: nothing near this band in these 64 samples
+    // -- phase A: one lane per sample, results in registers
+    int grow[4], arow[4];
+    float wt[4];
+    float4 par;
+    bool owner;
+    geometry(xy_cur, a_cur, live, grow, arow, wt, par, owner);
+    unsigned long long own_mask = __ballot(owner);
+    unsigned long long touch_mask = __ballot(arow[0] < R || arow[1] < R || arow[2] < R || arow[3] < R);
+    if (dbg & 1) own_mask = 0;    // ablation (COMBO_MSDA_BWD_DBG): no gather phase
+    if (dbg & 2) touch_mask = 0;  // ablation: no scatter phase
+    if ((own_mask | touch_mask) == 0ull) {
+      if (full_level) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // (the DMA must not land in the next iteration's rows)
+      continue;  // wave-uniform
     }
-    if (!full_level) prefetch();
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (full_level) {
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // the two LDS-DMA pieces have landed (the two prefetch loads stay in flight)
+    } else {
+      request_gout();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // -- phase B: the owner's gather -> d out / d w, d out / d loc (8 samples per step, 8 lanes x 4 channels per sample)
+
+    // -- phase B: gather.  Step j = point j of the 16 queries; lane (qi, kt) owns tap kt of sample 4 qi + j.
+    if (own_mask) {
+      float4 gq[8];  // this lane's query row of grad_out, all 32 channels
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (((own_mask >> (8 * j)) & 0xffull) == 0ull) continue;  // wave-uniform
-      const int s = j * 8 + g8;
-      const int i = ibase + s;
-      const int ic = i < n_samples ? i : n_samples - 1;
-      const int q = ic / P, p = ic - q * P;
-      const long long qm = ((long long)b * Lq + q) * M + m;
-      const float4 tg = tgB[j];
-      const float4 pp = c1[s];
-      const uint2 o = c2[s];
-      const float* sl = slab + cg * 4;
-      const float4 v0 = *reinterpret_cast<const float4*>(sl + (o.x & 0xffffu) * kD);
-      const float4 v1 = *reinterpret_cast<const float4*>(sl + (o.x >> 16) * kD);
-      const float4 v2 = *reinterpret_cast<const float4*>(sl + (o.y & 0xffffu) * kD);
-      const float4 v3 = *reinterpret_cast<const float4*>(sl + (o.y >> 16) * kD);
-      const float d0 = tg.x * v0.x + tg.y * v0.y + tg.z * v0.z + tg.w * v0.w;
-      const float d1 = tg.x * v1.x + tg.y * v1.y + tg.z * v1.z + tg.w * v1.w;
-      const float d2 = tg.x * v2.x + tg.y * v2.y + tg.z * v2.z + tg.w * v2.w;
-      const float d3 = tg.x * v3.x + tg.y * v3.y + tg.z * v3.z + tg.w * v3.w;
-      const float lh = pp.x, lw = pp.y, hh = 1.f - lh, hw = 1.f - lw;
-      float sw = hh * hw * d0 + hh * lw * d1 + lh * hw * d2 + lh * lw * d3;  // d out / d w
-      float sy = (-hw * d0 - lw * d1 + hw * d2 + lw * d3) * pp.w;              // * a * H  (.cuh:162-163)
-      float sx = (-hh * d0 + hh * d1 - lh * d2 + lh * d3) * pp.z;              // * a * W
-      sw += dppf<0xB1>(sw); sx += dppf<0xB1>(sx); sy += dppf<0xB1>(sy);     // quad_perm [1,0,3,2]
-      sw += dppf<0x4E>(sw); sx += dppf<0x4E>(sx); sy += dppf<0x4E>(sy);     // quad_perm [2,3,0,1]
-      sw += dppf<0x141>(sw); sx += dppf<0x141>(sx); sy += dppf<0x141>(sy);  // row_half_mirror
-      if (cg == 0 && ((own_mask >> s) & 1ull)) {
-        const long long e = qm * LP + lv * P + p;
-        gaw[e] = sw;
-        *reinterpret_cast<float2*>(gloc + e * 2) = make_float2(sx, sy);
+      for (int c = 0; c < 8; ++c) gq[c] = *reinterpret_cast<const float4*>(gbuf + qi * kD + c * 4);
+      const unsigned r01 = (unsigned)grow[0] | ((unsigned)grow[1] << 16), r23 = (unsigned)grow[2] | ((unsigned)grow[3] << 16);
+      float keep_w = 0.f, keep_x = 0.f, keep_y = 0.f;  // lane kt == j keeps the results of point j
+#pragma unroll 1
+      for (int j = 0; j < 4; ++j) {
+        const int src = 4 * qi + j;
+        const float lh = bperm(par.x, src), lw = bperm(par.y, src), aW = bperm(par.z, src), aH = bperm(par.w, src);
+        const unsigned ra = bperm_u(r01, src), rb = bperm_u(r23, src);
+        const unsigned pair = (kt & 2) ? rb : ra;
+        const int row = (int)((kt & 1) ? (pair >> 16) : (pair & 0xffffu));  // slab row of this lane's tap (NR: the zero row)
+        float d = 0.f;
+        if (row < NR) {
+          float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+          const float* vr = slab + row * kD;
+          const int sw7 = row & 7;  // LDS slab: chunk c sits at position c ^ (row & 7)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {  // two halves of the 128-byte row: 16 registers of value in flight, not 32
+            float4 v[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = *reinterpret_cast<const float4*>(vr + (((4 * h + c) ^ sw7) * 4));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              d0 = fmaf(v[c].x, gq[4 * h + c].x, d0); d1 = fmaf(v[c].y, gq[4 * h + c].y, d1);
+              d2 = fmaf(v[c].z, gq[4 * h + c].z, d2); d3 = fmaf(v[c].w, gq[4 * h + c].w, d3);
+            }
+          }
+          d = (d0 + d1) + (d2 + d3);
+        }
+        // per-tap coefficients: d/dw = sum_k bw_k d_k; d/dx = a W sum_k bx_k d_k; d/dy = a H sum_k by_k d_k  (.cuh:148-163)
+        const float wy = (kt & 2) ? lh : 1.f - lh, wx = (kt & 1) ? lw : 1.f - lw;
+        float sw = wy * wx * d;
+        float sx = ((kt & 1) ? wy : -wy) * d * aW;
+        float sy = ((kt & 2) ? wx : -wx) * d * aH;
+        sw += dppf<0xB1>(sw); sx += dppf<0xB1>(sx); sy += dppf<0xB1>(sy);  // quad_perm [1,0,3,2]
+        sw += dppf<0x4E>(sw); sx += dppf<0x4E>(sx); sy += dppf<0x4E>(sy);  // quad_perm [2,3,0,1]
+        if (kt == j) { keep_w = sw; keep_x = sx; keep_y = sy; }
+      }
+      // lane (qi, kt) stores point kt of query qbase + qi when the sample is owned here
+      if ((own_mask >> (4 * qi + kt)) & 1ull) {
+        const long long e = (((long long)b * Lq + qbase + qi) * M + m) * LP + lv * P + kt;
+        gaw[e] = keep_w;
+        *reinterpret_cast<float2*>(gloc + e * 2) = make_float2(keep_x, keep_y);
       }
     }
-    // -- phase C: scatter, one ds_add_u64 wave instruction per sample (4 taps x 16 channel pairs); the records of 8 samples are
-    //    read ahead of their 8 atomics (the wave-uniform skips would otherwise serialise read -> wait -> add per sample)
+
+    // -- phase C: scatter.  Records of 32 samples at a time through the wave's 1 KiB record buffer; lane (u4, cp) adds the four
+    //    taps of sample 4 q + u4 for channel pair cp: a ds_add_u64 wave instruction covers 4 rows x 128 B.
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      if (((touch_mask >> (8 * g)) & 0xffull) == 0ull) continue;  // wave-uniform
-      float2 wr[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) wr[u] = c0[(g * 8 + u) * 4 + kk];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int s = g * 8 + u;
-        if (!full_level && !((touch_mask >> s) & 1ull)) continue;  // wave-uniform (a skipped sample of a full level adds 0 to the sink row)
-        const float g0 = gq[s / P].x, g1 = gq[s / P].y;
-        const int ar = __float_as_int(wr[u].y);
-        const int v0 = cvt_rpi(wr[u].x * g0), v1 = cvt_rpi(wr[u].x * g1);
-        const unsigned long long x = ((unsigned long long)(unsigned)(v1 + (v0 >> 31)) << 32) | (unsigned)v0;
-        __hip_atomic_fetch_add(acc + ar * 16 + cp, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (int half = 0; half < 2; ++half) {
+      if (((touch_mask >> (32 * half)) & 0xffffffffull) == 0ull) continue;  // wave-uniform
+      if ((lane >> 5) == half) {
+        const int sl = lane & 31;
+        rec[sl * 2] = make_float4(wt[0] * rowscale[arow[0]], __int_as_float(arow[0] * 128), wt[1] * rowscale[arow[1]],
+                                  __int_as_float(arow[1] * 128));
+        rec[sl * 2 + 1] = make_float4(wt[2] * rowscale[arow[2]], __int_as_float(arow[2] * 128), wt[3] * rowscale[arow[3]],
+                                      __int_as_float(arow[3] * 128));
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int q8 = 0; q8 < 8; ++q8) {
+        if (((touch_mask >> (32 * half + 4 * q8)) & 0xfull) == 0ull) continue;  // wave-uniform: none of the query's 4 samples
+        const float2 g2 = *reinterpret_cast<const float2*>(gbuf + (half * 8 + q8) * kD + 2 * cp);
+        const float g0 = g2.x * inv0, g1 = g2.y * inv1;  // normalised to [-1, 1] per channel
+        const float4 ra = rec[(q8 * 4 + u4) * 2], rb = rec[(q8 * 4 + u4) * 2 + 1];
+        const float wsk[4] = {ra.x, ra.z, rb.x, rb.z};
+        const int ark[4] = {__float_as_int(ra.y), __float_as_int(ra.w), __float_as_int(rb.y), __float_as_int(rb.w)};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int v0 = cvt_rpi(wsk[k] * g0), v1 = cvt_rpi(wsk[k] * g1);
+          const unsigned long long x = ((unsigned long long)(unsigned)(v1 + (v0 >> 31)) << 32) | (unsigned)v0;
+          __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(acc_lane + ark[k]), x, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
 
@@ -385,9 +425,49 @@ msda_bwd_win_d32(const float* __restrict__ gout, const float* __restrict__ value
   combo_ts_end(ts);
 }
 
-inline size_t win_lds_bytes(int R, int halo, int nw) {
-  return (size_t)(R + halo + 1) * 128 + (size_t)(R + 1) * 128 + (size_t)((R + 1 + 3) & ~3) * 4 + (size_t)(nw * 36 + 36) * 4 +
-         (size_t)nw * kRecBytes + 16;
+// the window table of a pyramid: per level, the fewest equal bands of image rows whose accumulator + value rows (+ one halo
+// image row) fit `cap`
+bool build_windows(const int* host_shapes, const int* host_start, int L, size_t cap, int nw, WinArgs& wa, size_t& lds_max,
+                   long long& rows_total) {
+  wa.n_win = 0;
+  lds_max = 0;
+  rows_total = 0;
+  for (int l = 0; l < L; ++l) {
+    const int H = host_shapes[2 * l], W = host_shapes[2 * l + 1];
+    if (H <= 0 || W <= 0 || H > 32767 || W > 4096) return false;
+    wa.H[l] = H; wa.W[l] = W; wa.start[l] = host_start ? host_start[l] : (int)rows_total;
+    rows_total += (long long)H * W;
+    int rmax = 0;
+    for (int rows = 1; rows <= H; ++rows)
+      if (win_lds_bytes(rows * W, rows < H ? W : 0, nw) <= cap && (long long)(rows + 1) * W < 65000) rmax = rows; else break;
+    if (rmax == 0) return false;
+    const int bands = (H + rmax - 1) / rmax;
+    const int per = (H + bands - 1) / bands;
+    for (int y = 0; y < H; y += per) {
+      if (wa.n_win >= kMaxWin) return false;
+      const int ye = y + per < H ? y + per : H;
+      wa.lvl[wa.n_win] = (short)l; wa.y0[wa.n_win] = (short)y; wa.y1[wa.n_win] = (short)ye; wa.slab[wa.n_win] = 1;
+      const size_t need = win_lds_bytes((ye - y) * W, ye < H ? W : 0, nw);
+      lds_max = need > lds_max ? need : lds_max;
+      ++wa.n_win;
+    }
+  }
+  return true;
+}
+
+// LDS budget and width of a workgroup: 8 waves, two workgroups per CU when that gives a short window table; else 16 waves
+// and the whole CU.  COMBO_MSDA_BWD_LDS_KB / COMBO_MSDA_BWD_WAVES override (A/B).
+bool plan_windows(const int* host_shapes, const int* host_start, int L, WinArgs& wa, size_t& lds_max, long long& rows_total, int& nw) {
+  static const int cap_kb = [] { const char* e = getenv("COMBO_MSDA_BWD_LDS_KB"); return e ? atoi(e) : 0; }();
+  static const int nw_env = [] { const char* e = getenv("COMBO_MSDA_BWD_WAVES"); return e ? atoi(e) : 0; }();
+  if (cap_kb > 0 || nw_env > 0) {
+    nw = nw_env == 16 ? 16 : 8;
+    return build_windows(host_shapes, host_start, L, (size_t)(cap_kb > 0 ? cap_kb : (nw == 16 ? 160 : 80)) * 1024, nw, wa, lds_max, rows_total);
+  }
+  nw = 8;
+  if (build_windows(host_shapes, host_start, L, (size_t)80 * 1024, 8, wa, lds_max, rows_total) && wa.n_win <= 3 * L) return true;
+  nw = 16;
+  return build_windows(host_shapes, host_start, L, (size_t)kLds, 16, wa, lds_max, rows_total);
 }
 
 }  // namespace
@@ -396,97 +476,50 @@ extern "C" {
 
 // 1 when combo_msda_backward_win_f32 takes this geometry (every output element is then written: no zero-fill needed)
 int combo_msda_backward_win_ok(const int* host_shapes, int L, int P, int D, int elem_bytes) {
-  if (!host_shapes || elem_bytes != 4 || D != kD || L <= 0 || L > kMaxLv || P != 4) return 0;  // (P: template instance)
-  int wins = 0;
-  for (int l = 0; l < L; ++l) {
-    const int H = host_shapes[2 * l], W = host_shapes[2 * l + 1];
-    if (H <= 0 || W <= 0 || H > 32767 || W > 4096) return 0;
-    if (win_lds_bytes(W, W, 8) > (size_t)kLds) return 0;  // not even one image row + halo fits
-    long long rmax = 0;
-    for (int rows = 1; rows <= H; ++rows)
-      if (win_lds_bytes(rows * W, rows < H ? W : 0, 8) <= (size_t)kLds) rmax = rows; else break;
-    if ((long long)rmax * W > 60000) return 0;  // 16-bit local rows
-    wins += (int)((H + rmax - 1) / rmax);
-  }
-  return wins <= kMaxWin ? 1 : 0;
+  if (!host_shapes || elem_bytes != 4 || D != kD || L <= 0 || L > kMaxLv || P != kP) return 0;
+  WinArgs wa;
+  size_t lds_max;
+  long long rows;
+  int nw;
+  return plan_windows(host_shapes, nullptr, L, wa, lds_max, rows, nw) ? 1 : 0;
 }
 
-/* Fused, windowed MSDeformAttn backward (D == 32, fp32).  Same operands as combo_msda_backward_f32 plus the level geometry ON
- * THE HOST (host_shapes [L,2] ints = spatial_shapes, host_start [L] = level_start_index): the window table and the LDS budget
- * are functions of the level sizes, and the reference's launcher receives them as device tensors only
+/* Fused, windowed MSDeformAttn backward (D == 32, P == 4, fp32).  Same operands as combo_msda_backward_f32 plus the level
+ * geometry ON THE HOST (host_shapes [L,2] ints = spatial_shapes, host_start [L] = level_start_index): the window table and the
+ * LDS budget are functions of the level sizes, and the reference's launcher receives them as device tensors only
  * (ms_deform_attn_cuda.cu:72-73).  Writes every element of the three gradients. */
 int combo_msda_backward_win_f32(const float* grad_out, const float* value, const int* host_shapes, const int* host_start,
                                 const float* sampling_loc, const float* attn_weight, int B, int S, int M, int D, int L, int Lq,
                                 int P, float* grad_value, float* grad_sampling_loc, float* grad_attn_weight,
                                 combo_stream_t stream) {
   if (!grad_out || !value || !host_shapes || !host_start || !sampling_loc || !attn_weight || !grad_value || !grad_sampling_loc ||
-      !grad_attn_weight || B <= 0 || S <= 0 || M <= 0 || Lq <= 0)
+      !grad_attn_weight || B <= 0 || S <= 0 || M <= 0 || Lq <= 0 || D != kD || P != kP || L <= 0 || L > kMaxLv)
     return COMBO_EINVAL;
-  if (!combo_msda_backward_win_ok(host_shapes, L, P, D, 4)) return COMBO_EINVAL;
-  static const int nw_env = [] { const char* e = getenv("COMBO_MSDA_BWD_WAVES"); return e ? atoi(e) : 0; }();
-  static const int per_cu = [] { const char* e = getenv("COMBO_MSDA_BWD_PER_CU"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 4 ? v : 1; }();
-  static const int cap_kb = [] { const char* e = getenv("COMBO_MSDA_BWD_LDS_KB"); return e ? atoi(e) : 0; }();
-  const size_t lds_cap = cap_kb > 0 ? (size_t)cap_kb * 1024 : (size_t)kLds / per_cu;
   static const int dbg = [] { const char* e = getenv("COMBO_MSDA_BWD_DBG"); return e ? atoi(e) : 0; }();  // ablation bits
   WinArgs wa;
-  wa.n_win = 0;
   size_t lds_max = 0;
   long long rows_total = 0;
-  int nw = (nw_env == 4 || nw_env == 6 || nw_env == 8 || nw_env == 12) ? nw_env : 12;
-  for (int pass = 0; pass < 2; ++pass) {
-    // pass 0 with the preferred wave count; if a level's single image row does not fit next to 12 waves of records, 8 waves
-    wa.n_win = 0;
-    lds_max = 0;
-    rows_total = 0;
-    bool ok = true;
-    for (int l = 0; l < L && ok; ++l) {
-      const int H = host_shapes[2 * l], W = host_shapes[2 * l + 1];
-      wa.H[l] = H; wa.W[l] = W; wa.start[l] = host_start[l];
-      rows_total += (long long)H * W;
-      int rmax = 0;
-      for (int rows = 1; rows <= H; ++rows)
-        if (win_lds_bytes(rows * W, rows < H ? W : 0, nw) <= lds_cap) rmax = rows; else break;
-      if (rmax == 0) { ok = false; break; }
-      const int bands = (H + rmax - 1) / rmax;
-      const int per = (H + bands - 1) / bands;
-      for (int y = 0; y < H; y += per) {
-        if (wa.n_win >= kMaxWin) { ok = false; break; }
-        const int ye = y + per < H ? y + per : H;
-        wa.lvl[wa.n_win] = (short)l; wa.y0[wa.n_win] = (short)y; wa.y1[wa.n_win] = (short)ye;
-        const size_t need = win_lds_bytes((ye - y) * W, ye < H ? W : 0, nw);
-        lds_max = need > lds_max ? need : lds_max;
-        ++wa.n_win;
-      }
-    }
-    if (ok) break;
-    if (pass == 1 || nw <= 8) return COMBO_EINVAL;
-    nw = 8;
-  }
-  if (rows_total != S) return COMBO_EINVAL;
+  int nw = 8;
+  if (!plan_windows(host_shapes, host_start, L, wa, lds_max, rows_total, nw) || rows_total != S) return COMBO_EINVAL;
   const long long grid = (long long)B * M * wa.n_win;
   if (grid > 0x7fffffffLL) return COMBO_EINVAL;
   // algorithmic bytes: value, grad_out, loc, w read once; the three gradients written once
   const double bytes = 4.0 * B * (2.0 * ((double)S + Lq) * M * kD + 2.0 * 3.0 * (double)Lq * M * L * P);
   unsigned long long* ts = combo_timing_next_slot(COMBO_TS_MSDA_BWD, bytes, bytes);
-  hipError_t e = hipSuccess;
-#define COMBO_LAUNCH_WIN(NWV)                                                                                                     \
-  do {                                                                                                                            \
-    static bool attr = false;                                                                                                     \
-    if (!attr) {                                                                                                                  \
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_win_d32<NWV, 4>),                                            \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kLds);                                                  \
-      if (e != hipSuccess) return (int)e;                                                                                         \
-      attr = true;                                                                                                                \
-    }                                                                                                                             \
-    hipLaunchKernelGGL((msda_bwd_win_d32<NWV, 4>), dim3((unsigned)grid), dim3(NWV * 64), lds_max, (hipStream_t)stream, grad_out,  \
-                       value, sampling_loc, attn_weight, B, S, M, L, Lq, grad_value, grad_sampling_loc, grad_attn_weight, wa,     \
-                       ts, dbg);                                                                                                  \
-  } while (0)
-  if (nw == 12) COMBO_LAUNCH_WIN(12);
-  else if (nw == 8) COMBO_LAUNCH_WIN(8);
-  else if (nw == 6) COMBO_LAUNCH_WIN(6);
-  else COMBO_LAUNCH_WIN(4);
-#undef COMBO_LAUNCH_WIN
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_win_d32<8>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_win_d32<16>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  if (nw == 16)
+    hipLaunchKernelGGL(msda_bwd_win_d32<16>, dim3((unsigned)grid), dim3(1024), lds_max, (hipStream_t)stream, grad_out, value,
+                       sampling_loc, attn_weight, B, S, M, L, Lq, grad_value, grad_sampling_loc, grad_attn_weight, wa, ts, dbg);
+  else
+    hipLaunchKernelGGL(msda_bwd_win_d32<8>, dim3((unsigned)grid), dim3(512), lds_max, (hipStream_t)stream, grad_out, value,
+                       sampling_loc, attn_weight, B, S, M, L, Lq, grad_value, grad_sampling_loc, grad_attn_weight, wa, ts, dbg);
   return (int)hipGetLastError();
 }
 

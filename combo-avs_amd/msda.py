@@ -23,10 +23,10 @@ _algo = ALGO_AUTO
 # registers them (no synchronisation); for a tensor of unknown origin the geometry is fetched once with a device->host copy -
 # unless the stream is being captured, in which case the two-kernel path (no host geometry needed) runs.
 _host_geometry = {}
-# OFF by default: measured on MI355X (tools/bench_msda.py, bench.py) the one-launch windowed kernel reads every operand once
-# (HBM traffic ~1.1x algorithmic instead of 1.77x) but takes 341 us per layer inside the bench step against 303 us for the
-# two-kernel path ("MSDeformAttn backward").  COMBO_MSDA_BWD_WIN=1 selects it.
-WINDOWED_BACKWARD = __import__("os").environ.get("COMBO_MSDA_BWD_WIN", "0") == "1"
+# ON by default: measured on MI355X inside the bench step (tools/ab_msda_bwd_model.sh) the one-launch windowed kernel takes
+# 247 us per layer against 295 us for the two-kernel path (185 + 110) and needs every operand once.  COMBO_MSDA_BWD_WIN=0
+# selects the two-kernel path.
+WINDOWED_BACKWARD = __import__("os").environ.get("COMBO_MSDA_BWD_WIN", "1") == "1"
 
 
 def register_level_shapes(spatial_shapes, shapes_list):

@@ -236,25 +236,27 @@ def test_512_shape_bt80_full_size_properties_all_three_gradients():
 
 @pytest.mark.parametrize("shapes,B", [(((7, 7), (14, 14), (28, 28)), 3), (((16, 16), (32, 32), (64, 64)), 2)])
 def test_windowed_fused_backward_matches_oracle_and_is_bitwise_deterministic(shapes, B):
-    """csrc/msda_bwd.hip (opt-in, COMBO_MSDA_BWD_WIN=1): the one-launch backward - workgroup = (frame, head, band of image rows
-    of one level), all 32 channels, 2 x 32-bit fixed point per 64-bit LDS word - against the CPU oracle (all three gradients),
-    against the two-kernel path (grad_loc / grad_w: the same arithmetic in the same order, bit for bit) and against itself."""
+    """csrc/msda_bwd.hip (the default backward for D = 32, P = 4): the one-launch kernel - workgroup = (frame, head, band of image
+    rows of one level), all 32 channels, 2 x 32-bit fixed point per 64-bit LDS word - against the CPU oracle (all three
+    gradients), against the two-kernel path (COMBO_MSDA_BWD_WIN=0) and against itself (bitwise deterministic)."""
     from combo_avs_amd import msda
     tag = f"win{len(shapes)}_{shapes[-1][0]}"
     v, shapes, loc, w = prod_inputs(B=B, shapes=shapes, seed_tag=tag)
     S = sum(h * w_ for h, w_ in shapes)
     go = synth.synth_tensor(tag + ".go", (B, S, 256), 0)
-    two = run_hip(v, shapes, loc, w, go)
     old = msda.WINDOWED_BACKWARD
-    msda.WINDOWED_BACKWARD = True
     try:
+        msda.WINDOWED_BACKWARD = False
+        two = run_hip(v, shapes, loc, w, go)
+        msda.WINDOWED_BACKWARD = True
         a = run_hip(v, shapes, loc, w, go)
         b = run_hip(v, shapes, loc, w, go)
     finally:
         msda.WINDOWED_BACKWARD = old
     for x, y in zip(a[1:], b[1:]):
         assert torch.equal(x, y)
-    assert torch.equal(a[2], two[2]) and torch.equal(a[3], two[3])
+    for x, y in zip(a[1:], two[1:]):  # two implementations, two summation orders: round-off apart
+        assert float((x - y).abs().max()) <= 1e-5 * float(y.abs().max()) + 1e-6
     v1, l1, w1 = (t.clone().requires_grad_(True) for t in (v, loc, w))
     ref = O.ms_deform_attn_core(v1, shapes, l1, w1)
     rg = torch.autograd.grad(ref, (v1, l1, w1), go)
