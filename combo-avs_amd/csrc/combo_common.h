@@ -24,7 +24,7 @@ __device__ __forceinline__ int xcd_contiguous(int id, int n) {
 // each, returning or not - a "last workgroup adds the duration" protocol cost 25 us on a 1280-workgroup launch, and plain
 // min / max on a single pair of words still 18 us; spread over 16 lines it is ~1 us.
 enum { COMBO_TS_MSDA_FWD = 0, COMBO_TS_GEMM_F32 = 1, COMBO_TS_GEMM_X3 = 2, COMBO_TS_GEMM_TN = 3, COMBO_TS_ATTN_FWD = 4,
-       COMBO_TS_ATTN_BWD = 5, COMBO_TS_MSDA_BWD = 6, COMBO_TS_KINDS = 8 };
+       COMBO_TS_ATTN_BWD = 5, COMBO_TS_MSDA_BWD = 6, COMBO_TS_BIFUSE = 7, COMBO_TS_GEMM_BF16 = 8, COMBO_TS_KINDS = 9 };
 enum { COMBO_TS_SUBS = 16, COMBO_TS_SUB_U64 = 16, COMBO_TS_SLOT_U64 = 256 };
 // host; nullptr when timing is off (timing.hip).  work: flops (bytes for the HBM-bound kinds); bytes: algorithmic HBM bytes
 // of the launch (operands read once + result written once) for the kinds that report a second, HBM-side fraction

@@ -120,8 +120,10 @@ __global__ void __launch_bounds__(256, Cfg::LDS <= 80 * 1024 ? 2 : 1)
 gemm_nt2_kernel(const float* __restrict__ A, long long lda, const float* __restrict__ Bimg, long long ldb,
                 const float* __restrict__ bias, float* __restrict__ C, long long ldc, int M, int N, int K, int relu,
                 int stagger, ConvGeom2 cg, int c_bytes, int batch, long long sA, long long sB, long long sC,
-                const float* __restrict__ mask, unsigned long long* ts) {
+                const float* __restrict__ mask, unsigned long long* ts, int products) {
   combo_ts_begin(ts);
+  // products == 1: ONE bf16 product per multiply-add (hi . hi: plain bf16 inputs, fp32 accumulate) - the head's bf16 throughput
+  // mode (forward GEMMs only); 3: the fp32-accurate split (hi . hi + hi . lo + lo . hi)
   // mask != nullptr (same shape / pitch as C): C = mask > 0 ? value : 0 - the ReLU backward of the layer whose OUTPUT was
   // the A operand's producer, folded into the input-gradient GEMM (dH = (dY . W2) o [H > 0] of an FFN)
   // batch > 1: `batch` independent problems of the same shape, operand b at A + b*sA, Bimg + b*sB, C + b*sC (elements)
@@ -294,14 +296,16 @@ gemm_nt2_kernel(const float* __restrict__ A, long long lda, const float* __restr
       }
 #pragma unroll
       for (int i = 0; i < TI; ++i) split8(ra[i][0], ra[i][1], ah[i], al[i]);
+      if (products == 3) {  // wave-uniform
 #pragma unroll
-      for (int i = 0; i < TI; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < TI; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+      }
 #pragma unroll
       for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -415,6 +419,8 @@ struct NtBatch {
   long long sA, sB, sC;
 };
 
+int g_products = 3;  // combo_gemm_nt2_products: bf16 products per multiply-add of the launches that follow (host state, read at launch)
+
 template <bool CONV, typename Cfg>
 int launch_nt2_cfg(const float* A, long long lda, const float* Bimg, const float* bias, float* C, long long ldc, long long M,
                    int N, int K, int relu, ConvGeom2 cg, int n_cu, combo_stream_t stream, NtBatch nb = NtBatch{1, 0, 0, 0},
@@ -443,8 +449,9 @@ int launch_nt2_cfg(const float* A, long long lda, const float* Bimg, const float
   if (c_bytes >= 0x7fffffffLL) return COMBO_EINVAL;
   hipLaunchKernelGGL((gemm_nt2_kernel<CONV, Cfg>), dim3((unsigned)grid), dim3(256), Cfg::LDS, (hipStream_t)stream, A, lda, Bimg,
                      (long long)K, bias, C, ldc, (int)M, N, K, relu, stagger, cg, (int)c_bytes, nb.batch, nb.sA, nb.sB, nb.sC, mask,
-                     combo_timing_next_slot(COMBO_TS_GEMM_X3, 2.0 * M * N * K * nb.batch,
-                                            4.0 * nb.batch * ((double)M * (CONV ? K / 9 : K) + (double)N * K + (double)M * N)));
+                     combo_timing_next_slot(g_products == 3 ? COMBO_TS_GEMM_X3 : COMBO_TS_GEMM_BF16, 2.0 * M * N * K * nb.batch,
+                                            4.0 * nb.batch * ((double)M * (CONV ? K / 9 : K) + (double)N * K + (double)M * N)),
+                     g_products);
   return (int)hipGetLastError();
 }
 
@@ -465,6 +472,15 @@ int launch_nt2(const float* A, long long lda, const float* Bimg, const float* bi
 }
 
 }  // namespace
+
+/* bf16 products per fp32 multiply-add of the combo_gemm_nt_x3_* / combo_conv3x3_nhwc_x3_* launches that FOLLOW (3 = the
+ * fp32-accurate split, the default; 1 = plain bf16 inputs with fp32 accumulation: the head's bf16 throughput mode, forward GEMMs
+ * only).  Returns the previous value.  Host-side state, read when a launch is issued (a captured graph keeps what was set). */
+extern "C" int combo_gemm_nt2_products(int products) {
+  const int prev = g_products;
+  if (products == 1 || products == 3) g_products = products;
+  return prev;
+}
 
 extern "C" int combo_presplit_bf16x2_f32(const float* src, long long ld_row, long long ld_col, int N, int K, float* img,
                                          combo_stream_t stream) {

@@ -35,13 +35,24 @@ def _conv_tokens(x_tok, wm, bias, B, H, W, cin, cout, exact, relu=False):
     y = torch.empty(B * H * W, cout, device=x_tok.device, dtype=torch.float32)
     assert B * H * W * cout * 4 < 2 ** 31 - 1  # (the kernels address Y with 32-bit byte offsets)
     lib, st = _lib.lib(), _lib.current_stream()
+    from . import linear as L
+    if exact and L.FORWARD_PRECISION == "bf16":  # the head's bf16 throughput mode: one bf16 product per multiply-add
+        img = L.forward_image(wm)
+        prev = lib.combo_gemm_nt2_products(1)
+        try:
+            with _lib.timed("conv3x3_bf16", (B * H * W, cout, 9 * cin)):
+                rc = lib.combo_conv3x3_nhwc_x3_pre_f32(x_tok.data_ptr(), x_tok.stride(0), img.data_ptr(), _lib.ptr(bias), y.data_ptr(),
+                                                       cout, B, H, W, cin, cout, 1 if relu else 0, st)
+        finally:
+            lib.combo_gemm_nt2_products(prev)
+        _lib.check(rc, "combo_conv3x3_nhwc_x3_pre_f32 (bf16 mode)")
+        return y
     if exact:
         with _lib.timed("conv3x3_f32", (B * H * W, cout, 9 * cin)):
             rc = lib.combo_conv3x3_nhwc_f32(x_tok.data_ptr(), x_tok.stride(0), wm.data_ptr(), _lib.ptr(bias), y.data_ptr(), cout,
                                             B, H, W, cin, cout, 1 if relu else 0, st)
         _lib.check(rc, "combo_conv3x3_nhwc_f32")
         return y
-    from . import linear as L
     img = L.presplit(wm)
     with _lib.timed("conv3x3_x3", (B * H * W, cout, 9 * cin)):
         rc = lib.combo_conv3x3_nhwc_x3_pre_f32(x_tok.data_ptr(), x_tok.stride(0), img.data_ptr(), _lib.ptr(bias), y.data_ptr(),

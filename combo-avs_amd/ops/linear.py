@@ -42,9 +42,18 @@ def gemm_nt_f32(a, w, bias=None, relu=False, out=None):
     N = w.shape[0]
     if out is None:
         out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    lib = _lib.lib()
+    splits = lib.combo_gemm_nt_splitk_plan(M, N, K) if (K >= 1024 and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0) else 1
+    if splits > 1:  # a long reduction with few output tiles: K slices as the batch entries of one launch + a finishing sum
+        ws = torch.empty(splits, M, N, device=a.device, dtype=torch.float32)
+        with _lib.timed("gemm_nt_f32", (M, N, K)):
+            rc = lib.combo_gemm_nt_splitk_f32(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), _lib.ptr(bias), out.data_ptr(),
+                                              out.stride(0), M, N, K, 1 if relu else 0, splits, ws.data_ptr(), _lib.current_stream())
+        _lib.check(rc, "combo_gemm_nt_splitk_f32")
+        return out
     with _lib.timed("gemm_nt_f32", (M, N, K)):
-        rc = _lib.lib().combo_gemm_nt_f32(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), _lib.ptr(bias), out.data_ptr(),
-                                          out.stride(0), M, N, K, 1 if relu else 0, _lib.current_stream())
+        rc = lib.combo_gemm_nt_f32(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), _lib.ptr(bias), out.data_ptr(),
+                                   out.stride(0), M, N, K, 1 if relu else 0, _lib.current_stream())
     _lib.check(rc, "combo_gemm_nt_f32")
     return out
 
@@ -94,15 +103,17 @@ class grouped_presplit:
     the weights whose input-gradient GEMMs will run (expect_input_grad), the first of those GEMMs splits all of them at once."""
 
     def __enter__(self):
-        global _split_images
+        global _split_images, _fwd_images
         self.prev, _split_images = (_split_images, _split_pending[:]), {}
+        self.prev_fwd, _fwd_images = _fwd_images, {}
         del _split_pending[:]
         return self
 
     def __exit__(self, *exc):
-        global _split_images
+        global _split_images, _fwd_images
         _split_images = self.prev[0]
         _split_pending[:] = self.prev[1]
+        _fwd_images = self.prev_fwd
         return False
 
 
@@ -210,7 +221,63 @@ def gemm_smallm_f32(a, w, bias=None, relu=False):
     return out
 
 
+# ---- the head's bf16 throughput mode ---------------------------------------------------------------------------------------
+# FORWARD_PRECISION = "bf16": every forward GEMM of the head (linear layers, 1x1 / 3x3 convolutions, the mask-logit
+# contraction) runs on csrc/gemm_nt2.hip with ONE bf16 product per multiply-add (bf16 inputs rounded to nearest even, fp32
+# accumulation): ~1/16 of the matrix-pipe time of the exact-fp32 instruction.  It is NOT the default: bf16 products move a
+# mask logit by ~3e-3 of its scale, the north-star's 1e-3 bound needs the fp32 path.  Stated tolerance
+# and its test: tests/test_head_gpu.py::test_bf16_forward_mode_stated_tolerance.  Gradient GEMMs keep the 3-product split.
+FORWARD_PRECISION = "fp32"
+_fwd_images = None  # {weight view key: bf16 hi/lo image [N, K]} of the current step (grouped_presplit context)
+
+
+def set_forward_precision(mode):
+    global FORWARD_PRECISION
+    if mode not in ("fp32", "bf16"):
+        raise ValueError(mode)
+    FORWARD_PRECISION = mode
+
+
+def forward_image(weight):
+    """bf16 image of a forward weight [N, K] (cached for the step inside grouped_presplit())"""
+    if _fwd_images is None:
+        return presplit(weight)
+    key = _split_key(weight)
+    img = _fwd_images.get(key)
+    if img is None:
+        img = _fwd_images[key] = presplit(weight)
+    return img
+
+
+def gemm_nt_bf16(a, w, bias=None, relu=False, out=None, img=None):
+    """C = a @ w^T (+ bias) (+ ReLU) with ONE bf16 product per multiply-add, fp32 accumulation (csrc/gemm_nt2.hip)"""
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    if img is None:
+        img = forward_image(w)
+    lib, st = _lib.lib(), _lib.current_stream()
+    prev = lib.combo_gemm_nt2_products(1)
+    try:
+        with _lib.timed("gemm_nt_bf16", (M, N, K)):
+            rc = lib.combo_gemm_nt_x3_pre_f32(a.data_ptr(), a.stride(0), img.data_ptr(), _lib.ptr(bias), out.data_ptr(), out.stride(0),
+                                              M, N, K, 1 if relu else 0, st)
+    finally:
+        lib.combo_gemm_nt2_products(prev)
+    _lib.check(rc, "combo_gemm_nt_x3_pre_f32 (bf16 mode)")
+    return out
+
+
+def _bf16_ok(x2d, weight, out):
+    return (FORWARD_PRECISION == "bf16" and x3_ok(x2d, weight.shape[0]) and weight.dtype == torch.float32 and weight.dim() == 2
+            and weight.shape[1] % 16 == 0 and weight.shape[0] % 4 == 0 and x2d.shape[0] > 64
+            and (out is None or (out.stride(1) == 1 and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0)))
+
+
 def forward_gemm(x2d, weight, bias, relu, out=None):
+    if _bf16_ok(x2d, weight, out) and (bias is None or bias.is_contiguous()):
+        return gemm_nt_bf16(x2d, weight, bias, relu, out)
     if f32_ok(x2d, weight) and (bias is None or bias.is_contiguous()):
         if out is None and x2d.shape[0] <= 64 and x2d.shape[1] % 64 == 0 and weight.shape[0] * x2d.shape[1] >= (1 << 18):
             return gemm_smallm_f32(x2d, weight, bias, relu)  # a few rows against a large weight: stream the weight

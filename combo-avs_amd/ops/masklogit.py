@@ -81,8 +81,19 @@ def mask_bits(mask_embed, mfd, reset_full_rows=True, with_bytes=False):
 def mask_logits_all_into(mask_embeds, mf_tok, out):
     """no-grad: out[h] = mask_embeds[h] @ mf_tok^T for ALL prediction heads in one launch (exact fp32, csrc/gemm_f32.hip);
     mask_embeds: list of [BT, Q, C]; out [heads, BT, Q, HW]"""
-    me = torch.stack([m.detach() for m in mask_embeds])  # [heads, BT, Q, C]
+    from . import linear as L
     mf = mf_tok.detach()
+    if L.FORWARD_PRECISION == "bf16":  # the head's bf16 throughput mode: per head, one bf16 product per multiply-add
+        img = presplit_batched(mf, transpose=False)
+        lib = _lib.lib()
+        prev = lib.combo_gemm_nt2_products(1)
+        try:
+            for h, m in enumerate(mask_embeds):
+                gemm_nt_batched(m.detach().contiguous(), img, out[h])
+        finally:
+            lib.combo_gemm_nt2_products(prev)
+        return out
+    me = torch.stack([m.detach() for m in mask_embeds])  # [heads, BT, Q, C]
     heads, BT, Q, C = me.shape
     HW = mf.shape[1]
     if not (_hip_ok(me, mf, out) and C % 16 == 0 and Q * HW * 4 < 2 ** 31 - 1):

@@ -252,6 +252,16 @@ int combo_gemm_nt_f32(const float* A, long long lda, const float* B, long long l
 int combo_gemm_nt_batched_f32(const float* A, long long lda, long long sA, const float* B, long long ldb, long long sB,
                               float* C, long long ldc, long long sC, int M, int N, int K, int batch, int relu,
                               combo_stream_t stream);
+/*   Split-K for long reductions with few output tiles (decoder FFN linear2 4000 x 2048 -> 256, the res5 / res4 input
+ *   projections): combo_gemm_nt_splitk_plan -> number of K slices (1: do not split); combo_gemm_nt_splitk_f32 runs the slices
+ *   as the batch entries of one launch into workspace [splits, M, N] and finishes with a fixed-order sum + bias + ReLU. */
+/*   bf16 products per fp32 multiply-add of the combo_gemm_nt_x3_* / combo_conv3x3_nhwc_x3_* launches that follow: 3 (default)
+ *   = the fp32-accurate split, 1 = plain bf16 inputs, fp32 accumulation (the head's bf16 throughput mode).  Returns the
+ *   previous value. */
+int combo_gemm_nt2_products(int products);
+int combo_gemm_nt_splitk_plan(int M, int N, int K);
+int combo_gemm_nt_splitk_f32(const float* A, long long lda, const float* B, long long ldb, const float* bias, float* C,
+                             long long ldc, int M, int N, int K, int relu, int splits, float* workspace, combo_stream_t stream);
 int combo_conv3x3_nhwc_f32(const float* X, long long ldx, const float* Wm, const float* bias, float* Y, long long ldy,
                            int B, int H, int W, int Cin, int Cout, int relu, combo_stream_t stream);
 

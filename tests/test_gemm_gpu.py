@@ -61,7 +61,8 @@ def test_linear_forward_backward_vs_fp64(M, K, N, relu):
                                              (20001, 64, 288, True, True), (16384, 2048, 256, False, False),
                                              (300, 16, 40, True, False), (4000, 256, 256, True, False),
                                              (4000, 2048, 256, True, False), (1960, 256, 512, True, False),
-                                             (100, 256, 3136, False, False), (3, 16, 5, True, False)])
+                                             (100, 256, 3136, False, False), (3, 16, 5, True, False),
+                                             (1960, 2048, 256, True, True), (7840, 1024, 256, False, False)])  # split-K shapes
 def test_gemm_nt_f32_exact(M, K, N, bias, relu, capsys):
     """C = A B^T (+bias, +ReLU) on csrc/gemm_f32.hip vs fp64: ragged M / N tiles, every tile configuration (COMBO_F32_TILE
     is not set: the launcher's own choice), error of fp32 round-off (~1e-7), never the bf16 split's 4e-6."""

@@ -407,3 +407,64 @@ def test_fused_criterion_path_equals_unfused(head_run, mode):
         assert abs(la[k] - lb[k]) <= 1e-5 * abs(lb[k]) + 1e-6, (k, la[k], lb[k])
     for a, b in zip(ga, gb):
         assert (a - b).abs().max() <= 2e-4 * b.abs().max() + 1e-8, float((a - b).abs().max() / b.abs().max())
+
+
+def test_bf16_forward_mode_stated_tolerance():
+    """The head's bf16 throughput mode (ops.linear.set_forward_precision("bf16"), bench.py --head-dtype bf16): every forward
+    GEMM / convolution / mask-logit contraction of the head on ONE bf16 product per multiply-add (csrc/gemm_nt2.hip, fp32
+    accumulation) - the product's own kernels, not torch autocast.  Stated tolerance against the reference's fp32 outputs
+    (golden head.npz), which is NOT the north-star's 1e-3 (that is what the default fp32 path is for):
+      * prediction head #0 (no thresholded mask upstream): every sampled mask logit within 5e-2 x RMS + 2e-2 x |ref|
+        (measured: max 2.7e-2 RMS, relative L2 error 7.5e-3);
+      * all 10 heads: >= 97.5 % of the sampled mask logits within 1e-1 x RMS + 1e-1 x |ref| (measured >= 99 %: a flipped
+        attention-mask cell re-routes a query for the rest of the decoder), relative L2 error of every head <= 0.1
+        (measured <= 4.5e-2);
+      * class logits: within 0.25 absolute of the reference for >= 97 % of the entries.
+    The S4 losses of this forward stay within 5 % of the reference's."""
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.ops import linear as L
+    z = np.load(os.path.join(G, "head.npz"))
+    spec = json.loads(str(z["spec"]))
+    head, cfg = build_head()
+    head.load_state_dict(synth.synth_state_dict(spec, 0))
+    head = head.cuda().eval()
+    feats, audio = gen_inputs.head_inputs()
+    feats = {k: v.cuda() for k, v in feats.items()}
+    L.set_forward_precision("bf16")
+    try:
+        with torch.no_grad(), L.grouped_presplit():
+            out = head(dict(feats), audio.cuda())
+        torch.cuda.synchronize()
+    finally:
+        L.set_forward_precision("fp32")
+    masks = [a["pred_masks"] for a in out["aux_outputs"]] + [out["pred_masks"]]
+    report = []
+    for i, m in enumerate(masks):
+        d = synth.unpack(f"dec/pred_masks{i}", z)
+        idx = synth.digest_indices(m.numel(), 4096, f"dec/pred_masks{i}")
+        got = m.reshape(-1).cpu().numpy()[idx].astype(np.float64)
+        ref = np.asarray(d["sample"]).astype(np.float64)
+        rms = float(np.sqrt((ref ** 2).mean()))
+        err = np.abs(got - ref)
+        tight = float((err > 5e-2 * rms + 2e-2 * np.abs(ref)).mean())
+        loose = float((err > 1e-1 * rms + 1e-1 * np.abs(ref)).mean())
+        l2 = float(np.sqrt((err ** 2).sum() / (ref ** 2).sum()))
+        report.append((i, round(tight, 4), round(loose, 4), round(l2, 4), round(float(err.max() / rms), 3)))
+    if os.environ.get("COMBO_TEST_VERBOSE") == "1":
+        print("[bf16 mode] head: (frac beyond 5e-2, frac beyond 1e-1, rel L2, max err / RMS)", report)
+    assert report[0][1] == 0.0, report
+    assert all(r[2] <= 0.025 and r[3] <= 0.1 for r in report), report
+    logits = torch.stack([a["pred_logits"] for a in out["aux_outputs"]] + [out["pred_logits"]]).cpu().numpy()
+    bad = np.abs(logits - z["dec/pred_logits"]) > 0.25
+    assert bad.mean() <= 0.03, float(bad.mean())
+    # losses of this forward (S4 targets, replayed points)
+    zc = np.load(os.path.join(G, "criterion.npz"))
+    crit, wd = make_criterion("s4")
+    torch.manual_seed(11)
+    targets = [{k: v.cuda() for k, v in t.items()} for t in gen_inputs.make_targets("s4")]
+    o = {"pred_logits": out["pred_logits"], "pred_masks": out["pred_masks"], "aux_outputs": [dict(a) for a in out["aux_outputs"]],
+         "middles_attn_mask": list(out["middles_attn_mask"])}
+    losses = crit(o, targets)
+    keys = json.loads(str(zc["s4/keys"]))
+    total = sum(float(losses[k]) * wd[k] for k in keys)
+    assert abs(total - float(zc["s4/total"])) <= 0.05 * abs(float(zc["s4/total"])), (total, float(zc["s4/total"]))
