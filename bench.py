@@ -341,7 +341,8 @@ def main():
         model.backbone_dtype = torch.bfloat16
     opt = FlatAdamW(model, base_lr=cfg.SOLVER.BASE_LR, weight_decay=cfg.SOLVER.WEIGHT_DECAY,
                     backbone_multiplier=cfg.SOLVER.BACKBONE_MULTIPLIER, clip_value=cfg.SOLVER.CLIP_GRADIENTS.CLIP_VALUE,
-                    grad_comm_dtype=torch.bfloat16 if args.grad_comm == "bf16" else torch.float32)
+                    grad_comm_dtype=torch.bfloat16 if args.grad_comm == "bf16" else torch.float32,
+                    early=lambda name: name.startswith("sem_seg_head."))  # the head's gradients are all-reduced first
     T, H, W = wl["T"], wl["HW"], wl["HW"]
 
     def make_batch(seed):
@@ -556,7 +557,10 @@ def main():
             "config": {"workload": f"{wl['name']}: bs={args.clips} clips x {T} frames x {H}x{W} per GPU, K={wl['K']}, full train step "
                                    "(fwd + 39-term loss + bwd + all-reduce + clip + AdamW), random-init weights",
                        "name": args.config,
-                       "launch": "eager" if (args.no_graph or eager_slots) else "hipGraph (fwd+loss+bwd captured; all-reduce + AdamW eager)",
+                       "launch": "eager" if (args.no_graph or eager_slots) else (
+                           "2 hipGraphs (fwd + loss + head bwd | backbone bwd; the head's gradient all-reduce overlaps the second; AdamW eager)"
+                           if world > 1 and os.environ.get("COMBO_DP_OVERLAP", "1") == "1" else
+                           "hipGraph (fwd+loss+bwd captured; all-reduce + AdamW eager)"),
                        "instrumentation": "the instrumented kernels' timing atomics (2 per workgroup) and one fold launch per step run "
                                           "inside the timed region" if slot_timing else "HIP events around the MSDeformAttn core",
                        "arithmetic": "forward GEMMs / convolutions / attention of the head in exact fp32 on v_mfma_f32_* (peak 157.3 "

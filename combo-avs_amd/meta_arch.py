@@ -189,6 +189,11 @@ class MaskFormer(nn.Module):
         else:
             with amp:
                 features = self.backbone(images)
+        # the head's inputs: where a data-parallel trainer cuts the backward pass in two (the head's gradients are complete - and
+        # on their way through the all-reduce - while the backbones' backward still runs; trainer.FlatAdamW.backward_early)
+        # (recorded only on request: holding them keeps the step's autograd graph alive beyond the backward pass)
+        self._head_inputs = ([v for v in features.values() if torch.is_tensor(v) and v.requires_grad]
+                             if self.training and getattr(self, "record_head_inputs", False) else None)
         outputs = self.sem_seg_head(features, audio_feature)
         if self.training:
             if "instances" not in batched_inputs[0]:

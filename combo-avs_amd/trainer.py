@@ -49,13 +49,19 @@ class FlatAdamW:
 
     def __init__(self, model, base_lr=1e-4, weight_decay=0.05, backbone_multiplier=0.1, clip_value=0.01,
                  betas=(0.9, 0.999), eps=1e-8, weight_decay_norm=0.0, weight_decay_embed=0.0, grad_dtype=torch.float32,
-                 grad_comm_dtype=torch.float32):
+                 grad_comm_dtype=torch.float32, early=None):
+        """early(name) -> True for the parameters whose gradients are COMPLETE once the backward pass has reached the head's
+        inputs (everything downstream of the cut: `sem_seg_head.*`): they form the front region of the flat buffers, so that
+        their all-reduce can start while the rest of the backward pass (the backbones) still runs - see backward_early /
+        backward_late / all_reduce_grads(region).  None: one region (the whole buffer)."""
         entries = param_groups(model, base_lr, weight_decay, backbone_multiplier, weight_decay_norm, weight_decay_embed)
+        is_early = (lambda n: True) if early is None else early
         ref_index = {id(e[0]): i for i, e in enumerate(entries)}  # position in the reference's optimizer (train_net.py:170-194)
         # stable: contiguous (lr, wd) segments; inside a segment the head's matrix weights come first - their gradients are
         # written in place by the grouped weight-gradient launches (ops.linear.grad_targets), the rest forms few long runs
         # for the concatenation that fills the flat gradient buffer
-        entries.sort(key=lambda e: (e[2], e[3], 0 if (e[0].dim() == 2 and "sem_seg_head" in e[1]) else 1))
+        entries.sort(key=lambda e: (0 if is_early(e[1]) else 1, e[2], e[3], 0 if (e[0].dim() == 2 and "sem_seg_head" in e[1]) else 1))
+        self.n_early = sum(1 for e in entries if is_early(e[1]))
         self.ref_order = [ref_index[id(e[0])] for e in entries]
         self.entries = entries
         # every (lr, wd) segment starts on a 16-byte boundary (vectorised fused AdamW kernel)
@@ -84,12 +90,19 @@ class FlatAdamW:
             else:
                 self.segments.append([off, off + n, lr, wd])
             off += n
+            if len(self.offsets) == self.n_early:
+                self.split = (off + 3) // 4 * 4  # end of the early region (16-byte aligned) = start of the late one
         # optionally transport the gradient in bf16 (half the xGMI bytes), fp32 master + fp32 optimiser
         self.grad_comm_dtype = grad_comm_dtype
         self.betas, self.eps, self.clip_value = betas, eps, clip_value
         self.step_count = 0
         self.lr_scale = 1.0  # WarmupPolyLR factor, set by the caller each iteration
         self.numel = total
+        if self.n_early == 0:
+            self.split = 0
+        if self.n_early == len(entries):
+            self.split = total
+        self._comm_stream = None
         self.unused = ()  # indices (into self.params) of parameters the last backward pass produced no gradient for
 
     def zero_grad(self):
@@ -97,47 +110,79 @@ class FlatAdamW:
 
     def backward(self, loss):
         """d loss / d params straight into the flat gradient buffer: `autograd.grad` (no per-parameter AccumulateGrad
-        add kernels - 530 launches/step for this model) followed by ONE batched concatenation into the flat buffer
-        (`torch.cat(out=)`: ~5 launches; a `_foreach_copy_` decays into one D2D memcpy per parameter here)."""
+        add kernels - 530 launches/step for this model); weight gradients computed by the head's own kernels are written in
+        place (ops.linear.grad_targets), every maximal run of the others is filled by one concatenation."""
+        grads = self._grad(loss, self.params, None)
+        self.unused = tuple(i for i, g in enumerate(grads) if g is None)
+        self._collect(grads, 0, len(self.params))
+
+    def backward_early(self, loss, cut):
+        """First half of a backward pass cut at the tensors `cut` (the head's inputs, meta_arch.MaskFormer._head_inputs):
+        gradients of the EARLY parameters (complete now: their region may be all-reduced) -> returns d loss / d cut."""
+        cut = [t for t in cut if t.requires_grad]
+        n = self.n_early
+        grads = self._grad(loss, self.params[:n] + cut, None)
+        self._unused_early = tuple(i for i, g in enumerate(grads[:n]) if g is None)
+        self._collect(grads[:n], 0, n)
+        self._cut = cut
+        return list(grads[n:])
+
+    def backward_late(self, cut_grads):
+        """Second half: the parameters upstream of the cut from the gradients backward_early returned."""
+        n = self.n_early
+        pairs = [(t, g) for t, g in zip(self._cut, cut_grads) if g is not None]
+        grads = self._grad([t for t, _ in pairs], self.params[n:], [g for _, g in pairs]) if pairs else [None] * (len(self.params) - n)
+        self.unused = self._unused_early + tuple(n + i for i, g in enumerate(grads) if g is None)
+        self._collect(grads, n, len(self.params))
+        self._cut = None
+        del pairs, grads
+
+    def _grad(self, outputs, inputs, grad_outputs):
         from .ops.linear import deferred_dw, grad_targets
         in_place = self.flat_grad.dtype == torch.float32 and self.flat_grad.is_cuda
         targets = {p.data_ptr(): v for p, v in zip(self.params, self.grad_views) if p.dim() == 2} if in_place else {}
         with grad_targets(targets), deferred_dw():  # latency-bound decoder weight gradients: one grouped launch when the context closes
-            grads = torch.autograd.grad(loss, self.params, allow_unused=True)
+            return torch.autograd.grad(outputs, inputs, grad_outputs, allow_unused=True)
+
+    def _collect(self, grads, lo, hi):
+        """gradients of self.params[lo:hi] -> their range of the flat buffer"""
         # torch.optim.AdamW (the reference's optimizer) skips parameters whose gradient is None - no decay, no moment update:
         # `step` leaves them out (a static property of the model / recipe, so it is safe inside a captured graph)
-        self.unused = tuple(i for i, g in enumerate(grads) if g is None)
+        start = self.offsets[lo] if lo < len(self.offsets) else self.numel
+        if lo > 0:
+            start = self.split
+        end = self.split if hi == self.n_early and hi < len(self.params) else (self.numel if hi == len(self.params) else self.offsets[hi])
+        if hi <= lo:
+            return
         if self.flat_grad.dtype != torch.float32 or any(g is not None and g.dtype != torch.float32 for g in grads):
-            dst = [v for v, g in zip(self.grad_views, grads) if g is not None]
+            dst = [v for v, g in zip(self.grad_views[lo:hi], grads) if g is not None]
             src = [g for g in grads if g is not None]
             if len(src) != len(grads):
-                self.flat_grad.zero_()
+                self.flat_grad[start:end].zero_()
             torch._foreach_copy_(dst, src)
             return
         # gradients that were written in place (they ARE their flat-buffer views) stay; every maximal run of the others is
         # filled by one concatenation (alignment gaps and parameters without a gradient: cached zeros)
-        pieces, run_start, cursor = [], 0, 0
+        pieces, run_start, cursor = [], start, start
 
-        def flush(end):
+        def flush(end_):
             nonlocal pieces, run_start
             if pieces:
-                torch.cat(pieces, out=self.flat_grad[run_start:end])
-            pieces, run_start = [], end
-        for g, p, off, view in zip(grads, self.params, self.offsets, self.grad_views):
+                torch.cat(pieces, out=self.flat_grad[run_start:end_])
+            pieces, run_start = [], end_
+        for g, p, off, view in zip(grads, self.params[lo:hi], self.offsets[lo:hi], self.grad_views[lo:hi]):
             n = p.numel()
+            if off > cursor:
+                pieces.append(self._zeros(off - cursor))
             if g is not None and g.data_ptr() == view.data_ptr() and g.is_contiguous():
-                if off > cursor:
-                    pieces.append(self._zeros(off - cursor))
                 flush(off)
                 run_start = off + n
             else:
-                if off > cursor:
-                    pieces.append(self._zeros(off - cursor))
                 pieces.append(g.reshape(-1) if g is not None else self._zeros(n))
             cursor = off + n
-        if self.numel > cursor:
-            pieces.append(self._zeros(self.numel - cursor))
-        flush(self.numel)
+        if end > cursor:
+            pieces.append(self._zeros(end - cursor))
+        flush(end)
 
     def _zeros(self, n):
         """cached zero filler (alignment gaps of the flat layout, parameters without a gradient)"""
@@ -146,19 +191,46 @@ class FlatAdamW:
             cache[n] = torch.zeros(n, dtype=torch.float32, device=self.flat_grad.device)
         return cache[n]
 
-    def all_reduce_grads(self):
+    def _dist_on(self):
         # COMBO_FORCE_PG=1 (bench.py's one-rank process group on a 1-GPU box) also runs the collective at world size 1,
         # so that the RCCL all-reduce of the flat gradient buffer is exercised on the GPU
         forced = os.environ.get("COMBO_FORCE_PG") == "1"
-        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or forced):
-            world = dist.get_world_size()
-            if self.grad_comm_dtype != self.flat_grad.dtype:
-                buf = (self.flat_grad / world).to(self.grad_comm_dtype)  # pre-divide: keeps the sum inside bf16's range
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or forced)
+
+    def all_reduce_grads(self, region=None, overlap=False):
+        """Sum over ranks / world (DDP semantics).  region: None = the whole flat buffer in ONE collective (RCCL over xGMI on GPU;
+        gloo in the CPU tests), "early" / "late" = the two regions of a cut backward pass.  overlap: issue the collective on a
+        side stream that waits for the work enqueued so far (the caller goes on enqueueing the late backward on the main
+        stream) - finish with wait_comm()."""
+        if not self._dist_on():
+            return
+        lo, hi = {None: (0, self.numel), "early": (0, self.split), "late": (self.split, self.numel)}[region]
+        if hi <= lo:
+            return
+        world = dist.get_world_size()
+        g = self.flat_grad[lo:hi]
+
+        def run():
+            if self.grad_comm_dtype != g.dtype:
+                buf = (g / world).to(self.grad_comm_dtype)  # pre-divide: keeps the sum inside bf16's range
                 dist.all_reduce(buf)
-                self.flat_grad.copy_(buf)
+                g.copy_(buf)
             else:
-                dist.all_reduce(self.flat_grad)  # ONE collective (RCCL over xGMI on GPU; gloo in the CPU tests)
-                self.flat_grad.div_(world)
+                dist.all_reduce(g)
+                g.div_(world)
+        if overlap and g.is_cuda:
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(device=g.device)
+            self._comm_stream.wait_stream(torch.cuda.current_stream(g.device))
+            with torch.cuda.stream(self._comm_stream):
+                run()
+        else:
+            run()
+
+    def wait_comm(self):
+        """the main stream waits for the collectives issued with overlap=True"""
+        if self._comm_stream is not None:
+            torch.cuda.current_stream(self.flat_grad.device).wait_stream(self._comm_stream)
 
     @torch.no_grad()
     def step(self):
@@ -249,13 +321,24 @@ def poly_lr_factor(it, max_iter, power=0.9, constant_ending=0.0):
 def train_step(model, optimizer, batched_inputs):
     """forward -> 39-term loss -> backward -> one all-reduce -> clip + AdamW.  Returns the loss dict (device tensors)."""
     from .ops.linear import grouped_presplit
+    model.record_head_inputs = bool(0 < optimizer.n_early < len(optimizer.params) and optimizer._dist_on())
     with grouped_presplit():  # one grouped weight pre-split for all input-gradient GEMMs of the step
         loss_dict = model(batched_inputs)
         total = getattr(loss_dict, "total", None)  # family-wise sum from the meta-arch (modeling.criterion.LossDict)
         if total is None:
             total = torch.stack(list(loss_dict.values())).sum()
-        optimizer.backward(total)
-    optimizer.all_reduce_grads()
+        cut = getattr(model, "_head_inputs", None)
+        model._head_inputs = None
+        if cut and 0 < optimizer.n_early < len(optimizer.params) and optimizer._dist_on():
+            # data parallel: the head's gradients travel (side stream) while the backbones' backward runs
+            cut_grads = optimizer.backward_early(total, cut)
+            optimizer.all_reduce_grads("early", overlap=True)
+            optimizer.backward_late(cut_grads)
+            optimizer.all_reduce_grads("late")
+            optimizer.wait_comm()
+        else:
+            optimizer.backward(total)
+            optimizer.all_reduce_grads()
     optimizer.step()
     # detached: a caller holding the losses must not keep this step's autograd graph (and the parameters'
     # AccumulateGrad nodes, which remember the stream they were created on) alive into the next step
@@ -335,6 +418,7 @@ class GraphedTrainStep:
 
     def _fwd_bwd(self, batch):
         from .ops.linear import grouped_presplit
+        self.model.record_head_inputs = False
         with grouped_presplit():
             loss_dict = self.model(batch)
             total = getattr(loss_dict, "total", None)
@@ -342,6 +426,23 @@ class GraphedTrainStep:
                 total = torch.stack(list(loss_dict.values())).sum()
             self.opt.backward(total)
         return {k: v.detach() for k, v in loss_dict.items()}
+
+    def _cut_backward(self):
+        """Data parallel: the step is captured as TWO graphs - forward + loss + the head's backward, then the backbones'
+        backward - so that the all-reduce of the head's gradients (the front region of the flat buffer) runs on a side stream
+        while the second graph executes."""
+        o = self.opt
+        return o._dist_on() and 0 < o.n_early < len(o.params) and os.environ.get("COMBO_DP_OVERLAP", "1") == "1"
+
+    def _fwd_early(self, batch):
+        self.model.record_head_inputs = True
+        loss_dict = self.model(batch)
+        total = getattr(loss_dict, "total", None)
+        if total is None:
+            total = torch.stack(list(loss_dict.values())).sum()
+        cut, self.model._head_inputs = self.model._head_inputs, None
+        cut_grads = self.opt.backward_early(total, cut)
+        return {k: v.detach() for k, v in loss_dict.items()}, cut_grads
 
     def _capture(self, batched_inputs, num_masks):
         from .ops import bifuse
@@ -351,20 +452,38 @@ class GraphedTrainStep:
         crit = self.model.criterion
         crit.num_masks_override = static_num
         counter = bifuse.step_counter(dev)
+        from .ops.linear import grouped_presplit
+        cut = self._cut_backward()
         try:
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
                 for _ in range(self.warmup_iters):  # autotuning / lazy initialisation outside the capture
-                    self._fwd_bwd(static_batch)
+                    if cut:
+                        with grouped_presplit():
+                            _, cg = self._fwd_early(static_batch)
+                            self.opt.backward_late(cg)
+                    else:
+                        self._fwd_bwd(static_batch)
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
             graph = torch.cuda.CUDAGraph()
             # thread_local: RCCL's watchdog thread may poll events while this thread captures; that must not
             # invalidate the capture (the default "global" mode would)
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                counter.add_(1)
-                static_losses = self._fwd_bwd(static_batch)
+            if cut:
+                graph_b = torch.cuda.CUDAGraph()
+                with grouped_presplit():  # spans both captures: the second graph's input-gradient GEMMs use images split in the first
+                    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                        counter.add_(1)
+                        static_losses, cut_grads = self._fwd_early(static_batch)
+                    with torch.cuda.graph(graph_b, pool=graph.pool(), capture_error_mode="thread_local"):
+                        self.opt.backward_late(cut_grads)
+                    del cut_grads
+                graph = (graph, graph_b)
+            else:
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    counter.add_(1)
+                    static_losses = self._fwd_bwd(static_batch)
         finally:
             crit.num_masks_override = None
         return graph, static_batch, static_num, static_losses
@@ -387,7 +506,14 @@ class GraphedTrainStep:
         if src:
             torch._foreach_copy_(dst, src)
         static_num.copy_(num_masks)
-        graph.replay()
-        self.opt.all_reduce_grads()
+        if isinstance(graph, tuple):  # cut backward: the head's gradients travel while the backbones' backward replays
+            graph[0].replay()
+            self.opt.all_reduce_grads("early", overlap=True)
+            graph[1].replay()
+            self.opt.all_reduce_grads("late")
+            self.opt.wait_comm()
+        else:
+            graph.replay()
+            self.opt.all_reduce_grads()
         self.opt.step()
         return static_losses

@@ -30,7 +30,7 @@ def _loss(m, x, y):
     return ((out - y) ** 2).mean() * 100
 
 
-def _worker(rank, world, port, ret, comm_dtype=torch.float32):
+def _worker(rank, world, port, ret, comm_dtype=torch.float32, cut=False):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
@@ -40,13 +40,26 @@ def _worker(rank, world, port, ret, comm_dtype=torch.float32):
     from combo_avs_amd.modeling.criterion import SetCriterion
     from combo_avs_amd.trainer import FlatAdamW
     m = _model()
-    opt = FlatAdamW(m, base_lr=1e-2, weight_decay=0.05, backbone_multiplier=0.1, clip_value=0.01, grad_comm_dtype=comm_dtype)
+    opt = FlatAdamW(m, base_lr=1e-2, weight_decay=0.05, backbone_multiplier=0.1, clip_value=0.01, grad_comm_dtype=comm_dtype,
+                    early=(lambda n: not n.startswith("backbone")) if cut else None)
+    if cut:
+        assert 0 < opt.n_early < len(opt.params) and 0 < opt.split < opt.numel
     g = torch.Generator().manual_seed(7)
     for it in range(4):
         x, y = torch.randn(8, 12, generator=g), torch.randn(8, 4, generator=g)
         xs, ys = x[rank::world], y[rank::world]  # clip i -> rank i mod world
-        opt.backward(_loss(m, xs, ys))
-        opt.all_reduce_grads()
+        if cut:  # the backward pass cut at the head's input: early region reduced first (asynchronously on a GPU), then the rest
+            feat = m["backbone"](xs)
+            out = m["sem_seg_head"](feat) + m["emb"].weight[0]
+            loss = ((out - ys) ** 2).mean() * 100
+            cg = opt.backward_early(loss, [feat])
+            opt.all_reduce_grads("early", overlap=True)
+            opt.backward_late(cg)
+            opt.all_reduce_grads("late")
+            opt.wait_comm()
+        else:
+            opt.backward(_loss(m, xs, ys))
+            opt.all_reduce_grads()
         opt.step()
     # num_masks: sum over ranks / world, clamped at 1 (criterion.py:261-265)
     crit = SetCriterion(2, matcher=None, weight_dict={}, eos_coef=0.1, losses=[], num_points=4, oversample_ratio=3.0,
@@ -80,6 +93,20 @@ def test_two_rank_step_equals_single_process_reference_optimizer():
     for k, v in m.state_dict().items():
         torch.testing.assert_close(ret["params"][k], v, rtol=1e-5, atol=1e-7, msg=k)
     assert ret["num_masks"] == 2.0  # (1 + 3) / 2
+
+
+def test_cut_backward_with_two_region_all_reduce_equals_the_single_collective():
+    """The data-parallel overlap path (trainer.train_step / GraphedTrainStep with world_size > 1): the backward pass cut at the
+    head's input, the head's region of the flat gradient buffer all-reduced first, the backbone's region after the second
+    half - must give exactly the parameters of the one-collective path."""
+    res = []
+    for cut in (False, True):
+        port = _free_port()
+        ret = mp.Manager().dict()
+        mp.spawn(_worker, args=(2, port, ret, torch.float32, cut), nprocs=2, join=True)
+        res.append(dict(ret["params"]))
+    for k in res[0]:
+        torch.testing.assert_close(res[0][k], res[1][k], rtol=1e-6, atol=1e-8, msg=k)
 
 
 def test_bf16_gradient_transport_stays_close_to_fp32():
