@@ -364,7 +364,11 @@ def main():
     def trace(msg):  # progress markers on stderr (debugging aid for multi-rank runs)
         if trace_on:
             torch.cuda.synchronize()
-            print(f"[bench rank {rank} +{time.perf_counter() - t_start:.1f}s] {msg}", file=sys.stderr, flush=True)
+            st = model.criterion.matcher._lsap_status
+            print(f"[bench rank {rank} +{time.perf_counter() - t_start:.1f}s] {msg} (LSAP status word {None if st is None else int(st.item())}, "
+                  f"params finite {bool(torch.isfinite(opt.flat_param).all())}, grads finite {bool(torch.isfinite(opt.flat_grad).all())}, "
+                  f"|grad| {float(torch.linalg.vector_norm(opt.flat_grad)):.4g})",
+                  file=sys.stderr, flush=True)
     t_start = time.perf_counter()
 
     # several distinct synthetic batches of one signature, rotated over the steps (inputs resident in HBM; the graphed step

@@ -89,15 +89,27 @@ def _p(param, wts):
     return param if wts is None else wts.get(id(param), param)
 
 
+# Bias gradients: autograd's grad_output.sum(...) splits these long reductions over workgroups behind a memset node, which a
+# replayed hipGraph does not execute reliably on this stack (ops/colsum.py, tools/graph_reduce_repro.py) - the linears and
+# convolutions below take their bias gradient from csrc/colsum.hip instead.
 def _linear(x, mod, wts):
     w = _p(mod.weight, wts)
-    return F.linear(x if x.dtype == w.dtype else x.to(w.dtype), w, None if mod.bias is None else _p(mod.bias, wts))
+    x = x if x.dtype == w.dtype else x.to(w.dtype)
+    if mod.bias is None:
+        return F.linear(x, w)
+    if x.is_cuda and torch.is_grad_enabled():
+        from .ops.colsum import linear_bias
+        return linear_bias(x, w, _p(mod.bias, wts))
+    return F.linear(x, w, _p(mod.bias, wts))
 
 
 def _conv(x, mod, wts):
     w = _p(mod.weight, wts)
-    return F.conv2d(x if x.dtype == w.dtype else x.to(w.dtype), w, None if mod.bias is None else _p(mod.bias, wts), mod.stride,
-                    mod.padding, mod.dilation, mod.groups)
+    x = x if x.dtype == w.dtype else x.to(w.dtype)
+    if mod.bias is not None and x.is_cuda and torch.is_grad_enabled():
+        from .ops.colsum import add_channel_vector
+        return add_channel_vector(F.conv2d(x, w, None, mod.stride, mod.padding, mod.dilation, mod.groups), _p(mod.bias, wts), 1)
+    return F.conv2d(x, w, None if mod.bias is None else _p(mod.bias, wts), mod.stride, mod.padding, mod.dilation, mod.groups)
 
 
 def _ln(x, mod, wts):

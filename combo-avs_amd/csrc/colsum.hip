@@ -1,0 +1,234 @@
+// Channel sums  out[c] = sum_{a, l} x[a, c, l]  of a contiguous [A, C, L] tensor (bf16 or fp32): the bias gradients of the
+// host-PyTorch backbones' linears / convolutions (L = 1: column sums of dY[M, C]; L = H*W: NCHW convolution outputs) and the
+// level-embedding gradients of the head.
+//
+// Why not ATen's sum: when one output is split over several workgroups ATen (Reduce.cuh) zeroes its semaphores with a
+// hipMemsetAsync per launch; the HIP runtime's AQL packet capture replays such memset nodes of a hipGraph wrongly on this
+// stack (ROCm 7.2, torch 2.10: tools/graph_reduce_repro.py - 99 of 100 replays return stale memory), so the captured
+// training step must hold none.  Here the arrival counters re-arm themselves: the last workgroup of a column block resets
+// its counter, so the buffer is zeroed ONCE when it is allocated and no launch needs a memset.  The result is deterministic:
+// partial sums land in partial[slice][c] and the last workgroup adds them in slice order.
+//
+// HBM-bound: x is read once (A*C*L*elem bytes), everything else is C-sized.
+#include "combo_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kTargetGroups = 2048;  // workgroups to aim for: 8 per CU
+
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ unsigned short to_bf16(float v) {
+  unsigned u = __float_as_uint(v);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+struct ColArgs {
+  const void* x;
+  void* out;
+  float* partial;     // [slices][C]
+  unsigned* counters; // one per column block (rows mode) / per channel (planes mode); zero on entry, zero on exit
+  long long A, L;
+  int C, slices, in_bf16, out_bf16;
+  int tx_log2;        // rows mode: lanes along the columns = 1 << tx_log2 (16, 32 or 64), each owning 4 columns
+};
+
+// the last-arriving workgroup of a column block adds the slices in order (fixed summation order) and re-arms the counter
+__device__ __forceinline__ bool arrive_last(unsigned* counter, int slices, bool* flag) {
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned prev = atomicAdd(counter, 1u);
+    *flag = prev == (unsigned)slices - 1u;
+    if (*flag) atomicExch(counter, 0u);
+  }
+  __syncthreads();
+  const bool last = *flag;
+  if (last) __threadfence();
+  return last;
+}
+
+__device__ __forceinline__ void store_out(const ColArgs& a, int c, float v) {
+  if (a.out_bf16) reinterpret_cast<unsigned short*>(a.out)[c] = to_bf16(v);
+  else reinterpret_cast<float*>(a.out)[c] = v;
+}
+
+// L == 1: x[M, C], C % 4 == 0.  Workgroup = tx lanes along the columns (4 columns each) x ty = 256 / tx rows in flight;
+// grid = (column blocks, slices of the rows).
+__global__ void __launch_bounds__(kThreads)
+colsum_rows_kernel(const ColArgs a) {
+  __shared__ float4 red[kThreads];
+  __shared__ bool flag;
+  const int tx = 1 << a.tx_log2, ty = kThreads >> a.tx_log2;
+  const int lx = threadIdx.x & (tx - 1), ly = threadIdx.x >> a.tx_log2;
+  const int col = (blockIdx.x * tx + lx) * 4;
+  const long long M = a.A;
+  const long long rows_per = (M + a.slices - 1) / a.slices;
+  const long long r0 = rows_per * blockIdx.y, r1 = min(M, r0 + rows_per);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (col < a.C) {
+    if (a.in_bf16) {
+      const uint2* p = reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(a.x) + col);
+      const long long pitch = a.C / 4;  // in uint2
+      long long r = r0 + ly;
+      for (; r + 3ll * ty < r1; r += 4ll * ty) {  // four independent loads in flight
+        const uint2 v0 = p[r * pitch], v1 = p[(r + ty) * pitch], v2 = p[(r + 2 * ty) * pitch], v3 = p[(r + 3 * ty) * pitch];
+        acc.x += (bf16_lo(v0.x) + bf16_lo(v1.x)) + (bf16_lo(v2.x) + bf16_lo(v3.x));
+        acc.y += (bf16_hi(v0.x) + bf16_hi(v1.x)) + (bf16_hi(v2.x) + bf16_hi(v3.x));
+        acc.z += (bf16_lo(v0.y) + bf16_lo(v1.y)) + (bf16_lo(v2.y) + bf16_lo(v3.y));
+        acc.w += (bf16_hi(v0.y) + bf16_hi(v1.y)) + (bf16_hi(v2.y) + bf16_hi(v3.y));
+      }
+      for (; r < r1; r += ty) {
+        const uint2 v = p[r * pitch];
+        acc.x += bf16_lo(v.x); acc.y += bf16_hi(v.x); acc.z += bf16_lo(v.y); acc.w += bf16_hi(v.y);
+      }
+    } else {
+      const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.x) + col);
+      const long long pitch = a.C / 4;
+      long long r = r0 + ly;
+      for (; r + 3ll * ty < r1; r += 4ll * ty) {
+        const float4 v0 = p[r * pitch], v1 = p[(r + ty) * pitch], v2 = p[(r + 2 * ty) * pitch], v3 = p[(r + 3 * ty) * pitch];
+        acc.x += (v0.x + v1.x) + (v2.x + v3.x); acc.y += (v0.y + v1.y) + (v2.y + v3.y);
+        acc.z += (v0.z + v1.z) + (v2.z + v3.z); acc.w += (v0.w + v1.w) + (v2.w + v3.w);
+      }
+      for (; r < r1; r += ty) {
+        const float4 v = p[r * pitch];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = ty >> 1; s > 0; s >>= 1) {  // over the rows in flight, fixed tree
+    if (ly < s) {
+      const float4 o = red[threadIdx.x + s * tx];
+      acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+      red[threadIdx.x] = acc;
+    }
+    __syncthreads();
+  }
+  if (a.slices == 1) {
+    if (ly == 0 && col < a.C) { store_out(a, col, acc.x); store_out(a, col + 1, acc.y); store_out(a, col + 2, acc.z); store_out(a, col + 3, acc.w); }
+    return;
+  }
+  if (ly == 0 && col < a.C) *reinterpret_cast<float4*>(a.partial + (long long)blockIdx.y * a.C + col) = acc;
+  if (!arrive_last(a.counters + blockIdx.x, a.slices, &flag)) return;
+  if (ly == 0 && col < a.C) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < a.slices; ++s) {
+      const float4 o = *reinterpret_cast<const float4*>(a.partial + (long long)s * a.C + col);
+      t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+    }
+    store_out(a, col, t.x); store_out(a, col + 1, t.y); store_out(a, col + 2, t.z); store_out(a, col + 3, t.w);
+  }
+}
+
+// L > 1: x[A, C, L].  Workgroup = (channel c, slice of the A planes); waves take planes in turn, lanes run along L.
+template <int V>
+__global__ void __launch_bounds__(kThreads)
+colsum_planes_kernel(const ColArgs a) {
+  __shared__ float red[kThreads / COMBO_WAVE];
+  __shared__ bool flag;
+  const int c = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long per = (a.A + a.slices - 1) / a.slices;
+  const long long a0 = per * blockIdx.y, a1 = min(a.A, a0 + per);
+  float acc = 0.f;
+  for (long long pl = a0 + wave; pl < a1; pl += kThreads / COMBO_WAVE) {
+    const long long base = (pl * a.C + c) * a.L;
+    if (a.in_bf16) {
+      const unsigned short* p = reinterpret_cast<const unsigned short*>(a.x) + base;
+      if (V == 4) {
+        for (long long l = lane * 4ll; l < a.L; l += 256) {
+          const uint2 v = *reinterpret_cast<const uint2*>(p + l);
+          acc += (bf16_lo(v.x) + bf16_hi(v.x)) + (bf16_lo(v.y) + bf16_hi(v.y));
+        }
+      } else {
+        for (long long l = lane; l < a.L; l += 64) acc += __uint_as_float((unsigned)p[l] << 16);
+      }
+    } else {
+      const float* p = reinterpret_cast<const float*>(a.x) + base;
+      if (V == 4) {
+        for (long long l = lane * 4ll; l < a.L; l += 256) {
+          const float4 v = *reinterpret_cast<const float4*>(p + l);
+          acc += (v.x + v.y) + (v.z + v.w);
+        }
+      } else {
+        for (long long l = lane; l < a.L; l += 64) acc += p[l];
+      }
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  const float total = (red[0] + red[1]) + (red[2] + red[3]);
+  if (a.slices == 1) {
+    if (threadIdx.x == 0) store_out(a, c, total);
+    return;
+  }
+  if (threadIdx.x == 0) a.partial[(long long)blockIdx.y * a.C + c] = total;
+  if (!arrive_last(a.counters + c, a.slices, &flag)) return;
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int s = 0; s < a.slices; ++s) t += a.partial[(long long)s * a.C + c];
+    store_out(a, c, t);
+  }
+}
+
+struct Plan { int blocks_x, slices, tx_log2, counters; };
+
+Plan plan(long long A, int C, long long L) {
+  Plan p{};
+  if (L == 1) {
+    const int groups = C / 4;
+    // lanes along the columns: the width (16 / 32 / 64) that wastes the fewest lanes, wider on ties
+    int best = 64, best_waste = 1 << 30;
+    for (int tx = 64; tx >= 16; tx >>= 1) {
+      const int waste = (groups + tx - 1) / tx * tx - groups;
+      if (waste < best_waste) { best = tx; best_waste = waste; }
+    }
+    p.tx_log2 = best == 64 ? 6 : best == 32 ? 5 : 4;
+    p.blocks_x = (groups + best - 1) / best;
+    const int ty = kThreads / best;
+    long long s = kTargetGroups / p.blocks_x;
+    const long long max_s = A / (8ll * ty);  // at least 8 rows per thread and slice
+    if (s > max_s) s = max_s;
+    p.slices = (int)(s < 1 ? 1 : s > 1024 ? 1024 : s);
+  } else {
+    p.blocks_x = C;
+    long long s = kTargetGroups / (C > 0 ? C : 1);
+    if (s > A) s = A;
+    p.slices = (int)(s < 1 ? 1 : s);
+  }
+  p.counters = p.blocks_x;
+  return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int combo_colsum_plan(long long A, int C, long long L, int* slices, int* counters) {
+  if (A <= 0 || C <= 0 || L <= 0 || (L == 1 && C % 4 != 0)) return COMBO_EINVAL;
+  const Plan p = plan(A, C, L);
+  if (slices) *slices = p.slices;
+  if (counters) *counters = p.counters;
+  return 0;
+}
+
+int combo_colsum(const void* x, long long A, int C, long long L, int in_bf16, void* out, int out_bf16, float* partial,
+                 unsigned* counters, combo_stream_t stream) {
+  if (!x || !out || A <= 0 || C <= 0 || L <= 0 || (L == 1 && C % 4 != 0)) return COMBO_EINVAL;
+  const Plan p = plan(A, C, L);
+  if (p.slices > 1 && (!partial || !counters)) return COMBO_EINVAL;
+  ColArgs a{x, out, partial, counters, A, L, C, p.slices, in_bf16, out_bf16, p.tx_log2};
+  const dim3 grid(p.blocks_x, p.slices);
+  if (L == 1) hipLaunchKernelGGL(colsum_rows_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, a);
+  else if (L % 4 == 0) hipLaunchKernelGGL(colsum_planes_kernel<4>, grid, dim3(kThreads), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(colsum_planes_kernel<1>, grid, dim3(kThreads), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

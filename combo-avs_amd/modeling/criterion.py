@@ -319,7 +319,8 @@ class SetCriterion(nn.Module):
         target_classes[lidx, frame[None].expand(L, Nm), src_q] = lab[frame[None].expand(L, Nm), tgt_g]
         nll = F.cross_entropy(logits.reshape(L * F_ * Q, -1), target_classes.view(-1), reduction="none").view(L, -1)
         wgt = self.empty_weight[target_classes].view(L, -1)
-        loss_ce = (nll * wgt).sum(1) / wgt.sum(1)
+        from ..ops.colsum import row_sum  # (no ATen reduction over >= 2 000 inputs inside the captured step: ops/colsum.py)
+        loss_ce = row_sum(nll * wgt) / row_sum(wgt)
         # ---- mask losses (criterion.py:137-186), all outputs at once: three fused launches (csrc/maskloss.hip) ----------
         from ..ops import maskloss
         frame_b = frame[None].expand(L, Nm)

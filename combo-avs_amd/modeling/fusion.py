@@ -20,6 +20,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .layers import position_embedding_sine
+from ..ops.colsum import add_channel_vector
 
 
 class BiMultiHeadAttention(nn.Module):
@@ -155,6 +156,7 @@ class AVFuse(nn.Module):
             # the LAST level's PE is what reaches b_attn (AVFuse.py:103,109); one level in every shipped config
             image_pos = position_embedding_sine(1, f.shape[2], f.shape[3], f.device, self.fused_backbone_dim[0] // 2)
             image_pos = image_pos.flatten(2).permute(0, 2, 1)  # [1,HW,C]
-            visual_features[name] = f + self.level_embed.weight[i][None, :, None, None]  # AVFuse.py:104-106
+            # AVFuse.py:104-106; the embedding's gradient from csrc/colsum.hip (ops/colsum.py: no ATen multi-workgroup reduction)
+            visual_features[name] = add_channel_vector(f, self.level_embed.weight[i], 1)
         v, a = self.b_attn(visual_features, audio_features, pos_v=image_pos, pos_a=audio_pos)
         return {"visual": v, "audio": a}

@@ -21,6 +21,7 @@ from .layers import MLP, position_embedding_sine
 
 
 import os as _os
+from ..ops.colsum import add_channel_vector
 FUSED_MASKS = _os.environ.get("COMBO_FUSED_MASKS", "1") == "1"  # 0: per-head full logits + csrc/attnmask.hip (A/B)
 
 
@@ -221,7 +222,7 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
             size_list.append(tuple(x[i].shape[-2:]))
             p = position_embedding_sine(1, x[i].shape[2], x[i].shape[3], x[i].device, self.hidden_dim // 2)
             pos.append(p.flatten(2).transpose(1, 2))  # [1,hw,C]
-            s = self.input_proj[i](x[i]).flatten(2) + self.level_embed.weight[i][None, :, None]
+            s = add_channel_vector(self.input_proj[i](x[i]).flatten(2), self.level_embed.weight[i], 1)  # (ops/colsum.py)
             src.append(s.transpose(1, 2))  # [BT,hw,C]
         src_k = [s_ + p_ for s_, p_ in zip(src, pos)]  # key input of the cross-attention layers of a level: once, not per layer
         query_embed = self.query_embed.weight.unsqueeze(0)  # [1,Q,C]

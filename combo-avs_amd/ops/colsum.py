@@ -1,0 +1,147 @@
+"""Channel sums without ATen's multi-workgroup reduction (csrc/colsum.hip): bias gradients of the host-PyTorch backbones and
+the level-embedding gradients.  ATen splits long reductions over workgroups behind a hipMemsetAsync of its semaphores; those
+memset nodes do not replay reliably from a hipGraph on this stack (tools/graph_reduce_repro.py), so the training step uses
+these ops wherever a reduction has >= ~2 000 inputs per output (tools/graph_reductions.py lists what is left)."""
+import ctypes
+
+import torch
+from torch.autograd import Function
+
+from .. import _lib
+
+_counters = {}
+
+
+def _counter_buffer(dev, n):
+    """zeroed once; every launch re-arms what it used.  One buffer per (device, stream): launches on one stream are ordered."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    buf = _counters.get(key)
+    if buf is None or buf.numel() < n:
+        buf = torch.zeros(max(n, 4096), dtype=torch.int32, device=dev)
+        _counters[key] = buf
+    return buf
+
+
+def _code(dt):
+    if dt == torch.bfloat16:
+        return 1
+    if dt == torch.float32:
+        return 0
+    raise RuntimeError("colsum: float32 / bfloat16 tensors only")
+
+
+def channel_sum(x, A, C, L, out_dtype=None):
+    """out[c] = sum over a, l of x viewed as [A, C, L] (x contiguous in that view)."""
+    if not (x.is_cuda and x.is_contiguous() and x.numel() == A * C * L):
+        raise RuntimeError("colsum: a contiguous CUDA tensor of A*C*L elements expected")
+    out = torch.empty(C, dtype=out_dtype or x.dtype, device=x.device)
+    lib = _lib.lib()
+    slices, ncnt = ctypes.c_int(), ctypes.c_int()
+    _lib.check(lib.combo_colsum_plan(A, C, L, ctypes.byref(slices), ctypes.byref(ncnt)), "combo_colsum_plan")
+    partial = counters = None
+    if slices.value > 1:
+        partial = torch.empty(slices.value, C, dtype=torch.float32, device=x.device)
+        counters = _counter_buffer(x.device, ncnt.value)
+    _lib.check(lib.combo_colsum(x.data_ptr(), A, C, L, _code(x.dtype), out.data_ptr(), _code(out.dtype),
+                                0 if partial is None else partial.data_ptr(), 0 if counters is None else counters.data_ptr(),
+                                _lib.current_stream()), "combo_colsum")
+    return out
+
+
+def supported(x, channel_dim):
+    """the kernel's envelope: CUDA fp32 / bf16; channels last needs C % 4 == 0"""
+    if not x.is_cuda or x.dtype not in (torch.float32, torch.bfloat16) or x.numel() == 0:
+        return False
+    cd = channel_dim % x.dim()
+    return cd != x.dim() - 1 or x.shape[-1] % 4 == 0
+
+
+def sum_to_channels(x, channel_dim=-1, out_dtype=None):
+    """sum of x over every dimension but `channel_dim` (last: x[..., C]; 1: x[B, C, ...])"""
+    cd = channel_dim % x.dim()
+    if cd == 1 and x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last) \
+            and x.shape[1] % 4 == 0:
+        x, cd = x.permute(0, 2, 3, 1), 3  # NHWC in memory: rows of C
+    x = x.contiguous()
+    if cd == x.dim() - 1:
+        return channel_sum(x, x.numel() // x.shape[-1], x.shape[-1], 1, out_dtype)
+    if cd == 1:
+        return channel_sum(x, x.shape[0], x.shape[1], x.numel() // (x.shape[0] * x.shape[1]), out_dtype)
+    raise RuntimeError("colsum: channel dimension must be 1 or the last one")
+
+
+def sum_leading(x, dims):
+    """x.sum(dims) for the two layouts above (used by tools/graph_reduce_repro.py)"""
+    dims = tuple(sorted(d % x.dim() for d in dims))
+    keep = [d for d in range(x.dim()) if d not in dims]
+    if len(keep) != 1:
+        raise RuntimeError("colsum: exactly one kept dimension")
+    return sum_to_channels(x, keep[0])
+
+
+class _AddChannelVector(Function):
+    """y = x + v broadcast along `channel_dim`; dv by channel_sum (autograd would call ATen's sum)."""
+
+    @staticmethod
+    def forward(ctx, x, v, channel_dim):
+        ctx.channel_dim = channel_dim % x.dim()
+        ctx.v_dtype = v.dtype
+        shape = [1] * x.dim()
+        shape[ctx.channel_dim] = -1
+        return x + v.to(x.dtype).view(shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dv = sum_to_channels(dy, ctx.channel_dim, out_dtype=ctx.v_dtype) if ctx.needs_input_grad[1] else None
+        return dy, dv, None
+
+
+def add_channel_vector(x, v, channel_dim=1):
+    if supported(x, channel_dim) and v.dtype in (torch.float32, torch.bfloat16):
+        return _AddChannelVector.apply(x, v, channel_dim)
+    shape = [1] * x.dim()
+    shape[channel_dim % x.dim()] = -1
+    return x + v.view(shape)  # CPU / other dtypes (unit tests of the host logic)
+
+
+class _LinearBias(Function):
+    """F.linear with a bias whose gradient is channel_sum(dy) (backbone_pvt._linear)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return torch.nn.functional.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        dx = (dy2 @ w).view_as(x) if ctx.needs_input_grad[0] else None
+        dw = dy2.t() @ x.reshape(-1, x.shape[-1]) if ctx.needs_input_grad[1] else None
+        db = sum_to_channels(dy2, -1) if ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+def linear_bias(x, w, b):
+    if supported(x, -1) and w.shape[0] % 4 == 0 and x.dtype == w.dtype == b.dtype:
+        return _LinearBias.apply(x, w, b)
+    return torch.nn.functional.linear(x, w, b)
+
+
+class _RowSum(Function):
+    """x[R, n].sum(1) (the weighted class-loss sums of the criterion: n = frames x queries per output)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.n = x.shape[1]
+        return channel_sum(x.contiguous(), 1, x.shape[0], x.shape[1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy[:, None].expand(-1, ctx.n)
+
+
+def row_sum(x):
+    if x.is_cuda and x.dim() == 2 and x.dtype in (torch.float32, torch.bfloat16) and x.numel() > 0:
+        return _RowSum.apply(x)
+    return x.sum(1)

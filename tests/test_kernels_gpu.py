@@ -636,3 +636,100 @@ def test_mask_logits_of_all_heads_in_one_launch_equal_per_head_launches():
     for h in range(heads):
         masklogit.mask_logits_into(mes[h], mf, one)
         assert torch.equal(one, allb[h])  # the same kernel, the same k order: bit for bit
+
+
+# ---- channel sums (csrc/colsum.hip): the bias / level-embedding gradients that must not go through ATen's split reduction ----
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,cd,dt", [
+    ((7840, 320), -1, torch.bfloat16), ((7840, 1280), -1, torch.bfloat16), ((125440, 64), -1, torch.bfloat16),
+    ((31360, 512), -1, torch.bfloat16), ((3000, 256), -1, torch.float32), ((37, 12), -1, torch.float32),
+    ((40, 320, 14, 14), 1, torch.bfloat16), ((40, 64, 56, 56), 1, torch.bfloat16), ((40, 256, 784), 1, torch.float32),
+    ((40, 256, 49), 1, torch.float32), ((3, 5, 7), 1, torch.float32), ((1, 256, 56, 56), 1, torch.float32)])
+def test_channel_sum_matches_float64_and_is_deterministic(shape, cd, dt):
+    from combo_avs_amd.ops import colsum
+    torch.manual_seed(len(shape) * 131 + shape[0])
+    x = torch.randn(shape, device="cuda").to(dt)
+    got = colsum.sum_to_channels(x, cd, out_dtype=torch.float32)
+    dims = [d for d in range(x.dim()) if d != cd % x.dim()]
+    want = x.double().sum(dims)
+    n = x.numel() // want.numel()
+    # fp32 accumulation of n terms of unit variance: error ~ 1e-7 * sqrt(n) * a few (the stated tolerance)
+    assert float((got.double() - want).abs().max()) <= 4e-6 * n ** 0.5 + 1e-6
+    again = colsum.sum_to_channels(x, cd, out_dtype=torch.float32)
+    assert torch.equal(got, again)  # fixed summation order
+    for buf in colsum._counters.values():
+        assert int(buf.abs().sum()) == 0  # every launch re-arms its counters
+
+
+@pytest.mark.gpu
+def test_channel_sum_channels_last_and_autograd_wrappers():
+    from combo_avs_amd.ops import colsum
+    torch.manual_seed(5)
+    x = torch.randn(6, 64, 9, 11, device="cuda").to(memory_format=torch.channels_last)
+    got = colsum.sum_to_channels(x, 1)
+    assert torch.allclose(got, x.sum((0, 2, 3)), atol=1e-4)
+    # y = x + v[channel]: dv against autograd's own reduction
+    for shape, cd in (((4, 32, 10, 10), 1), ((4, 32, 50), 1)):
+        xx = torch.randn(shape, device="cuda", requires_grad=True)
+        v = torch.randn(32, device="cuda", requires_grad=True)
+        g = torch.randn(shape, device="cuda")
+        colsum.add_channel_vector(xx, v, cd).backward(g)
+        view = [1, -1] + [1] * (len(shape) - 2)
+        x2, v2 = xx.detach().clone().requires_grad_(), v.detach().clone().requires_grad_()
+        (x2 + v2.view(view)).backward(g)
+        assert torch.equal(xx.grad, x2.grad) and torch.allclose(v.grad, v2.grad, atol=1e-4)
+    # linear with bias: all three gradients against F.linear's
+    a = torch.randn(5, 77, 64, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    w = torch.randn(128, 64, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    b = torch.randn(128, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    gy = torch.randn(5, 77, 128, device="cuda", dtype=torch.bfloat16)
+    y = colsum.linear_bias(a, w, b)
+    y.backward(gy)
+    a2, w2, b2 = (t.detach().clone().requires_grad_() for t in (a, w, b))
+    y2 = torch.nn.functional.linear(a2, w2, b2)
+    y2.backward(gy)
+    assert torch.equal(y, y2)
+    for p, q in ((a, a2), (w, w2), (b, b2)):  # bf16 results of fp32-accumulated sums in different orders: 1 bf16 ulp
+        assert float((p.grad.float() - q.grad.float()).abs().max()) <= 2 ** -7 * float(q.grad.float().abs().max())
+
+
+@pytest.mark.gpu
+def test_channel_sum_survives_hipgraph_replays_where_the_library_reduction_does_not():
+    """the hazard itself is documented by tools/graph_reduce_repro.py; this pins the replacement: 30 replays with an eager kernel
+    between two synchronisations before each, every result equal to the eager one"""
+    from combo_avs_amd.ops import colsum
+    torch.manual_seed(1)
+    xs = [torch.randn(15680, 1280, device="cuda").bfloat16(), torch.randn(8, 5376, 256, device="cuda"),
+          torch.randn(40, 256, 28, 28, device="cuda")]
+    cds = [-1, -1, 1]
+    want = [colsum.sum_to_channels(x, cd).clone() for x, cd in zip(xs, cds)]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        [colsum.sum_to_channels(x, cd) for x, cd in zip(xs, cds)]
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        outs = [[colsum.sum_to_channels(x, cd) for x, cd in zip(xs, cds)] for _ in range(4)]
+    junk = torch.ones(64, device="cuda")
+    for _ in range(30):
+        torch.cuda.synchronize()
+        junk[:16].zero_()
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        for row in outs:
+            for o, w in zip(row, want):
+                assert torch.equal(o, w)
+
+
+@pytest.mark.gpu
+def test_row_sum_forward_backward():
+    from combo_avs_amd.ops import colsum
+    torch.manual_seed(2)
+    x = torch.randn(10, 4000, device="cuda", requires_grad=True)
+    g = torch.randn(10, device="cuda")
+    y = colsum.row_sum(x)
+    y.backward(g)
+    assert torch.allclose(y, x.detach().double().sum(1).float(), atol=1e-4)
+    assert torch.equal(x.grad, g[:, None].expand(-1, 4000))

@@ -257,3 +257,18 @@ def test_configs4_ms3_ten_frames_four_clips_full_size_steps():
     GPUs), every frame annotated: one eager step, then two replays of the captured hipGraph."""
     _full_size_steps("avs_ms3/COMBO_PVTV2B5_bs8_20k.yaml", clips=4, T=10, HW=224, K=2, avss=False,
                      opts=("MODEL.FUSE_CONFIG.NUM_FRAMES", 10))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["r50_s4", "pvt_ms3_t10"])
+def test_training_step_holds_no_split_library_reductions(workload):
+    """ATen reductions that split one output over several workgroups zero their semaphores with a memset node, which a replayed
+    hipGraph does not execute reliably on this stack (tools/graph_reduce_repro.py: stale results in 99 of 100 replays).  The
+    forward + backward pass that GraphedTrainStep captures must not contain any (tools/graph_reductions.py lists them)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "graph_reductions.py"), workload], capture_output=True,
+                         text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "candidate launches inside the captured step: 0" in out.stdout, out.stdout[-3000:]
