@@ -39,6 +39,7 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
+import combo_avs_amd  # noqa: E402,F401  (first: it sets DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before the process's first HIP call)
 
 
 def synth_batch(n_clips, T, H, W, device, seed, K=2, gt="first", avss=False):

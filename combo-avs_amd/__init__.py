@@ -8,7 +8,26 @@ library is missing (see _lib.py).
 """
 __version__ = "0.1.0"
 
-from . import _lib  # noqa: F401
+import os as _os
+
+
+def _guard_graph_memsets():
+    """hipGraph memset nodes replay wrongly with the HIP runtime's AQL packet capture on this stack (ROCm 7.2 / torch 2.10:
+    tools/graph_reduce_repro.py - stale results in 99 of 100 replays, none with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0; measured cost
+    of switching it off on the captured training step: none, 55.98 vs 56.46 ms).  This package's own ops put no memset node
+    into the captured step (ops/colsum.py), but library calls may (MIOpen's backward of the stride-2 3x3 convolutions does:
+    tools/memset_sites.py), so the switch is turned off here unless the caller has set it.  The runtime reads it at its first
+    HIP call, which may already lie behind us - trainer.GraphedTrainStep therefore TESTS the behaviour before it captures
+    (trainer.graph_memset_selftest) instead of trusting this."""
+    if "DEBUG_CLR_GRAPH_PACKET_CAPTURE" in _os.environ:
+        return "user"
+    _os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"
+    return "set"
+
+
+GRAPH_MEMSET_GUARD = _guard_graph_memsets()
+
+from . import _lib  # noqa: E402,F401
 
 from .config import (CfgNode, add_audio_config, add_fuse_config, add_maskformer2_config, combo_cfg, get_cfg)  # noqa: E402,F401
 from .registry import (BACKBONE_REGISTRY, META_ARCH_REGISTRY, SEM_SEG_HEADS_REGISTRY,  # noqa: E402,F401

@@ -193,7 +193,8 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
         shapes_list = [(int(s.shape[2]), int(s.shape[3])) for s in srcs]
         spatial_shapes, level_start_index, ref, normalizer = self._geometry(shapes_list, srcs[0].device)
         src = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
-        pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[l].view(1, 1, -1)
+        from ..ops.colsum import add_channel_vector  # level_embed's gradient from csrc/colsum.hip (ops/colsum.py)
+        pos = torch.cat([add_channel_vector(p.flatten(2).transpose(1, 2), self.level_embed[l], -1)
                          for l, p in enumerate(pos_embeds)], 1)
         ref = ref.expand(src.shape[0], -1, -1, -1)
         out, fan = src, None

@@ -76,8 +76,11 @@ class _BifuseTokenOp(Function):
             dp.data_ptr(),
             rtot.data_ptr(), B, N, C, H, dx.data_ptr(), du_part.data_ptr(), dc_part.data_ptr(), dln_part.data_ptr(), st),
             "combo_bifuse_backward2_f32")
-        dgb = dgb_part.sum((0, 1))
-        dln = dln_part.sum((0, 1))
+        # [B*chunks, 2C] -> [2C] by csrc/colsum.hip (ATen would split these sums over workgroups behind a memset node, which a
+        # replayed hipGraph does not execute reliably: ops/colsum.py)
+        from .colsum import channel_sum
+        dgb = channel_sum(dgb_part, B * chunks, 2 * C, 1).view(2, C)
+        dln = channel_sum(dln_part, B * chunks, 2 * C, 1).view(2, C)
         # inputs: x, ln_w, ln_b, eps, pos, u, c, z, b_ov, gamma_v, p_drop, drop_v, drop_a, seed
         return (dx, dln[0], dln[1], None, None, du_part.sum(1), dc_part.sum(1), dz_part.sum(1), dgb[1], dgb[0], None,
                 None, None, None)

@@ -105,25 +105,33 @@ def add_channel_vector(x, v, channel_dim=1):
 
 
 class _LinearBias(Function):
-    """F.linear with a bias whose gradient is channel_sum(dy) (backbone_pvt._linear)."""
+    """F.linear with a bias whose gradient is channel_sum(dy) (backbone_pvt._linear).  Under autocast the forward computes in
+    the autocast dtype while x / w / b may be fp32: the backward GEMMs then run in dy's dtype and the gradients are cast to the
+    inputs' dtypes, as autocast's own cast nodes would do."""
 
     @staticmethod
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
+        ctx.b_dtype = b.dtype
         return torch.nn.functional.linear(x, w, b)
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dy2 = dy.reshape(-1, dy.shape[-1])
-        dx = (dy2 @ w).view_as(x) if ctx.needs_input_grad[0] else None
-        dw = dy2.t() @ x.reshape(-1, x.shape[-1]) if ctx.needs_input_grad[1] else None
-        db = sum_to_channels(dy2, -1) if ctx.needs_input_grad[2] else None
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = (dy2 @ w.to(dy2.dtype)).view_as(x).to(x.dtype)
+        if ctx.needs_input_grad[1]:
+            dw = (dy2.t() @ x.reshape(-1, x.shape[-1]).to(dy2.dtype)).to(w.dtype)
+        if ctx.needs_input_grad[2]:
+            db = sum_to_channels(dy2, -1, out_dtype=ctx.b_dtype)
         return dx, dw, db
 
 
 def linear_bias(x, w, b):
-    if supported(x, -1) and w.shape[0] % 4 == 0 and x.dtype == w.dtype == b.dtype:
+    ok = (torch.float32, torch.bfloat16)
+    if x.is_cuda and x.numel() > 0 and w.shape[0] % 4 == 0 and x.dtype in ok and w.dtype in ok and b.dtype in ok:
         return _LinearBias.apply(x, w, b)
     return torch.nn.functional.linear(x, w, b)
 

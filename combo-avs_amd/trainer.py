@@ -381,6 +381,46 @@ def _clone_batch(batched_inputs):
     return out
 
 
+_memset_selftest = {}
+
+
+def graph_memset_selftest(dev, replays=4):
+    """Does a replayed hipGraph execute its memset nodes?  Captures a library reduction that zeroes its semaphores with
+    hipMemsetAsync (ATen's sum of a [15680, 1280] bf16 matrix over the rows: one output split over several workgroups), replays
+    it with an eager kernel between two synchronisations before each replay and compares with the eager result.  On the stack
+    this was written for the check fails in 99 of 100 replays with the runtime's AQL packet capture on and never with it off
+    (tools/graph_reduce_repro.py).  ~50 ms, once per process and device."""
+    key = (dev.type, dev.index)
+    if key in _memset_selftest:
+        return _memset_selftest[key]
+    with torch.no_grad():
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(1234)
+        x = torch.randn(15680, 1280, device=dev, generator=gen).to(torch.bfloat16)
+        want = x.sum(0)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            x.sum(0)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            outs = [x.sum(0) for _ in range(4)]
+        junk = torch.ones(64, device=dev)
+        ok = True
+        for _ in range(replays):
+            torch.cuda.synchronize(dev)
+            junk[:16].zero_()
+            torch.cuda.synchronize(dev)
+            g.replay()
+            torch.cuda.synchronize(dev)
+            ok = ok and all(torch.equal(o, want) for o in outs)
+        del g, outs
+    _memset_selftest[key] = ok
+    return ok
+
+
 class GraphedTrainStep:
     """`train_step` with forward + loss + backward replayed from ONE captured hipGraph.
 
@@ -400,6 +440,14 @@ class GraphedTrainStep:
         self.model, self.opt = model, optimizer
         self.warmup_iters, self.max_graphs = warmup_iters, max_graphs
         self.graphs = {}
+        dev = getattr(model, "device", None)
+        if dev is not None and torch.device(dev).type == "cuda" and os.environ.get("COMBO_ALLOW_PACKET_CAPTURE") != "1":
+            if not graph_memset_selftest(torch.device(dev)):
+                raise RuntimeError(
+                    "GraphedTrainStep: memset nodes of a replayed hipGraph are not executed reliably in this process (HIP runtime "
+                    "graph packet capture; tools/graph_reduce_repro.py) and library calls inside the step use them.  Export "
+                    "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, or import combo_avs_amd before the first HIP call of the process (it sets "
+                    "the variable); COMBO_ALLOW_PACKET_CAPTURE=1 skips this check.")
 
     def _num_masks(self, batched_inputs, dev):
         n = 0

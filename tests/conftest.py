@@ -15,6 +15,7 @@ def pytest_configure(config):
 
 def pytest_collection_modifyitems(config, items):
     import torch
+    import combo_avs_amd  # noqa: F401  (before the first HIP call: the package switches off the runtime's graph packet capture)
     if torch.cuda.is_available():
         return
     skip = pytest.mark.skip(reason="no GPU in this container")

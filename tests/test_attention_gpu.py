@@ -112,7 +112,7 @@ def test_attention_timing_at_decoder_shapes(capsys):
             e.record()
             torch.cuda.synchronize()
             return s.elapsed_time(e) / n * 1e3
-        tf = t(fwd)
+        tf = min(t(fwd) for _ in range(5))  # best of five: the first launches on a fresh box run at idle clocks
         tfb = t(lambda: torch.autograd.grad(fwd(), (q, k, v), g))
         with capsys.disabled():
             print(f"\n[attention Lk={Lk}] forward {tf:.1f} us, forward+backward {tfb:.1f} us "

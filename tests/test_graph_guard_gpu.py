@@ -1,0 +1,53 @@
+"""The captured training step and hipGraph memset nodes (found in round 3: bench.py --config pvt_ms3_t10 diverged).
+
+ATen reductions that split one output over several workgroups - and some MIOpen backward kernels - zero a buffer with
+hipMemsetAsync; captured into a hipGraph these become memset nodes, which the HIP runtime's AQL packet capture replays wrongly on
+this stack (tools/graph_reduce_repro.py).  Three lines of defence, each pinned here:
+  1. the package's own reductions use csrc/colsum.hip (no memset; tests/test_kernels_gpu.py, tests/test_model_gpu.py),
+  2. importing the package switches the packet capture off (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0) before the first HIP call,
+  3. GraphedTrainStep tests the behaviour before capturing and refuses loudly when memset nodes misbehave."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_memset_nodes_replay_correctly_in_this_process():
+    import combo_avs_amd
+    from combo_avs_amd.trainer import graph_memset_selftest
+    assert combo_avs_amd.GRAPH_MEMSET_GUARD in ("set", "user")
+    assert os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") is not None
+    assert graph_memset_selftest(torch.device("cuda", 0))
+
+
+@pytest.mark.gpu
+def test_own_channel_sum_is_clean_even_with_packet_capture_on():
+    env = dict(os.environ, DEBUG_CLR_GRAPH_PACKET_CAPTURE="1", EXPECT_OWN_CLEAN="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "graph_reduce_repro.py"), "30"], capture_output=True, text=True,
+                         timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "ops.colsum inside the graph" in out.stdout and ": 0 of 30 replays returned a wrong reduction" in out.stdout
+
+
+@pytest.mark.gpu
+def test_graphed_step_refuses_when_memset_nodes_misbehave():
+    """with the packet capture forced on: whatever the self-test finds on this runtime, GraphedTrainStep raises exactly when it
+    fails (a runtime that has fixed the replay passes both)"""
+    code = (
+        "import torch, combo_avs_amd\n"
+        "from combo_avs_amd.trainer import GraphedTrainStep, graph_memset_selftest\n"
+        "class M:\n    device = torch.device('cuda', 0)\n"
+        "ok = graph_memset_selftest(M.device)\n"
+        "try:\n    GraphedTrainStep(M(), None); raised = False\n"
+        "except RuntimeError as e:\n    raised = 'memset nodes' in str(e)\n"
+        "print('SELFTEST', ok, 'RAISED', raised)\n")
+    env = dict(os.environ, DEBUG_CLR_GRAPH_PACKET_CAPTURE="1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("SELFTEST")][0].split()
+    assert (line[1] == "True") != (line[3] == "True"), out.stdout

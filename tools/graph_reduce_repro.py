@@ -10,6 +10,8 @@ usage: python tools/graph_reduce_repro.py [replays]"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("SET_IN_PROCESS") == "1":  # what combo_avs_amd/__init__.py does: before the first HIP call of the process
+    os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"
 import torch
 
 n_rep = int(sys.argv[1]) if len(sys.argv) > 1 else 200
@@ -68,5 +70,7 @@ try:
     import combo_avs_amd  # noqa: F401
     from combo_avs_amd.ops.colsum import sum_leading
     bad_own = run("ops.colsum inside the graph", lambda x, d: sum_leading(x, d))
+    if os.environ.get("EXPECT_OWN_CLEAN") == "1" and bad_own:
+        sys.exit(1)
 except ImportError as e:
     print("ops.colsum not available:", e)
