@@ -20,8 +20,8 @@ _SIGNATURES = {
     "combo_dwconv3x3_wgrad_slices": [c_int] * 4,
     "combo_dwconv3x3_wgrad_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "combo_fold_cast_grouped": [c_void_p, c_int, c_void_p],
-    "combo_colsum_plan": [c_longlong, c_int, c_longlong, c_void_p, c_void_p],
-    "combo_colsum": [c_void_p, c_longlong, c_int, c_longlong, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p],
+    "combo_colsum_slices": [c_longlong, c_int, c_longlong],
+    "combo_colsum": [c_void_p, c_longlong, c_int, c_longlong, c_int, c_void_p, c_int, c_void_p, c_void_p],
     "combo_bias_act_bf16": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p],
     "combo_bias_act_f32": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p],
     "combo_relu_grad_bf16": [c_void_p, c_void_p, c_longlong, c_void_p, c_void_p],

@@ -5,9 +5,10 @@
 // Why not ATen's sum: when one output is split over several workgroups ATen (Reduce.cuh) zeroes its semaphores with a
 // hipMemsetAsync per launch; the HIP runtime's AQL packet capture replays such memset nodes of a hipGraph wrongly on this
 // stack (ROCm 7.2, torch 2.10: tools/graph_reduce_repro.py - 99 of 100 replays return stale memory), so the captured
-// training step must hold none.  Here the arrival counters re-arm themselves: the last workgroup of a column block resets
-// its counter, so the buffer is zeroed ONCE when it is allocated and no launch needs a memset.  The result is deterministic:
-// partial sums land in partial[slice][c] and the last workgroup adds them in slice order.
+// training step must hold none.  Here a first launch writes partial[slice][c] and a second, tiny one adds the slices in a
+// fixed order: no memset, no atomics, deterministic.  (v1 did it in one launch with "last workgroup to arrive adds the
+// partials": the agent-scope release/acquire fence every workgroup needs for that costs ~17 ns and serialises chip-wide -
+// 120-140 us per launch at 2 048 workgroups, whatever the size of the input; the kernel boundary does the same job once.)
 //
 // HBM-bound: x is read once (A*C*L*elem bytes), everything else is C-sized.
 #include "combo_common.h"
@@ -16,6 +17,8 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kTargetGroups = 2048;  // workgroups to aim for: 8 per CU
+constexpr int kMaxSlices = 256;
+constexpr int kFinishThreads = 1024;
 
 __device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
@@ -29,27 +32,11 @@ __device__ __forceinline__ unsigned short to_bf16(float v) {
 struct ColArgs {
   const void* x;
   void* out;
-  float* partial;     // [slices][C]
-  unsigned* counters; // one per column block (rows mode) / per channel (planes mode); zero on entry, zero on exit
+  float* partial;  // [slices][C]
   long long A, L;
   int C, slices, in_bf16, out_bf16;
-  int tx_log2;        // rows mode: lanes along the columns = 1 << tx_log2 (16, 32 or 64), each owning 4 columns
+  int tx_log2;     // rows mode: lanes along the columns = 1 << tx_log2 (16, 32 or 64), each owning 4 columns
 };
-
-// the last-arriving workgroup of a column block adds the slices in order (fixed summation order) and re-arms the counter
-__device__ __forceinline__ bool arrive_last(unsigned* counter, int slices, bool* flag) {
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned prev = atomicAdd(counter, 1u);
-    *flag = prev == (unsigned)slices - 1u;
-    if (*flag) atomicExch(counter, 0u);
-  }
-  __syncthreads();
-  const bool last = *flag;
-  if (last) __threadfence();
-  return last;
-}
 
 __device__ __forceinline__ void store_out(const ColArgs& a, int c, float v) {
   if (a.out_bf16) reinterpret_cast<unsigned short*>(a.out)[c] = to_bf16(v);
@@ -61,7 +48,6 @@ __device__ __forceinline__ void store_out(const ColArgs& a, int c, float v) {
 __global__ void __launch_bounds__(kThreads)
 colsum_rows_kernel(const ColArgs a) {
   __shared__ float4 red[kThreads];
-  __shared__ bool flag;
   const int tx = 1 << a.tx_log2, ty = kThreads >> a.tx_log2;
   const int lx = threadIdx.x & (tx - 1), ly = threadIdx.x >> a.tx_log2;
   const int col = (blockIdx.x * tx + lx) * 4;
@@ -70,10 +56,10 @@ colsum_rows_kernel(const ColArgs a) {
   const long long r0 = rows_per * blockIdx.y, r1 = min(M, r0 + rows_per);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (col < a.C) {
+    const long long pitch = a.C / 4;  // in 4-column groups
+    long long r = r0 + ly;
     if (a.in_bf16) {
       const uint2* p = reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(a.x) + col);
-      const long long pitch = a.C / 4;  // in uint2
-      long long r = r0 + ly;
       for (; r + 3ll * ty < r1; r += 4ll * ty) {  // four independent loads in flight
         const uint2 v0 = p[r * pitch], v1 = p[(r + ty) * pitch], v2 = p[(r + 2 * ty) * pitch], v3 = p[(r + 3 * ty) * pitch];
         acc.x += (bf16_lo(v0.x) + bf16_lo(v1.x)) + (bf16_lo(v2.x) + bf16_lo(v3.x));
@@ -87,8 +73,6 @@ colsum_rows_kernel(const ColArgs a) {
       }
     } else {
       const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.x) + col);
-      const long long pitch = a.C / 4;
-      long long r = r0 + ly;
       for (; r + 3ll * ty < r1; r += 4ll * ty) {
         const float4 v0 = p[r * pitch], v1 = p[(r + ty) * pitch], v2 = p[(r + 2 * ty) * pitch], v3 = p[(r + 3 * ty) * pitch];
         acc.x += (v0.x + v1.x) + (v2.x + v3.x); acc.y += (v0.y + v1.y) + (v2.y + v3.y);
@@ -110,20 +94,9 @@ colsum_rows_kernel(const ColArgs a) {
     }
     __syncthreads();
   }
-  if (a.slices == 1) {
-    if (ly == 0 && col < a.C) { store_out(a, col, acc.x); store_out(a, col + 1, acc.y); store_out(a, col + 2, acc.z); store_out(a, col + 3, acc.w); }
-    return;
-  }
-  if (ly == 0 && col < a.C) *reinterpret_cast<float4*>(a.partial + (long long)blockIdx.y * a.C + col) = acc;
-  if (!arrive_last(a.counters + blockIdx.x, a.slices, &flag)) return;
-  if (ly == 0 && col < a.C) {
-    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < a.slices; ++s) {
-      const float4 o = *reinterpret_cast<const float4*>(a.partial + (long long)s * a.C + col);
-      t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
-    }
-    store_out(a, col, t.x); store_out(a, col + 1, t.y); store_out(a, col + 2, t.z); store_out(a, col + 3, t.w);
-  }
+  if (ly != 0 || col >= a.C) return;
+  if (a.slices == 1) { store_out(a, col, acc.x); store_out(a, col + 1, acc.y); store_out(a, col + 2, acc.z); store_out(a, col + 3, acc.w); }
+  else *reinterpret_cast<float4*>(a.partial + (long long)blockIdx.y * a.C + col) = acc;
 }
 
 // L > 1: x[A, C, L].  Workgroup = (channel c, slice of the A planes); waves take planes in turn, lanes run along L.
@@ -131,7 +104,6 @@ template <int V>
 __global__ void __launch_bounds__(kThreads)
 colsum_planes_kernel(const ColArgs a) {
   __shared__ float red[kThreads / COMBO_WAVE];
-  __shared__ bool flag;
   const int c = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long long per = (a.A + a.slices - 1) / a.slices;
   const long long a0 = per * blockIdx.y, a1 = min(a.A, a0 + per);
@@ -163,21 +135,32 @@ colsum_planes_kernel(const ColArgs a) {
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
   if (lane == 0) red[wave] = acc;
   __syncthreads();
+  if (threadIdx.x != 0) return;
   const float total = (red[0] + red[1]) + (red[2] + red[3]);
-  if (a.slices == 1) {
-    if (threadIdx.x == 0) store_out(a, c, total);
-    return;
-  }
-  if (threadIdx.x == 0) a.partial[(long long)blockIdx.y * a.C + c] = total;
-  if (!arrive_last(a.counters + c, a.slices, &flag)) return;
-  if (threadIdx.x == 0) {
-    float t = 0.f;
-    for (int s = 0; s < a.slices; ++s) t += a.partial[(long long)s * a.C + c];
-    store_out(a, c, t);
-  }
+  if (a.slices == 1) store_out(a, c, total);
+  else a.partial[(long long)blockIdx.y * a.C + c] = total;
 }
 
-struct Plan { int blocks_x, slices, tx_log2, counters; };
+// out[c] = sum_s partial[s][c]: 64 columns per workgroup, 16 row groups; row group ly adds slices ly, ly + 16, ... in ascending
+// order, then a fixed tree over the row groups.
+__global__ void __launch_bounds__(kFinishThreads)
+colsum_finish_kernel(const ColArgs a) {
+  __shared__ float red[kFinishThreads];
+  const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lx;
+  float t = 0.f;
+  if (c < a.C)
+    for (int s = ly; s < a.slices; s += kFinishThreads / 64) t += a.partial[(long long)s * a.C + c];
+  red[threadIdx.x] = t;
+  __syncthreads();
+  for (int s = kFinishThreads / 128; s > 0; s >>= 1) {
+    if (ly < s) { t += red[threadIdx.x + s * 64]; red[threadIdx.x] = t; }
+    __syncthreads();
+  }
+  if (ly == 0 && c < a.C) store_out(a, c, t);
+}
+
+struct Plan { int blocks_x, slices, tx_log2; };
 
 Plan plan(long long A, int C, long long L) {
   Plan p{};
@@ -195,14 +178,13 @@ Plan plan(long long A, int C, long long L) {
     long long s = kTargetGroups / p.blocks_x;
     const long long max_s = A / (8ll * ty);  // at least 8 rows per thread and slice
     if (s > max_s) s = max_s;
-    p.slices = (int)(s < 1 ? 1 : s > 1024 ? 1024 : s);
+    p.slices = (int)(s < 1 ? 1 : s > kMaxSlices ? kMaxSlices : s);
   } else {
     p.blocks_x = C;
     long long s = kTargetGroups / (C > 0 ? C : 1);
     if (s > A) s = A;
-    p.slices = (int)(s < 1 ? 1 : s);
+    p.slices = (int)(s < 1 ? 1 : s > kMaxSlices ? kMaxSlices : s);
   }
-  p.counters = p.blocks_x;
   return p;
 }
 
@@ -210,24 +192,23 @@ Plan plan(long long A, int C, long long L) {
 
 extern "C" {
 
-int combo_colsum_plan(long long A, int C, long long L, int* slices, int* counters) {
+int combo_colsum_slices(long long A, int C, long long L) {
   if (A <= 0 || C <= 0 || L <= 0 || (L == 1 && C % 4 != 0)) return COMBO_EINVAL;
-  const Plan p = plan(A, C, L);
-  if (slices) *slices = p.slices;
-  if (counters) *counters = p.counters;
-  return 0;
+  return plan(A, C, L).slices;
 }
 
 int combo_colsum(const void* x, long long A, int C, long long L, int in_bf16, void* out, int out_bf16, float* partial,
-                 unsigned* counters, combo_stream_t stream) {
+                 combo_stream_t stream) {
   if (!x || !out || A <= 0 || C <= 0 || L <= 0 || (L == 1 && C % 4 != 0)) return COMBO_EINVAL;
   const Plan p = plan(A, C, L);
-  if (p.slices > 1 && (!partial || !counters)) return COMBO_EINVAL;
-  ColArgs a{x, out, partial, counters, A, L, C, p.slices, in_bf16, out_bf16, p.tx_log2};
+  if (p.slices > 1 && !partial) return COMBO_EINVAL;
+  ColArgs a{x, out, partial, A, L, C, p.slices, in_bf16, out_bf16, p.tx_log2};
   const dim3 grid(p.blocks_x, p.slices);
   if (L == 1) hipLaunchKernelGGL(colsum_rows_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, a);
   else if (L % 4 == 0) hipLaunchKernelGGL(colsum_planes_kernel<4>, grid, dim3(kThreads), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(colsum_planes_kernel<1>, grid, dim3(kThreads), 0, (hipStream_t)stream, a);
+  if (p.slices > 1)
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 63) / 64), dim3(kFinishThreads), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 

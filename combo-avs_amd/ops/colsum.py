@@ -2,25 +2,10 @@
 the level-embedding gradients.  ATen splits long reductions over workgroups behind a hipMemsetAsync of its semaphores; those
 memset nodes do not replay reliably from a hipGraph on this stack (tools/graph_reduce_repro.py), so the training step uses
 these ops wherever a reduction has >= ~2 000 inputs per output (tools/graph_reductions.py lists what is left)."""
-import ctypes
-
 import torch
 from torch.autograd import Function
 
 from .. import _lib
-
-_counters = {}
-
-
-def _counter_buffer(dev, n):
-    """zeroed once; every launch re-arms what it used.  One buffer per (device, stream): launches on one stream are ordered."""
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
-    buf = _counters.get(key)
-    if buf is None or buf.numel() < n:
-        buf = torch.zeros(max(n, 4096), dtype=torch.int32, device=dev)
-        _counters[key] = buf
-    return buf
-
 
 def _code(dt):
     if dt == torch.bfloat16:
@@ -36,15 +21,12 @@ def channel_sum(x, A, C, L, out_dtype=None):
         raise RuntimeError("colsum: a contiguous CUDA tensor of A*C*L elements expected")
     out = torch.empty(C, dtype=out_dtype or x.dtype, device=x.device)
     lib = _lib.lib()
-    slices, ncnt = ctypes.c_int(), ctypes.c_int()
-    _lib.check(lib.combo_colsum_plan(A, C, L, ctypes.byref(slices), ctypes.byref(ncnt)), "combo_colsum_plan")
-    partial = counters = None
-    if slices.value > 1:
-        partial = torch.empty(slices.value, C, dtype=torch.float32, device=x.device)
-        counters = _counter_buffer(x.device, ncnt.value)
+    slices = lib.combo_colsum_slices(A, C, L)
+    if slices < 1:
+        raise RuntimeError(f"colsum: unsupported shape A={A} C={C} L={L} (L == 1 needs C % 4 == 0)")
+    partial = torch.empty(slices, C, dtype=torch.float32, device=x.device) if slices > 1 else None
     _lib.check(lib.combo_colsum(x.data_ptr(), A, C, L, _code(x.dtype), out.data_ptr(), _code(out.dtype),
-                                0 if partial is None else partial.data_ptr(), 0 if counters is None else counters.data_ptr(),
-                                _lib.current_stream()), "combo_colsum")
+                                0 if partial is None else partial.data_ptr(), _lib.current_stream()), "combo_colsum")
     return out
 
 

@@ -84,14 +84,13 @@ int combo_fold_cast_grouped(const combo_fold_problem* problems, int count, combo
  * Channel sums out[c] = sum_{a,l} x[a,c,l] of a contiguous [A, C, L] tensor (bf16 or fp32; L == 1: column sums of a
  * [A, C] matrix, C % 4 == 0): the bias gradients of the backbones' linears / convolutions (what autograd's
  * grad_output.sum(...) computes for nn.Linear / nn.Conv2d in pvtv2.py) and the level-embedding gradients (AVFuse.py:104-106,
- * mask2former_transformer_decoder.py:399).  Deterministic (partials per slice, added in slice order by the last workgroup
- * to arrive) and free of memset nodes, which a replayed hipGraph does not execute reliably on this stack (csrc/colsum.hip).
- *   combo_colsum_plan: slices = rows of `partial` ([slices, C] fp32; unused when 1), counters = length of `counters`
- *   counters: u32, zero before the FIRST launch; every launch leaves them zero (one buffer per stream serves all launches)
+ * mask2former_transformer_decoder.py:399).  Deterministic (partials per slice, added in a fixed order by a second launch)
+ * and free of memset nodes, which a replayed hipGraph does not execute reliably on this stack (csrc/colsum.hip).
+ *   combo_colsum_slices: rows of `partial` ([slices, C] fp32 scratch; may be NULL when 1), < 0 on invalid shapes
  * ---------------------------------------------------------------------------------------------- */
-int combo_colsum_plan(long long A, int C, long long L, int* slices, int* counters);
+int combo_colsum_slices(long long A, int C, long long L);
 int combo_colsum(const void* x, long long A, int C, long long L, int in_bf16, void* out, int out_bf16, float* partial,
-                 unsigned* counters, combo_stream_t stream);
+                 combo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Backbone epilogue (host-PyTorch ResNets, bf16 NHWC): y <- relu(y + bias[c] (+ residual)) in place, one pass (MIOpen

@@ -657,8 +657,6 @@ def test_channel_sum_matches_float64_and_is_deterministic(shape, cd, dt):
     assert float((got.double() - want).abs().max()) <= 4e-6 * n ** 0.5 + 1e-6
     again = colsum.sum_to_channels(x, cd, out_dtype=torch.float32)
     assert torch.equal(got, again)  # fixed summation order
-    for buf in colsum._counters.values():
-        assert int(buf.abs().sum()) == 0  # every launch re-arms its counters
 
 
 @pytest.mark.gpu
@@ -733,3 +731,30 @@ def test_row_sum_forward_backward():
     y.backward(g)
     assert torch.allclose(y, x.detach().double().sum(1).float(), atol=1e-4)
     assert torch.equal(x.grad, g[:, None].expand(-1, 4000))
+
+
+@pytest.mark.gpu
+def test_channel_sum_timing(capsys):
+    """HBM-bound: the input is read once.  Printed, not asserted (host-timed on a shared box)."""
+    from combo_avs_amd.ops import colsum
+    for shape, cd, dt in (((125440, 256), -1, torch.float32), ((125440, 64), -1, torch.bfloat16), ((7840, 1280), -1, torch.bfloat16),
+                          ((31360, 512), -1, torch.bfloat16), ((40, 256, 28, 28), 1, torch.float32), ((520, 512), -1, torch.float32)):
+        x = torch.randn(shape, device="cuda").to(dt)
+        dims = [d for d in range(x.dim()) if d != cd % x.dim()]
+
+        def t(fn, n=30):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(n):
+                fn()
+            e.record()
+            torch.cuda.synchronize()
+            return s.elapsed_time(e) / n * 1e3
+        own = min(t(lambda: colsum.sum_to_channels(x, cd)) for _ in range(3))
+        lib = min(t(lambda: x.sum(dims)) for _ in range(3))
+        gb = x.numel() * x.element_size() / 1e9
+        with capsys.disabled():
+            print(f"\n[colsum {tuple(shape)} {str(dt)[6:]}] {own:.1f} us = {gb / own * 1e6 / 1e3:.2f} TB/s (library sum: {lib:.1f} us)")
