@@ -20,6 +20,10 @@ _SIGNATURES = {
     "combo_dwconv3x3_wgrad_slices": [c_int] * 4,
     "combo_dwconv3x3_wgrad_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "combo_fold_cast_grouped": [c_void_p, c_int, c_void_p],
+    "combo_prenorm_forward": [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_float, c_longlong, c_int, c_void_p, c_void_p,
+                              c_int, c_void_p, c_void_p, c_void_p],
+    "combo_prenorm_backward": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_longlong, c_int,
+                               c_void_p, c_void_p, c_void_p, c_void_p],
     "combo_colsum_slices": [c_longlong, c_int, c_longlong],
     "combo_colsum": [c_void_p, c_longlong, c_int, c_longlong, c_int, c_void_p, c_int, c_void_p, c_void_p],
     "combo_bias_act_bf16": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p],

@@ -32,6 +32,9 @@ def drop_path(x, p, training):
     return x * (mask / keep)
 
 
+PRENORM = __import__("os").environ.get("COMBO_PVT_PRENORM", "1") == "1"  # 0: per-op formulation (A/B, tests)
+
+
 class _NullCtx:
     def __enter__(self):
         return self
@@ -288,7 +291,50 @@ class PyramidVisionTransformerV2(nn.Module):
         with torch.autocast("cuda", enabled=False) if wts is not None else _NullCtx():
             return self._forward(x, wts)
 
+    def _drop_path_scales(self, B, device):
+        """stochastic-depth multipliers (mask / keep) of ALL residual branches of one forward pass, [2 * blocks, B] fp32, from one
+        random draw (the per-branch formulation costs three tiny launches per branch, ~600 per step for two PVTv2-B5)"""
+        ps = [blk.drop_path.p if isinstance(blk.drop_path, DropPath) else 0.0
+              for i in range(self.num_stages) for blk in getattr(self, f"block{i + 1}")]
+        if not self.training or not any(ps):
+            return None
+        key = str(device)
+        cache = self.__dict__.setdefault("_keep_cache", {})
+        if key not in cache:
+            cache[key] = (1.0 - torch.tensor(ps, dtype=torch.float32, device=device)).repeat_interleave(2)[:, None]
+        keep = cache[key]
+        return (torch.rand(keep.shape[0], B, device=device) < keep).to(torch.float32) / keep
+
+    def _forward_prenorm(self, x, wts):
+        """the reduced-precision training path: every LayerNorm of the blocks runs as ONE pre-norm residual step
+        (ops/prenorm.py: residual add with the stochastic-depth multiplier + LayerNorm + cast to the compute dtype)"""
+        from .ops.prenorm import prenorm
+        B = x.shape[0]
+        outs = {}
+        scales = self._drop_path_scales(B, x.device)
+        k = 0
+        for i in range(self.num_stages):
+            x, H, W = getattr(self, f"patch_embed{i + 1}")(x, wts)
+            stream, branch, s = x.contiguous(), None, None
+            for blk in getattr(self, f"block{i + 1}"):
+                if branch is None:
+                    y = prenorm(stream, None, None, blk.norm1)
+                else:
+                    stream, y = prenorm(stream, branch, s, blk.norm1)
+                branch, s = blk.attn(y, H, W, wts), (None if scales is None else scales[k])
+                stream, y = prenorm(stream, branch, s, blk.norm2)
+                branch, s = blk.mlp(y, H, W, wts), (None if scales is None else scales[k + 1])
+                k += 2
+            _, x = prenorm(stream, branch, s, getattr(self, f"norm{i + 1}"), out_fp32=True)
+            x = x.view(B, H, W, -1).permute(0, 3, 1, 2)
+            stage = f"res{i + 2}"
+            if stage in self._out_features:
+                outs[stage] = x
+        return outs
+
     def _forward(self, x, wts):
+        if wts is not None and x.is_cuda and torch.is_grad_enabled() and PRENORM:
+            return self._forward_prenorm(x, wts)
         B = x.shape[0]
         outs = {}
         for i in range(self.num_stages):

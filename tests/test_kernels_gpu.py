@@ -758,3 +758,89 @@ def test_channel_sum_timing(capsys):
         gb = x.numel() * x.element_size() / 1e9
         with capsys.disabled():
             print(f"\n[colsum {tuple(shape)} {str(dt)[6:]}] {own:.1f} us = {gb / own * 1e6 / 1e3:.2f} TB/s (library sum: {lib:.1f} us)")
+
+
+# ---- pre-norm residual step of the PVTv2 blocks (csrc/prenorm.hip) ---------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,N,with_r,with_scale,out_fp32", [(64, 50, True, True, False), (128, 33, True, False, False),
+                                                            (320, 21, False, False, False), (512, 7, True, True, True),
+                                                            (256, 19, True, True, False)])
+def test_prenorm_step_matches_float64(C, N, with_r, with_scale, out_fp32):
+    from combo_avs_amd.ops.prenorm import _PreNorm
+    torch.manual_seed(C + N)
+    B = 5
+    x = torch.randn(B, N, C, device="cuda", requires_grad=True)
+    r = (torch.randn(B, N, C, device="cuda") * 0.5).bfloat16().requires_grad_() if with_r else None
+    scale = torch.tensor([0.0, 1.25, 1.25, 0.0, 1.25], device="cuda") if with_scale else None
+    w = (torch.randn(C, device="cuda") * 0.3 + 1).requires_grad_()
+    b = (torch.randn(C, device="cuda") * 0.1).requires_grad_()
+    out = _PreNorm.apply(x, r, scale, w, b, 1e-6, out_fp32, False)
+    z, y = out if with_r else (None, out)
+    assert y.dtype == (torch.float32 if out_fp32 else torch.bfloat16)
+    # float64 reference
+    xd, wd, bd = x.detach().double().requires_grad_(), w.detach().double().requires_grad_(), b.detach().double().requires_grad_()
+    rd = r.detach().double().requires_grad_() if with_r else None
+    zd = xd if not with_r else xd + (scale.double()[:, None, None] if with_scale else 1.0) * rd
+    yd = torch.nn.functional.layer_norm(zd, (C,), wd, bd, 1e-6)
+    if with_r:
+        assert torch.allclose(z.double(), zd, atol=1e-6)
+    tol = 2e-6 if out_fp32 else 2 ** -8
+    assert float((y.double() - yd).abs().max()) <= tol * float(yd.abs().max()) + 1e-6
+    gy = torch.randn(B, N, C, device="cuda").to(y.dtype)
+    gz = torch.randn(B, N, C, device="cuda") if with_r else None
+    torch.autograd.backward([t for t in (z, y) if t is not None], [g for g in (gz, gy) if g is not None])
+    loss = (yd * gy.double()).sum() + ((zd * gz.double()).sum() if with_r else 0.0)
+    loss.backward()
+    assert float((x.grad.double() - xd.grad).abs().max()) <= 1e-5 * float(xd.grad.abs().max()) + 1e-6
+    if with_r:
+        assert r.grad.dtype == torch.bfloat16
+        assert float((r.grad.double() - rd.grad).abs().max()) <= 2 ** -8 * float(rd.grad.abs().max()) + 1e-6
+        if with_scale:
+            assert float(r.grad[0].abs().max()) == 0.0  # a dropped sample passes no gradient to its branch
+    assert float((w.grad.double() - wd.grad).abs().max()) <= 1e-4 * float(wd.grad.abs().max()) + 1e-5
+    assert float((b.grad.double() - bd.grad).abs().max()) <= 1e-4 * float(bd.grad.abs().max()) + 1e-5
+
+
+@pytest.mark.gpu
+def test_pvt_prenorm_path_matches_per_op_path():
+    """PVTv2 (bf16 training path) with the fused pre-norm residual steps against the per-op formulation, stochastic depth off:
+    same outputs and gradients up to bf16 rounding; with stochastic depth on the multipliers are 0 or 1 / keep per sample."""
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd import backbone_pvt as BP
+    torch.manual_seed(0)
+    m = BP.PyramidVisionTransformerV2(embed_dims=(64, 128, 320, 512), num_heads=(1, 2, 5, 8), qkv_bias=True, norm_eps=1e-6,
+                                      depths=(2, 2, 3, 2), drop_path_rate=0.0).cuda().train()
+    x = torch.randn(2, 3, 96, 96, device="cuda")
+    params = [p for p in m.parameters()]
+
+    def run(flag):
+        old, BP.PRENORM = BP.PRENORM, flag
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = m(x)
+            g = torch.autograd.grad(sum(v.float().pow(2).mean() for v in out.values()), params, allow_unused=True)
+        finally:
+            BP.PRENORM = old
+        return out, g
+    a, ga = run(True)
+    b, gb = run(False)
+    for k in a:
+        assert a[k].shape == b[k].shape and a[k].dtype == b[k].dtype
+        assert float((a[k].float() - b[k].float()).abs().max()) <= 0.03 * float(b[k].float().abs().max()), k
+    fa = torch.cat([g.flatten() for g in ga if g is not None])
+    fb = torch.cat([g.flatten() for g in gb if g is not None])
+    assert fa.numel() == fb.numel() and bool(torch.isfinite(fa).all())
+    assert float((fa - fb).norm() / fb.norm()) < 0.1
+    # stochastic depth: the table of multipliers
+    m2 = BP.PyramidVisionTransformerV2(embed_dims=(64, 128, 320, 512), num_heads=(1, 2, 5, 8), qkv_bias=True, norm_eps=1e-6,
+                                       depths=(2, 2, 3, 2), drop_path_rate=0.3).cuda().train()
+    sc = m2._drop_path_scales(64, torch.device("cuda"))
+    assert sc.shape == (18, 64)
+    keep = 1.0 - torch.tensor([0.3 * i / 8 for i in range(9)]).repeat_interleave(2)[:, None].cuda()
+    assert bool(((sc == 0) | ((sc - 1.0 / keep).abs() < 1e-6)).all())
+    assert float(sc[0].min()) == 1.0 and 0.5 < float((sc[-1] > 0).float().mean()) < 0.9  # first block never dropped, last ~30 %
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = m2(x)
+    torch.autograd.grad(sum(v.float().pow(2).mean() for v in out.values()), [p for p in m2.parameters()], allow_unused=True)
+    m2.eval()
+    assert m2._drop_path_scales(4, torch.device("cuda")) is None
