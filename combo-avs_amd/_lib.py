@@ -22,7 +22,7 @@ _SIGNATURES = {
     "combo_fold_cast_grouped": [c_void_p, c_int, c_void_p],
     "combo_prenorm_forward": [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_float, c_longlong, c_int, c_void_p, c_void_p,
                               c_int, c_void_p, c_void_p, c_void_p],
-    "combo_prenorm_backward": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_longlong, c_int,
+    "combo_prenorm_backward": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_longlong, c_int,
                                c_void_p, c_void_p, c_void_p, c_void_p],
     "combo_colsum_slices": [c_longlong, c_int, c_longlong],
     "combo_colsum": [c_void_p, c_longlong, c_int, c_longlong, c_int, c_void_p, c_int, c_void_p, c_void_p],

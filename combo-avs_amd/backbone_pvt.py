@@ -196,17 +196,20 @@ class Attention(nn.Module):
             self.sr = nn.Conv2d(dim, dim, kernel_size=sr_ratio, stride=sr_ratio)
             self.norm = nn.LayerNorm(dim)
 
-    def forward(self, x, H, W, wts=None):
+    def forward(self, x, H, W, wts=None, x_kv=None):
+        """x_kv: an alias of x for the key / value path (ops/prenorm.py fan-out: the two consumers' gradients then meet inside the
+        LayerNorm's backward kernel instead of in an accumulation kernel)"""
         B, N, C = x.shape
         h, d = self.num_heads, C // self.num_heads
         q = _linear(x, self.q, wts).view(B, N, h, d).transpose(1, 2)
+        xs = x if x_kv is None else x_kv
         if self.sr_ratio > 1:
-            x_ = _conv(x.view(B, H, W, C).permute(0, 3, 1, 2), self.sr, wts)  # [B,C,H/sr,W/sr]
+            x_ = _conv(xs.view(B, H, W, C).permute(0, 3, 1, 2), self.sr, wts)  # [B,C,H/sr,W/sr]
             x_ = _ln(x_.flatten(2).transpose(1, 2), self.norm, wts)
         else:
-            x_ = x
-        kv = _linear(x_, self.kv, wts).view(B, -1, 2, h, d)
-        k, v = kv[:, :, 0].transpose(1, 2), kv[:, :, 1].transpose(1, 2)
+            x_ = xs
+        k, v = _linear(x_, self.kv, wts).view(B, -1, 2, h, d).unbind(2)  # (unbind: ONE stack in the backward pass, not two
+        k, v = k.transpose(1, 2), v.transpose(1, 2)                      # zero-filled select gradients and their sum)
         o = F.scaled_dot_product_attention(q, k, v, dropout_p=self.attn_drop.p if self.training else 0.0, scale=self.scale)
         return self.proj_drop(_linear(o.transpose(1, 2).reshape(B, N, C), self.proj, wts))
 
@@ -318,10 +321,10 @@ class PyramidVisionTransformerV2(nn.Module):
             stream, branch, s = x.contiguous(), None, None
             for blk in getattr(self, f"block{i + 1}"):
                 if branch is None:
-                    y = prenorm(stream, None, None, blk.norm1)
+                    y, y_kv = prenorm(stream, None, None, blk.norm1, fanout=2)
                 else:
-                    stream, y = prenorm(stream, branch, s, blk.norm1)
-                branch, s = blk.attn(y, H, W, wts), (None if scales is None else scales[k])
+                    stream, y, y_kv = prenorm(stream, branch, s, blk.norm1, fanout=2)
+                branch, s = blk.attn(y, H, W, wts, x_kv=y_kv), (None if scales is None else scales[k])
                 stream, y = prenorm(stream, branch, s, blk.norm2)
                 branch, s = blk.mlp(y, H, W, wts), (None if scales is None else scales[k + 1])
                 k += 2

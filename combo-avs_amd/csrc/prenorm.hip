@@ -3,7 +3,7 @@
 //   forward   z = x + s[b] * r        (fp32 residual stream; r = the previous branch's bf16 output, s = the stochastic-depth
 //             y = LN(z) -> bf16        multiplier of sample b, 1 when absent)   - the input of the next branch, already in the
 //                                                                                 compute dtype
-//   backward  d  = LN'(dy) + dz       (dy bf16 from the branch, dz fp32 from the later part of the stream)
+//   backward  d  = LN'(dy + dy2) + dz (dy, dy2 bf16 from the branch's one or two consumers of y, dz fp32 from the later stream)
 //             dx = d (fp32),  dr = bf16(s[b] * d),  dy32 = float(dy) for the deferred parameter-gradient launch (csrc/lngrad.hip)
 // The host-PyTorch formulation runs, per LayerNorm, a cast (fp32 -> bf16), a stochastic-depth multiply, a mixed-dtype add and
 // the LayerNorm forward, and their four counterparts backward: ~1 900 launches and ~20 ms of a 160 ms PVTv2-B5 step at
@@ -67,7 +67,7 @@ prenorm_fwd_kernel(const PreArgs a) {
 }
 
 struct PreBwdArgs {
-  const void* dy; int dy_bf16; const float* dz; const float* z; const float* mean; const float* rstd; const float* w;
+  const void* dy; const void* dy2; int dy_bf16; const float* dz; const float* z; const float* mean; const float* rstd; const float* w;
   const float* scale; long long rows, rows_per_sample;
   float* dx; unsigned short* dr; float* dy32;
 };
@@ -87,7 +87,9 @@ prenorm_bwd_kernel(const PreBwdArgs a) {
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-      const float t = a.dy_bf16 ? bf2f(reinterpret_cast<const unsigned short*>(a.dy)[off + i]) : reinterpret_cast<const float*>(a.dy)[off + i];
+      float t = a.dy_bf16 ? bf2f(reinterpret_cast<const unsigned short*>(a.dy)[off + i]) : reinterpret_cast<const float*>(a.dy)[off + i];
+      if (a.dy2)  // the second consumer of y (fan-out: the autograd node hands out two aliases of y)
+        t += a.dy_bf16 ? bf2f(reinterpret_cast<const unsigned short*>(a.dy2)[off + i]) : reinterpret_cast<const float*>(a.dy2)[off + i];
       if (a.dy32) a.dy32[off + i] = t;
       g[i] = t * a.w[lane * VEC + i];
       xh[i] = (a.z[off + i] - mu) * rs;
@@ -142,13 +144,13 @@ extern "C" int combo_prenorm_forward(const float* x, const void* r_bf16, const f
   return (int)hipGetLastError();
 }
 
-extern "C" int combo_prenorm_backward(const void* dy, int dy_bf16, const float* dz, const float* z, const float* mean, const float* rstd,
+extern "C" int combo_prenorm_backward(const void* dy, const void* dy2, int dy_bf16, const float* dz, const float* z, const float* mean, const float* rstd,
                                       const float* w, const float* scale, long long rows_per_sample, long long rows, int C, float* dx,
                                       void* dr_bf16, float* dy32, combo_stream_t stream) {
-  if ((!dy && !dz) || !dx || rows <= 0 || !c_ok(C) || (dy && (!z || !mean || !rstd || !w)) || (scale && rows_per_sample <= 0) ||
-      (((uintptr_t)dz | (uintptr_t)z | (uintptr_t)dx | (uintptr_t)w | (uintptr_t)dy32) & 15) || (((uintptr_t)dy | (uintptr_t)dr_bf16) & 7))
+  if ((!dy && !dz) || (dy2 && !dy) || !dx || rows <= 0 || !c_ok(C) || (dy && (!z || !mean || !rstd || !w)) || (scale && rows_per_sample <= 0) ||
+      (((uintptr_t)dz | (uintptr_t)z | (uintptr_t)dx | (uintptr_t)w | (uintptr_t)dy32) & 15) || (((uintptr_t)dy | (uintptr_t)dy2 | (uintptr_t)dr_bf16) & 7))
     return COMBO_EINVAL;
-  PreBwdArgs a{dy, dy_bf16, dz, z, mean, rstd, w, scale, rows, rows_per_sample > 0 ? rows_per_sample : rows, dx,
+  PreBwdArgs a{dy, dy2, dy_bf16, dz, z, mean, rstd, w, scale, rows, rows_per_sample > 0 ? rows_per_sample : rows, dx,
                reinterpret_cast<unsigned short*>(dr_bf16), dy32};
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   by_width(C, [&](auto v) { hipLaunchKernelGGL(prenorm_bwd_kernel<decltype(v)::value>, grid, block, 0, (hipStream_t)stream, a); });

@@ -18,10 +18,11 @@ def usable(x, C):
 
 class _PreNorm(Function):
     """(x fp32 [B, N, C], r bf16 [B, N, C] or None, scale fp32 [B] or None) -> (z, y) with r, y alone without.
-    y is bf16 unless out_fp32."""
+    y is bf16 unless out_fp32.  fanout = 2: y is returned twice (aliases of one buffer, one autograd output per consumer) so that
+    the two consumers' gradients arrive separately and are summed inside the backward kernel, not by an accumulation kernel."""
 
     @staticmethod
-    def forward(ctx, x, r, scale, weight, bias, eps, out_fp32, defer):
+    def forward(ctx, x, r, scale, weight, bias, eps, out_fp32, defer, fanout=1):
         B, N, C = x.shape
         rows = B * N
         x2 = x.reshape(rows, C)
@@ -39,32 +40,41 @@ class _PreNorm(Function):
                                                     rows, C, _lib.ptr(z), y.data_ptr(), 0 if out_fp32 else 1, mean.data_ptr(),
                                                     rstd.data_ptr(), _lib.current_stream()), "combo_prenorm_forward")
         ctx.save_for_backward(z if z is not None else x2, mean, rstd, weight, scale)
-        ctx.has_r, ctx.defer, ctx.shape, ctx.N = r is not None, defer, x.shape, N
+        ctx.has_r, ctx.defer, ctx.shape, ctx.N, ctx.fanout = r is not None, defer, x.shape, N, fanout
+        y = y.view(x.shape)
+        ys = (y,) if fanout == 1 else (y, y.view_as(y))
         if r is None:
-            return y.view(x.shape)
-        return z.view(x.shape), y.view(x.shape)
+            return ys[0] if fanout == 1 else ys
+        return (z.view(x.shape),) + ys
 
     @staticmethod
     @once_differentiable
     def backward(ctx, *grads):
         z, mean, rstd, weight, scale = ctx.saved_tensors
-        dz, dy = (grads if ctx.has_r else (None, grads[0]))
+        dz = grads[0] if ctx.has_r else None
+        dys = [g for g in (grads[1:] if ctx.has_r else grads) if g is not None]
         rows, C = z.shape
-        if dz is None and dy is None:
-            return (None,) * 8
-        if dy is not None:
-            dy = dy.reshape(rows, C)
-            dy = dy if dy.is_contiguous() else dy.contiguous()
-            if dy.dtype not in (torch.bfloat16, torch.float32):
-                dy = dy.float()
+        if dz is None and not dys:
+            return (None,) * 9
+
+        def flat(g):
+            g = g.reshape(rows, C)
+            return g if g.is_contiguous() else g.contiguous()
+        dy = dy2 = None
+        if dys:
+            dys = [flat(g) for g in dys]
+            if len({g.dtype for g in dys}) > 1 or dys[0].dtype not in (torch.bfloat16, torch.float32):
+                dys = [g.float() for g in dys]
+            dy, dy2 = dys[0], (dys[1] if len(dys) > 1 else None)
         if dz is not None:
             dz = dz.reshape(rows, C)
             dz = dz if dz.is_contiguous() else dz.contiguous()
         want_param = dy is not None and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
-        dy32 = torch.empty(rows, C, device=z.device, dtype=torch.float32) if (want_param and dy.dtype != torch.float32) else None
+        dy32 = torch.empty(rows, C, device=z.device, dtype=torch.float32) \
+            if (want_param and (dy.dtype != torch.float32 or dy2 is not None)) else None
         dx = torch.empty(rows, C, device=z.device, dtype=torch.float32)
         dr = torch.empty(rows, C, device=z.device, dtype=torch.bfloat16) if (ctx.has_r and ctx.needs_input_grad[1]) else None
-        _lib.check(_lib.lib().combo_prenorm_backward(_lib.ptr(dy), 1 if (dy is not None and dy.dtype == torch.bfloat16) else 0, _lib.ptr(dz),
+        _lib.check(_lib.lib().combo_prenorm_backward(_lib.ptr(dy), _lib.ptr(dy2), 1 if (dy is not None and dy.dtype == torch.bfloat16) else 0, _lib.ptr(dz),
                                                      z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), weight.data_ptr(), _lib.ptr(scale),
                                                      ctx.N, rows, C, dx.data_ptr(), _lib.ptr(dr), _lib.ptr(dy32), _lib.current_stream()),
                    "combo_prenorm_backward")
@@ -78,9 +88,9 @@ class _PreNorm(Function):
             else:
                 _linear_mod._flush_ln([[[use], out]])
             dw, db = out[0], out[1]
-        return (dx.view(ctx.shape), None if dr is None else dr.view(ctx.shape), None, dw, db, None, None, None)
+        return (dx.view(ctx.shape), None if dr is None else dr.view(ctx.shape), None, dw, db, None, None, None, None)
 
 
-def prenorm(x, r, scale, norm, out_fp32=False, defer=True):
-    """norm: an nn.LayerNorm; returns (z, y) when r is given, y alone otherwise"""
-    return _PreNorm.apply(x, r, scale, norm.weight, norm.bias, norm.eps, out_fp32, defer)
+def prenorm(x, r, scale, norm, out_fp32=False, defer=True, fanout=1):
+    """norm: an nn.LayerNorm; returns (z, y[, y alias]) when r is given, y[, y alias] otherwise"""
+    return _PreNorm.apply(x, r, scale, norm.weight, norm.bias, norm.eps, out_fp32, defer, fanout)

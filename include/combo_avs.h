@@ -95,14 +95,15 @@ int combo_colsum(const void* x, long long A, int C, long long L, int in_bf16, vo
 /* ------------------------------------------------------------------------------------------------
  * Pre-norm residual step of a PVTv2 block (backbone/pvtv2.py:162-175: x = x + drop_path(branch(norm(x)))), one pass per
  * LayerNorm.  forward: z = x + scale[row / rows_per_sample] * r (x, z fp32; r bf16 or NULL: z = x, not written; scale NULL:
- * 1), y = LN(z) as bf16 (y_bf16 != 0) or fp32, mean / rstd per row.  backward: d = LN'(dy) + dz (either may be NULL),
+ * 1), y = LN(z) as bf16 (y_bf16 != 0) or fp32, mean / rstd per row.  backward: d = LN'(dy + dy2) + dz (each may be NULL; dy2
+ * is the gradient of a second consumer of y),
  * dx = d, dr = bf16(scale * d) (NULL: no branch), dy32 = float(dy) (optional, for the deferred parameter gradients).
  * C in {64, 128, 256, 320, 512}.
  * ---------------------------------------------------------------------------------------------- */
 int combo_prenorm_forward(const float* x, const void* r_bf16, const float* scale, long long rows_per_sample, const float* w,
                           const float* b, float eps, long long rows, int C, float* z, void* y, int y_bf16, float* mean,
                           float* rstd, combo_stream_t stream);
-int combo_prenorm_backward(const void* dy, int dy_bf16, const float* dz, const float* z, const float* mean, const float* rstd,
+int combo_prenorm_backward(const void* dy, const void* dy2, int dy_bf16, const float* dz, const float* z, const float* mean, const float* rstd,
                            const float* w, const float* scale, long long rows_per_sample, long long rows, int C, float* dx,
                            void* dr_bf16, float* dy32, combo_stream_t stream);
 

@@ -802,6 +802,28 @@ def test_prenorm_step_matches_float64(C, N, with_r, with_scale, out_fp32):
 
 
 @pytest.mark.gpu
+def test_prenorm_fanout_sums_both_consumers_gradients():
+    from combo_avs_amd.ops.prenorm import _PreNorm
+    torch.manual_seed(3)
+    B, N, C = 3, 17, 128
+    x = torch.randn(B, N, C, device="cuda", requires_grad=True)
+    r = torch.randn(B, N, C, device="cuda").bfloat16().requires_grad_()
+    w = torch.ones(C, device="cuda", requires_grad=True)
+    b = torch.zeros(C, device="cuda", requires_grad=True)
+    z, y1, y2 = _PreNorm.apply(x, r, None, w, b, 1e-6, False, False, 2)
+    assert y1.data_ptr() == y2.data_ptr()
+    g1, g2 = torch.randn_like(y1), torch.randn_like(y1)
+    torch.autograd.backward([y1, y2], [g1, g2])
+    got = [t.grad.clone() for t in (x, r, w, b)]
+    for t in (x, r, w, b):
+        t.grad = None
+    z, y = _PreNorm.apply(x, r, None, w, b, 1e-6, True, False, 1)  # fp32 output: takes the exact fp32 sum of the two bf16
+    y.backward(g1.float() + g2.float())                              # gradients, which is what the fan-out kernel forms
+    for a, t in zip(got, (x, r, w, b)):
+        assert torch.allclose(a.float(), t.grad.float(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
 def test_pvt_prenorm_path_matches_per_op_path():
     """PVTv2 (bf16 training path) with the fused pre-norm residual steps against the per-op formulation, stochastic depth off:
     same outputs and gradients up to bf16 rounding; with stochastic depth on the multipliers are 0 or 1 / keep per sample."""

@@ -16,12 +16,16 @@ from combo_avs_amd.trainer import FlatAdamW, train_step
 from bench import synth_batch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-cfg = combo_cfg(os.path.join(ROOT, "configs/avs_s4/COMBO_R50_bs8_90k.yaml"))
+import bench
+wl = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "r50_s4"]  # usage: tools/aten_sites.py [bench config]
+cfg = combo_cfg(os.path.join(ROOT, "configs", wl["yaml"]), opts=wl.get("opts", ()))
 dev = torch.device("cuda")
 torch.manual_seed(0)
 model = build_model(cfg).to(dev).train()
+if wl["dtype"] == "bf16":
+    model.backbone_dtype = torch.bfloat16
 opt = FlatAdamW(model)
-batch = synth_batch(8, 5, 224, 224, dev, 1)
+batch = synth_batch(wl["clips"], wl["T"], wl["HW"], wl["HW"], dev, seed=1, K=wl["K"], gt=wl["gt"], avss=wl["avss"])
 for _ in range(2):
     train_step(model, opt, batch)
 torch.cuda.synchronize()
