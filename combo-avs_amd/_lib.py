@@ -24,6 +24,9 @@ _SIGNATURES = {
                               c_int, c_void_p, c_void_p, c_void_p],
     "combo_prenorm_backward": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_longlong, c_int,
                                c_void_p, c_void_p, c_void_p, c_void_p],
+    "combo_bias_ln_bf16_forward": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "combo_bias_ln_bf16_backward": [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p,
+                                    c_void_p, c_void_p],
     "combo_colsum_slices": [c_longlong, c_int, c_longlong],
     "combo_colsum": [c_void_p, c_longlong, c_int, c_longlong, c_int, c_void_p, c_int, c_void_p, c_void_p],
     "combo_bias_act_bf16": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p],

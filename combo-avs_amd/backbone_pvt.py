@@ -204,8 +204,15 @@ class Attention(nn.Module):
         q = _linear(x, self.q, wts).view(B, N, h, d).transpose(1, 2)
         xs = x if x_kv is None else x_kv
         if self.sr_ratio > 1:
-            x_ = _conv(xs.view(B, H, W, C).permute(0, 3, 1, 2), self.sr, wts)  # [B,C,H/sr,W/sr]
-            x_ = _ln(x_.flatten(2).transpose(1, 2), self.norm, wts)
+            w_sr = _p(self.sr.weight, wts)
+            if wts is not None and PRENORM and xs.is_cuda and xs.dtype == w_sr.dtype == torch.bfloat16 and torch.is_grad_enabled():
+                # reduced-precision training path: the convolution without its bias, then bias + LayerNorm -> bf16 in one pass
+                from .ops.prenorm import bias_ln
+                x_ = F.conv2d(xs.view(B, H, W, C).permute(0, 3, 1, 2), w_sr, None, self.sr.stride)
+                x_ = bias_ln(x_.flatten(2).transpose(1, 2), _p(self.sr.bias, wts), self.norm)
+            else:
+                x_ = _conv(xs.view(B, H, W, C).permute(0, 3, 1, 2), self.sr, wts)  # [B,C,H/sr,W/sr]
+                x_ = _ln(x_.flatten(2).transpose(1, 2), self.norm, wts)
         else:
             x_ = xs
         k, v = _linear(x_, self.kv, wts).view(B, -1, 2, h, d).unbind(2)  # (unbind: ONE stack in the backward pass, not two

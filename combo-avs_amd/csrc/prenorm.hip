@@ -116,6 +116,63 @@ prenorm_bwd_kernel(const PreBwdArgs a) {
   }
 }
 
+
+// Channel bias + LayerNorm on bf16 rows (the key / value path of a spatial-reduction attention block, pvtv2.py:104-108:
+// `self.norm(self.sr(x_))`): y = LN(x + xb[c]) -> bf16, backward dx = LN'(dy) -> bf16 (+ fp32 dy for the deferred parameter
+// gradients).  The convolution runs without its bias; the bias gradient is the channel sum of dx (csrc/colsum.hip).
+struct BiasLnArgs {
+  const unsigned short* x; const void* xb; int xb_bf16; const float* w; const float* b; float eps; long long rows;
+  unsigned short* y; float* mean; float* rstd;
+  const unsigned short* dy; unsigned short* dx; float* dy32; float* z32;
+};
+
+template <int VEC, bool BWD>
+__global__ void __launch_bounds__(256)
+bias_ln_kernel(const BiasLnArgs a) {
+  constexpr int C = 64 * VEC;
+  const long long row = blockIdx.x * 4LL + (threadIdx.x >> 6);
+  if (row >= a.rows) return;
+  const int lane = threadIdx.x & 63;
+  const long long off = row * C + lane * VEC;
+  float v[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const int c = lane * VEC + i;
+    const float xb = !a.xb ? 0.f : a.xb_bf16 ? bf2f(reinterpret_cast<const unsigned short*>(a.xb)[c]) : reinterpret_cast<const float*>(a.xb)[c];
+    v[i] = bf2f(a.x[off + i]) + xb;
+  }
+  if (!BWD) {
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) sum += v[i];
+    const float mu = wsum(sum) * (1.f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) q += (v[i] - mu) * (v[i] - mu);
+    const float rs = rsqrtf(wsum(q) * (1.f / C) + a.eps);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) a.y[off + i] = f2bf((v[i] - mu) * rs * a.w[lane * VEC + i] + a.b[lane * VEC + i]);
+    if (lane == 0) { a.mean[row] = mu; a.rstd[row] = rs; }
+  } else {
+    const float mu = a.mean[row], rs = a.rstd[row];
+    float g[VEC], xh[VEC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const float t = bf2f(a.dy[off + i]);
+      if (a.dy32) { a.dy32[off + i] = t; a.z32[off + i] = v[i]; }  // (dy, z) in fp32 for the deferred parameter-gradient launch
+      g[i] = t * a.w[lane * VEC + i];
+      xh[i] = (v[i] - mu) * rs;
+      s1 += g[i];
+      s2 += g[i] * xh[i];
+    }
+    s1 = wsum(s1) * (1.f / C);
+    s2 = wsum(s2) * (1.f / C);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) a.dx[off + i] = f2bf(rs * (g[i] - s1 - xh[i] * s2));
+  }
+}
+
 inline bool c_ok(int C) { return C == 64 || C == 128 || C == 256 || C == 320 || C == 512; }
 
 template <typename F>
@@ -154,5 +211,27 @@ extern "C" int combo_prenorm_backward(const void* dy, const void* dy2, int dy_bf
                reinterpret_cast<unsigned short*>(dr_bf16), dy32};
   const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   by_width(C, [&](auto v) { hipLaunchKernelGGL(prenorm_bwd_kernel<decltype(v)::value>, grid, block, 0, (hipStream_t)stream, a); });
+  return (int)hipGetLastError();
+}
+
+extern "C" int combo_bias_ln_bf16_forward(const void* x, const void* xb, int xb_bf16, const float* w, const float* b, float eps,
+                                          long long rows, int C, void* y, float* mean, float* rstd, combo_stream_t stream) {
+  if (!x || !w || !b || !y || !mean || !rstd || rows <= 0 || !c_ok(C) || (((uintptr_t)x | (uintptr_t)y) & 7)) return COMBO_EINVAL;
+  BiasLnArgs a{reinterpret_cast<const unsigned short*>(x), xb, xb_bf16, w, b, eps, rows, reinterpret_cast<unsigned short*>(y), mean, rstd,
+               nullptr, nullptr, nullptr, nullptr};
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  by_width(C, [&](auto v) { hipLaunchKernelGGL((bias_ln_kernel<decltype(v)::value, false>), grid, block, 0, (hipStream_t)stream, a); });
+  return (int)hipGetLastError();
+}
+
+extern "C" int combo_bias_ln_bf16_backward(const void* dy, const void* x, const void* xb, int xb_bf16, const float* mean,
+                                           const float* rstd, const float* w, long long rows, int C, void* dx, float* dy32,
+                                           float* z32, combo_stream_t stream) {
+  if (!dy || !x || !mean || !rstd || !w || !dx || rows <= 0 || !c_ok(C) || ((dy32 != nullptr) != (z32 != nullptr)) || (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 7))
+    return COMBO_EINVAL;
+  BiasLnArgs a{reinterpret_cast<const unsigned short*>(x), xb, xb_bf16, w, nullptr, 0.f, rows, nullptr, const_cast<float*>(mean),
+               const_cast<float*>(rstd), reinterpret_cast<const unsigned short*>(dy), reinterpret_cast<unsigned short*>(dx), dy32, z32};
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  by_width(C, [&](auto v) { hipLaunchKernelGGL((bias_ln_kernel<decltype(v)::value, true>), grid, block, 0, (hipStream_t)stream, a); });
   return (int)hipGetLastError();
 }

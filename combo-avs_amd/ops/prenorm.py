@@ -94,3 +94,63 @@ class _PreNorm(Function):
 def prenorm(x, r, scale, norm, out_fp32=False, defer=True, fanout=1):
     """norm: an nn.LayerNorm; returns (z, y[, y alias]) when r is given, y[, y alias] otherwise"""
     return _PreNorm.apply(x, r, scale, norm.weight, norm.bias, norm.eps, out_fp32, defer, fanout)
+
+
+class _BiasLn(Function):
+    """y = LN(x + xb[c]) on bf16 rows, bf16 out (the key / value path of a spatial-reduction attention block: the strided
+    convolution runs without its bias, which is added here; its gradient is the channel sum of dx)."""
+
+    @staticmethod
+    def forward(ctx, x, xb, weight, bias, eps, defer):
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C)
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        rows = x2.shape[0]
+        y = torch.empty_like(x2)
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+        _lib.check(_lib.lib().combo_bias_ln_bf16_forward(x2.data_ptr(), _lib.ptr(xb), 1 if (xb is not None and xb.dtype == torch.bfloat16) else 0,
+                                                         weight.data_ptr(), bias.data_ptr(), eps, rows, C, y.data_ptr(), mean.data_ptr(),
+                                                         rstd.data_ptr(), _lib.current_stream()), "combo_bias_ln_bf16_forward")
+        ctx.save_for_backward(x2, xb, mean, rstd, weight)
+        ctx.defer, ctx.shape = defer, x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x2, xb, mean, rstd, weight = ctx.saved_tensors
+        rows, C = x2.shape
+        dy = dy.reshape(rows, C)
+        dy = dy if dy.is_contiguous() else dy.contiguous()
+        want_param = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
+        dy32 = torch.empty(rows, C, device=x2.device, dtype=torch.float32) if want_param else None
+        z32 = torch.empty(rows, C, device=x2.device, dtype=torch.float32) if want_param else None
+        dx = torch.empty_like(x2)
+        _lib.check(_lib.lib().combo_bias_ln_bf16_backward(dy.data_ptr(), x2.data_ptr(), _lib.ptr(xb),
+                                                          1 if (xb is not None and xb.dtype == torch.bfloat16) else 0, mean.data_ptr(),
+                                                          rstd.data_ptr(), weight.data_ptr(), rows, C, dx.data_ptr(), _lib.ptr(dy32),
+                                                          _lib.ptr(z32), _lib.current_stream()), "combo_bias_ln_bf16_backward")
+        dxb = None
+        if xb is not None and ctx.needs_input_grad[1]:
+            from .colsum import channel_sum
+            dxb = channel_sum(dx, rows, C, 1, out_dtype=xb.dtype)
+        dw = db = None
+        if want_param:
+            use = (dy32, z32, mean, rstd)  # (the deferred kernel normalises (z - mean) * rstd itself)
+            q = _linear_mod._ln_queue
+            out = torch.empty(2, C, device=x2.device, dtype=torch.float32)
+            if ctx.defer and q is not None:
+                q.append([[use], out])
+            else:
+                _linear_mod._flush_ln([[[use], out]])
+            dw, db = out[0], out[1]
+        return dx.view(ctx.shape), dxb, dw, db, None, None
+
+
+def bias_ln_usable(x, C):
+    return x.is_cuda and x.dtype == torch.bfloat16 and C in WIDTHS and C % 4 == 0
+
+
+def bias_ln(x, xb, norm, defer=True):
+    return _BiasLn.apply(x, xb, norm.weight, norm.bias, norm.eps, defer)

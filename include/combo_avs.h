@@ -107,6 +107,15 @@ int combo_prenorm_backward(const void* dy, const void* dy2, int dy_bf16, const f
                            const float* w, const float* scale, long long rows_per_sample, long long rows, int C, float* dx,
                            void* dr_bf16, float* dy32, combo_stream_t stream);
 
+/* Channel bias + LayerNorm on bf16 rows: y = LN(x + xb[c]) as bf16; backward dx = LN'(dy) as bf16 (+ dy32 = float(dy) and
+ * z32 = x + xb in fp32, both or neither: the operands of the deferred parameter-gradient launch).
+ * The key / value path of PVTv2's spatial-reduction attention (backbone/pvtv2.py:104-108, `self.norm(self.sr(x_))` with the
+ * convolution's bias folded in here; its gradient is combo_colsum of dx).  xb: bf16 (xb_bf16 != 0) or fp32, may be NULL. */
+int combo_bias_ln_bf16_forward(const void* x, const void* xb, int xb_bf16, const float* w, const float* b, float eps,
+                               long long rows, int C, void* y, float* mean, float* rstd, combo_stream_t stream);
+int combo_bias_ln_bf16_backward(const void* dy, const void* x, const void* xb, int xb_bf16, const float* mean, const float* rstd,
+                                const float* w, long long rows, int C, void* dx, float* dy32, float* z32, combo_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Backbone epilogue (host-PyTorch ResNets, bf16 NHWC): y <- relu(y + bias[c] (+ residual)) in place, one pass (MIOpen
  * runs conv, bias and ReLU as three kernels); backward dx = dy * (y > 0).  Replaces d2 BottleneckBlock's

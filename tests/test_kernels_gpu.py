@@ -866,3 +866,27 @@ def test_pvt_prenorm_path_matches_per_op_path():
     torch.autograd.grad(sum(v.float().pow(2).mean() for v in out.values()), [p for p in m2.parameters()], allow_unused=True)
     m2.eval()
     assert m2._drop_path_scales(4, torch.device("cuda")) is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,rows", [(64, 49 * 3), (320, 49 * 5), (128, 11)])
+def test_bias_ln_bf16_matches_float64(C, rows):
+    from combo_avs_amd.ops.prenorm import _BiasLn
+    torch.manual_seed(C)
+    x = torch.randn(1, rows, C, device="cuda").bfloat16().requires_grad_()
+    xb = (torch.randn(C, device="cuda") * 0.5).bfloat16().requires_grad_()
+    w = (torch.randn(C, device="cuda") * 0.3 + 1).requires_grad_()
+    b = (torch.randn(C, device="cuda") * 0.1).requires_grad_()
+    y = _BiasLn.apply(x, xb, w, b, 1e-5, False)
+    g = torch.randn_like(y)
+    y.backward(g)
+    xd, xbd, wd, bd = (t.detach().double().requires_grad_() for t in (x, xb, w, b))
+    yd = torch.nn.functional.layer_norm(xd + xbd, (C,), wd, bd, 1e-5)
+    yd.backward(g.double())
+    assert y.dtype == torch.bfloat16 and x.grad.dtype == torch.bfloat16 and xb.grad.dtype == torch.bfloat16
+    assert float((y.double() - yd).abs().max()) <= 2 ** -8 * float(yd.abs().max()) + 1e-6
+    assert float((x.grad.double() - xd.grad).abs().max()) <= 2 ** -8 * float(xd.grad.abs().max()) + 1e-6
+    # the bias gradient is the channel sum of the bf16-rounded dx: error ~ sqrt(rows) * 2^-9 * max|dx|
+    assert float((xb.grad.double() - xbd.grad).abs().max()) <= 2 ** -7 * rows ** 0.5 * float(xd.grad.abs().max()) + 1e-3
+    assert float((w.grad.double() - wd.grad).abs().max()) <= 1e-4 * float(wd.grad.abs().max()) + 1e-5
+    assert float((b.grad.double() - bd.grad).abs().max()) <= 1e-4 * float(bd.grad.abs().max()) + 1e-5
