@@ -27,6 +27,8 @@ _SIGNATURES = {
     "combo_bias_ln_bf16_forward": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "combo_bias_ln_bf16_backward": [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p,
                                     c_void_p, c_void_p],
+    "combo_colsum_grouped_slices": [c_longlong, c_int],
+    "combo_colsum_grouped": [c_void_p, c_int, c_void_p],
     "combo_colsum_slices": [c_longlong, c_int, c_longlong],
     "combo_colsum": [c_void_p, c_longlong, c_int, c_longlong, c_int, c_void_p, c_int, c_void_p, c_void_p],
     "combo_bias_act_bf16": [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p],

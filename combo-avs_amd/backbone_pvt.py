@@ -72,6 +72,8 @@ class _CastAll(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
+        from .ops.colsum import flush_deferred
+        flush_deferred()  # the bias gradients queued by _linear (ops/colsum.py): one grouped launch instead of ~300 pairs
         idx = [i for i, g in enumerate(grads) if g is not None]
         g32 = [torch.empty(grads[i].shape, dtype=torch.float32, device=grads[i].device) for i in idx]
         if idx and grads[idx[0]].is_cuda:
@@ -102,7 +104,8 @@ def _linear(x, mod, wts):
         return F.linear(x, w)
     if x.is_cuda and torch.is_grad_enabled():
         from .ops.colsum import linear_bias
-        return linear_bias(x, w, _p(mod.bias, wts))
+        # with the batched casts (wts) every bias gradient is consumed by _CastAll.backward, which flushes the queue first
+        return linear_bias(x, w, _p(mod.bias, wts), defer=wts is not None)
     return F.linear(x, w, _p(mod.bias, wts))
 
 

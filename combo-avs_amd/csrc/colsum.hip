@@ -45,15 +45,13 @@ __device__ __forceinline__ void store_out(const ColArgs& a, int c, float v) {
 
 // L == 1: x[M, C], C % 4 == 0.  Workgroup = tx lanes along the columns (4 columns each) x ty = 256 / tx rows in flight;
 // grid = (column blocks, slices of the rows).
-__global__ void __launch_bounds__(kThreads)
-colsum_rows_kernel(const ColArgs a) {
-  __shared__ float4 red[kThreads];
+__device__ __forceinline__ void colsum_rows_body(const ColArgs& a, int bx, int by, float4* red) {
   const int tx = 1 << a.tx_log2, ty = kThreads >> a.tx_log2;
   const int lx = threadIdx.x & (tx - 1), ly = threadIdx.x >> a.tx_log2;
-  const int col = (blockIdx.x * tx + lx) * 4;
+  const int col = (bx * tx + lx) * 4;
   const long long M = a.A;
   const long long rows_per = (M + a.slices - 1) / a.slices;
-  const long long r0 = rows_per * blockIdx.y, r1 = min(M, r0 + rows_per);
+  const long long r0 = rows_per * by, r1 = min(M, r0 + rows_per);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (col < a.C) {
     const long long pitch = a.C / 4;  // in 4-column groups
@@ -96,7 +94,40 @@ colsum_rows_kernel(const ColArgs a) {
   }
   if (ly != 0 || col >= a.C) return;
   if (a.slices == 1) { store_out(a, col, acc.x); store_out(a, col + 1, acc.y); store_out(a, col + 2, acc.z); store_out(a, col + 3, acc.w); }
-  else *reinterpret_cast<float4*>(a.partial + (long long)blockIdx.y * a.C + col) = acc;
+  else *reinterpret_cast<float4*>(a.partial + (long long)by * a.C + col) = acc;
+}
+
+__global__ void __launch_bounds__(kThreads)
+colsum_rows_kernel(const ColArgs a) {
+  __shared__ float4 red[kThreads];
+  colsum_rows_body(a, blockIdx.x, blockIdx.y, red);
+}
+
+// Many small column sums in ONE launch (+ one finish launch): the ~630 bias gradients of two PVTv2-B5 backbones cost 5 + 5 us
+// each as separate launches (6.4 ms of a 140 ms step) for 1 - 20 MB of input.  The problem table travels in the kernel
+// arguments; a workgroup finds its problem by its block index.
+constexpr int kMaxGroup = 40;
+struct GroupArgs {
+  int count;
+  int block_start[kMaxGroup + 1];   // rows kernel: first workgroup of problem i
+  int finish_start[kMaxGroup + 1];  // finish kernel: likewise
+  int blocks_x[kMaxGroup];
+  ColArgs p[kMaxGroup];
+};
+
+__device__ __forceinline__ int find_problem(const int* start, int count, int b) {
+  int pi = 0;
+  for (int i = 1; i < count; ++i)
+    if (b >= start[i]) pi = i;
+  return pi;
+}
+
+__global__ void __launch_bounds__(kThreads)
+colsum_rows_grouped_kernel(const GroupArgs g) {
+  __shared__ float4 red[kThreads];
+  const int pi = find_problem(g.block_start, g.count, blockIdx.x);
+  const int lb = blockIdx.x - g.block_start[pi];
+  colsum_rows_body(g.p[pi], lb % g.blocks_x[pi], lb / g.blocks_x[pi], red);
 }
 
 // L > 1: x[A, C, L].  Workgroup = (channel c, slice of the A planes); waves take planes in turn, lanes run along L.
@@ -143,11 +174,9 @@ colsum_planes_kernel(const ColArgs a) {
 
 // out[c] = sum_s partial[s][c]: 64 columns per workgroup, 16 row groups; row group ly adds slices ly, ly + 16, ... in ascending
 // order, then a fixed tree over the row groups.
-__global__ void __launch_bounds__(kFinishThreads)
-colsum_finish_kernel(const ColArgs a) {
-  __shared__ float red[kFinishThreads];
+__device__ __forceinline__ void colsum_finish_body(const ColArgs& a, int bx, float* red) {
   const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lx;
+  const int c = bx * 64 + lx;
   float t = 0.f;
   if (c < a.C)
     for (int s = ly; s < a.slices; s += kFinishThreads / 64) t += a.partial[(long long)s * a.C + c];
@@ -158,6 +187,19 @@ colsum_finish_kernel(const ColArgs a) {
     __syncthreads();
   }
   if (ly == 0 && c < a.C) store_out(a, c, t);
+}
+
+__global__ void __launch_bounds__(kFinishThreads)
+colsum_finish_kernel(const ColArgs a) {
+  __shared__ float red[kFinishThreads];
+  colsum_finish_body(a, blockIdx.x, red);
+}
+
+__global__ void __launch_bounds__(kFinishThreads)
+colsum_finish_grouped_kernel(const GroupArgs g) {
+  __shared__ float red[kFinishThreads];
+  const int pi = find_problem(g.finish_start, g.count, blockIdx.x);
+  if (g.p[pi].slices > 1) colsum_finish_body(g.p[pi], blockIdx.x - g.finish_start[pi], red);
 }
 
 struct Plan { int blocks_x, slices, tx_log2; };
@@ -188,9 +230,52 @@ Plan plan(long long A, int C, long long L) {
   return p;
 }
 
+// inside a grouped launch a problem takes fewer slices (the launch as a whole fills the chip)
+int grouped_slices(const Plan& p, long long A) {
+  const int ty = kThreads >> p.tx_log2;
+  long long s = 256 / p.blocks_x;
+  const long long max_s = A / (8ll * ty);
+  if (s > max_s) s = max_s;
+  return (int)(s < 1 ? 1 : s > 64 ? 64 : s);
+}
+
 }  // namespace
 
 extern "C" {
+
+int combo_colsum_grouped_slices(long long rows, int C) {
+  if (rows <= 0 || C <= 0 || C % 4 != 0) return COMBO_EINVAL;
+  return grouped_slices(plan(rows, C, 1), rows);
+}
+
+int combo_colsum_grouped(const combo_colsum_problem* problems, int count, combo_stream_t stream) {
+  if (!problems || count <= 0) return COMBO_EINVAL;
+  for (int base = 0; base < count; base += kMaxGroup) {
+    GroupArgs g;
+    g.count = count - base < kMaxGroup ? count - base : kMaxGroup;
+    int blocks = 0, fin = 0;
+    bool any_finish = false;
+    for (int i = 0; i < g.count; ++i) {
+      const combo_colsum_problem& pr = problems[base + i];
+      if (!pr.x || !pr.out || pr.rows <= 0 || pr.C <= 0 || pr.C % 4 != 0) return COMBO_EINVAL;
+      const Plan p = plan(pr.rows, pr.C, 1);
+      const int slices = grouped_slices(p, pr.rows);
+      if (slices > 1 && !pr.partial) return COMBO_EINVAL;
+      g.p[i] = ColArgs{pr.x, pr.out, pr.partial, pr.rows, 1, pr.C, slices, pr.in_bf16, pr.out_bf16, p.tx_log2};
+      g.blocks_x[i] = p.blocks_x;
+      g.block_start[i] = blocks;
+      g.finish_start[i] = fin;
+      blocks += p.blocks_x * slices;
+      fin += (pr.C + 63) / 64;
+      any_finish |= slices > 1;
+    }
+    g.block_start[g.count] = blocks;
+    g.finish_start[g.count] = fin;
+    hipLaunchKernelGGL(colsum_rows_grouped_kernel, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, g);
+    if (any_finish) hipLaunchKernelGGL(colsum_finish_grouped_kernel, dim3(fin), dim3(kFinishThreads), 0, (hipStream_t)stream, g);
+  }
+  return (int)hipGetLastError();
+}
 
 int combo_colsum_slices(long long A, int C, long long L) {
   if (A <= 0 || C <= 0 || L <= 0 || (L == 1 && C % 4 != 0)) return COMBO_EINVAL;

@@ -7,6 +7,52 @@ from torch.autograd import Function
 
 from .. import _lib
 
+import ctypes
+
+_pending = []        # [(dy2 [rows, C], out [C])]: bias gradients queued by linear_bias(..., defer=True)
+_pending_bytes = 0
+PENDING_CAP = int(__import__("os").environ.get("COMBO_COLSUM_PENDING_MB", "1024")) << 20  # queued inputs stay alive until the flush
+DEFER = __import__("os").environ.get("COMBO_COLSUM_DEFER", "1") == "1"  # A/B switch
+
+
+class _ColsumProblem(ctypes.Structure):  # combo_colsum_problem (include/combo_avs.h)
+    _fields_ = [("x", ctypes.c_void_p), ("out", ctypes.c_void_p), ("partial", ctypes.c_void_p), ("rows", ctypes.c_longlong),
+                ("C", ctypes.c_int), ("in_bf16", ctypes.c_int), ("out_bf16", ctypes.c_int)]
+
+
+def flush_deferred():
+    """computes every queued bias gradient with one grouped launch (+ one finish launch) per 40 problems.  Called by the
+    consumer of those gradients (backbone_pvt._CastAll.backward) and whenever the queued inputs exceed PENDING_CAP."""
+    global _pending, _pending_bytes
+    if not _pending:
+        return
+    q, _pending, _pending_bytes = _pending, [], 0
+    lib = _lib.lib()
+    arr = (_ColsumProblem * len(q))()
+    sl = [lib.combo_colsum_grouped_slices(x.shape[0], x.shape[1]) for x, _ in q]
+    need = sum(s * x.shape[1] for s, (x, _) in zip(sl, q) if s > 1)
+    scratch = torch.empty(max(need, 1), dtype=torch.float32, device=q[0][0].device)
+    off = 0
+    for i, (s_i, (x, out)) in enumerate(zip(sl, q)):
+        part = 0
+        if s_i > 1:
+            part = scratch.data_ptr() + 4 * off
+            off += s_i * x.shape[1]
+        arr[i] = _ColsumProblem(x.data_ptr(), out.data_ptr(), part, x.shape[0], x.shape[1], _code(x.dtype), _code(out.dtype))
+    _lib.check(lib.combo_colsum_grouped(ctypes.cast(arr, ctypes.c_void_p), len(q), _lib.current_stream()), "combo_colsum_grouped")
+
+
+def _queue_column_sum(x2, out_dtype):
+    """x2 [rows, C] contiguous -> a [C] tensor that is filled at the next flush_deferred()"""
+    global _pending_bytes
+    out = torch.empty(x2.shape[1], dtype=out_dtype, device=x2.device)
+    _pending.append((x2, out))
+    _pending_bytes += x2.numel() * x2.element_size()
+    if _pending_bytes > PENDING_CAP:
+        flush_deferred()
+    return out
+
+
 def _code(dt):
     if dt == torch.bfloat16:
         return 1
@@ -89,12 +135,13 @@ def add_channel_vector(x, v, channel_dim=1):
 class _LinearBias(Function):
     """F.linear with a bias whose gradient is channel_sum(dy) (backbone_pvt._linear).  Under autocast the forward computes in
     the autocast dtype while x / w / b may be fp32: the backward GEMMs then run in dy's dtype and the gradients are cast to the
-    inputs' dtypes, as autocast's own cast nodes would do."""
+    inputs' dtypes, as autocast's own cast nodes would do.  defer: the bias gradient is queued and computed by the next
+    flush_deferred() (the caller guarantees one before anything reads it)."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, defer):
         ctx.save_for_backward(x, w)
-        ctx.b_dtype = b.dtype
+        ctx.b_dtype, ctx.defer = b.dtype, defer
         return torch.nn.functional.linear(x, w, b)
 
     @staticmethod
@@ -107,14 +154,17 @@ class _LinearBias(Function):
         if ctx.needs_input_grad[1]:
             dw = (dy2.t() @ x.reshape(-1, x.shape[-1]).to(dy2.dtype)).to(w.dtype)
         if ctx.needs_input_grad[2]:
-            db = sum_to_channels(dy2, -1, out_dtype=ctx.b_dtype)
-        return dx, dw, db
+            if ctx.defer and DEFER and dy2.is_contiguous():
+                db = _queue_column_sum(dy2, ctx.b_dtype)
+            else:
+                db = sum_to_channels(dy2, -1, out_dtype=ctx.b_dtype)
+        return dx, dw, db, None
 
 
-def linear_bias(x, w, b):
+def linear_bias(x, w, b, defer=False):
     ok = (torch.float32, torch.bfloat16)
     if x.is_cuda and x.numel() > 0 and w.shape[0] % 4 == 0 and x.dtype in ok and w.dtype in ok and b.dtype in ok:
-        return _LinearBias.apply(x, w, b)
+        return _LinearBias.apply(x, w, b, defer)
     return torch.nn.functional.linear(x, w, b)
 
 

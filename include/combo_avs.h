@@ -91,6 +91,15 @@ int combo_fold_cast_grouped(const combo_fold_problem* problems, int count, combo
 int combo_colsum_slices(long long A, int C, long long L);
 int combo_colsum(const void* x, long long A, int C, long long L, int in_bf16, void* out, int out_bf16, float* partial,
                  combo_stream_t stream);
+/* Many column sums (L == 1) in one launch + one finish launch: the bias gradients of a whole backbone's nn.Linear layers,
+ * queued during the backward pass (ops/colsum.py).  partial: [combo_colsum_grouped_slices(rows, C), C] fp32 per problem. */
+typedef struct {
+  const void* x; void* out; float* partial;
+  long long rows;
+  int C, in_bf16, out_bf16;
+} combo_colsum_problem;
+int combo_colsum_grouped_slices(long long rows, int C);
+int combo_colsum_grouped(const combo_colsum_problem* problems, int count, combo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Pre-norm residual step of a PVTv2 block (backbone/pvtv2.py:162-175: x = x + drop_path(branch(norm(x)))), one pass per

@@ -890,3 +890,26 @@ def test_bias_ln_bf16_matches_float64(C, rows):
     assert float((xb.grad.double() - xbd.grad).abs().max()) <= 2 ** -7 * rows ** 0.5 * float(xd.grad.abs().max()) + 1e-3
     assert float((w.grad.double() - wd.grad).abs().max()) <= 1e-4 * float(wd.grad.abs().max()) + 1e-5
     assert float((b.grad.double() - bd.grad).abs().max()) <= 1e-4 * float(bd.grad.abs().max()) + 1e-5
+
+
+@pytest.mark.gpu
+def test_deferred_grouped_column_sums_match_immediate_ones():
+    from combo_avs_amd.ops import colsum
+    torch.manual_seed(9)
+    shapes = [(7840, 320), (7840, 1280), (31360, 128), (1960, 512), (49 * 40, 640), (125440, 64), (37, 12), (300, 2048)] * 7  # > 40 problems
+    xs = [torch.randn(s, device="cuda").to(torch.bfloat16 if i % 3 else torch.float32) for i, s in enumerate(shapes)]
+    outs = [colsum._queue_column_sum(x, x.dtype) for x in xs]
+    assert len(colsum._pending) > 0
+    colsum.flush_deferred()
+    assert not colsum._pending
+    for x, o in zip(xs, outs):
+        want = x.double().sum(0)
+        tol = (2 ** -8 if x.dtype == torch.bfloat16 else 1e-6) * float(want.abs().max()) + 4e-6 * x.shape[0] ** 0.5
+        assert float((o.double() - want).abs().max()) <= tol
+    # the byte cap flushes by itself
+    old, colsum.PENDING_CAP = colsum.PENDING_CAP, 1 << 20
+    try:
+        o = colsum._queue_column_sum(xs[1], torch.float32)
+        assert not colsum._pending and torch.allclose(o, xs[1].float().sum(0), rtol=1e-3, atol=1e-2)
+    finally:
+        colsum.PENDING_CAP = old
