@@ -59,5 +59,5 @@ torch.cuda.synchronize()
 tot_n = sum(v[0] for v in agg.values())
 tot_b = sum(v[1] for v in agg.values())
 print(f"watched ATen ops: {tot_n} calls, {tot_b / 1e6:.0f} MB of outputs")
-for (name, shapes, site), (n, b) in sorted(agg.items(), key=lambda kv: -(kv[1][1] + 2e5 * kv[1][0]))[:int(os.environ.get("TOP", "70"))]:
+for (name, shapes, site), (n, b) in sorted(agg.items(), key=(lambda kv: -kv[1][0]) if os.environ.get("SORT") == "calls" else (lambda kv: -(kv[1][1] + 2e5 * kv[1][0])))[:int(os.environ.get("TOP", "70"))]:
     print(f"{n:4d}x {b / 1e6:8.1f} MB  {name:14s} {shapes:60s} {site}")
