@@ -98,6 +98,64 @@ dwconv3x3_wgrad_kernel(const u16* __restrict__ x, const u16* __restrict__ dy, in
   }
 }
 
+
+// v2 of the weight gradient (round 3): v1 gives one thread a whole slice of tokens to walk serially - ~64 k threads, one wave
+// per SIMD, nothing to hide the load latency behind (76 us per launch on average against 10 - 30 us of HBM time).  Here a
+// workgroup = 32 channel groups x 32 token lanes: token lane tl takes tokens p0 + tl, p0 + tl + 32, ... of the slice, the 32
+// lanes are summed at the end (lane ^ 32 by shuffle, the 16 waves through LDS, one tap at a time) and ONE partial per
+// workgroup goes out - 32 x fewer partials per thread than v1 at the same slice count.
+__global__ void __launch_bounds__(1024)
+dwconv3x3_wgrad2_kernel(const u16* __restrict__ x, const u16* __restrict__ dy, int B, int H, int W, int C8, int slices,
+                        int tok_per_slice, float* __restrict__ partial) {
+  __shared__ float red[16][32][8];
+  const int c8l = threadIdx.x & 31, tl = threadIdx.x >> 5, wave = threadIdx.x >> 6;
+  const int c8 = blockIdx.x * 32 + c8l, s = blockIdx.y;
+  const long long tokens = (long long)B * H * W;
+  const long long p0 = (long long)s * tok_per_slice, p1 = min(tokens, p0 + tok_per_slice);
+  float acc[10][8];
+#pragma unroll
+  for (int t = 0; t < 10; ++t)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[t][k] = 0.f;
+  for (long long p = p0 + tl; p < p1; p += 32) {
+    const int w = (int)(p % W), h = (int)((p / W) % H);
+    float g[8];
+    unpack8(*reinterpret_cast<const uint4*>(dy + (p * C8 + c8) * 8), g);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[9][k] += g[k];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int ddy = t / 3 - 1, ddx = t % 3 - 1;
+      const int hh = h + ddy, ww = w + ddx;
+      if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+      float xv[8];
+      unpack8(*reinterpret_cast<const uint4*>(x + ((p + ddy * W + ddx) * C8 + c8) * 8), xv);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[t][k] += g[k] * xv[k];
+    }
+  }
+  const int C = C8 * 8;
+  float* o = partial + (long long)s * 10 * C;
+#pragma unroll
+  for (int t = 0; t < 10; ++t) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[t][k] += __shfl_xor(acc[t][k], 32, 64);  // the wave's two token lanes
+    if ((threadIdx.x & 32) == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) red[wave][c8l][k] = acc[t][k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {  // (channel group, k): fixed order over the 16 waves
+      const int cl = threadIdx.x >> 3, k = threadIdx.x & 7;
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v += red[q][cl][k];
+      o[t * C + (blockIdx.x * 32 + cl) * 8 + k] = v;
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -113,8 +171,18 @@ int combo_dwconv3x3_bf16(const void* x, const float* w_tap_major, const float* b
   return (int)hipGetLastError();
 }
 
+static bool wgrad_v2() {
+  static const bool on = [] { const char* e = getenv("COMBO_DWCONV_WGRAD_V2"); return !e || atoi(e) != 0; }();  // A/B switch
+  return on;
+}
+
 int combo_dwconv3x3_wgrad_slices(int B, int H, int W, int C) {
   const long long tokens = (long long)B * H * W;
+  if (wgrad_v2() && C % 256 == 0) {  // v2: 32 channel groups x 32 token lanes per workgroup, ~512 workgroups
+    long long s = 512 / (C / 256);
+    if (s > tokens / 128) s = tokens / 128;  // at least 4 tokens per token lane
+    return (int)(s < 1 ? 1 : s);
+  }
   long long s = (65536LL * 8) / (C > 0 ? C : 8);  // ~64k threads
   if (s > tokens / 8) s = tokens / 8;             // at least 8 tokens per thread
   if (s < 1) s = 1;
@@ -128,6 +196,11 @@ int combo_dwconv3x3_wgrad_bf16(const void* x, const void* dy, int B, int H, int 
     return COMBO_EINVAL;
   const long long tokens = (long long)B * H * W;
   const int tps = (int)((tokens + slices - 1) / slices);
+  if (wgrad_v2() && C % 256 == 0) {
+    hipLaunchKernelGGL(dwconv3x3_wgrad2_kernel, dim3(C / 256, slices), dim3(1024), 0, (hipStream_t)stream, (const u16*)x,
+                       (const u16*)dy, B, H, W, C / 8, slices, tps, partials);
+    return (int)hipGetLastError();
+  }
   const long long threads = (long long)slices * (C / 8);
   hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const u16*)x, (const u16*)dy, B, H, W, C / 8, slices, tps, partials);

@@ -323,7 +323,8 @@ def test_bias_act_kernels_exact():
             assert torch.equal(gg, want)
 
 
-@pytest.mark.parametrize("B,H,W,C", [(3, 14, 14, 1280), (2, 7, 9, 64), (4, 56, 56, 256)])
+@pytest.mark.parametrize("B,H,W,C", [(3, 14, 14, 1280), (2, 7, 9, 64), (4, 56, 56, 256), (40, 14, 14, 1280), (5, 7, 7, 2048),
+                                     (2, 28, 28, 512), (1, 3, 5, 256)])
 def test_dwconv3x3_bf16_vs_torch(B, H, W, C):
     """csrc/dwconv.hip (PVTv2 DWConv) forward / backward-data / weight + bias gradients against F.conv2d in fp32 on the
     same bf16-rounded inputs."""
