@@ -335,6 +335,12 @@ def main():
         # MIOpen exhaustive find for the host-PyTorch backbone convolutions (+8 % frames/s; costs ~2 min of search in
         # the first warm-up step on a box with an empty MIOpen user db; COMBO_MIOPEN_BENCHMARK=0 skips it)
         torch.backends.cudnn.benchmark = True
+    if os.environ.get("COMBO_GEMM_TUNING", "1") == "1":
+        # the same for the host-PyTorch backbones' library GEMMs: PyTorch's TunableOp times the hipBLASLt / rocBLAS solutions of
+        # every GEMM shape it meets in the eager first step and keeps the fastest (pvt_ms3_t10: 135 -> 117 ms per step; ~40 s of
+        # tuning; nothing is written to disk).  COMBO_GEMM_TUNING=0 leaves the library's own heuristic.
+        from combo_avs_amd.trainer import enable_library_gemm_tuning
+        enable_library_gemm_tuning()
     cfg = combo_cfg(os.path.join(ROOT, "configs", wl["yaml"]), opts=wl.get("opts", ()))
     torch.manual_seed(0)  # identical random-init weights on every rank (DDP broadcast equivalent)
     model = build_model(cfg).to(dev).train()

@@ -381,6 +381,24 @@ def _clone_batch(batched_inputs):
     return out
 
 
+def enable_library_gemm_tuning(max_ms_per_solution=20):
+    """PyTorch TunableOp for the library GEMMs of the host-PyTorch backbones (the PVTv2 linears under bf16 autocast are small -
+    7 840 x 320 x 1 280 in stage 3 - and hipBLASLt's default heuristic runs them at ~85 TFLOP/s).  Every new GEMM shape is timed
+    over the available solutions the first time it is met, so the first (eager) step must see all shapes before a hipGraph is
+    captured: GraphedTrainStep's eager warm-up does that.  Returns False when this PyTorch has no TunableOp."""
+    try:
+        from torch.cuda import tunable
+    except ImportError:
+        return False
+    tunable.enable(True)
+    tunable.tuning_enable(True)
+    tunable.set_max_tuning_duration(int(max_ms_per_solution))
+    import tempfile
+    # the results file PyTorch writes at exit goes to the temp directory, not to the working directory
+    tunable.set_filename(os.path.join(tempfile.gettempdir(), f"combo_tunableop_{os.getpid()}.csv"), True)
+    return True
+
+
 _memset_selftest = {}
 
 
