@@ -78,7 +78,14 @@ class _CastAll(torch.autograd.Function):
         g32 = [torch.empty(grads[i].shape, dtype=torch.float32, device=grads[i].device) for i in idx]
         if idx and grads[idx[0]].is_cuda:
             from .ops.foldcast import fold_cast
-            fold_cast([grads[i].contiguous() for i in idx], g32)
+            # the strided-convolution weight gradients arrive channels_last: one strided copy_ each (a .contiguous() for the
+            # grouped cast would be a second kernel over the same tensor)
+            dense = [j for j, i in enumerate(idx) if grads[i].is_contiguous()]
+            for j, i in enumerate(idx):
+                if not grads[i].is_contiguous():
+                    g32[j].copy_(grads[i])
+            if dense:
+                fold_cast([grads[idx[j]] for j in dense], [g32[j] for j in dense])
         elif idx:
             torch._foreach_copy_(g32, [grads[i] for i in idx])
         out = [None] * len(grads)

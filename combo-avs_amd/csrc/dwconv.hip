@@ -156,6 +156,28 @@ dwconv3x3_wgrad2_kernel(const u16* __restrict__ x, const u16* __restrict__ dy, i
   }
 }
 
+// dw[c][tap] = sum_s partial[s][tap][c], db[c] = sum_s partial[s][9][c]: the weight gradient in the parameter's layout [C][9]
+// and the bias gradient in ONE launch (v1: two levels of the generic split-K reduce + a transpose copy).  Block = 32 channels
+// x 8 slice lanes, grid = (C / 32, 10 taps); fixed summation order.
+__global__ void __launch_bounds__(256)
+dwconv3x3_wgrad_finish_kernel(const float* __restrict__ partial, int slices, int C, float* __restrict__ dw, float* __restrict__ db) {
+  __shared__ float red[8][32];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl, t = blockIdx.y;
+  float v = 0.f;
+  if (c < C)
+    for (int s = sl; s < slices; s += 8) v += partial[((long long)s * 10 + t) * C + c];
+  red[sl][cl] = v;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    float a = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a += red[q][cl];
+    if (t < 9) dw[(long long)c * 9 + t] = a;
+    else if (db) db[c] = a;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -168,6 +190,13 @@ int combo_dwconv3x3_bf16(const void* x, const float* w_tap_major, const float* b
   const long long total = (long long)B * H * W * (C / 8);
   hipLaunchKernelGGL(dwconv3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const u16*)x, w_tap_major, bias, B, H, W, C / 8, flip, (u16*)y);
+  return (int)hipGetLastError();
+}
+
+int combo_dwconv3x3_wgrad_finish_f32(const float* partials, int slices, int C, float* dw, float* db, combo_stream_t stream) {
+  if (!partials || !dw || slices <= 0 || C <= 0) return COMBO_EINVAL;
+  hipLaunchKernelGGL(dwconv3x3_wgrad_finish_kernel, dim3((C + 31) / 32, 10), dim3(256), 0, (hipStream_t)stream, partials, slices, C,
+                     dw, db);
   return (int)hipGetLastError();
 }
 

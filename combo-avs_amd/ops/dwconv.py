@@ -17,42 +17,38 @@ class _DWConv3x3(Function):
     def forward(ctx, x, weight, bias):
         """x [B,H,W,C] bf16 contiguous (token-major), weight [C,1,3,3] fp32, bias [C] fp32 -> [B,H,W,C] bf16"""
         B, H, W, C = x.shape
-        wT = weight.view(C, 9).t().contiguous()  # tap-major [9][C]
+        # tap-major [9][C]: a thread's 8 channels of one tap are 32 contiguous bytes and a wave reads 2 KB in a row (the
+        # parameter's own [C][9] layout was measured: every lane then walks its own 288-byte chunk, +2.6 ms per PVTv2 step)
+        w = weight.view(C, 9).t().contiguous()
         y = torch.empty_like(x)
-        _lib.check(_lib.lib().combo_dwconv3x3_bf16(x.data_ptr(), wT.data_ptr(), _lib.ptr(bias), B, H, W, C, 0, y.data_ptr(),
+        _lib.check(_lib.lib().combo_dwconv3x3_bf16(x.data_ptr(), w.data_ptr(), _lib.ptr(bias), B, H, W, C, 0, y.data_ptr(),
                                                    _lib.current_stream()), "combo_dwconv3x3_bf16")
-        ctx.save_for_backward(x, wT)
+        ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        x, wT = ctx.saved_tensors
+        x, w = ctx.saved_tensors
         B, H, W, C = x.shape
         lib, st = _lib.lib(), _lib.current_stream()
         dy = dy.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _lib.check(lib.combo_dwconv3x3_bf16(dy.data_ptr(), wT.data_ptr(), 0, B, H, W, C, 1, dx.data_ptr(), st),
+            _lib.check(lib.combo_dwconv3x3_bf16(dy.data_ptr(), w.data_ptr(), 0, B, H, W, C, 1, dx.data_ptr(), st),
                        "combo_dwconv3x3_bf16")
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             slices = lib.combo_dwconv3x3_wgrad_slices(B, H, W, C)
-            # two-level sum of the per-slice partials: slice s = s2 * 16 + s1; pass 1 sums over s2 (many threads), pass 2
-            # over the 16 s1 (the split-K reduce kernel walks its split axis serially, so that axis must stay short)
-            slices = -(-slices // 16) * 16
             part = torch.empty(slices, 10, C, device=x.device, dtype=torch.float32)
             _lib.check(lib.combo_dwconv3x3_wgrad_bf16(x.data_ptr(), dy.data_ptr(), B, H, W, C, slices, part.data_ptr(), st),
                        "combo_dwconv3x3_wgrad_bf16")
-            tmp = torch.empty(16, 10, C, device=x.device, dtype=torch.float32)
-            tot = torch.empty(10, C, device=x.device, dtype=torch.float32)
-            _lib.check(lib.combo_splitk_reduce_f32(part.data_ptr(), slices // 16, 16 * 10 * C, tmp.data_ptr(), 0, 0, 0, st),
-                       "combo_splitk_reduce_f32")
-            _lib.check(lib.combo_splitk_reduce_f32(tmp.data_ptr(), 16, 10 * C, tot.data_ptr(), 0, 0, 0, st),
-                       "combo_splitk_reduce_f32")
-            dw = tot[:9].t().reshape(C, 1, 3, 3)
-            db = tot[9] if ctx.has_bias else None
+            dw = torch.empty(C, 1, 3, 3, device=x.device, dtype=torch.float32)
+            db = torch.empty(C, device=x.device, dtype=torch.float32) if ctx.has_bias else None
+            # one launch: sums the per-slice partials and writes the parameter's layout (v1: two reduce launches + a transpose)
+            _lib.check(lib.combo_dwconv3x3_wgrad_finish_f32(part.data_ptr(), slices, C, dw.data_ptr(), _lib.ptr(db), st),
+                       "combo_dwconv3x3_wgrad_finish_f32")
         return dx, dw, db
 
 

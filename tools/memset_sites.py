@@ -90,8 +90,41 @@ def parse(d):
         print(f"{n:5d} x {f:16s} {where}")
 
 
+def kernels(d, pattern):
+    """which ops launch the kernels whose name matches `pattern`?  Needs --kernel-trace as well:
+    rocprofv3 --hip-trace --kernel-trace --marker-trace --output-format csv -d DIR -o t -- python3 tools/memset_sites.py run CFG
+    python3 tools/memset_sites.py kernels DIR direct_copy"""
+    import re
+    api = list(csv.DictReader(open(glob.glob(os.path.join(d, "**", "*hip_api_trace.csv"), recursive=True)[0])))
+    mk = list(csv.DictReader(open(glob.glob(os.path.join(d, "**", "*marker_api_trace.csv"), recursive=True)[0])))
+    kt = list(csv.DictReader(open(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0])))
+    s_key = [k for k in api[0] if k.lower().startswith("start")][0]
+    e_key = [k for k in api[0] if k.lower().startswith("end")][0]
+    corr = [k for k in api[0] if "orrelation" in k][0]
+    kcorr = [k for k in kt[0] if "orrelation" in k][0]
+    kname = [k for k in kt[0] if k.lower() in ("kernel_name", "name")][0]
+    launch_time = {r[corr]: int(r[s_key]) for r in api}
+    ranges = [(int(r[s_key]), int(r[e_key]), r["Function"]) for r in mk]
+    step = [r for r in ranges if r[2] == "COMBO_MARKED_STEP"][0]
+    inner = sorted((r for r in ranges if step[0] <= r[0] and r[1] <= step[1] and r[2] != "COMBO_MARKED_STEP"), key=lambda r: r[0])
+    agg = collections.Counter()
+    rx = re.compile(pattern)
+    for r in kt:
+        if not rx.search(r[kname]):
+            continue
+        t = launch_time.get(r[kcorr])
+        if t is None or not (step[0] <= t <= step[1]):
+            continue
+        around = sorted((x for x in inner if x[0] <= t <= x[1]), key=lambda x: x[1] - x[0])
+        agg[" <- ".join((x[2] if x[2].startswith("SHAPES") else x[2].split(",")[0])[:110] for x in around[:3]) or "(no range)"] += 1
+    for where, n in agg.most_common(int(os.environ.get("TOP", "25"))):
+        print(f"{n:5d} x {where}")
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "run":
         run(sys.argv[2])
+    elif sys.argv[1] == "kernels":
+        kernels(sys.argv[2], sys.argv[3])
     else:
         parse(sys.argv[2])
