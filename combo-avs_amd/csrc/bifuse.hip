@@ -98,6 +98,9 @@ __device__ __forceinline__ void drop8(float (&m)[8], const float* inj, long long
   }
 }
 
+// value of `v` in lane k (k uniform over the wave): v_readlane_b32
+__device__ __forceinline__ float lane_value(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
+
 struct TokenLN {
   float4 xn;   // normalised + affine
   float4 xh;   // (x - mean) * rstd
@@ -237,23 +240,43 @@ bifuse_apply(const float* __restrict__ x, const float* __restrict__ ln_w, const 
   float sacc[NH];
 #pragma unroll
   for (int h = 0; h < NH; ++h) { acc[h] = make_float4(0.f, 0.f, 0.f, 0.f); sacc[h] = 0.f; }
-  for (int i = i0 + wave; i < i1; i += WAVES) {
-    const float4 xv = reinterpret_cast<const float4*>(x + ((long long)b * N + i) * C)[lane];
-    const TokenLN t = layer_norm_token(xv, w, bb, eps);
-    float mv[NH], ma[NH];
-    drop8(mv, drop_v, B, N, b, i, p_drop, seed, 0);
-    drop8(ma, drop_a, B, N, b, i, p_drop, seed, 1);
-    float4 o = bo;
+  // Per-token scalars (8 probabilities, 16 dropout multipliers = 4 Philox blocks, 8 exponentials) are the same in all 64 lanes
+  // of the token's wave: computed there they cost ~300 of the ~400 vector instructions per token and made this kernel
+  // VALU-bound (180 us for 274 MB).  Instead lane k computes them for the wave's k-th token (up to 64 tokens per round) and
+  // the token loop reads them back with v_readlane (100 us).
+  for (int base = i0 + wave; base < i1; base += WAVES * 64) {
+    const int ik = base + lane * WAVES;  // this lane's token of the round
+    float pvl[NH], pal[NH];
+    if (ik < i1) {
+      float mv[NH], ma[NH];
+      drop8(mv, drop_v, B, N, b, ik, p_drop, seed, 0);
+      drop8(ma, drop_a, B, N, b, ik, p_drop, seed, 1);
 #pragma unroll
-    for (int h = 0; h < NH; ++h) {
-      const float p = __expf(s[((long long)b * NH + h) * N + i] - mx[h]) * iz[h];
-      const float pv = p * mv[h], pa = p * ma[h];
-      o.x += pv * zz[h].x; o.y += pv * zz[h].y; o.z += pv * zz[h].z; o.w += pv * zz[h].w;
-      acc[h].x += pa * t.xn.x; acc[h].y += pa * t.xn.y; acc[h].z += pa * t.xn.z; acc[h].w += pa * t.xn.w;
-      sacc[h] += pa;
+      for (int h = 0; h < NH; ++h) {
+        const float p = __expf(s[((long long)b * NH + h) * N + ik] - mx[h]) * iz[h];
+        pvl[h] = p * mv[h];
+        pal[h] = p * ma[h];
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < NH; ++h) pvl[h] = pal[h] = 0.f;
     }
-    reinterpret_cast<float4*>(y + ((long long)b * N + i) * C)[lane] =
-        make_float4(t.xn.x + gv.x * o.x, t.xn.y + gv.y * o.y, t.xn.z + gv.z * o.z, t.xn.w + gv.w * o.w);
+    const int cnt = min(64, (i1 - base + WAVES - 1) / WAVES);
+    for (int k = 0; k < cnt; ++k) {
+      const int i = base + k * WAVES;
+      const float4 xv = reinterpret_cast<const float4*>(x + ((long long)b * N + i) * C)[lane];
+      const TokenLN t = layer_norm_token(xv, w, bb, eps);
+      float4 o = bo;
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        const float pv = lane_value(pvl[h], k), pa = lane_value(pal[h], k);
+        o.x += pv * zz[h].x; o.y += pv * zz[h].y; o.z += pv * zz[h].z; o.w += pv * zz[h].w;
+        acc[h].x += pa * t.xn.x; acc[h].y += pa * t.xn.y; acc[h].z += pa * t.xn.z; acc[h].w += pa * t.xn.w;
+        sacc[h] += pa;
+      }
+      reinterpret_cast<float4*>(y + ((long long)b * N + i) * C)[lane] =
+          make_float4(t.xn.x + gv.x * o.x, t.xn.y + gv.y * o.y, t.xn.z + gv.z * o.z, t.xn.w + gv.w * o.w);
+    }
   }
   if (lane == 0) {
 #pragma unroll
@@ -303,35 +326,49 @@ bifuse_bwd1(const float* __restrict__ x, const float* __restrict__ ln_w, const f
   for (int h = 0; h < NH; ++h) dzacc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 dgacc = make_float4(0.f, 0.f, 0.f, 0.f), dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
   float racc = 0.f;  // for head myh (valid on lanes with (lane&7)==0)
-  for (int i = i0 + wave; i < i1; i += WAVES) {
-    const float4 xv = reinterpret_cast<const float4*>(x + ((long long)b * N + i) * C)[lane];
-    const TokenLN t = layer_norm_token(xv, w, bb, eps);
-    const float4 dyv = reinterpret_cast<const float4*>(dy + ((long long)b * N + i) * C)[lane];
-    const float4 g = make_float4(dyv.x * gv.x, dyv.y * gv.y, dyv.z * gv.z, dyv.w * gv.w);
-    float mv[NH], ma[NH], pr[NH], d1[NH], d2[NH];
-    drop8(mv, drop_v, B, N, b, i, p_drop, seed, 0);
-    drop8(ma, drop_a, B, N, b, i, p_drop, seed, 1);
-    float4 o = bo;
+  // (per-token scalars computed by lane k for the wave's k-th token and read back with v_readlane: see bifuse_apply)
+  for (int base = i0 + wave; base < i1; base += WAVES * 64) {
+    const int ik = base + lane * WAVES;
+    float mvl[NH], mal[NH], prl[NH];
+    if (ik < i1) {
+      drop8(mvl, drop_v, B, N, b, ik, p_drop, seed, 0);
+      drop8(mal, drop_a, B, N, b, ik, p_drop, seed, 1);
 #pragma unroll
-    for (int h = 0; h < NH; ++h) {
-      pr[h] = __expf(s[((long long)b * NH + h) * N + i] - mx[h]) * iz[h];
-      const float pv = pr[h] * mv[h];
-      o.x += pv * zz[h].x; o.y += pv * zz[h].y; o.z += pv * zz[h].z; o.w += pv * zz[h].w;
-      dzacc[h].x += pv * g.x; dzacc[h].y += pv * g.y; dzacc[h].z += pv * g.z; dzacc[h].w += pv * g.w;
-      d1[h] = dot4(g, zz[h]);        // d pv[h]
-      d2[h] = dot4(t.xn, dpl[h]);    // d pa[h] (without dspa)
+      for (int h = 0; h < NH; ++h) prl[h] = __expf(s[((long long)b * NH + h) * N + ik] - mx[h]) * iz[h];
+    } else {
+#pragma unroll
+      for (int h = 0; h < NH; ++h) mvl[h] = mal[h] = prl[h] = 0.f;
     }
-    dgacc.x += dyv.x * o.x; dgacc.y += dyv.y * o.y; dgacc.z += dyv.z * o.z; dgacc.w += dyv.w * o.w;
-    dbacc.x += g.x; dbacc.y += g.y; dbacc.z += g.z; dbacc.w += g.w;
-    const float r1 = reduce8(d1, lane), r2 = reduce8(d2, lane);
-    float mvh = mv[0], mah = ma[0], prh = pr[0], dsh = dsp[0];
+    const int cnt = min(64, (i1 - base + WAVES - 1) / WAVES);
+    for (int k = 0; k < cnt; ++k) {
+      const int i = base + k * WAVES;
+      const float4 xv = reinterpret_cast<const float4*>(x + ((long long)b * N + i) * C)[lane];
+      const TokenLN t = layer_norm_token(xv, w, bb, eps);
+      const float4 dyv = reinterpret_cast<const float4*>(dy + ((long long)b * N + i) * C)[lane];
+      const float4 g = make_float4(dyv.x * gv.x, dyv.y * gv.y, dyv.z * gv.z, dyv.w * gv.w);
+      float mv[NH], ma[NH], pr[NH], d1[NH], d2[NH];
+      float4 o = bo;
 #pragma unroll
-    for (int h = 1; h < NH; ++h)
-      if (myh == h) { mvh = mv[h]; mah = ma[h]; prh = pr[h]; dsh = dsp[h]; }
-    const float dph = r1 * mvh + (r2 + dsh) * mah;
-    if ((lane & 7) == 0) {
-      dp[((long long)b * NH + myh) * N + i] = dph;
-      racc += prh * dph;
+      for (int h = 0; h < NH; ++h) {
+        mv[h] = lane_value(mvl[h], k); ma[h] = lane_value(mal[h], k); pr[h] = lane_value(prl[h], k);
+        const float pv = pr[h] * mv[h];
+        o.x += pv * zz[h].x; o.y += pv * zz[h].y; o.z += pv * zz[h].z; o.w += pv * zz[h].w;
+        dzacc[h].x += pv * g.x; dzacc[h].y += pv * g.y; dzacc[h].z += pv * g.z; dzacc[h].w += pv * g.w;
+        d1[h] = dot4(g, zz[h]);        // d pv[h]
+        d2[h] = dot4(t.xn, dpl[h]);    // d pa[h] (without dspa)
+      }
+      dgacc.x += dyv.x * o.x; dgacc.y += dyv.y * o.y; dgacc.z += dyv.z * o.z; dgacc.w += dyv.w * o.w;
+      dbacc.x += g.x; dbacc.y += g.y; dbacc.z += g.z; dbacc.w += g.w;
+      const float r1 = reduce8(d1, lane), r2 = reduce8(d2, lane);
+      float mvh = mv[0], mah = ma[0], prh = pr[0], dsh = dsp[0];
+#pragma unroll
+      for (int h = 1; h < NH; ++h)
+        if (myh == h) { mvh = mv[h]; mah = ma[h]; prh = pr[h]; dsh = dsp[h]; }
+      const float dph = r1 * mvh + (r2 + dsh) * mah;
+      if ((lane & 7) == 0) {
+        dp[((long long)b * NH + myh) * N + i] = dph;
+        racc += prh * dph;
+      }
     }
   }
   // ---- workgroup reductions -> partial buffers ----
@@ -391,35 +428,52 @@ bifuse_bwd2(const float* __restrict__ x, const float* __restrict__ ln_w, const f
 #pragma unroll
   for (int h = 0; h < NH; ++h) { duacc[h] = make_float4(0.f, 0.f, 0.f, 0.f); dcacc[h] = 0.f; }
   float4 dwacc = make_float4(0.f, 0.f, 0.f, 0.f), dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int i = i0 + wave; i < i1; i += WAVES) {
-    const float4 xv = reinterpret_cast<const float4*>(x + ((long long)b * N + i) * C)[lane];
-    const TokenLN t = layer_norm_token(xv, w, bb, eps);
-    const float4 pv = reinterpret_cast<const float4*>(pos + (long long)i * C)[lane];
-    const float4 tt = make_float4(t.xn.x + pv.x, t.xn.y + pv.y, t.xn.z + pv.z, t.xn.w + pv.w);
-    float4 dxn = reinterpret_cast<const float4*>(dy + ((long long)b * N + i) * C)[lane];
-    float ma[NH];
-    drop8(ma, drop_a, B, N, b, i, p_drop, seed, 1);
+  // (per-token scalars - the audio-side probability pa and the score gradient ds of the 8 heads - computed by lane k for the
+  // wave's k-th token and read back with v_readlane: see bifuse_apply)
+  for (int base = i0 + wave; base < i1; base += WAVES * 64) {
+    const int ik = base + lane * WAVES;
+    float pal[NH], dsl[NH];
+    if (ik < i1) {
+      float ma[NH];
+      drop8(ma, drop_a, B, N, b, ik, p_drop, seed, 1);
 #pragma unroll
-    for (int h = 0; h < NH; ++h) {
-      const float sc = s[((long long)b * NH + h) * N + i];
-      const float p = __expf(sc - mx[h]) * iz[h];
-      // the clamp of the scores has zero gradient outside +-5e4
-      const float ds = (sc > -50000.f && sc < 50000.f) ? p * (dp[((long long)b * NH + h) * N + i] - rt[h]) : 0.f;
-      const float pa = p * ma[h];
-      dxn.x += pa * dpl[h].x + ds * uu[h].x; dxn.y += pa * dpl[h].y + ds * uu[h].y;
-      dxn.z += pa * dpl[h].z + ds * uu[h].z; dxn.w += pa * dpl[h].w + ds * uu[h].w;
-      duacc[h].x += ds * tt.x; duacc[h].y += ds * tt.y; duacc[h].z += ds * tt.z; duacc[h].w += ds * tt.w;
-      dcacc[h] += ds;
+      for (int h = 0; h < NH; ++h) {
+        const float sc = s[((long long)b * NH + h) * N + ik];
+        const float p = __expf(sc - mx[h]) * iz[h];
+        // the clamp of the scores has zero gradient outside +-5e4
+        dsl[h] = (sc > -50000.f && sc < 50000.f) ? p * (dp[((long long)b * NH + h) * N + ik] - rt[h]) : 0.f;
+        pal[h] = p * ma[h];
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < NH; ++h) pal[h] = dsl[h] = 0.f;
     }
-    // LayerNorm backward: dx = rstd * (gw - mean(gw) - xh * mean(gw * xh)),  gw = dxn * w
-    dwacc.x += dxn.x * t.xh.x; dwacc.y += dxn.y * t.xh.y; dwacc.z += dxn.z * t.xh.z; dwacc.w += dxn.w * t.xh.w;
-    dbacc.x += dxn.x; dbacc.y += dxn.y; dbacc.z += dxn.z; dbacc.w += dxn.w;
-    const float4 gw = make_float4(dxn.x * w.x, dxn.y * w.y, dxn.z * w.z, dxn.w * w.w);
-    const float m1 = wave_sum(gw.x + gw.y + gw.z + gw.w) * (1.f / C);
-    const float m2 = wave_sum(gw.x * t.xh.x + gw.y * t.xh.y + gw.z * t.xh.z + gw.w * t.xh.w) * (1.f / C);
-    reinterpret_cast<float4*>(dx + ((long long)b * N + i) * C)[lane] =
-        make_float4(t.rstd * (gw.x - m1 - t.xh.x * m2), t.rstd * (gw.y - m1 - t.xh.y * m2),
-                    t.rstd * (gw.z - m1 - t.xh.z * m2), t.rstd * (gw.w - m1 - t.xh.w * m2));
+    const int cnt = min(64, (i1 - base + WAVES - 1) / WAVES);
+    for (int k = 0; k < cnt; ++k) {
+      const int i = base + k * WAVES;
+      const float4 xv = reinterpret_cast<const float4*>(x + ((long long)b * N + i) * C)[lane];
+      const TokenLN t = layer_norm_token(xv, w, bb, eps);
+      const float4 pv = reinterpret_cast<const float4*>(pos + (long long)i * C)[lane];
+      const float4 tt = make_float4(t.xn.x + pv.x, t.xn.y + pv.y, t.xn.z + pv.z, t.xn.w + pv.w);
+      float4 dxn = reinterpret_cast<const float4*>(dy + ((long long)b * N + i) * C)[lane];
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        const float ds = lane_value(dsl[h], k), pa = lane_value(pal[h], k);
+        dxn.x += pa * dpl[h].x + ds * uu[h].x; dxn.y += pa * dpl[h].y + ds * uu[h].y;
+        dxn.z += pa * dpl[h].z + ds * uu[h].z; dxn.w += pa * dpl[h].w + ds * uu[h].w;
+        duacc[h].x += ds * tt.x; duacc[h].y += ds * tt.y; duacc[h].z += ds * tt.z; duacc[h].w += ds * tt.w;
+        dcacc[h] += ds;
+      }
+      // LayerNorm backward: dx = rstd * (gw - mean(gw) - xh * mean(gw * xh)),  gw = dxn * w
+      dwacc.x += dxn.x * t.xh.x; dwacc.y += dxn.y * t.xh.y; dwacc.z += dxn.z * t.xh.z; dwacc.w += dxn.w * t.xh.w;
+      dbacc.x += dxn.x; dbacc.y += dxn.y; dbacc.z += dxn.z; dbacc.w += dxn.w;
+      const float4 gw = make_float4(dxn.x * w.x, dxn.y * w.y, dxn.z * w.z, dxn.w * w.w);
+      const float m1 = wave_sum(gw.x + gw.y + gw.z + gw.w) * (1.f / C);
+      const float m2 = wave_sum(gw.x * t.xh.x + gw.y * t.xh.y + gw.z * t.xh.z + gw.w * t.xh.w) * (1.f / C);
+      reinterpret_cast<float4*>(dx + ((long long)b * N + i) * C)[lane] =
+          make_float4(t.rstd * (gw.x - m1 - t.xh.x * m2), t.rstd * (gw.y - m1 - t.xh.y * m2),
+                      t.rstd * (gw.z - m1 - t.xh.z * m2), t.rstd * (gw.w - m1 - t.xh.w * m2));
+    }
   }
   if (lane == 0) {
 #pragma unroll
