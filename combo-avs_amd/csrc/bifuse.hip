@@ -150,7 +150,8 @@ __device__ __forceinline__ void block_reduce_heads(float4 (*red)[4][64], const f
 __global__ void __launch_bounds__(THREADS)
 bifuse_scores(const float* __restrict__ x, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps,
               const float* __restrict__ pos, const float* __restrict__ u, const float* __restrict__ cc, int B, int N,
-              int chunks, float* __restrict__ s, float* __restrict__ part /* [B,chunks,NH,2] */) {
+              int chunks, float* __restrict__ s, float* __restrict__ part /* [B,chunks,NH,2] */, unsigned long long* __restrict__ ts) {
+  combo_ts_begin(ts);
   __shared__ float sm[WAVES][NH][2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
@@ -191,6 +192,7 @@ bifuse_scores(const float* __restrict__ x, const float* __restrict__ ln_w, const
     part[(((long long)b * chunks + chunk) * NH + threadIdx.x) * 2] = m;
     part[(((long long)b * chunks + chunk) * NH + threadIdx.x) * 2 + 1] = z;
   }
+  combo_ts_end(ts);
 }
 
 // combine the per-chunk partials -> stat[b,h] = (max, 1/sum)
@@ -218,7 +220,8 @@ bifuse_apply(const float* __restrict__ x, const float* __restrict__ ln_w, const 
              const float* __restrict__ b_ov, const float* __restrict__ gamma_v, const float* __restrict__ drop_v,
              const float* __restrict__ drop_a, float p_drop, unsigned long long seed, const unsigned long long* seed_step, int B, int N, int chunks,
              float* __restrict__ y, float* __restrict__ pooled_part /* [B,chunks,NH,C] */,
-             float* __restrict__ spa_part /* [B,chunks,NH] */) {
+             float* __restrict__ spa_part /* [B,chunks,NH] */, unsigned long long* __restrict__ ts) {
+  combo_ts_begin(ts);
   __shared__ float4 red[WAVES][4][64];
   __shared__ float reds[WAVES][NH];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -288,6 +291,7 @@ bifuse_apply(const float* __restrict__ x, const float* __restrict__ ln_w, const 
     for (int wv = 0; wv < WAVES; ++wv) ss += reds[wv][threadIdx.x];
     spa_part[((long long)b * chunks + chunk) * NH + threadIdx.x] = ss;
   }
+  combo_ts_end(ts);
 }
 
 // =====================================================================================================
@@ -300,7 +304,8 @@ bifuse_bwd1(const float* __restrict__ x, const float* __restrict__ ln_w, const f
             const float* __restrict__ drop_a, float p_drop, unsigned long long seed, const unsigned long long* seed_step, const float* __restrict__ dy,
             const float* __restrict__ dpooled, const float* __restrict__ dspa, int B, int N, int chunks,
             float* __restrict__ dp /* [B,NH,N] */, float* __restrict__ r_part /* [B,chunks,NH] */,
-            float* __restrict__ dz_part /* [B,chunks,NH,C] */, float* __restrict__ dgb_part /* [B,chunks,2,C] */) {
+            float* __restrict__ dz_part /* [B,chunks,NH,C] */, float* __restrict__ dgb_part /* [B,chunks,2,C] */, unsigned long long* __restrict__ ts) {
+  combo_ts_begin(ts);
   __shared__ float4 red[WAVES][4][64];
   __shared__ float reds[WAVES][NH];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -392,6 +397,7 @@ bifuse_bwd1(const float* __restrict__ x, const float* __restrict__ ln_w, const f
     }
     reinterpret_cast<float4*>(dgb_part + (((long long)b * chunks + chunk) * 2 + k) * C)[lane] = t;
   }
+  combo_ts_end(ts);
 }
 
 // =====================================================================================================
@@ -404,7 +410,8 @@ bifuse_bwd2(const float* __restrict__ x, const float* __restrict__ ln_w, const f
             const float* __restrict__ dy, const float* __restrict__ dpooled, const float* __restrict__ dp,
             const float* __restrict__ rtot /* [B,NH] */, int B, int N, int chunks, float* __restrict__ dx,
             float* __restrict__ du_part /* [B,chunks,NH,C] */, float* __restrict__ dc_part /* [B,chunks,NH] */,
-            float* __restrict__ dln_part /* [B,chunks,2,C] */) {
+            float* __restrict__ dln_part /* [B,chunks,2,C] */, unsigned long long* __restrict__ ts) {
+  combo_ts_begin(ts);
   __shared__ float4 red[WAVES][4][64];
   __shared__ float reds[WAVES][NH];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -498,6 +505,7 @@ bifuse_bwd2(const float* __restrict__ x, const float* __restrict__ ln_w, const f
     }
     reinterpret_cast<float4*>(dln_part + (((long long)b * chunks + chunk) * 2 + k) * C)[lane] = t;
   }
+  combo_ts_end(ts);
 }
 
 }  // namespace
@@ -523,11 +531,14 @@ int combo_bifuse_forward_f32(const float* x, const float* ln_w, const float* ln_
     return COMBO_EINVAL;
   const int chunks = combo_bifuse_chunks(B, N);
   hipStream_t st = (hipStream_t)stream;
+  // device-side timing slots (bench.py's `other_kernels.bifuse`); work = algorithmic HBM bytes of the launch
+  const double act = (double)B * N * C * 4.0, sc = (double)B * NH * N * 4.0, ps = (double)N * C * 4.0;
   hipLaunchKernelGGL(bifuse_scores, dim3(B * chunks), dim3(THREADS), 0, st, x, ln_w, ln_b, eps, pos, u, c, B, N, chunks,
-                     scores, part_ws);
+                     scores, part_ws, combo_timing_next_slot(COMBO_TS_BIFUSE, act + ps + sc, act + ps + sc));
   hipLaunchKernelGGL(bifuse_softmax_stats, dim3((B * NH + 63) / 64), dim3(64), 0, st, part_ws, B, chunks, stat);
   hipLaunchKernelGGL(bifuse_apply, dim3(B * chunks), dim3(THREADS), 0, st, x, ln_w, ln_b, eps, scores, stat, z, b_ov,
-                     gamma_v, drop_v, drop_a, p_drop, seed, seed_step, B, N, chunks, y, pooled_part, spa_part);
+                     gamma_v, drop_v, drop_a, p_drop, seed, seed_step, B, N, chunks, y, pooled_part, spa_part,
+                     combo_timing_next_slot(COMBO_TS_BIFUSE, 2.0 * act + sc, 2.0 * act + sc));
   return (int)hipGetLastError();
 }
 
@@ -543,7 +554,9 @@ int combo_bifuse_backward1_f32(const float* x, const float* ln_w, const float* l
   const int chunks = combo_bifuse_chunks(B, N);
   hipLaunchKernelGGL(bifuse_bwd1, dim3(B * chunks), dim3(THREADS), 0, (hipStream_t)stream, x, ln_w, ln_b, eps, scores,
                      stat, z, b_ov, gamma_v, drop_v, drop_a, p_drop, seed, seed_step, dy, dpooled, dspa, B, N, chunks, dp, r_part,
-                     dz_part, dgb_part);
+                     dz_part, dgb_part,
+                     combo_timing_next_slot(COMBO_TS_BIFUSE, 2.0 * B * N * C * 4.0 + 2.0 * B * NH * N * 4.0,
+                                            2.0 * B * N * C * 4.0 + 2.0 * B * NH * N * 4.0));
   return (int)hipGetLastError();
 }
 
@@ -558,7 +571,9 @@ int combo_bifuse_backward2_f32(const float* x, const float* ln_w, const float* l
   const int chunks = combo_bifuse_chunks(B, N);
   hipLaunchKernelGGL(bifuse_bwd2, dim3(B * chunks), dim3(THREADS), 0, (hipStream_t)stream, x, ln_w, ln_b, eps, pos,
                      scores, stat, u, drop_a, p_drop, seed, seed_step, dy, dpooled, dp, rtot, B, N, chunks, dx, du_part, dc_part,
-                     dln_part);
+                     dln_part,
+                     combo_timing_next_slot(COMBO_TS_BIFUSE, 3.0 * B * N * C * 4.0 + (double)N * C * 4.0 + 2.0 * B * NH * N * 4.0,
+                                            3.0 * B * N * C * 4.0 + (double)N * C * 4.0 + 2.0 * B * NH * N * 4.0));
   return (int)hipGetLastError();
 }
 
