@@ -522,6 +522,13 @@ def main():
         else:
             ach = d["work"] / secs / scale
         rec = pmc.get(name, {}) if pmc.get("frames_per_launch") == bt else {}
+        if not rec and pmc.get("frames_per_launch") == bt:
+            # families whose launches are several kernels of the PMC file: the mean over the family's launches of one step
+            members = {"msda_bwd": ("msda_bwd_win_d32",),
+                       "bifuse": ("bifuse_scores", "bifuse_apply", "bifuse_bwd1", "bifuse_bwd2")}.get(name, ())
+            got = [pmc[m]["hbm_bytes_per_launch"] for m in members if isinstance(pmc.get(m), dict) and "hbm_bytes_per_launch" in pmc[m]]
+            if got and len(got) == len(members):
+                rec = {"hbm_bytes_per_launch": int(sum(got) / len(got))}
         r = {"kernel": name, "bound": bound, "achieved": round(ach, 1), "peak": round(peak, 1), "unit": unit, "frac": round(ach / peak, 4),
              "traffic": rec.get("hbm_bytes_per_launch"), "traffic_commit": pmc.get("commit") if rec else None,
              "avg_launch_us": round(d["us"] / d["launches"], 2), "launches": d["launches"],

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_bench.txt
 : > $OUT
 for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT"; do
-  COMBO_MIOPEN_BENCHMARK=0 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc -o p -- python3 $GRAFT_REPO_ROOT/bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  COMBO_MIOPEN_BENCHMARK=0 COMBO_GEMM_TUNING=0 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc -o p -- python3 $GRAFT_REPO_ROOT/bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
   python3 - <<PY | tee -a $OUT
 import csv,glob,collections,re
 fs=glob.glob("/tmp/pmc/**/*counter_collection.csv", recursive=True)
