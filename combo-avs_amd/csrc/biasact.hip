@@ -23,7 +23,7 @@ bias_act_kernel(u16* __restrict__ y, const float* __restrict__ bias, const u16* 
                 int relu) {
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= n8) return;
-  const int c8 = (int)(i % C8);
+  const int c8 = fast_mod(i, C8);
   uint4 v = reinterpret_cast<const uint4*>(y)[i];
   uint4 r = make_uint4(0, 0, 0, 0);
   if (res) r = reinterpret_cast<const uint4*>(res)[i];
@@ -89,7 +89,7 @@ bias_act_f32_kernel(float* __restrict__ y, const float* __restrict__ bias, const
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= n4) return;
   float4 v = reinterpret_cast<const float4*>(y)[i];
-  const float4 b = reinterpret_cast<const float4*>(bias)[(int)(i % C4)];
+  const float4 b = reinterpret_cast<const float4*>(bias)[fast_mod(i, C4)];
   v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
   if (res) {
     const float4 r = reinterpret_cast<const float4*>(res)[i];

@@ -14,6 +14,18 @@ __device__ __forceinline__ int xcd_contiguous(int id, int n) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
 }
 
+
+// Index arithmetic of the element-wise kernels: a 64-bit integer division costs ~100+ vector instructions on CDNA (no hardware
+// divider), more than the whole body of a bandwidth-bound kernel - the depth-wise convolution ran at 1.2 TB/s because of three
+// of them per thread.  Every tensor here has < 2^32 elements, so: 32-bit division whenever the dividend fits (the 64-bit path
+// stays for safety).
+__device__ __forceinline__ long long fast_div(long long a, int b) {
+  return ((unsigned long long)a >> 32) == 0 ? (long long)((unsigned)a / (unsigned)b) : a / b;
+}
+__device__ __forceinline__ int fast_mod(long long a, int b) {
+  return ((unsigned long long)a >> 32) == 0 ? (int)((unsigned)a % (unsigned)b) : (int)(a % b);
+}
+
 // ---- device-side launch timing (works inside a replayed hipGraph, where HIP refuses event records) ----
 // A slot = COMBO_TS_SLOT_U64 x u64: 16 sub-slots, one 128-byte line each, {earliest workgroup start, latest workgroup end}
 // in wall-clock ticks; sub-slot 0 also carries {sum of durations, launches} at +2 / +3.  The host hands every instrumented

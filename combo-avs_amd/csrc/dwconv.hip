@@ -57,6 +57,78 @@ dwconv3x3_kernel(const u16* __restrict__ x, const float* __restrict__ wT, const 
   *reinterpret_cast<uint4*>(y + i * 8) = o;
 }
 
+
+// v3 of the forward / backward-data kernel (round 3): v1 (one output token x 8 channels per thread) executes ~700 instructions
+// per 16 bytes written - nine bounds-checked taps with their own 64-bit address arithmetic and 18 weight loads - and runs at
+// 1.2 TB/s of (one read + one write) at every size: instruction-bound, not memory-bound (the HBM counters show exactly one
+// read and one write of the activation).  Here a thread walks a vertical strip of R output rows at one (w, 8 channels): the
+// 72 weights are loaded once, the 3 x 3 window slides down (3 new loads per output instead of 9), column validity is a
+// per-thread constant and a row outside the map is a row of zeros.
+template <int R>
+__global__ void __launch_bounds__(256)
+dwconv3x3_strip_kernel(const u16* __restrict__ x, const float* __restrict__ wT, const float* __restrict__ bias, int B, int H,
+                       int W, int C8, int flip, u16* __restrict__ y) {
+  const int HS = (H + R - 1) / R;
+  const long long id = xcd_contiguous(blockIdx.x, gridDim.x) * (long long)blockDim.x + threadIdx.x;
+  if (id >= (long long)B * HS * W * C8) return;
+  // (b, strip, w, c8), c8 fastest: a wave covers consecutive channels / neighbouring columns = contiguous memory
+  unsigned t = (unsigned)id;
+  const int c8 = t % (unsigned)C8; t /= (unsigned)C8;
+  const int w = t % (unsigned)W; t /= (unsigned)W;
+  const int hs = t % (unsigned)HS;
+  const int b = t / (unsigned)HS;
+  const int h0 = hs * R, C = C8 * 8;
+  float wt[9][8];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const float* wp = wT + (flip ? 8 - k : k) * C + c8 * 8;
+    const float4 a = *reinterpret_cast<const float4*>(wp), c = *reinterpret_cast<const float4*>(wp + 4);
+    wt[k][0] = a.x; wt[k][1] = a.y; wt[k][2] = a.z; wt[k][3] = a.w; wt[k][4] = c.x; wt[k][5] = c.y; wt[k][6] = c.z; wt[k][7] = c.w;
+  }
+  float bs[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) bs[k] = bias ? bias[c8 * 8 + k] : 0.f;
+  const bool lok = w > 0, rok = w < W - 1;
+  const long long rs = (long long)W * C8 * 8;                               // elements per image row
+  const u16* xc = x + (((long long)b * H * W + w) * C8 + c8) * 8;           // token (b, 0, w)
+  u16* yc = y + (((long long)b * H * W + w) * C8 + c8) * 8;
+  const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+  uint4 win[3][3];  // [row of the window][column w - 1, w, w + 1], packed bf16
+  auto load_row = [&](int hh, uint4 (&row)[3]) {
+    if (hh < 0 || hh >= H) { row[0] = row[1] = row[2] = zero; return; }
+    const u16* p = xc + hh * rs;
+    row[0] = lok ? *reinterpret_cast<const uint4*>(p - C8 * 8) : zero;
+    row[1] = *reinterpret_cast<const uint4*>(p);
+    row[2] = rok ? *reinterpret_cast<const uint4*>(p + C8 * 8) : zero;
+  };
+  load_row(h0 - 1, win[0]);
+  load_row(h0, win[1]);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int h = h0 + r;
+    if (h >= H) break;
+    load_row(h + 1, win[2]);
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = bs[k];
+#pragma unroll
+    for (int iy = 0; iy < 3; ++iy)
+#pragma unroll
+      for (int ix = 0; ix < 3; ++ix) {
+        float xv[8];
+        unpack8(win[iy][ix], xv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += wt[iy * 3 + ix][k] * xv[k];
+      }
+    uint4 o;
+    o.x = f2bf(acc[0]) | (f2bf(acc[1]) << 16); o.y = f2bf(acc[2]) | (f2bf(acc[3]) << 16);
+    o.z = f2bf(acc[4]) | (f2bf(acc[5]) << 16); o.w = f2bf(acc[6]) | (f2bf(acc[7]) << 16);
+    *reinterpret_cast<uint4*>(yc + h * rs) = o;
+#pragma unroll
+    for (int ix = 0; ix < 3; ++ix) { win[0][ix] = win[1][ix]; win[1][ix] = win[2][ix]; }
+  }
+}
+
 // partial[s][tap][c] = sum over the tokens of slice s of dy[p,c] * x[p + off(tap), c];  partial[s][9][c] = sum dy[p,c]
 __global__ void __launch_bounds__(256)
 dwconv3x3_wgrad_kernel(const u16* __restrict__ x, const u16* __restrict__ dy, int B, int H, int W, int C8, int slices,
@@ -117,8 +189,9 @@ dwconv3x3_wgrad2_kernel(const u16* __restrict__ x, const u16* __restrict__ dy, i
   for (int t = 0; t < 10; ++t)
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[t][k] = 0.f;
+  // (w, h) of the token, carried along instead of two integer divisions per token
+  int w = (int)((p0 + tl) % W), h = (int)(((p0 + tl) / W) % H);
   for (long long p = p0 + tl; p < p1; p += 32) {
-    const int w = (int)(p % W), h = (int)((p / W) % H);
     float g[8];
     unpack8(*reinterpret_cast<const uint4*>(dy + (p * C8 + c8) * 8), g);
 #pragma unroll
@@ -133,6 +206,8 @@ dwconv3x3_wgrad2_kernel(const u16* __restrict__ x, const u16* __restrict__ dy, i
 #pragma unroll
       for (int k = 0; k < 8; ++k) acc[t][k] += g[k] * xv[k];
     }
+    w += 32;
+    while (w >= W) { w -= W; if (++h == H) h = 0; }
   }
   const int C = C8 * 8;
   float* o = partial + (long long)s * 10 * C;
@@ -187,6 +262,19 @@ int combo_dwconv3x3_bf16(const void* x, const float* w_tap_major, const float* b
   if (!x || !w_tap_major || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 != 0 || ((uintptr_t)x & 15) ||
       ((uintptr_t)y & 15) || ((uintptr_t)w_tap_major & 15) || ((uintptr_t)bias & 15))
     return COMBO_EINVAL;
+  static const int strip = [] { const char* e = getenv("COMBO_DWCONV_STRIP"); return e ? atoi(e) : 1; }();  // A/B switch
+  if (strip && (long long)B * H * W * (C / 8) < (1ll << 31)) {
+    if (H >= 32) {
+      const long long total = (long long)B * ((H + 7) / 8) * W * (C / 8);
+      hipLaunchKernelGGL(dwconv3x3_strip_kernel<8>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                         (const u16*)x, w_tap_major, bias, B, H, W, C / 8, flip, (u16*)y);
+    } else {
+      const long long total = (long long)B * ((H + 3) / 4) * W * (C / 8);
+      hipLaunchKernelGGL(dwconv3x3_strip_kernel<4>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                         (const u16*)x, w_tap_major, bias, B, H, W, C / 8, flip, (u16*)y);
+    }
+    return (int)hipGetLastError();
+  }
   const long long total = (long long)B * H * W * (C / 8);
   hipLaunchKernelGGL(dwconv3x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const u16*)x, w_tap_major, bias, B, H, W, C / 8, flip, (u16*)y);

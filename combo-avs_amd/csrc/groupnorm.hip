@@ -56,9 +56,9 @@ gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, con
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= total4) return;
   const int C4 = C >> 2;
-  const int c = (int)(i % C4) * 4;
-  const long long tok = i / C4;
-  const int b = (int)(tok / HW);
+  const int c = fast_mod(i, C4) * 4;
+  const long long tok = fast_div(i, C4);
+  const int b = (int)fast_div(tok, HW);
   const int cpg = C / G;
   const float4 v = reinterpret_cast<const float4*>(x)[i];
   float r[4] = {v.x, v.y, v.z, v.w};
@@ -138,9 +138,9 @@ gn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, c
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= total4) return;
   const int C4 = C >> 2;
-  const int c = (int)(i % C4) * 4;
-  const long long tok = i / C4;
-  const int b = (int)(tok / HW);
+  const int c = fast_mod(i, C4) * 4;
+  const long long tok = fast_div(i, C4);
+  const int b = (int)fast_div(tok, HW);
   const int cpg = C / G;
   const float inv_n = 1.f / ((float)HW * cpg);
   const float4 gv = reinterpret_cast<const float4*>(dy)[i];

@@ -53,7 +53,7 @@ add_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ r, cons
     if (z) z[off + i] = v[i];
     const float o = (v[i] - mu) * rs * w[lane * VEC + i] + b[lane * VEC + i];
     y[off + i] = o;
-    if (yp) yp[off + i] = o + pos[(row % pos_rows) * C + lane * VEC + i];
+    if (yp) yp[off + i] = o + pos[(long long)fast_mod(row, (int)pos_rows) * C + lane * VEC + i];
   }
   if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }

@@ -44,7 +44,7 @@ prenorm_fwd_kernel(const PreArgs a) {
 #pragma unroll
   for (int i = 0; i < VEC; ++i) v[i] = a.x[off + i];
   if (a.r) {
-    const float s = a.scale ? a.scale[row / a.rows_per_sample] : 1.f;
+    const float s = a.scale ? a.scale[fast_div(row, (int)a.rows_per_sample)] : 1.f;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) v[i] += s * bf2f(a.r[off + i]);
   }
@@ -108,7 +108,7 @@ prenorm_bwd_kernel(const PreBwdArgs a) {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) d[i] += a.dz[off + i];
   }
-  const float s = (a.dr && a.scale) ? a.scale[row / a.rows_per_sample] : 1.f;
+  const float s = (a.dr && a.scale) ? a.scale[fast_div(row, (int)a.rows_per_sample)] : 1.f;
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
     a.dx[off + i] = d[i];

@@ -19,11 +19,11 @@ up2_fwd_kernel(const float* __restrict__ x, long long x_bstride4, int B, int H, 
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   const int OH = 2 * H, OW = 2 * W;
   if (i >= (long long)B * OH * OW * C4) return;
-  const int c = (int)(i % C4);
-  long long p = i / C4;
-  const int ox = (int)(p % OW); p /= OW;
-  const int oy = (int)(p % OH);
-  const int b = (int)(p / OH);
+  const int c = fast_mod(i, C4);
+  long long p = fast_div(i, C4);
+  const int ox = fast_mod(p, OW); p = fast_div(p, OW);
+  const int oy = fast_mod(p, OH);
+  const int b = (int)fast_div(p, OH);
   int y0, y1, x0, x1; float ly, lx;
   taps(oy, H, y0, y1, ly); taps(ox, W, x0, x1, lx);
   const float4* xb = reinterpret_cast<const float4*>(x) + (long long)b * x_bstride4 + c;
@@ -40,11 +40,11 @@ __global__ void __launch_bounds__(256)
 up2_bwd_kernel(const float* __restrict__ dy, int B, int H, int W, int C4, float* __restrict__ dx, long long dx_bstride4) {
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= (long long)B * H * W * C4) return;
-  const int c = (int)(i % C4);
-  long long p = i / C4;
-  const int ix = (int)(p % W); p /= W;
-  const int iy = (int)(p % H);
-  const int b = (int)(p / H);
+  const int c = fast_mod(i, C4);
+  long long p = fast_div(i, C4);
+  const int ix = fast_mod(p, W); p = fast_div(p, W);
+  const int iy = fast_mod(p, H);
+  const int b = (int)fast_div(p, H);
   const int OH = 2 * H, OW = 2 * W;
   const float4* gb = reinterpret_cast<const float4*>(dy) + (long long)b * OH * OW * C4 + c;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
