@@ -70,3 +70,22 @@ def test_product_never_imports_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b|combo_oracle", s, flags=re.M):
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_import_switches_off_the_graph_packet_capture_unless_the_caller_set_it():
+    """combo_avs_amd/__init__.py: hipGraph memset nodes replay wrongly with the HIP runtime's AQL packet capture on this stack
+    (DESIGN section 4); the package sets DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 at import - before the process's first HIP call - and
+    leaves a value the caller chose alone."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys; sys.path.insert(0, %r); import combo_avs_amd; "
+            "print(combo_avs_amd.GRAPH_MEMSET_GUARD, os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE'))" % root)
+    env = {k: v for k, v in os.environ.items() if k != "DEBUG_CLR_GRAPH_PACKET_CAPTURE"}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-1500:]
+    assert out.stdout.split()[-2:] == ["set", "0"]
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, DEBUG_CLR_GRAPH_PACKET_CAPTURE="1"),
+                         timeout=300)
+    assert out.returncode == 0, out.stderr[-1500:]
+    assert out.stdout.split()[-2:] == ["user", "1"]
