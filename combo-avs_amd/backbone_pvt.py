@@ -62,6 +62,9 @@ class _CastAll(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, dtype, *params):
+        if params[0].is_cuda:
+            from .ops.colsum import discard_deferred
+            discard_deferred()  # (bias-gradient work of an aborted backward pass, if any)
         out = [torch.empty_like(p, dtype=dtype) for p in params]
         if params[0].is_cuda and all(p.is_contiguous() for p in params):
             from .ops.foldcast import fold_cast  # csrc/foldcast.hip: tables of 56 tensors per launch

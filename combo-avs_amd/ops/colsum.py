@@ -42,6 +42,13 @@ def flush_deferred():
     _lib.check(lib.combo_colsum_grouped(ctypes.cast(arr, ctypes.c_void_p), len(q), _lib.current_stream()), "combo_colsum_grouped")
 
 
+def discard_deferred():
+    """drops queued work of a backward pass that never reached its flush (an exception on the way): the forward pass of the next
+    step calls this, so stale inputs are neither kept alive nor summed"""
+    global _pending, _pending_bytes
+    _pending, _pending_bytes = [], 0
+
+
 def _queue_column_sum(x2, out_dtype):
     """x2 [rows, C] contiguous -> a [C] tensor that is filled at the next flush_deferred()"""
     global _pending_bytes
