@@ -577,7 +577,7 @@ def main():
                        "name": args.config,
                        "launch": "eager" if (args.no_graph or eager_slots) else (
                            "2 hipGraphs (fwd + loss + head bwd | backbone bwd; the head's gradient all-reduce overlaps the second; AdamW eager)"
-                           if world > 1 and os.environ.get("COMBO_DP_OVERLAP", "1") == "1" else
+                           if dist.is_initialized() and os.environ.get("COMBO_DP_OVERLAP", "1") == "1" else
                            "hipGraph (fwd+loss+bwd captured; all-reduce + AdamW eager)"),
                        "instrumentation": "the instrumented kernels' timing atomics (2 per workgroup) and one fold launch per step run "
                                           "inside the timed region" if slot_timing else "HIP events around the MSDeformAttn core",
@@ -586,6 +586,9 @@ def main():
                                      "its '>= 40 % of the bf16 MFMA peak' target does not apply to this line; gradient GEMMs issue 3 bf16 "
                                      "products per fp32 multiply-add (ceiling 833 TFLOP/s useful)",
                        "grad_all_reduce": args.grad_comm,
+                       "collective": ("none (one rank)" if not dist.is_initialized() else
+                                      f"{dist.get_backend()} all-reduce (forced one-rank process group)" if world == 1 else
+                                      f"{dist.get_backend()} all-reduce of the flat gradient buffer"),
                        "global_batch_clips": args.clips * world, "frames_per_clip": T, "parallelism": f"dp{world}",
                        "precision": ("bf16 backbones (host PyTorch), " if args.dtype == "bf16" else "fp32 backbones, ")
                                     + ("head forward GEMMs on ONE bf16 product per multiply-add (own kernels; NOT the quoted metric)"

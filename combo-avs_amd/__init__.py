@@ -21,7 +21,13 @@ def _guard_graph_memsets():
     (trainer.graph_memset_selftest) instead of trusting this."""
     if "DEBUG_CLR_GRAPH_PACKET_CAPTURE" in _os.environ:
         return "user"
+    if _os.environ.get("COMBO_GRAPH_MEMSET_GUARD", "1") == "0":  # the embedding application manages the runtime's switches itself
+        return "off"
     _os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"
+    import logging
+    logging.getLogger(__name__).info(
+        "combo_avs_amd: set DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 for this process and its children (hipGraph memset nodes, "
+        "INTEGRATION.md section 6); COMBO_GRAPH_MEMSET_GUARD=0 leaves the environment alone")
     return "set"
 
 

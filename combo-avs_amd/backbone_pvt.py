@@ -61,10 +61,8 @@ class _CastAll(torch.autograd.Function):
     for PVTv2-B5)."""
 
     @staticmethod
-    def forward(ctx, dtype, *params):
-        if params[0].is_cuda:
-            from .ops.colsum import discard_deferred
-            discard_deferred()  # (bias-gradient work of an aborted backward pass, if any)
+    def forward(ctx, dtype, queue, *params):
+        ctx.queue = queue  # this application's deferred bias gradients (ops.colsum.DeferredColumnSums) or None
         out = [torch.empty_like(p, dtype=dtype) for p in params]
         if params[0].is_cuda and all(p.is_contiguous() for p in params):
             from .ops.foldcast import fold_cast  # csrc/foldcast.hip: tables of 56 tensors per launch
@@ -75,8 +73,8 @@ class _CastAll(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        from .ops.colsum import flush_deferred
-        flush_deferred()  # the bias gradients queued by _linear (ops/colsum.py): one grouped launch instead of ~300 pairs
+        if ctx.queue is not None:
+            ctx.queue.flush()  # the bias gradients queued by _linear (ops/colsum.py): one grouped launch instead of ~300 pairs
         idx = [i for i, g in enumerate(grads) if g is not None]
         g32 = [torch.empty(grads[i].shape, dtype=torch.float32, device=grads[i].device) for i in idx]
         if idx and grads[idx[0]].is_cuda:
@@ -94,7 +92,7 @@ class _CastAll(torch.autograd.Function):
         out = [None] * len(grads)
         for i, g in zip(idx, g32):
             out[i] = g
-        return (None,) + tuple(out)
+        return (None, None) + tuple(out)
 
 
 # Explicit-precision helpers.  `wts` maps id(parameter) -> its compute-dtype copy (from _CastAll) when the backbone runs
@@ -115,7 +113,7 @@ def _linear(x, mod, wts):
     if x.is_cuda and torch.is_grad_enabled():
         from .ops.colsum import linear_bias
         # with the batched casts (wts) every bias gradient is consumed by _CastAll.backward, which flushes the queue first
-        return linear_bias(x, w, _p(mod.bias, wts), defer=wts is not None)
+        return linear_bias(x, w, _p(mod.bias, wts), queue=None if wts is None else wts.get("colsum_queue"))
     return F.linear(x, w, _p(mod.bias, wts))
 
 
@@ -310,7 +308,12 @@ class PyramidVisionTransformerV2(nn.Module):
         if x.is_cuda and torch.is_autocast_enabled("cuda"):
             dtype = torch.get_autocast_dtype("cuda")
             params = self._cast_params()
-            wts = {id(p): c for p, c in zip(params, _CastAll.apply(dtype, *params))}
+            queue = None
+            if torch.is_grad_enabled():
+                from .ops.colsum import DeferredColumnSums
+                queue = DeferredColumnSums()  # one per application: flushed by THIS application's _CastAll.backward
+            wts = {id(p): c for p, c in zip(params, _CastAll.apply(dtype, queue, *params))}
+            wts["colsum_queue"] = queue
         with torch.autocast("cuda", enabled=False) if wts is not None else _NullCtx():
             return self._forward(x, wts)
 

@@ -76,11 +76,14 @@ def batch_miou_fscore(output, target, nclass, T=10, beta2=0.3):
     predict = predict * (tgt > 0)
     inter = predict * (predict == tgt)
 
-    def hist(x):  # [BF, C] counts of the values 1..C (0 = not counted, as histc with min = 1)
+    def hist(x):  # [BF, C] counts of the values 1..C; anything else is not counted, as histc(min = 1, max = C) drops it:
+        # 0 and below (unlabelled) AND ids above C - 1 such as the AVSS ignore label 255 (256 after the + 1)
         h = torch.zeros(BF, nclass + 1, device=x.device, dtype=torch.float32)
-        h.scatter_add_(1, x.reshape(BF, -1).clamp(0, nclass), torch.ones(BF, x[0].numel(), device=x.device))
+        x = x.reshape(BF, -1)
+        x = torch.where((x < 0) | (x > nclass), torch.zeros_like(x), x)
+        h.scatter_add_(1, x, torch.ones(BF, x.shape[1], device=x.device))
         return h[:, 1:]
-    a_i, a_p, a_l = hist(inter), hist(predict), hist(tgt.clamp(min=0))
+    a_i, a_p, a_l = hist(inter), hist(predict), hist(tgt)
     a_u = a_p + a_l - a_i
     iou = a_i / (2.220446049250313e-16 + a_u)
     prec, rec = a_i / a_p, a_i / a_l

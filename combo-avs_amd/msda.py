@@ -22,35 +22,55 @@ _algo = ALGO_AUTO
 # window table and LDS from the level sizes ON THE HOST: the pixel decoder, which builds the tensors from python ints,
 # registers them (no synchronisation); for a tensor of unknown origin the geometry is fetched once with a device->host copy -
 # unless the stream is being captured, in which case the two-kernel path (no host geometry needed) runs.
-_host_geometry = {}
+_host_geometry = {}  # id(spatial_shapes tensor) -> (weakref to it, its _version, entry): entries die with their tensor
+_geometry_by_value = {}  # (H0, W0, H1, W1, ...) -> (ctypes shapes, ctypes starts, tuple): one per distinct pyramid, tiny
 # ON by default: measured on MI355X inside the bench step (tools/ab_msda_bwd_model.sh) the one-launch windowed kernel takes
 # 247 us per layer against 295 us for the two-kernel path (185 + 110) and needs every operand once.  COMBO_MSDA_BWD_WIN=0
 # selects the two-kernel path.
 WINDOWED_BACKWARD = __import__("os").environ.get("COMBO_MSDA_BWD_WIN", "1") == "1"
 
 
-def register_level_shapes(spatial_shapes, shapes_list):
-    """spatial_shapes: the int64 [L,2] device tensor handed to the op; shapes_list: the same (H, W) pairs as python ints"""
+def _host_entry(shapes_list):
     import ctypes
-    flat = [int(v) for hw in shapes_list for v in hw]
-    start, acc = [], 0
-    for h, w in shapes_list:
-        start.append(acc)
-        acc += int(h) * int(w)
-    L = len(shapes_list)
-    entry = ((ctypes.c_int * (2 * L))(*flat), (ctypes.c_int * L)(*start), tuple(flat), spatial_shapes)  # (keeps the tensor alive)
-    _host_geometry[(spatial_shapes.data_ptr(), L)] = entry
-    return entry
+    flat = tuple(int(v) for hw in shapes_list for v in hw)
+    e = _geometry_by_value.get(flat)
+    if e is None:
+        start, acc = [], 0
+        for h, w in shapes_list:
+            start.append(acc)
+            acc += int(h) * int(w)
+        L = len(shapes_list)
+        e = _geometry_by_value[flat] = ((ctypes.c_int * (2 * L))(*flat), (ctypes.c_int * L)(*start), flat)
+    return e
+
+
+def register_level_shapes(spatial_shapes, shapes_list):
+    """spatial_shapes: the int64 [L,2] device tensor handed to the op; shapes_list: the same (H, W) pairs as python ints.
+    The association lives as long as the tensor does (weak reference: nothing is pinned, the table cannot grow beyond the live
+    shape tensors) and is dropped when the tensor is modified in place (`_version`)."""
+    import weakref
+    e = _host_entry(shapes_list)
+    key = id(spatial_shapes)
+    ref = weakref.ref(spatial_shapes, lambda _r, k=key: _host_geometry.pop(k, None) if _host_geometry.get(k, (None,))[0] is _r else None)
+    _host_geometry[key] = (ref, spatial_shapes._version, e)
+    return e
 
 
 def _geometry_of(spatial_shapes, level_start_index):
-    key = (spatial_shapes.data_ptr(), spatial_shapes.shape[0])
-    g = _host_geometry.get(key)
-    if g is None and not torch.cuda.is_current_stream_capturing():
-        hs, st = spatial_shapes.cpu().tolist(), level_start_index.cpu().tolist()  # once per shapes tensor
-        g = register_level_shapes(spatial_shapes, hs)
-        if list(g[1]) != [int(v) for v in st]:  # a level_start_index that is not the running sum of H*W: not this kernel's layout
-            _host_geometry[key] = g = (None, None, None, spatial_shapes)
+    """-> (ctypes shapes, ctypes level starts, tuple) or (None, None, None) when the layout is not this kernel's, or None when
+    unknown and not fetchable (stream capture).  A shapes tensor the caller did not register costs ONE device->host copy per
+    tensor object (a caller that builds a new tensor per forward, as the reference's pixel decoder does, pays it per call:
+    register_level_shapes avoids it)."""
+    rec = _host_geometry.get(id(spatial_shapes))
+    if rec is not None and rec[0]() is spatial_shapes and rec[1] == spatial_shapes._version:
+        return rec[2]
+    if torch.cuda.is_current_stream_capturing():
+        return None
+    hs, st = spatial_shapes.cpu().tolist(), level_start_index.cpu().tolist()
+    g = register_level_shapes(spatial_shapes, hs)
+    if list(g[1]) != [int(v) for v in st]:  # a level_start_index that is not the running sum of H*W: not this kernel's layout
+        g = (None, None, None)
+        _host_geometry[id(spatial_shapes)] = (_host_geometry[id(spatial_shapes)][0], spatial_shapes._version, g)
     return g
 
 

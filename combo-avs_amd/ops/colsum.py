@@ -9,8 +9,6 @@ from .. import _lib
 
 import ctypes
 
-_pending = []        # [(dy2 [rows, C], out [C])]: bias gradients queued by linear_bias(..., defer=True)
-_pending_bytes = 0
 PENDING_CAP = int(__import__("os").environ.get("COMBO_COLSUM_PENDING_MB", "1024")) << 20  # queued inputs stay alive until the flush
 DEFER = __import__("os").environ.get("COMBO_COLSUM_DEFER", "1") == "1"  # A/B switch
 
@@ -20,44 +18,53 @@ class _ColsumProblem(ctypes.Structure):  # combo_colsum_problem (include/combo_a
                 ("C", ctypes.c_int), ("in_bf16", ctypes.c_int), ("out_bf16", ctypes.c_int)]
 
 
-def flush_deferred():
-    """computes every queued bias gradient with one grouped launch (+ one finish launch) per 40 problems.  Called by the
-    consumer of those gradients (backbone_pvt._CastAll.backward) and whenever the queued inputs exceed PENDING_CAP."""
-    global _pending, _pending_bytes
-    if not _pending:
-        return
-    q, _pending, _pending_bytes = _pending, [], 0
-    lib = _lib.lib()
-    arr = (_ColsumProblem * len(q))()
-    sl = [lib.combo_colsum_grouped_slices(x.shape[0], x.shape[1]) for x, _ in q]
-    need = sum(s * x.shape[1] for s, (x, _) in zip(sl, q) if s > 1)
-    scratch = torch.empty(max(need, 1), dtype=torch.float32, device=q[0][0].device)
-    off = 0
-    for i, (s_i, (x, out)) in enumerate(zip(sl, q)):
-        part = 0
-        if s_i > 1:
-            part = scratch.data_ptr() + 4 * off
-            off += s_i * x.shape[1]
-        arr[i] = _ColsumProblem(x.data_ptr(), out.data_ptr(), part, x.shape[0], x.shape[1], _code(x.dtype), _code(out.dtype))
-    _lib.check(lib.combo_colsum_grouped(ctypes.cast(arr, ctypes.c_void_p), len(q), _lib.current_stream()), "combo_colsum_grouped")
+class DeferredColumnSums:
+    """The bias gradients ONE backbone application queues during its backward pass (linear_bias(..., queue=q)) and the consumer
+    of those gradients (backbone_pvt._CastAll.backward of the SAME application) computes with one grouped launch (+ one finish
+    launch) per 40 problems.  One queue per application, not a module global: the two PVT backbones run their backward passes
+    on different HIP streams, and a queue they shared would be flushed by whichever finishes first - on its own stream, with
+    no event between it and the other backbone's producers.  Every entry is produced and flushed inside one autograd-stream
+    context; `flush` checks that.  A queue that dies unflushed (an exception inside the backward pass) frees its inputs with
+    the autograd graph that holds it - nothing is kept alive or summed into a later step."""
 
+    def __init__(self):
+        self.items, self.bytes, self.stream = [], 0, None
 
-def discard_deferred():
-    """drops queued work of a backward pass that never reached its flush (an exception on the way): the forward pass of the next
-    step calls this, so stale inputs are neither kept alive nor summed"""
-    global _pending, _pending_bytes
-    _pending, _pending_bytes = [], 0
+    def __len__(self):
+        return len(self.items)
 
+    def add(self, x2, out_dtype):
+        """x2 [rows, C] contiguous -> a [C] tensor that is filled at the next flush()"""
+        st = torch.cuda.current_stream(x2.device)
+        if self.items and st != self.stream:
+            raise RuntimeError("colsum: one deferred queue fed from two HIP streams (a queue belongs to ONE backbone application)")
+        self.stream = st
+        out = torch.empty(x2.shape[1], dtype=out_dtype, device=x2.device)
+        self.items.append((x2, out))
+        self.bytes += x2.numel() * x2.element_size()
+        if self.bytes > PENDING_CAP:
+            self.flush()
+        return out
 
-def _queue_column_sum(x2, out_dtype):
-    """x2 [rows, C] contiguous -> a [C] tensor that is filled at the next flush_deferred()"""
-    global _pending_bytes
-    out = torch.empty(x2.shape[1], dtype=out_dtype, device=x2.device)
-    _pending.append((x2, out))
-    _pending_bytes += x2.numel() * x2.element_size()
-    if _pending_bytes > PENDING_CAP:
-        flush_deferred()
-    return out
+    def flush(self):
+        if not self.items:
+            return
+        if torch.cuda.current_stream(self.items[0][0].device) != self.stream:
+            raise RuntimeError("colsum: deferred bias gradients flushed on another HIP stream than the one that queued them")
+        q, self.items, self.bytes = self.items, [], 0
+        lib = _lib.lib()
+        arr = (_ColsumProblem * len(q))()
+        sl = [lib.combo_colsum_grouped_slices(x.shape[0], x.shape[1]) for x, _ in q]
+        need = sum(s * x.shape[1] for s, (x, _) in zip(sl, q) if s > 1)
+        scratch = torch.empty(max(need, 1), dtype=torch.float32, device=q[0][0].device)
+        off = 0
+        for i, (s_i, (x, out)) in enumerate(zip(sl, q)):
+            part = 0
+            if s_i > 1:
+                part = scratch.data_ptr() + 4 * off
+                off += s_i * x.shape[1]
+            arr[i] = _ColsumProblem(x.data_ptr(), out.data_ptr(), part, x.shape[0], x.shape[1], _code(x.dtype), _code(out.dtype))
+        _lib.check(lib.combo_colsum_grouped(ctypes.cast(arr, ctypes.c_void_p), len(q), _lib.current_stream()), "combo_colsum_grouped")
 
 
 def _code(dt):
@@ -142,13 +149,13 @@ def add_channel_vector(x, v, channel_dim=1):
 class _LinearBias(Function):
     """F.linear with a bias whose gradient is channel_sum(dy) (backbone_pvt._linear).  Under autocast the forward computes in
     the autocast dtype while x / w / b may be fp32: the backward GEMMs then run in dy's dtype and the gradients are cast to the
-    inputs' dtypes, as autocast's own cast nodes would do.  defer: the bias gradient is queued and computed by the next
-    flush_deferred() (the caller guarantees one before anything reads it)."""
+    inputs' dtypes, as autocast's own cast nodes would do.  queue (a DeferredColumnSums): the bias gradient is queued there and
+    computed by the queue's next flush() (the caller guarantees one before anything reads it)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, defer):
+    def forward(ctx, x, w, b, queue):
         ctx.save_for_backward(x, w)
-        ctx.b_dtype, ctx.defer = b.dtype, defer
+        ctx.b_dtype, ctx.queue = b.dtype, queue
         return torch.nn.functional.linear(x, w, b)
 
     @staticmethod
@@ -161,17 +168,17 @@ class _LinearBias(Function):
         if ctx.needs_input_grad[1]:
             dw = (dy2.t() @ x.reshape(-1, x.shape[-1]).to(dy2.dtype)).to(w.dtype)
         if ctx.needs_input_grad[2]:
-            if ctx.defer and DEFER and dy2.is_contiguous():
-                db = _queue_column_sum(dy2, ctx.b_dtype)
+            if ctx.queue is not None and DEFER and dy2.is_contiguous():
+                db = ctx.queue.add(dy2, ctx.b_dtype)
             else:
                 db = sum_to_channels(dy2, -1, out_dtype=ctx.b_dtype)
         return dx, dw, db, None
 
 
-def linear_bias(x, w, b, defer=False):
+def linear_bias(x, w, b, queue=None):
     ok = (torch.float32, torch.bfloat16)
     if x.is_cuda and x.numel() > 0 and w.shape[0] % 4 == 0 and x.dtype in ok and w.dtype in ok and b.dtype in ok:
-        return _LinearBias.apply(x, w, b, defer)
+        return _LinearBias.apply(x, w, b, queue)
     return torch.nn.functional.linear(x, w, b)
 
 

@@ -46,6 +46,8 @@ class _AddLayerNorm(Function):
         ctx.save_for_backward(z if z is not None else x2, mean, rstd, weight)
         ctx.has_r, ctx.defer, ctx.shape = r is not None, defer, x.shape
         ctx.n_out = fanout + (1 if pos is not None else 0)
+        ctx.pos_rows = pos2.shape[0] if pos2 is not None else 0
+        ctx.pos_shape = pos.shape if pos is not None else None
         if ctx.n_out == 1:
             return y.view(x.shape)
         y = y.view(x.shape)
@@ -66,6 +68,14 @@ class _AddLayerNorm(Function):
                 gs.append(d if d.is_contiguous() else d.contiguous())
         if not gs:
             return (None,) * 8
+        dpos = None
+        if ctx.pos_rows and ctx.needs_input_grad[7] and dys[-1] is not None:
+            # d(y + pos)/dpos = 1, broadcast over the frames: dpos = the y + pos output's gradient summed over the frames
+            # (csrc/colsum.hip: no memset node in a captured step); pos is learnable at every call site (query_embed, the
+            # level embedding inside the pixel decoder's position rows)
+            from .colsum import channel_sum
+            dyp = gs[-1]
+            dpos = channel_sum(dyp, dyp.shape[0] // ctx.pos_rows, ctx.pos_rows * C, 1).view(ctx.pos_shape)
         while len(gs) > 4:  # (never with this model's fan-outs <= 4)
             gs = [gs[0] + gs[1]] + gs[2:]
         want_param = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
@@ -103,7 +113,7 @@ class _AddLayerNorm(Function):
                 out = torch.empty(2, C, device=z.device, dtype=torch.float32)
                 _linear_mod._flush_ln([[[use], out]])
                 dw, db = out[0], out[1]
-        return dz, (dz if ctx.has_r else None), dw, db, None, None, None, None
+        return dz, (dz if ctx.has_r else None), dw, db, None, None, None, dpos
 
 
 class LayerNorm(nn.LayerNorm):

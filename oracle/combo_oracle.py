@@ -446,7 +446,8 @@ def hungarian_matcher(pred_logits, pred_masks, targets, num_points=12544, rand=t
 # a15-a16  SetCriterion / SetCriterion_SS             modeling/criterion.py:121-287, criterion_ss.py:238-289
 # =====================================================================================================
 
-def uncertain_point_coords(src_masks, num_points, oversample_ratio, importance_sample_ratio, rand=torch.rand, topk_mask=None):
+def uncertain_point_coords(src_masks, num_points, oversample_ratio, importance_sample_ratio, rand=torch.rand, topk_mask=None,
+                           record=None):
     """detectron2 get_uncertain_point_coords_with_randomness with uncertainty = -|logit| (criterion.py:70-84,159-165).
     topk_mask: bool [n, oversampled points] - test hook: the frozen top-k SETS of the reference (golden `*/topk_bits`) instead
     of this function's own selection (the random stream is consumed identically; the order inside a set only changes the
@@ -463,6 +464,8 @@ def uncertain_point_coords(src_masks, num_points, oversample_ratio, importance_s
         logits = point_sample(src_masks, pc)
         unc = -logits.abs()
         idx = torch.topk(unc[:, 0, :], k=nu, dim=1)[1]
+        if record is not None:  # test hook: this run's own top-k SETS, in the form `topk_mask` accepts
+            record.append(torch.zeros(n, ns, dtype=torch.bool).scatter_(1, idx, True))
         idx = idx + ns * torch.arange(n, dtype=torch.long)[:, None]
         pc = pc.view(-1, 2)[idx.view(-1)].view(n, nu, 2)
     if nr > 0:
@@ -482,13 +485,13 @@ def loss_labels(pred_logits, targets, indices, num_classes, eos_coef=0.1):
 
 
 def loss_masks(pred_masks, targets, indices, num_masks, num_points=12544, oversample=3.0, importance=0.75,
-               rand=torch.rand, topk_mask=None):
+               rand=torch.rand, topk_mask=None, record=None):
     """criterion.py:137-186 -> (loss_mask, loss_dice)"""
     src = torch.cat([pred_masks[b, s] for b, (s, _) in enumerate(indices)])  # [Nm,h,w]
     tgt = torch.cat([targets[b]["masks"][t] for b, (_, t) in enumerate(indices)]).to(src.dtype)
     src, tgt = src[:, None], tgt[:, None]
     with torch.no_grad():
-        pc = uncertain_point_coords(src, num_points, oversample, importance, rand, topk_mask)
+        pc = uncertain_point_coords(src, num_points, oversample, importance, rand, topk_mask, record)
         labels = point_sample(tgt, pc).squeeze(1)
     logits = point_sample(src, pc).squeeze(1)
     l_mask = F.binary_cross_entropy_with_logits(logits, labels, reduction="none").mean(1).sum() / num_masks  # :44-62
@@ -512,13 +515,17 @@ def similarity_loss(middle, n_frame=5):
 
 
 def set_criterion(outputs, targets, num_classes=2, gt_frame_index=None, world_size=1, rand=torch.rand,
-                  num_points=12544, n_frame=5, frozen=None):
+                  num_points=12544, n_frame=5, frozen=None, record=None):
     """SetCriterion.forward (criterion.py:233-287).  `gt_frame_index`: None -> S4 rule (frames 0,5,10,... when
     len(outputs) != len(targets), :241-254); a LongTensor -> AVSS rule (criterion_ss.py:246-257).
     Returns the 39 un-weighted losses keyed like the reference.
     frozen: test hook - {"match_src", "match_tgt": int64 [10, Nm], "topk": bool [10, Nm, oversampled points]}: the reference's
     own discrete choices (golden `*/match_all_*`, `*/topk_bits`) replace the matcher's / the importance sampling's, so that a
-    gradient comparison is not at the mercy of a near-tie falling the other way."""
+    gradient comparison is not at the mercy of a near-tie falling the other way.
+    record: test hook - a dict that receives THIS run's choices in the same form ("match_src", "match_tgt", "topk"), for
+    injection into the implementation under test at sizes the golden fixtures do not cover (bs = 8)."""
+    rec_src, rec_tgt, rec_topk = [], [], []
+
     def select(t):
         if gt_frame_index is not None:
             return t.index_select(0, gt_frame_index)
@@ -540,11 +547,18 @@ def set_criterion(outputs, targets, num_classes=2, gt_frame_index=None, world_si
             topk_mask = frozen["topk"][li]
         sfx = "" if li == 0 else f"_{li - 1}"
         losses["loss_ce" + sfx] = loss_labels(lg, targets, ind, num_classes)
-        lm, ld = loss_masks(mk, targets, ind, num_masks, num_points, rand=rand, topk_mask=topk_mask)
+        rec_src.append(torch.cat([i for i, _ in ind]))
+        rec_tgt.append(torch.cat([j for _, j in ind]))
+        lm, ld = loss_masks(mk, targets, ind, num_masks, num_points, rand=rand, topk_mask=topk_mask,
+                            record=rec_topk if record is not None else None)
         losses["loss_mask" + sfx] = lm
         losses["loss_dice" + sfx] = ld
     for i, mid in enumerate(outputs["middles_attn_mask"]):  # :282-286
         losses[f"loss_cosine_{i}"] = similarity_loss(mid, n_frame)
+    if record is not None:
+        record.update(match_src=torch.stack(rec_src), match_tgt=torch.stack(rec_tgt))
+        if rec_topk:
+            record["topk"] = torch.stack(rec_topk)
     return losses
 
 
@@ -627,9 +641,11 @@ PIXEL_MEAN = (123.675, 116.280, 103.530)
 PIXEL_STD = (58.395, 57.120, 57.375)
 
 
-def maskformer_forward(P, batched_inputs, num_classes=2, training=True, rand=torch.rand, world_size=1):
+def maskformer_forward(P, batched_inputs, num_classes=2, training=True, rand=torch.rand, world_size=1, record=None):
     """Full model step on CPU: normalise, VGGish (no grad), dual R50, SEM mix, head, then the weighted
-    39-term loss (training) or the per-frame sem_seg maps (eval).  S4/MS3 path (is_avss_data False)."""
+    39-term loss (training) or the per-frame sem_seg maps (eval).  S4/MS3 path (is_avss_data False).
+    record: test hook - a dict that receives this run's discrete choices: "attn_masks" (list of 9 bool [BT,Q,hw], the form
+    `transformer_decoder(attn_override=...)` accepts) and the criterion's "match_src" / "match_tgt" / "topk"."""
     mean = torch.tensor(PIXEL_MEAN).view(1, 3, 1, 1)
     std = torch.tensor(PIXEL_STD).view(1, 3, 1, 1)
     images = torch.cat([b["images"] for b in batched_inputs]).float()
@@ -649,7 +665,9 @@ def maskformer_forward(P, batched_inputs, num_classes=2, training=True, rand=tor
     for b in batched_inputs:  # prepare_targets :443-458 (no padding needed at 224)
         for inst in b["instances"]:
             targets.append({"labels": inst["gt_classes"], "masks": inst["gt_masks"]})
-    losses = set_criterion(out, targets, num_classes, None, world_size, rand)
+    losses = set_criterion(out, targets, num_classes, None, world_size, rand, record=record)
+    if record is not None:
+        record["attn_masks"] = [a[::8].clone() for a in out["attn_masks"][:9]]  # one of the 8 identical head replicas
     wd = loss_weights()
     return {k: v * wd[k] for k, v in losses.items()}  # :384-391
 

@@ -245,6 +245,22 @@ def gen_head_and_criterion(R):
         "fusion_module.b_attn.attn_list.0.v_proj.weight", "fusion_module.b_attn.gamma_a",
         "fusion_module.b_attn.attn_list.0.values_v_proj.weight",
         "audio_transformation.embeddings.0.weight", "predictor.class_embed.weight",
+        # round 4: the small tensors (position / level embeddings, biases, norm affines) - the ones a whole-buffer comparison
+        # cannot see and whose gradients the product computes on separate paths (ops/layernorm.py's `y + pos` output,
+        # csrc/colsum.hip, the deferred LayerNorm-parameter launch)
+        "predictor.query_embed.weight", "predictor.level_embed.weight", "pixel_decoder.transformer.level_embed",
+        "fusion_module.level_embed.weight", "fusion_module.audio_pos.weight",
+        "predictor.decoder_norm.weight", "predictor.decoder_norm.bias",
+        "predictor.transformer_ffn_layers.4.norm.bias", "predictor.transformer_cross_attention_layers.7.norm.weight",
+        "predictor.transformer_self_attention_layers.2.self_attn.in_proj_bias",
+        "predictor.transformer_ffn_layers.6.linear1.bias", "predictor.mask_embed.layers.0.bias",
+        "pixel_decoder.transformer.encoder.layers.2.norm2.weight", "pixel_decoder.transformer.encoder.layers.4.norm1.bias",
+        "pixel_decoder.transformer.encoder.layers.3.linear1.bias",
+        "pixel_decoder.transformer.encoder.layers.1.self_attn.attention_weights.bias",
+        "pixel_decoder.transformer.encoder.layers.1.self_attn.sampling_offsets.bias",
+        "pixel_decoder.input_proj.1.0.bias", "pixel_decoder.input_proj.2.1.weight", "pixel_decoder.layer_1.norm.bias",
+        "pixel_decoder.mask_features.bias", "fusion_module.b_attn.attn_list.0.out_v_proj.bias",
+        "fusion_module.b_attn.layer_norm_v_list.0.weight", "fusion_module.b_attn.gamma_v_list.0",
     ]
     named = dict(head.named_parameters())
 

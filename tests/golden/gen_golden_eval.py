@@ -72,6 +72,8 @@ def gen_avss(out_path):
         logits[:, 6] += 0.8 * (torch.rand(T, H, W, generator=g) > 0.8)     # a class that is predicted but never present
         logits[:, 7] -= 100.0        # never predicted, never present: empty union in every frame (0 / 0 in `evaluate`)
         logits[1::2, 5] -= 100.0     # predicted (wrongly) in the even frames only: cls_count 5
+        if clip == 1:                # round 4: the ignore label the reference registers for AVSS (255 -> 256 after the + 1:
+            tgt[:, :3, :] = 255      # above histc's range, i.e. in NO class's ground-truth area; the prediction there counts)
         miou, fscore, cls, vid = R.calc_color_miou_fscore(logits, tgt, T=T)
         out[f"ss{clip}/logits"] = logits.numpy().astype(np.float32)
         out[f"ss{clip}/target"] = tgt.numpy().astype(np.int64)

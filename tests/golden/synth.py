@@ -120,7 +120,18 @@ def check_digest(t: torch.Tensor, d, name: str, rtol: float, atol: float, k: int
     return float(err.max())
 
 
-def check_digest_l2(t: torch.Tensor, d, name: str, rel_l2: float, cap_rms: float, k: int = 4096):
+# Gradients that sit downstream (in the backward flow) of MSDeformAttn's bilinear taps: the inputs, the 7x7 level's projection,
+# encoder layer 0's offsets and - round 4 - the pixel decoder's level embedding (it reaches the loss only through the queries
+# `src + pos`, i.e. through sampling offsets / attention weights of all six layers).  A tap within round-off of a pixel
+# boundary is a discrete event no injection can freeze; these are compared in energy form (check_digest_l2).
+PIXEL_BOUNDARY = ("feat.res3", "feat.res4", "feat.res5", "pixel_decoder.input_proj.0.0.weight",
+                  "pixel_decoder.transformer.encoder.layers.0.self_attn.sampling_offsets.weight",
+                  "pixel_decoder.transformer.level_embed",
+                  "pixel_decoder.transformer.encoder.layers.1.self_attn.sampling_offsets.bias",  # = a plain sum of grad_loc
+                  "pixel_decoder.transformer.encoder.layers.1.self_attn.attention_weights.bias")  # 96 entries, 2 of them
+
+
+def check_digest_l2(t: torch.Tensor, d, name: str, rel_l2: float, cap_rms: float, k: int = 4096, frac_2e3_cap: float = 0.25):
     """Energy form of check_digest for gradients that sit downstream of a non-smooth operation (a bilinear tap of the
     deformable encoder within round-off of a pixel boundary lands on the other pixel in another implementation: that tap's
     gradient moves, and with it - slightly - every entry of the weight gradients the token feeds).  An outlier COUNT is the
@@ -135,10 +146,15 @@ def check_digest_l2(t: torch.Tensor, d, name: str, rel_l2: float, cap_rms: float
     rms = max(float(np.sqrt((b ** 2).mean())), 1e-30)
     l2 = float(np.sqrt((err ** 2).sum() / max((b ** 2).sum(), 1e-60)))
     worst = float((err - 2e-3 * np.abs(b)).max() / rms)
-    if os.environ.get("COMBO_TEST_VERBOSE") == "1":
-        print(f"[digest-l2] {name}: rel L2 err {l2:.3e} (allowed {rel_l2:g}), worst entry {worst:.4f} RMS (allowed {cap_rms:g})")
+    # the element-wise bound these tensors are excused from (2e-3 RMS + 2e-3 rel): the fraction beyond it is printed on every
+    # run and capped, so that a regression of the element-wise agreement is visible although it is not the pass criterion
+    # (measured on the CPU oracle, frozen choices: <= 15.5 %; s4 mode: 0 %)
+    frac = float((err > 2e-3 * rms + 2e-3 * np.abs(b)).mean())
+    print(f"[digest-l2] {name}: rel L2 err {l2:.3e} (allowed {rel_l2:g}), worst entry {worst:.4f} RMS (allowed {cap_rms:g}), "
+          f"{frac * 100:.2f}% of {len(a)} samples beyond 2e-3 RMS + 2e-3 rel (cap {frac_2e3_cap * 100:g}%)")
     assert l2 <= rel_l2, f"{name}: relative L2 error {l2:.3e} > {rel_l2:g}"
     assert worst <= cap_rms, f"{name}: an entry is {worst:.3f} RMS away from the reference (cap {cap_rms:g})"
+    assert frac <= frac_2e3_cap, f"{name}: {frac * 100:.2f}% of the samples beyond 2e-3 RMS + 2e-3 rel (cap {frac_2e3_cap * 100:g}%)"
     return l2
 
 

@@ -65,3 +65,23 @@ def test_bench_gpus_2_over_rccl_when_two_devices_exist():
     assert r.returncode == 0, r.stderr[-2000:]
     out = _json_line(r.stdout)
     assert out["n_gpus"] == 2 and out["config"]["global_batch_clips"] == 16 and out["value"] > 0
+
+
+def test_rccl_all_reduces_the_flat_gradient_buffer_on_one_gpu():
+    """RCCL itself, executed: a ONE-rank `nccl` process group on the one GPU (COMBO_FORCE_PG=1), so that `bench.py` initialises
+    RCCL (`dist.init_process_group("nccl", device_id=...)`), captures its graphs next to the live communicator and runs the
+    348 MB flat-buffer all-reduce (+ the overlapped head-region one on the side stream, + the `num_masks` one) through
+    `ncclAllReduce` every step - the code path of `train_net.py:284-291` / d2 `launch` at N = 8, at world size 1.  A fresh child
+    process, as the other tests of this file."""
+    env = dict(os.environ, COMBO_FORCE_PG="1", COMBO_MIOPEN_BENCHMARK="0", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT,
+               MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", NCCL_DEBUG="VERSION")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "COMBO_SINGLE_DEVICE", "COMBO_DIST_BACKEND"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--clips", "2",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _json_line(r.stdout)
+    assert out["n_gpus"] == 1 and out["value"] > 0
+    assert out["config"].get("collective") == "nccl all-reduce (forced one-rank process group)", out["config"]  # "nccl" IS RCCL on ROCm
+    assert out["config"]["launch"].startswith("2 hipGraphs"), out["config"]["launch"]  # the overlapped two-region flow ran

@@ -11,81 +11,68 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _to_gpu(batch):
-    return [{k: (v.cuda() if torch.is_tensor(v) else [{kk: vv.cuda() for kk, vv in i.items()} for i in v])
-             for k, v in b.items()} for b in batch]
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import graph_compare as GC  # noqa: E402
 
 
 @pytest.fixture(scope="module")
 def rig():
-    sys.path.insert(0, ROOT)
-    import combo_avs_amd  # noqa: F401
-    from bench import synth_batch
-    from combo_avs_amd import combo_cfg
-    from combo_avs_amd.meta_arch import build_model
-    from combo_avs_amd.trainer import FlatAdamW
-    cfg = combo_cfg(os.path.join(ROOT, "configs/avs_s4/COMBO_R50_bs8_90k.yaml"))
-    torch.manual_seed(0)
-    model = build_model(cfg).cuda().train()
-    for m in model.modules():  # no dropout: eager and replayed steps must agree number for number
-        if isinstance(m, torch.nn.Dropout):
-            m.p = 0.0
-        if isinstance(m, torch.nn.MultiheadAttention):
-            m.dropout = 0.0
-    for a in model.sem_seg_head.fusion_module.b_attn.attn_list:
-        a.dropout = 0.0
-    bank = torch.rand(40_000_000, generator=torch.Generator().manual_seed(5)).cuda()
-    state = {"off": 0}
-
-    def point_source(n, p):
-        o = state["off"]
-        state["off"] = o + n * p * 2
-        return bank[o:o + n * p * 2].view(n, p, 2)
-
-    model.criterion.point_source = point_source
-    # every forward (eager, the capture's warm-up iterations, the capture itself) reads the bank from offset 0
-    model.register_forward_pre_hook(lambda m, a: state.__setitem__("off", 0))
-    opt = FlatAdamW(model, base_lr=1e-4, weight_decay=0.05, backbone_multiplier=0.1, clip_value=0.01)
-    batches = [_to_gpu(synth_batch(2, 5, 224, 224, "cpu", seed=s)) for s in (11, 12)]
-    return model, opt, batches, state
+    return GC.build("r50")
 
 
-def _reset(opt, snap):
-    opt.flat_param.copy_(snap)
-    opt.exp_avg.zero_()
-    opt.exp_avg_sq.zero_()
-    opt.step_count = 0
+def _check_pair(i, ref_l, got_l, report, ref_p, got_p):
+    assert len(got_l) == 39
+    for k, v in got_l.items():
+        assert abs(v - ref_l[k]) <= 2e-4 * abs(ref_l[k]) + 1e-5, (i, k, v, ref_l[k])
+    # EVERY parameter of the optimiser's table on its own (round 4): relative L2 error <= 2e-3 and <= 1 % of ITS entries beyond
+    # 2e-3 RMS + 2e-3 rel.  A whole-buffer fraction cannot see the biases / level embeddings / norm affines (together far
+    # below 1 % of the 87 M entries) - which is how the wrong memset-node gradients of rounds 1-2 got through.
+    bad = GC.failures(report)
+    worst = sorted(report, key=lambda r: -r[3])[:5]
+    print(f"[graph vs eager, batch {i}] {len(report)} parameters, worst rel L2: " + ", ".join(f"{r[0]} {r[3]:.2e}" for r in worst))
+    assert not bad, [(r[0], r[1], f"rel_l2 {r[3]:.3e}", f"frac {r[4]:.4f}") for r in bad[:20]]
+    assert sum(1 for r in report if GC.small_tensor(r[0])) > 100  # the small tensors ARE in the table
+    # AdamW step 1 moves every parameter by lr * g / (|g| + eps): parameters whose gradient is ~eps (1e-8) amplify
+    # round-off differences, up to 2 * lr for a sign flip; everything else must agree
+    d = (got_p - ref_p).abs()
+    assert d.max() <= 2.1e-4 and float((d > 1e-5).float().mean()) < 1e-3, (float(d.max()), float((d > 1e-5).float().mean()))
 
 
 def test_graphed_step_equals_eager_step(rig):
-    from combo_avs_amd.trainer import GraphedTrainStep, train_step
     model, opt, batches, state = rig
-    snap = opt.flat_param.clone()
-    eager = []
-    for b in batches:
-        _reset(opt, snap)
-        losses = train_step(model, opt, b)
-        eager.append(({k: float(v) for k, v in losses.items()}, opt.flat_grad.clone(), opt.flat_param.clone()))
-    graphed = GraphedTrainStep(model, opt)
-    for i, b in enumerate(batches):
-        _reset(opt, snap)
-        losses = graphed(b)
-        ref_l, ref_g, ref_p = eager[i]
-        assert len(losses) == 39
-        for k, v in losses.items():
-            assert abs(float(v) - ref_l[k]) <= 2e-4 * abs(ref_l[k]) + 1e-5, (i, k, float(v), ref_l[k])
-        # boolean attention masks / top-k point selection flip on round-off (atomics in the eager torch ops are not
-        # bitwise reproducible), which moves a few gradient entries: bound the fraction, as the golden grad digests do
-        g = opt.flat_grad
-        bad = ((g - ref_g).abs() > 2e-3 * ref_g.abs().max()).float().mean()
-        assert float(bad) < 0.01, (i, float(bad), float((g - ref_g).abs().max()), float(ref_g.abs().max()))
-        # AdamW step 1 moves every parameter by lr * g / (|g| + eps): parameters whose gradient is ~eps (1e-8) amplify
-        # round-off differences, up to 2 * lr for a sign flip; everything else must agree
-        d = (opt.flat_param - ref_p).abs()
-        assert d.max() <= 2.1e-4 and float((d > 1e-5).float().mean()) < 1e-3, (float(d.max()), float((d > 1e-5).float().mean()))
+    graphed, out = GC.eager_and_graphed(model, opt, batches)
+    for i, (ref_l, got_l, report, ref_p, got_p, _, _) in enumerate(out):
+        _check_pair(i, ref_l, got_l, report, ref_p, got_p)
     assert len(graphed.graphs) == 1  # both batches share one signature -> one capture, second batch via static buffers
-    l1 = {k: float(v) for k, v in losses.items()}
-    assert any(abs(l1[k] - eager[0][0][k]) > 1e-4 for k in l1)  # the second batch really went through
+    assert any(abs(out[1][1][k] - out[0][0][k]) > 1e-4 for k in out[1][1])  # the second batch really went through
+
+
+def test_graphed_step_equals_eager_step_pvt_recipe():
+    """the same per-parameter comparison on the PVTv2-B5 recipe (bf16 backbones: ~630 bias gradients through the deferred
+    grouped column sums, the pre-norm kernels, stochastic depth off)"""
+    model, opt, batches, state = GC.build("pvt")
+    graphed, out = GC.eager_and_graphed(model, opt, batches[:1])
+    ref_l, got_l, report, ref_p, got_p, _, _ = out[0]
+    _check_pair(0, ref_l, got_l, report, ref_p, got_p)
+    assert len(graphed.graphs) == 1
+
+
+def test_per_parameter_comparison_catches_a_bypassed_colsum():
+    """The comparison above must FAIL on the build of rounds 1-2: ops.colsum replaced by ATen's split reductions (memset nodes
+    inside the captured step) with the runtime's graph packet capture on.  Run in a child process (the runtime reads the
+    switch at its first HIP call); skipped when this runtime replays memset nodes correctly (then there is nothing to catch)."""
+    import json
+    import subprocess
+    env = dict(os.environ, DEBUG_CLR_GRAPH_PACKET_CAPTURE="1", COMBO_ALLOW_PACKET_CAPTURE="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "graph_compare.py"), "r50", "--bypass-colsum"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    if res["selftest"]:
+        pytest.skip("this runtime replays hipGraph memset nodes correctly")
+    assert res["captured"]
+    assert res["failed_small"], res  # biases / level embeddings named one by one
+    print(f"[bypassed colsum] {len(res['failed'])} of {res['n']} parameters flagged, e.g. {res['failed_small'][:4]}")
 
 
 def test_fusion_dropout_is_fresh_on_every_replay():
@@ -123,6 +110,7 @@ def test_graphed_training_actually_learns(rig):
     must see the new values (a capture that froze copies of the weights would leave the loss where it started)."""
     from combo_avs_amd.trainer import GraphedTrainStep
     model, opt, batches, state = rig
+    _reset = GC.reset
     snap = opt.flat_param.clone()
     _reset(opt, snap)
     old = [(s[0], s[1], s[2], s[3]) for s in opt.segments]

@@ -561,16 +561,19 @@ def test_layernorm_fanout_aliases_and_pos_output_match_torch():
     ref.load_state_dict(ln.state_dict())
     x = torch.randn(B, S, C, device="cuda", requires_grad=True)
     r = torch.randn(B, S, C, device="cuda", requires_grad=True)
-    pos = torch.randn(1, S, C, device="cuda")
+    # pos is LEARNABLE at every call site (query_embed.weight; sine rows + level_embed): its gradient must come back
+    pos = torch.randn(1, S, C, device="cuda", requires_grad=True)
     w1, w2, w3 = (torch.randn(B, S, C, device="cuda") for _ in range(3))
     a, b, q = ln(x, r, fanout=2, pos=pos)
     assert a.data_ptr() == b.data_ptr() and q.data_ptr() != a.data_ptr()
     loss = (a * w1).sum() + (b * w2).sum() + (q * w3).sum()
-    got = torch.autograd.grad(loss, [x, r, ln.weight, ln.bias])
+    got = torch.autograd.grad(loss, [x, r, ln.weight, ln.bias, pos])
     x2, r2 = x.detach().clone().requires_grad_(True), r.detach().clone().requires_grad_(True)
+    pos2 = pos.detach().clone().requires_grad_(True)
     y = ref(x2 + r2)
-    loss2 = (y * w1).sum() + (y * w2).sum() + ((y + pos) * w3).sum()
-    want = torch.autograd.grad(loss2, [x2, r2, ref.weight, ref.bias])
+    loss2 = (y * w1).sum() + (y * w2).sum() + ((y + pos2) * w3).sum()
+    want = torch.autograd.grad(loss2, [x2, r2, ref.weight, ref.bias, pos2])
+    assert got[4].shape == pos.shape
     torch.testing.assert_close(a, y, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(q, y + pos, rtol=1e-5, atol=1e-5)
     for g, wnt in zip(got, want):
@@ -899,10 +902,11 @@ def test_deferred_grouped_column_sums_match_immediate_ones():
     torch.manual_seed(9)
     shapes = [(7840, 320), (7840, 1280), (31360, 128), (1960, 512), (49 * 40, 640), (125440, 64), (37, 12), (300, 2048)] * 7  # > 40 problems
     xs = [torch.randn(s, device="cuda").to(torch.bfloat16 if i % 3 else torch.float32) for i, s in enumerate(shapes)]
-    outs = [colsum._queue_column_sum(x, x.dtype) for x in xs]
-    assert len(colsum._pending) > 0
-    colsum.flush_deferred()
-    assert not colsum._pending
+    q = colsum.DeferredColumnSums()
+    outs = [q.add(x, x.dtype) for x in xs]
+    assert len(q) > 0
+    q.flush()
+    assert not len(q)
     for x, o in zip(xs, outs):
         want = x.double().sum(0)
         tol = (2 ** -8 if x.dtype == torch.bfloat16 else 1e-6) * float(want.abs().max()) + 4e-6 * x.shape[0] ** 0.5
@@ -910,7 +914,14 @@ def test_deferred_grouped_column_sums_match_immediate_ones():
     # the byte cap flushes by itself
     old, colsum.PENDING_CAP = colsum.PENDING_CAP, 1 << 20
     try:
-        o = colsum._queue_column_sum(xs[1], torch.float32)
-        assert not colsum._pending and torch.allclose(o, xs[1].float().sum(0), rtol=1e-3, atol=1e-2)
+        o = q.add(xs[1], torch.float32)
+        assert not len(q) and torch.allclose(o, xs[1].float().sum(0), rtol=1e-3, atol=1e-2)
     finally:
         colsum.PENDING_CAP = old
+    # a queue belongs to one backbone application = one autograd stream: feeding or flushing it from another stream raises
+    q.add(xs[0], torch.float32)
+    with torch.cuda.stream(torch.cuda.Stream()):
+        with pytest.raises(RuntimeError, match="two HIP streams"):
+            q.add(xs[1], torch.float32)
+        with pytest.raises(RuntimeError, match="another HIP stream"):
+            q.flush()

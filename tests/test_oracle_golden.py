@@ -203,9 +203,7 @@ def test_criterion_losses_and_grads(head_run, mode):
         P[p].requires_grad_(False)
 
 
-# gradients downstream of MSDeformAttn's bilinear taps (encoder layer 0's offsets, the 7x7 level's projection, the inputs)
-PIXEL_BOUNDARY = ("feat.res3", "feat.res4", "feat.res5", "pixel_decoder.input_proj.0.0.weight",
-                  "pixel_decoder.transformer.encoder.layers.0.self_attn.sampling_offsets.weight")
+PIXEL_BOUNDARY = synth.PIXEL_BOUNDARY  # (tests/golden/synth.py)
 
 
 @pytest.mark.parametrize("mode", ["s4", "all", "ss"])
