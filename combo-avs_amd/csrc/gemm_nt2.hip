@@ -120,7 +120,8 @@ __global__ void __launch_bounds__(256, Cfg::LDS <= 80 * 1024 ? 2 : 1)
 gemm_nt2_kernel(const float* __restrict__ A, long long lda, const float* __restrict__ Bimg, long long ldb,
                 const float* __restrict__ bias, float* __restrict__ C, long long ldc, int M, int N, int K, int relu,
                 int stagger, ConvGeom2 cg, int c_bytes, int batch, long long sA, long long sB, long long sC,
-                const float* __restrict__ mask, unsigned long long* ts, int products) {
+                const float* __restrict__ mask, unsigned long long* ts, int products, int dbg) {
+  // dbg: ablation bits (COMBO_NT2_DBG, tools/bench_nt2.py): 1 no DMA, 2 no LDS reads, 4 no barrier, 8 no stores, 16 no split, 32 no MFMA
   combo_ts_begin(ts);
   // products == 1: ONE bf16 product per multiply-add (hi . hi: plain bf16 inputs, fp32 accumulate) - the head's bf16 throughput
   // mode (forward GEMMs only); 3: the fp32-accurate split (hi . hi + hi . lo + lo . hi)
@@ -194,6 +195,7 @@ gemm_nt2_kernel(const float* __restrict__ A, long long lda, const float* __restr
     if (i_tile >= tiles) return;
     char* st = smem + i_slot * STAGE;
     const int k0 = i_s * kBK;
+    if (!(dbg & 1)) {
     // CONV: the stage's tap shifts the token rows by a wave-uniform element offset
     const long long a_off = CONV ? (long long)((i_tap / 3 - 1) * cg.W + (i_tap % 3 - 1)) * lda + i_cin0 : (long long)k0;
 #pragma unroll
@@ -209,6 +211,7 @@ gemm_nt2_kernel(const float* __restrict__ A, long long lda, const float* __restr
       } else {
         glds16(pb[u >= APW ? u - APW : 0] + k0, st + A_BYTES + (q - Cfg::A_PIECES) * 1024);
       }
+    }
     }
     ++issued;
     i_slot = i_slot == ST - 1 ? 0 : i_slot + 1;
@@ -256,10 +259,16 @@ gemm_nt2_kernel(const float* __restrict__ A, long long lda, const float* __restr
       // also drains the epilogue stores of the previous tile (stores and loads share vmcnt and may retire out of order).
       if (s == 0 && tile != w) wait_vm<0>();
       else wait_younger<PPW, ST>(issued - consumed - 1);
-      __builtin_amdgcn_s_barrier();  // everybody's pieces landed; everybody finished reading the slot refilled below
+      if (!(dbg & 4)) __builtin_amdgcn_s_barrier();  // everybody's pieces landed; everybody finished reading the slot refilled below
       issue_next();
       const unsigned so = (unsigned)(c_slot * STAGE);
       f4v ra[TI][2], rb[TJ][2];
+      if (dbg & 2) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i) ra[i][0] = ra[i][1] = f4v{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) rb[j][0] = rb[j][1] = f4v{1.f, 1.f, 1.f, 1.f};
+      } else {
 #pragma unroll
       for (int i = 0; i < TI; ++i) {
         ra[i][0] = i == 0 ? lds_read128<0>(a_c0 + so) : lds_read128<2048>(a_c0 + so);
@@ -288,6 +297,7 @@ gemm_nt2_kernel(const float* __restrict__ A, long long lda, const float* __restr
         static_assert((TI == 2 && TJ == 4) || (TI == 2 && TJ == 2) || (TI == 1 && TJ == 1), "add the register list of a new wave tile here");
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(rb[0][0]), "+v"(rb[0][1]) : : "memory");
       }
+      }
       bf16x8 bh[TJ], bl[TJ], ah[TI], al[TI];
 #pragma unroll
       for (int j = 0; j < TJ; ++j) {
@@ -295,7 +305,16 @@ gemm_nt2_kernel(const float* __restrict__ A, long long lda, const float* __restr
         bl[j] = __builtin_bit_cast(bf16x8, rb[j][1]);
       }
 #pragma unroll
-      for (int i = 0; i < TI; ++i) split8(ra[i][0], ra[i][1], ah[i], al[i]);
+      for (int i = 0; i < TI; ++i) {
+        if (dbg & 16) { ah[i] = __builtin_bit_cast(bf16x8, ra[i][0]); al[i] = __builtin_bit_cast(bf16x8, ra[i][1]); }
+        else split8(ra[i][0], ra[i][1], ah[i], al[i]);
+      }
+      if (dbg & 32) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) asm volatile("" : "+v"(acc[i][j]) : "v"(ah[i]), "v"(al[i]), "v"(bh[j]), "v"(bl[j]));
+      } else {
       if (products == 3) {  // wave-uniform
 #pragma unroll
         for (int i = 0; i < TI; ++i)
@@ -310,6 +329,7 @@ gemm_nt2_kernel(const float* __restrict__ A, long long lda, const float* __restr
       for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      }
       ++consumed;
       c_slot = c_slot == ST - 1 ? 0 : c_slot + 1;
     }
@@ -336,7 +356,8 @@ gemm_nt2_kernel(const float* __restrict__ A, long long lda, const float* __restr
             float v = acc[i][j][e] + bv;
             if (RELU) v = fmaxf(v, 0.f);
             if (MASK) v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(m_rsrc, off, 0, 0)) > 0.f ? v : 0.f;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), c_rsrc, off, 0, 0);
+            if (dbg & 8) asm volatile("" ::"v"(v));
+            else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), c_rsrc, off, 0, 0);
             off += (e & 3) == 3 ? uld5 : uld;  // rows 0-3, 8-11, 16-19, 24-27 (+4g); the next i starts 32 rows on
           }
       }
@@ -419,6 +440,11 @@ struct NtBatch {
   long long sA, sB, sC;
 };
 
+int nt2_dbg_bits() {
+  static const int d = [] { const char* e = getenv("COMBO_NT2_DBG"); return e ? atoi(e) : 0; }();
+  return d;
+}
+
 int g_products = 3;  // combo_gemm_nt2_products: bf16 products per multiply-add of the launches that follow (host state, read at launch)
 
 template <bool CONV, typename Cfg>
@@ -451,7 +477,7 @@ int launch_nt2_cfg(const float* A, long long lda, const float* Bimg, const float
                      (long long)K, bias, C, ldc, (int)M, N, K, relu, stagger, cg, (int)c_bytes, nb.batch, nb.sA, nb.sB, nb.sC, mask,
                      combo_timing_next_slot(g_products == 3 ? COMBO_TS_GEMM_X3 : COMBO_TS_GEMM_BF16, 2.0 * M * N * K * nb.batch,
                                             4.0 * nb.batch * ((double)M * (CONV ? K / 9 : K) + (double)N * K + (double)M * N)),
-                     g_products);
+                     g_products, nt2_dbg_bits());
   return (int)hipGetLastError();
 }
 

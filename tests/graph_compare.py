@@ -140,6 +140,9 @@ def main():
     for _, _, rep, *_ in out:
         bad += failures(rep)
     worst = sorted(out[0][2], key=lambda r: -r[3])[:8]
+    if "--dump" in sys.argv:
+        with open(sys.argv[sys.argv.index("--dump") + 1], "w") as f:
+            json.dump([o[2] for o in out], f)
     print(json.dumps({"selftest": selftest, "captured": bool(graphed.graphs), "n": len(out[0][2]),
                       "failed": sorted({r[0] for r in bad}), "failed_small": sorted({r[0] for r in bad if small_tensor(r[0])}),
                       "worst": [(r[0], r[1], r[3], r[4]) for r in worst]}))

@@ -394,7 +394,7 @@ def test_configs4_bf16_head_mode_at_full_size():
     for a in model.sem_seg_head.fusion_module.b_attn.attn_list:
         a.dropout = 0.0
     batch = synth_batch(4, 10, 224, 224, "cuda", seed=8, K=2, gt="all")
-    bank = torch.rand(60_000_000, generator=torch.Generator().manual_seed(5)).cuda()
+    bank = torch.rand(120_000_000, generator=torch.Generator().manual_seed(5)).cuda()  # ~72 M coordinates per forward
     state = {"off": 0}
 
     def point_source(n, p):
