@@ -316,6 +316,8 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "infer"],
                     help="train = the BASELINE metric (default); infer = eval-mode forward + fused semantic-inference tail "
                          "(SURVEY 8(f) rank 4: what pred.py times)")
+    ap.add_argument("--dump-slots", default="", help="comma-separated timing-slot kinds (csrc/combo_common.h COMBO_TS_*): print every "
+                                                     "instrumented launch of those kinds (work, bytes, average duration) to stderr")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_child:
@@ -491,8 +493,8 @@ def main():
             lib.combo_timing_slot_info(sl, ctypes.byref(kind), ctypes.byref(work))
             lib.combo_timing_slot_bytes(sl, ctypes.byref(nbytes))
             n_l = int(tsv[sl, 3])
-            if khz > 0 and n_l > 0 and os.environ.get("COMBO_BENCH_DUMP_SLOTS") and str(kind.value) in os.environ["COMBO_BENCH_DUMP_SLOTS"].split(","):
-                print(f"[slot {sl}] kind {kind.value} work {work.value:.4g} avg_us {float(tsv[sl, 2]) / khz * 1e3 / n_l:.1f}", file=sys.stderr)
+            if khz > 0 and n_l > 0 and args.dump_slots and str(kind.value) in args.dump_slots.split(","):
+                print(f"[slot {sl}] kind {kind.value} work {work.value:.4g} bytes {nbytes.value:.4g} avg_us {float(tsv[sl, 2]) / khz * 1e3 / n_l:.1f}", file=sys.stderr)
             if khz > 0 and n_l > 0:
                 d = per_kind.setdefault(kind.value, {"us": 0.0, "launches": 0, "work": 0.0, "bytes": 0.0, "nodes": 0, "big_us": 0.0,
                                                      "big_work": 0.0, "big_launches": 0})
@@ -533,9 +535,9 @@ def main():
              8: ("gemm_nt2_kernel (1 bf16 product: --head-dtype bf16)", "mfma", 2500.0, "TFLOP/s", 1e12)}
     # HBM traffic per launch: PMC passes of tools/pmc_bench.sh, valid only for the kernels of the commit they were taken at
     pmc, pmc_note = {}, None
-    pmc_path = os.path.join(ROOT, "profiles", os.environ.get("COMBO_PMC_FILE", "r03_pmc.json"))
+    pmc_path = os.path.join(ROOT, "profiles", "r04_pmc.json")
     if not os.path.exists(pmc_path):
-        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc.json")
+        pmc_path = os.path.join(ROOT, "profiles", "r03_pmc.json")
     if os.path.exists(pmc_path):
         with open(pmc_path) as f:
             pmc = json.load(f)

@@ -109,10 +109,7 @@ _SIGNATURES = {
     "combo_cosine_stats_f32": [c_void_p, c_longlong, c_longlong, c_int, c_void_p, c_void_p, c_void_p],
     "combo_cosine_grad_f32": [c_void_p, c_longlong, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_longlong, c_longlong, c_void_p],
     "combo_lsap_small_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
-    "combo_attn_mask_f32": [c_void_p] + [c_int] * 6 + [c_void_p, c_void_p],
-    "combo_attn_mask_pitched_f32": [c_void_p] + [c_int] * 7 + [c_void_p, c_void_p],
     "combo_attention_forward_f32": [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_int, c_void_p] + [c_int] * 5 + [c_float, c_void_p, c_void_p, c_void_p],
-    "combo_attn_mask_bits_f32": [c_void_p] + [c_int] * 7 + [c_void_p, c_int, c_void_p, c_void_p],
     "combo_attention_backward_f32": [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_int, c_void_p] + [c_int] * 5 + [c_float] + [c_void_p] * 8,
     "combo_adamw_f32": [c_void_p] * 4 + [c_longlong, c_void_p] + [c_float] * 7 + [c_void_p],
 }

@@ -32,7 +32,7 @@ def drop_path(x, p, training):
     return x * (mask / keep)
 
 
-PRENORM = __import__("os").environ.get("COMBO_PVT_PRENORM", "1") == "1"  # 0: per-op formulation (A/B, tests)
+PRENORM = True  # False: the per-op formulation (the reference of tests/test_kernels_gpu.py::test_pvt_prenorm_path_matches_per_op_path)
 
 
 class _NullCtx:

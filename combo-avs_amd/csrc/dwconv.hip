@@ -262,8 +262,7 @@ int combo_dwconv3x3_bf16(const void* x, const float* w_tap_major, const float* b
   if (!x || !w_tap_major || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 != 0 || ((uintptr_t)x & 15) ||
       ((uintptr_t)y & 15) || ((uintptr_t)w_tap_major & 15) || ((uintptr_t)bias & 15))
     return COMBO_EINVAL;
-  static const int strip = [] { const char* e = getenv("COMBO_DWCONV_STRIP"); return e ? atoi(e) : 1; }();  // A/B switch
-  if (strip && (long long)B * H * W * (C / 8) < (1ll << 31)) {
+  if ((long long)B * H * W * (C / 8) < (1ll << 31)) {  // strip kernel: 2.3 TB/s against 1.2 for the per-token kernel below
     if (H >= 32) {
       const long long total = (long long)B * ((H + 7) / 8) * W * (C / 8);
       hipLaunchKernelGGL(dwconv3x3_strip_kernel<8>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
@@ -288,10 +287,7 @@ int combo_dwconv3x3_wgrad_finish_f32(const float* partials, int slices, int C, f
   return (int)hipGetLastError();
 }
 
-static bool wgrad_v2() {
-  static const bool on = [] { const char* e = getenv("COMBO_DWCONV_WGRAD_V2"); return !e || atoi(e) != 0; }();  // A/B switch
-  return on;
-}
+static bool wgrad_v2() { return true; }  // (v1 below stays for channel counts that are not a multiple of 256)
 
 int combo_dwconv3x3_wgrad_slices(int B, int H, int W, int C) {
   const long long tokens = (long long)B * H * W;

@@ -493,7 +493,7 @@ int launch_one(F32Args a, hipStream_t stream, int cfg) {
 template <bool CONV>
 int launch_f32(F32Args a, hipStream_t stream) {
   static const int force = [] { const char* e = getenv("COMBO_F32_TILE"); return e ? atoi(e) : 0; }();  // 1 wide, 2 mid, 3 skinny (A/B)
-  static const int no_split = [] { const char* e = getenv("COMBO_F32_NOSPLIT"); return e ? atoi(e) : 0; }();
+  const int no_split = 0;
   if (force) return launch_one<CONV>(a, stream, force);
   const long long cus = n_cu_cached();
   const int bm[4] = {0, 256, 128, 64}, bn[4] = {0, 128, 128, 64};
@@ -584,8 +584,7 @@ splitk_finish_kernel(const float* __restrict__ part, int splits, long long M, in
  * library); the K slices run as the batch entries of ONE launch into [splits, M, N] partials, a second tiny launch sums them
  * in a fixed order and applies bias / ReLU.  Summation order differs from the unsplit kernel by re-association only. */
 extern "C" int combo_gemm_nt_splitk_plan(int M, int N, int K) {
-  static const int off = [] { const char* e = getenv("COMBO_F32_SPLITK"); return e ? atoi(e) == 0 : 0; }();
-  if (off || K < 1024 || N % 4 != 0) return 1;
+  if (K < 1024 || N % 4 != 0) return 1;
   const long long cus = n_cu_cached();
   const long long tiles = ((M + 127LL) / 128) * ((N + 127LL) / 128);  // mid tiles
   if (tiles * 2 > cus) return 1;

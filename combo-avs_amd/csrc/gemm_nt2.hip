@@ -5,7 +5,7 @@
 // 141 us = 18 launch/loop + 23 LDS-DMA + 5 LDS reads + 5 split + 43 MFMA + 49 epilogue, i.e. NOTHING overlapped):
 //   * persistent workgroups (grid = 2 per CU) walking the tile list: no workgroup launch / teardown between tiles and the
 //     first stages of the NEXT tile are already in flight while the epilogue of the current one is stored (an optional
-//     half-tile start stagger of the second workgroup per CU, COMBO_NT2_STAGGER=1, measured neutral to -3 us: off)
+//     half-tile start stagger of the second workgroup per CU measured neutral to -3 us: not kept)
 //   * the weight operand arrives PRE-SPLIT (combo_presplit_bf16x2_f32: per 8 k a 16-B bf16 `hi` group and a 16-B `lo`
 //     group, the same 4 bytes per element): v1 re-split every weight row in every workgroup (161 x 2 times)
 //   * waves 4 x 1 instead of 2 x 2: a wave owns 64 token rows x all 128 columns, so an A row is split once per workgroup
@@ -313,7 +313,7 @@ gemm_nt2_kernel(const float* __restrict__ A, long long lda, const float* __restr
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
-          for (int j = 0; j < TJ; ++j) asm volatile("" : "+v"(acc[i][j]) : "v"(ah[i]), "v"(al[i]), "v"(bh[j]), "v"(bl[j]));
+          for (int j = 0; j < TJ; ++j) asm volatile("" ::"v"(ah[i]), "v"(al[i]), "v"(bh[j]), "v"(bl[j]));  // (operands stay live, accumulators untouched)
       } else {
       if (products == 3) {  // wave-uniform
 #pragma unroll
@@ -460,16 +460,9 @@ int launch_nt2_cfg(const float* A, long long lda, const float* Bimg, const float
   }
   const long long tiles = ((M + Cfg::BM - 1) / Cfg::BM) * ((N + Cfg::BN - 1) / Cfg::BN) * nb.batch;
   if (tiles > 0x7fffffffLL) return COMBO_EINVAL;
-  static const int stagger_on = [] { const char* e = getenv("COMBO_NT2_STAGGER"); return e ? atoi(e) : 0; }();
   const long long slots = (Cfg::LDS <= 80 * 1024 ? 2LL : 1LL) * n_cu;  // resident workgroups
   const int grid = (int)(tiles < slots ? tiles : slots);
-  // half a tile of the main loop, in units of s_sleep(32) = 2048 cycles (a BK = 16 stage costs ~1500 cycles per wave)
-  int stagger = 0;
-  if (stagger_on && Cfg::ST == 3 && tiles > n_cu) {
-    stagger = (K / kBK) * 750 / 2048;
-    if (stagger < 1) stagger = 1;
-    if (stagger > 8) stagger = 8;
-  }
+  const int stagger = 0;  // (a half-tile start stagger of the second workgroup per CU measured neutral to -3 us: not kept)
   // extent of C in bytes for the epilogue's buffer descriptor (32-bit offsets)
   const long long c_bytes = ((M - 1) * ldc + N) * 4;
   if (c_bytes >= 0x7fffffffLL) return COMBO_EINVAL;

@@ -502,15 +502,11 @@ static int tn_variant(int N, int K) {  // 2: 256(n) x 128(k) block tiles, 1: 128
 }
 
 int combo_gemm_tn_splits(int M, int N, int K) {
-  if (const char* e = getenv("COMBO_GEMM_TN_SPLITS")) {  // tuning override
-    const int v = atoi(e);
-    if (v > 0) return v < (M + 127) / 128 ? v : (M + 127) / 128;
-  }
   if (N % 4 == 0 && K % 4 == 0 && N >= 64 && K >= 64 && M >= 256) {
     const int v = tn_variant(N, K);
     const long long tiles = v == 2 ? (long long)((N + 255) / 256) * ((K + 127) / 128)
                                    : (long long)((N + 127) / 128) * ((K + 255) / 256);
-    // measured (tools/bench_dw.py, COMBO_GEMM_TN_SPLITS sweep): one workgroup per CU for outputs of <= 4 tiles (every
+    // measured (tools/bench_dw.py, a sweep over the split count): one workgroup per CU for outputs of <= 4 tiles (every
     // extra split costs a 128-KiB partial tile written and re-read), two per CU for larger outputs
     long long s = ((tiles <= 4 ? 256 : 512) + tiles - 1) / tiles;
     const long long maxs = (M + 127) / 128;   // at least 8 stages per split
@@ -533,11 +529,9 @@ int combo_gemm_tn_x3_f32(const float* dY, long long ldy, const float* X, long lo
   mchunk = (mchunk + 15) / 16 * 16;
   const int nz = (M + mchunk - 1) / mchunk;
   if (nz != splits) return COMBO_EINVAL;  // caller sizes `out_partials` with combo_gemm_tn_splits / this rounding
-  const char* force = getenv("COMBO_GEMM_TN");  // "v1": direct-from-global kernel everywhere (A/B measurements)
-  if (glds_ok(dY, ldy, X, ldx, M, N, K) && !(force && force[0] == 'v' && force[1] == '1')) {
+  if (glds_ok(dY, ldy, X, ldx, M, N, K)) {  // (else: the direct-from-global kernel below, any alignment)
     constexpr int stage_bytes = kTS * 256 * 4 + kTS * 128 * 4;  // both variants: 24 KiB
-    int stages = 3;  // 3 stages x 2 workgroups/CU, or 5-6 stages x 1 workgroup/CU
-    if (const char* e = getenv("COMBO_GEMM_TN_STAGES")) stages = atoi(e) == 5 ? 5 : 3;
+    const int stages = 3;  // 3 stages x 2 workgroups/CU (measured against 5 stages x 1 workgroup/CU: the instances stay for tools)
     static bool attr = false;
     if (!attr) {
       const void* fns[4] = {reinterpret_cast<const void*>(gemm_tn_glds_kernel<2, 3>), reinterpret_cast<const void*>(gemm_tn_glds_kernel<1, 3>),
@@ -549,7 +543,7 @@ int combo_gemm_tn_x3_f32(const float* dY, long long ldy, const float* X, long lo
       attr = true;
     }
     const int lds = stages * stage_bytes;
-    static const int remap = [] { const char* e = getenv("COMBO_GEMM_XCD"); return e ? atoi(e) : 1; }();
+    const int remap = 1;  // XCD-contiguous tile order
     const bool v2 = tn_variant(N, K) == 2;
     const dim3 grid = v2 ? dim3((K + 127) / 128, (N + 255) / 256, nz) : dim3((K + 255) / 256, (N + 127) / 128, nz);
     if (v2 && stages == 3)
@@ -586,7 +580,7 @@ int combo_conv3x3_wgrad_x3_f32(const float* dY, long long ldy, const float* X, l
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  static const int remap = [] { const char* e = getenv("COMBO_GEMM_XCD"); return e ? atoi(e) : 1; }();
+  const int remap = 1;  // XCD-contiguous tile order
   TnConvGeom cg{H, W, Cin, (unsigned)(0xffffffffu / (unsigned)W + 1u), (unsigned)(0xffffffffu / (unsigned)H + 1u)};
   const dim3 grid((K + 127) / 128, (Cout + 255) / 256, splits);
   hipLaunchKernelGGL(conv3x3_wgrad_kernel, grid, dim3(256), lds, (hipStream_t)stream, dY, ldy, X, ldx, out_partials, (int)M,
@@ -604,7 +598,7 @@ int combo_gemm_tn_x3_grouped_f32(const combo_gemm_tn_problem* problems, int coun
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  static const int remap = [] { const char* e = getenv("COMBO_GEMM_XCD"); return e ? atoi(e) : 1; }();
+  const int remap = 1;  // XCD-contiguous tile order
   for (int base = 0; base < count; base += kMaxGroup) {
     TnGroupArgs a;
     a.count = count - base < kMaxGroup ? count - base : kMaxGroup;

@@ -1027,13 +1027,9 @@ int msda_forward(const T* value, const int64_t* shapes, const int64_t* lsi, cons
   if constexpr (sizeof(T) == 4)
     tap_ok = (D == 32) && S < 65535 && (L * P == 12 || L * P == 16) && fwd_tap_lds_bytes(S, L * P, 4) <= kLdsLimit;
   if (algo == 3 && !tap_ok) return COMBO_EINVAL;
-  if (const char* e = getenv("COMBO_MSDA_FWD")) {  // A/B switch: "v1" keeps the one-tile-per-workgroup kernel
-    if (e[0] == 'v' && e[1] == '1') tap_ok = tap_ok && algo == 3;
-  }
   if constexpr (sizeof(T) == 4) {
     if (tap_ok && (algo == 0 || algo == 3)) {
       int nw = 16;
-      if (const char* e = getenv("COMBO_MSDA_NW")) nw = atoi(e) >= 4 && atoi(e) <= 16 ? atoi(e) : nw;
       while (nw > 4 && fwd_tap_lds_bytes(S, L * P, nw) > kLdsLimit) --nw;
       static int n_cu = 0;
       if (n_cu == 0) {
@@ -1048,11 +1044,9 @@ int msda_forward(const T* value, const int64_t* shapes, const int64_t* lsi, cons
       int QT = rem ? n_cu / gcd(rem, n_cu) : 1;
       const int qt_max = Lq / (nw * kTapQW) > 0 ? Lq / (nw * kTapQW) : 1;
       if (QT > qt_max) QT = qt_max;
-      if (const char* e = getenv("COMBO_MSDA_QT")) QT = atoi(e) > 0 ? atoi(e) : QT;
       const int grid = NS >= n_cu ? n_cu : (NS * QT < n_cu ? NS * QT : n_cu);
       const size_t lds = fwd_tap_lds_bytes(S, L * P, nw);
-      int dbg = 0;  // ablation switch for tools/bench_msda.py (1: staging only, 3: no coordinate phase, 4: no gather)
-      if (const char* e = getenv("COMBO_MSDA_DBG")) dbg = atoi(e);
+      const int dbg = 0;  // (the kernel's ablation bits - 1: staging only, 3: no coordinate phase, 4: no gather - are compiled in)
       static bool attr12 = false, attr16 = false;
       if (L * P == 12) {
         if (!attr12) {
@@ -1080,7 +1074,6 @@ int msda_forward(const T* value, const int64_t* shapes, const int64_t* lsi, cons
       const int nw = fwd_lds_bytes(S, L, P, 12) <= kLdsLimit ? 12 : 8;
       int QT = 1;
       while ((long long)B * M * QT < 1024 && QT < 8 && Lq / (QT * 2) >= nw * kQW) QT *= 2;
-      if (const char* e = getenv("COMBO_MSDA_QT")) QT = atoi(e) > 0 ? atoi(e) : QT;
       const size_t lds = fwd_lds_bytes(S, L, P, nw);
       static bool attr_set = false;
       if (!attr_set) {
@@ -1089,8 +1082,7 @@ int msda_forward(const T* value, const int64_t* shapes, const int64_t* lsi, cons
         if (e != hipSuccess) return (int)e;
         attr_set = true;
       }
-      int dbg = 0;
-      if (const char* e = getenv("COMBO_MSDA_DBG")) dbg = atoi(e);
+      const int dbg = 0;
       hipLaunchKernelGGL(msda_fwd_lds_d32, dim3(B * M * QT), dim3(nw * 64), lds, stream, value, shapes, lsi, loc,
                          aw, B, S, M, L, Lq, P, QT, out, dbg);
       return (int)hipGetLastError();

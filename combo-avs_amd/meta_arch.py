@@ -119,7 +119,7 @@ class MaskFormer(nn.Module):
 
     # measured (bs = 8, hipGraph step, A/B in one session): 67.4 ms with the two encoders on two streams vs 66.7 ms on one -
     # the replayed graph does not overlap the branches and the fork/join costs a little; kept as an opt-in experiment
-    parallel_backbones = os.environ.get("COMBO_PARALLEL_BACKBONES", "0") == "1"
+    parallel_backbones = False
 
     def _loss_weights(self, keys, device):
         cache = self.__dict__.setdefault("_loss_weight_cache", {})

@@ -73,9 +73,11 @@ class SetCriterion(nn.Module):
         # Hungarian pairs and importance-sampling top-k sets (tests/golden `*/match_all_*`, `*/topk_bits`) used INSTEAD of the
         # device LSAP's / the selection kernel's, so that a gradient comparison does not hinge on a near-tie
         self.frozen_choices = None
+        # test hook: keep this forward's point coordinates (`last_coords`, next to `last_indices`) so that a second run can be
+        # given the same discrete choices as frozen_choices = {"match_src", "match_tgt", "coords"}
+        self.record_choices = False
         # True: SciPy on the host like the reference (always used when a frame has > 6 instances)
-        import os
-        self.host_lsap = os.environ.get("COMBO_HOST_LSAP", "0") == "1"
+        self.host_lsap = False
 
     # ---- individual losses -----------------------------------------------------------------------------
     def loss_labels(self, outputs, targets, indices, num_masks):
@@ -285,7 +287,7 @@ class SetCriterion(nn.Module):
         if self.frozen_choices is not None:
             src_q = self.frozen_choices["match_src"].to(dev)
             tgt_g = self.frozen_choices["match_tgt"].to(dev)
-            frame = frame.to(dev)
+            frame = self._static_match_index(tuple(G), L, Gmax, dev)[2]  # cached on the device: no copy inside a captured step
             assert src_q.shape == (L, Nm) and tgt_g.shape == (L, Nm)
             self.last_indices = (src_q, tgt_g, frame)
         elif Gmax <= self.matcher.LSAP_DEVICE_MAX_G and self.host_lsap is False:
@@ -330,6 +332,8 @@ class SetCriterion(nn.Module):
             coords = self._frozen_coords(over, extra, n_unc)
             if coords is None:
                 coords = maskloss.uncertain_points(xall.view(-1, *xall.shape[-2:]), mask_index, over, extra, n_unc)
+            if self.record_choices:
+                self.last_coords = coords
             n_mid = len(outputs.get("middles_attn_mask", []))
             bce, dice, dot, nrm = maskloss.mask_and_cosine(xall, n_mid, self.n_frame, mask_index, gt, gt_index, coords)
             bce, dice = bce.view(L, Nm), dice.view(L, Nm)
@@ -345,6 +349,8 @@ class SetCriterion(nn.Module):
         coords = self._frozen_coords(over, extra, n_unc)
         if coords is None:
             coords = maskloss.uncertain_points(masks32, mask_index, over, extra, n_unc)  # importance sampling, no sort
+        if self.record_choices:
+            self.last_coords = coords
         bce, dice = maskloss.mask_losses(masks32, mask_index, gt, gt_index, coords)
         bce, dice = bce.view(L, Nm), dice.view(L, Nm)
         loss_mask = bce.sum(1) / num_masks
@@ -355,6 +361,8 @@ class SetCriterion(nn.Module):
         """test hook (frozen_choices): the injected top-k SETS applied to this step's oversampled points -> [L*Nm, P, 2]"""
         if self.frozen_choices is None:
             return None
+        if "coords" in self.frozen_choices:  # the sampled coordinates themselves [L*Nm, P, 2] (a recorded run's `last_coords`)
+            return self.frozen_choices["coords"]
         keep = self.frozen_choices["topk"].to(over.device).reshape(over.shape[0], over.shape[1])
         assert bool((keep.sum(1) == n_unc).all())
         coords = over[keep].view(over.shape[0], n_unc, 2)

@@ -78,8 +78,7 @@ class MSDeformAttn(nn.Module):
         if offset_normalizer is None:
             offset_normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
         fused = (query.is_cuda and query.dtype == torch.float32 and not torch.is_autocast_enabled()
-                 and self.n_levels * self.n_points <= 16 and self.sampling_offsets.bias is not None
-                 and os.environ.get("COMBO_MSDA_PREP", "1") == "1")
+                 and self.n_levels * self.n_points <= 16 and self.sampling_offsets.bias is not None)
         if fused:
             # row a5 as two launches: ONE GEMM for both projections + the prologue kernel (loc = ref + off / (W,H); softmax)
             from ..ops.linear import linear_cat

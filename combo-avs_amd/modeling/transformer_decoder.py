@@ -20,9 +20,7 @@ from ..ops.linear import Linear, ffn, in_proj, linear
 from .layers import MLP, position_embedding_sine
 
 
-import os as _os
 from ..ops.colsum import add_channel_vector
-FUSED_MASKS = _os.environ.get("COMBO_FUSED_MASKS", "1") == "1"  # 0: per-head full logits + csrc/attnmask.hip (A/B)
 
 
 def _deferred_layer_norm(dim):
@@ -183,6 +181,9 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         # test hook: list of ops.masklogit.PackedMask, one per prediction head #0.., used INSTEAD of the masks computed from the
         # logits (tests inject the reference's own masks so that a gradient comparison does not hinge on a near-zero cell)
         self.attn_mask_override = None
+        # test hook: a list that receives the PackedMask of every prediction head of the next forward (what attn_mask_override
+        # accepts: a second run with the first run's masks injected has no discrete choice left in the decoder)
+        self.record_attn_masks = None
 
     @classmethod
     def from_config(cls, cfg, in_channels, mask_classification):
@@ -241,12 +242,11 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         # DOWNSAMPLED to the layer's memory size (interpolation and contraction commute), in one kernel whose MFMA result tile
         # is balloted into the bit-packed mask - the full-resolution logits are not needed inside the layer loop and are
         # computed for all heads by ONE launch after it.
-        self._fused_masks = (mf_tok.is_cuda and mf_tok.dtype == torch.float32 and c_m == 256 and mf_tok.is_contiguous()
-                             and max(h * w for h, w in size_list) <= 4096 and FUSED_MASKS)
-        self._mfd = {}
-        if self._fused_masks:
-            for sz in set(size_list):
-                self._mfd[sz] = masklogit.downsample_tokens(mf_tok, (h_m, w_m), sz)
+        if not (mf_tok.is_cuda and mf_tok.dtype == torch.float32 and c_m == 256 and mf_tok.is_contiguous()
+                and max(h * w for h, w in size_list) <= 4096):
+            raise RuntimeError("MultiScaleMaskedTransformerDecoder: contiguous fp32 CUDA mask features with 256 channels and memory "
+                               "levels of <= 4096 tokens expected (csrc/maskbits.hip; there is no CPU / generic fallback)")
+        self._mfd = {sz: masklogit.downsample_tokens(mf_tok, (h_m, w_m), sz) for sz in set(size_list)}
         predictions_class, mask_embeds = [], []
         self._head_no = 0
         outputs_class, mask_embed, blocked = self.forward_prediction_heads(output, mf_tok, (h_m, w_m), size_list[0], logit_buf[0])
@@ -269,8 +269,7 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
             predictions_class.append(outputs_class)
             mask_embeds.append(mask_embed)
         assert len(predictions_class) == self.num_layers + 1
-        if self._fused_masks:
-            masklogit.mask_logits_all_into(mask_embeds, mf_tok, logit_buf)  # all heads' full-resolution logits: one launch
+        masklogit.mask_logits_all_into(mask_embeds, mf_tok, logit_buf)  # all heads' full-resolution logits: one launch
         self._mfd = {}
         # ... and ONE autograd node carries the gradient of all heads back to mask_features / the mask embeddings
         logits_all = masklogit.attach_mask_logit_grads(mf_tok, logit_buf, mask_embeds)
@@ -293,12 +292,10 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         dec = self.decoder_norm(output)
         outputs_class = self.class_embed(dec)
         mask_embed = self.mask_embed(dec)
-        if self._fused_masks:
-            # (the mask of the LAST head is never used - the reference computes it anyway, transformer_decoder.py:474-478)
-            blocked = masklogit.mask_bits(mask_embed, self._mfd[tuple(attn_mask_target_size)]) if self._head_no < self.num_layers else None
-        else:
-            masklogit.mask_logits_into(mask_embed, mf_tok, logits_out)
-            blocked = masklogit.attn_mask_padded(logits_out.view(output.shape[0], self.num_queries, hw[0], hw[1]), attn_mask_target_size, True)
+        # (the mask of the LAST head is never used - the reference computes it anyway, transformer_decoder.py:474-478)
+        blocked = masklogit.mask_bits(mask_embed, self._mfd[tuple(attn_mask_target_size)]) if self._head_no < self.num_layers else None
+        if self.record_attn_masks is not None and blocked is not None:
+            self.record_attn_masks.append(blocked)
         if self.attn_mask_override is not None and self._head_no < len(self.attn_mask_override):
             blocked = self.attn_mask_override[self._head_no]
         self._head_no += 1

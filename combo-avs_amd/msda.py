@@ -24,10 +24,11 @@ _algo = ALGO_AUTO
 # unless the stream is being captured, in which case the two-kernel path (no host geometry needed) runs.
 _host_geometry = {}  # id(spatial_shapes tensor) -> (weakref to it, its _version, entry): entries die with their tensor
 _geometry_by_value = {}  # (H0, W0, H1, W1, ...) -> (ctypes shapes, ctypes starts, tuple): one per distinct pyramid, tiny
-# ON by default: measured on MI355X inside the bench step (tools/ab_msda_bwd_model.sh) the one-launch windowed kernel takes
-# 247 us per layer against 295 us for the two-kernel path (185 + 110) and needs every operand once.  COMBO_MSDA_BWD_WIN=0
-# selects the two-kernel path.
-WINDOWED_BACKWARD = __import__("os").environ.get("COMBO_MSDA_BWD_WIN", "1") == "1"
+# The one-launch windowed backward (csrc/msda_bwd.hip; 247 us per layer inside the bench step against 295 us for the pair) needs
+# the level sizes on the host.  The two-kernel pair behind combo_msda_backward_f32 - the reference's interface: device-side
+# shapes - remains the path for a shapes tensor of unknown content while the stream is being captured, and what tests compare
+# the windowed kernel with (module constant, not an environment switch).
+WINDOWED_BACKWARD = True
 
 
 def _host_entry(shapes_list):

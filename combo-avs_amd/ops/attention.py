@@ -4,7 +4,7 @@ Replaces `softmax(q k^T / sqrt(d) + mask) v` inside nn.MultiheadAttention as use
 (transformer_decoder/transformer_decoder.py:99-118, 50-58).  Operands are ROW VIEWS [B*L, >= H*32] (last dimension contiguous,
 any row stride that is a multiple of 4 floats): the q / k column blocks of a fused projection need no copy.  The mask is one
 byte per (frame, query, key) - not replicated over the heads - with rows padded to a multiple of 4 bytes
-(ops.masklogit.attn_mask_padded)."""
+(ops.masklogit.mask_bits / PackedMask)."""
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable

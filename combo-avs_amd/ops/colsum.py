@@ -9,8 +9,8 @@ from .. import _lib
 
 import ctypes
 
-PENDING_CAP = int(__import__("os").environ.get("COMBO_COLSUM_PENDING_MB", "1024")) << 20  # queued inputs stay alive until the flush
-DEFER = __import__("os").environ.get("COMBO_COLSUM_DEFER", "1") == "1"  # A/B switch
+PENDING_CAP = 1024 << 20  # bytes of queued inputs (they stay alive until the flush) beyond which a queue flushes by itself
+DEFER = True              # False: every bias gradient by its own pair of launches (A/B)
 
 
 class _ColsumProblem(ctypes.Structure):  # combo_colsum_problem (include/combo_avs.h)

@@ -19,12 +19,13 @@ from torch.autograd.function import once_differentiable
 from . import conv3x3 as C3
 from . import linear as L
 
-ENABLED = os.environ.get("COMBO_BACKBONE_WRW", "1") == "1"  # 0: the library's weight-gradient kernels (A/B)
+# Module constants (tests and tools/ flip them in-process; the measured A/B results are in DESIGN.md section 4):
+ENABLED = True   # weight gradients of the stride-1 1x1 / 3x3 convolutions on the head's grouped kernels (-1.9 ms per step)
 # input gradients on the head's 3-product kernels as well: bit 0 the 3x3 convolutions (measured: +1.3 ms per step, off), bit 1 the
 # 1x1 convolutions with >= DX_MIN_C channels (measured: -0.85 ms per step with all of them, on)
-DX_OWN = int(os.environ.get("COMBO_BACKBONE_DX", "2"))
-FWD_OWN = os.environ.get("COMBO_BACKBONE_FWD", "0") == "1"  # forward of the 1x1 layers on the exact-fp32 GEMM (A/B)
-DX_MIN_C = int(os.environ.get("COMBO_BACKBONE_DX_MINC", "64"))
+DX_OWN = 2
+FWD_OWN = False  # forward of the 1x1 layers on the exact-fp32 GEMM without a fused epilogue: +0.4 ms per step, off
+DX_MIN_C = 64
 
 
 def kind(x, w, stride, padding):

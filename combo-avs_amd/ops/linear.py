@@ -330,7 +330,7 @@ class _LnProblem(ctypes.Structure):  # combo_ln_grad_problem
                 ("partials", ctypes.c_void_p), ("tokens", ctypes.c_longlong), ("C", ctypes.c_int), ("tokens_per_slice", ctypes.c_int)]
 
 
-_GROUP_TOKENS_PER_SPLIT = int(_os.environ.get("COMBO_DW_TOKENS_PER_SPLIT", "1024"))
+_GROUP_TOKENS_PER_SPLIT = 1024  # token slice of a grouped weight-gradient problem (tools/bench_dw.py sweep)
 _dw_queue = None  # [[uses, dw_out, db_out, extras]] while a deferred_dw() context is open (uses = [(dy, x2d), ...])
 _dw_index = {}    # ("w" | "ln", parameter address) -> queue entry: repeated uses of one parameter join its entry
 _ln_queue = None  # [[uses, out[2,C]]]: LayerNorm parameter gradients, same idea (ops/layernorm.py)
@@ -735,7 +735,7 @@ def ffn(x, w1, b1, w2, b2, defer=True):
     return linear(h, w2, b2, defer=defer, mask_dx=fused)
 
 
-FFN_FUSED_RELU_GRAD = _os.environ.get("COMBO_FFN_FUSED_RELU_GRAD", "1") == "1"  # 0: separate ReLU-gradient kernel (A/B)
+FFN_FUSED_RELU_GRAD = True  # the ReLU gradient of an FFN rides in linear2's input-gradient GEMM (False: a separate kernel)
 
 
 class Linear(torch.nn.Linear):

@@ -1,8 +1,8 @@
 """`mask_embed @ pixel_embed` + next-layer attention mask (transformer_decoder.py:498-507 of the reference).
 HIP kernels: the forward contraction of every prediction head is a batched exact-fp32 MFMA GEMM (csrc/gemm_f32.hip, one
 problem per frame: [Q,C] x [HW,C]^T - its output is thresholded at 0 into the next layer's attention mask, so it computes in
-true fp32); csrc/attnmask.hip turns the logits into the mask (bilinear-downsample + sigmoid<0.5 + full-row reset in one
-launch); the two gradient GEMMs run ONCE over the concatenated heads on the 3-product bf16 kernels (csrc/gemm_nt2.hip
+true fp32); the mask itself comes from csrc/maskbits.hip (the same contraction against the DOWNSAMPLED pixel embedding, its MFMA
+result balloted into the bit-packed rows); the two gradient GEMMs run ONCE over the concatenated heads on the 3-product bf16 kernels (csrc/gemm_nt2.hip
 batched, csrc/gemm_tn.hip grouped, one problem per frame)."""
 import ctypes
 
@@ -105,24 +105,8 @@ def mask_logits_all_into(mask_embeds, mf_tok, out):
     return out
 
 
-def attn_mask_padded(logits, target_size, reset_full_rows=True):
-    """logits [BT,Q,H,W] fp32 -> PackedMask: blocked bytes [BT,Q,pitch] (pitch = h*w rounded up to 4, padding cells blocked)
-    and the same rows bit-packed, row reset of :458 applied; one launch."""
-    _lib.require_cuda(logits)
-    bt, Q, H, W = logits.shape
-    h, w = target_size
-    pitch = (h * w + 3) // 4 * 4
-    wpitch = (h * w + 63) // 64 * 2
-    out = torch.empty((bt, Q, pitch), dtype=torch.uint8, device=logits.device)
-    bits = torch.empty((bt, Q, wpitch), dtype=torch.int32, device=logits.device)
-    _lib.check(_lib.lib().combo_attn_mask_bits_f32(logits.data_ptr(), bt * Q, H, W, h, w, 1 if reset_full_rows else 0, pitch,
-                                                   out.data_ptr(), wpitch, bits.data_ptr(), _lib.current_stream()),
-               "combo_attn_mask_bits_f32")
-    return PackedMask(out, bits)
-
-
 def pack_mask(blocked, reset_full_rows=True):
-    """bool [BT,Q,n] (True = masked out; as produced by a prediction head) -> PackedMask in the layout attn_mask_padded
+    """bool [BT,Q,n] (True = masked out; as produced by a prediction head) -> PackedMask in the layout mask_bits
     writes, row reset of :458 applied.  Host-side torch ops: for tests that inject masks, not on the step's path."""
     bt, Q, n = blocked.shape
     b = blocked.clone()
@@ -136,12 +120,6 @@ def pack_mask(blocked, reset_full_rows=True):
     words = (full.view(bt, Q, wpitch, 32) << torch.arange(32, device=b.device)).sum(-1)  # bit k of word j = key 32 j + k
     words = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32)
     return PackedMask(by.contiguous(), words.contiguous())
-
-
-def attn_mask(logits, target_size, reset_full_rows=True):
-    """logits [BT,Q,H,W] fp32 -> blocked bool [BT,Q,h*w] (True = masked out), row reset of :458 applied."""
-    h, w = target_size
-    return attn_mask_padded(logits, target_size, reset_full_rows).bytes[:, :, :h * w].view(torch.bool)
 
 
 class _MaskLogitsAll(torch.autograd.Function):

@@ -461,30 +461,12 @@ int combo_splitk_reduce_f32(const float* partials, int splits, long long n, floa
                             float* db, combo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
- * a13 (tail)  next-layer attention mask
- *   replaces F.interpolate(outputs_mask, size, bilinear, align_corners=False).sigmoid() < 0.5 and the
- *   "fully blocked row" reset (models/modeling/transformer_decoder/transformer_decoder.py:502-507, :458).
- *   logits [N,H,W] fp32 (N = frames x queries), blocked [N,h*w] bytes (1 = masked out).  The same mask serves all
- *   8 heads (the reference repeats it 8x).  reset_full_rows != 0 applies the :458 rule.
- * ---------------------------------------------------------------------------------------------- */
-int combo_attn_mask_f32(const float* logits, int N, int H, int W, int h, int w, int reset_full_rows,
-                        unsigned char* blocked, combo_stream_t stream);
-/*   _pitched: rows of `blocked` are `pitch` >= h*w bytes apart and the padding cells are written as blocked: with pitch a
- *   multiple of 4 the attention kernels below read the 4 keys of a register group with one dword load. */
-int combo_attn_mask_pitched_f32(const float* logits, int N, int H, int W, int h, int w, int reset_full_rows, int pitch,
-                                unsigned char* blocked, combo_stream_t stream);
-/*   _bits: additionally (blocked may be NULL: only) the same rows bit-packed, bits [N, wpitch] words with bit k of word j =
- *   cell 32 j + k and every cell >= h*w set (blocked); wpitch >= ceil(h*w / 32).  The form the attention forward reads. */
-int combo_attn_mask_bits_f32(const float* logits, int N, int H, int W, int h, int w, int reset_full_rows, int pitch,
-                             unsigned char* blocked, int wpitch, unsigned* bits, combo_stream_t stream);
-
-/* ------------------------------------------------------------------------------------------------
  * a12  masked multi-head attention of the decoder layers, head_dim = 32 (csrc/attention.hip)
  *   replaces nn.MultiheadAttention's core `softmax(q k^T * scale + mask) v` as called by CrossAttentionLayer / SelfAttentionLayer
  *   (transformer_decoder/transformer_decoder.py:99-118, 50-58; the packed in_proj / out_proj GEMMs are combo_gemm_nt_f32).
  *   q [B, Lq, >= H*32] (row stride ldq), k / v [B, Lk, .] (ldk / ldv), head h at column h*32; blocked: bytes [B, Lq, pitch]
  *   (1 = masked out, shared by the H heads; NULL = no mask), pitch % 4 == 0; scale = head_dim^-0.5 is applied to q.
- *   Both also take the mask bit-packed (blocked_bits [B, Lq, wpitch] words from combo_attn_mask_bits_f32, NULL = use the
+ *   Both also take the mask bit-packed (blocked_bits [B, Lq, wpitch] words from combo_mask_bits_f32, NULL = use the
  *   bytes): one word per (query, 32-key tile) instead of 32 byte reads.
  *   forward:  out [B, Lq, H*32], lse [B, H, Lq] (log-sum-exp of the scaled masked scores, saved for backward), exact fp32 MFMA.
  *   backward: dq [B, Lq, H*32], dk / dv [B, Lk, H*32] from dout; delta_ws: [B, H, Lq] workspace.  A query whose keys are all

@@ -131,6 +131,24 @@ PIXEL_BOUNDARY = ("feat.res3", "feat.res4", "feat.res5", "pixel_decoder.input_pr
                   "pixel_decoder.transformer.encoder.layers.1.self_attn.attention_weights.bias")  # 96 entries, 2 of them
 
 
+def upstream_of_sampling(name):
+    """The RULE behind PIXEL_BOUNDARY, for implementations whose forward arithmetic is re-associated against the reference's (the
+    HIP path: exact-fp32 MFMA GEMMs sum in another order than torch's CPU kernels, so OTHER taps than the oracle's land within
+    round-off of a pixel boundary): every gradient that passes through the deformable encoder's bilinear sampling on its way
+    back - the head's inputs, the encoder's input projections (conv + GroupNorm), its level embedding, everything inside encoder
+    layers 0-4, and layer 5's offset / weight projections.  Layer 5's value / output / FFN / norm parameters, the FPN convolutions,
+    fusion, decoder and mask head are downstream only and stay on the element-wise bound.  Names as in head.npz (no
+    `sem_seg_head.` prefix) or with it."""
+    n = name[len("sem_seg_head."):] if name.startswith("sem_seg_head.") else name
+    if n.startswith(("feat.res3", "feat.res4", "feat.res5", "backbone.", "pre_sam_backbone.", "scale_factor_module.")):
+        return True
+    if n.startswith("pixel_decoder.input_proj") or n == "pixel_decoder.transformer.level_embed":
+        return True
+    if n.startswith("pixel_decoder.transformer.encoder.layers."):
+        return not n.startswith("pixel_decoder.transformer.encoder.layers.5.") or "sampling_offsets" in n or "attention_weights" in n
+    return False
+
+
 def check_digest_l2(t: torch.Tensor, d, name: str, rel_l2: float, cap_rms: float, k: int = 4096, frac_2e3_cap: float = 0.25):
     """Energy form of check_digest for gradients that sit downstream of a non-smooth operation (a bilinear tap of the
     deformable encoder within round-off of a pixel boundary lands on the other pixel in another implementation: that tap's

@@ -111,17 +111,9 @@ BS8_GRAD_PARAMS = (
 
 
 def _upstream_of_sampling(name):
-    """gradients that pass through the deformable encoder's bilinear taps on their way back (tests/golden/synth.PIXEL_BOUNDARY
-    explains why those are compared in energy form): the backbones, the SEM gates, the encoder's input projections, its level
-    embedding and everything inside layers 0-4; layer 5's own value / output / FFN / norm parameters are downstream only."""
-    if name.startswith(("backbone.", "pre_sam_backbone.", "scale_factor_module.")):
-        return True
-    pd = "sem_seg_head.pixel_decoder."
-    if name.startswith(pd + "input_proj") or name == pd + "transformer.level_embed":
-        return True
-    if name.startswith(pd + "transformer.encoder.layers."):
-        return not name.startswith(pd + "transformer.encoder.layers.5.") or "sampling_offsets" in name or "attention_weights" in name
-    return False
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import synth
+    return synth.upstream_of_sampling(name)
 
 
 def test_training_backward_bs8_matches_cpu_oracle(setup):

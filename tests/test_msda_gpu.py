@@ -238,7 +238,7 @@ def test_512_shape_bt80_full_size_properties_all_three_gradients():
 def test_windowed_fused_backward_matches_oracle_and_is_bitwise_deterministic(shapes, B):
     """csrc/msda_bwd.hip (the default backward for D = 32, P = 4): the one-launch kernel - workgroup = (frame, head, band of image
     rows of one level), all 32 channels, 2 x 32-bit fixed point per 64-bit LDS word - against the CPU oracle (all three
-    gradients), against the two-kernel path (COMBO_MSDA_BWD_WIN=0) and against itself (bitwise deterministic)."""
+    gradients), against the two-kernel path (msda.WINDOWED_BACKWARD = False) and against itself (bitwise deterministic)."""
     from combo_avs_amd import msda
     tag = f"win{len(shapes)}_{shapes[-1][0]}"
     v, shapes, loc, w = prod_inputs(B=B, shapes=shapes, seed_tag=tag)
