@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "combo_common.h"
+#include "gemm_nt3.h"
 
 namespace {
 
@@ -445,6 +446,11 @@ int nt2_dbg_bits() {
   return d;
 }
 
+bool use_nt3() {  // COMBO_DX_KERNEL=2: the round-3 kernel of this file (A/B during the round-4 rewrite, csrc/gemm_nt3.hip)
+  static const bool on = [] { const char* e = getenv("COMBO_DX_KERNEL"); return !(e && atoi(e) == 2); }();
+  return on;
+}
+
 int g_products = 3;  // combo_gemm_nt2_products: bf16 products per multiply-add of the launches that follow (host state, read at launch)
 
 template <bool CONV, typename Cfg>
@@ -556,8 +562,11 @@ extern "C" int combo_gemm_nt_x3_pre_batched_f32(const float* A, long long lda, l
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     return cus > 0 ? cus : 256;
   }();
-  const NtBatch nb{batch, sA, sB, sC};
   const int pad256 = (M + 255) / 256 * 256, pad128 = (M + 127) / 128 * 128;
+  if (use_nt3())
+    return combo_nt3_launch(A, lda, Bimg, K, nullptr, nullptr, C, ldc, M, N, K, relu, g_products, batch, sA, sB, sC, nullptr,
+                            pad128 < pad256 ? 2 : 1, stream);
+  const NtBatch nb{batch, sA, sB, sC};
   if (pad128 < pad256)
     return launch_nt2_cfg<false, NtMid>(A, lda, Bimg, nullptr, C, ldc, M, N, K, relu, ConvGeom2{1, 1, K}, n_cu, stream, nb);
   return launch_nt2_cfg<false, NtWide>(A, lda, Bimg, nullptr, C, ldc, M, N, K, relu, ConvGeom2{1, 1, K}, n_cu, stream, nb);
@@ -568,6 +577,8 @@ extern "C" int combo_gemm_nt_x3_pre_f32(const float* A, long long lda, const flo
   if (!A || !Bimg || !C || M <= 0 || N <= 0 || K <= 0 || K % kBK != 0 || lda % 4 != 0 || ((uintptr_t)A & 15) ||
       ((uintptr_t)Bimg & 15))
     return COMBO_EINVAL;
+  if (use_nt3() && !(bias && N > 2048))
+    return combo_nt3_launch(A, lda, Bimg, K, bias, nullptr, C, ldc, M, N, K, relu, g_products, 1, 0, 0, 0, nullptr, 0, stream);
   return launch_nt2<false>(A, lda, Bimg, bias, C, ldc, M, N, K, relu, ConvGeom2{1, 1, K}, stream);
 }
 
@@ -576,6 +587,8 @@ extern "C" int combo_gemm_nt_x3_pre_masked_f32(const float* A, long long lda, co
   if (!A || !Bimg || !C || !mask || M <= 0 || N <= 0 || K <= 0 || K % kBK != 0 || lda % 4 != 0 || ((uintptr_t)A & 15) ||
       ((uintptr_t)Bimg & 15))
     return COMBO_EINVAL;
+  if (use_nt3())
+    return combo_nt3_launch(A, lda, Bimg, K, nullptr, mask, C, ldc, M, N, K, 0, g_products, 1, 0, 0, 0, nullptr, 0, stream);
   return launch_nt2<false>(A, lda, Bimg, nullptr, C, ldc, M, N, K, 0, ConvGeom2{1, 1, K}, stream, mask);
 }
 
@@ -586,5 +599,9 @@ extern "C" int combo_conv3x3_nhwc_x3_pre_f32(const float* X, long long ldx, cons
   if (!X || !Wimg || !Y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % kBK != 0 || ldx % 4 != 0 ||
       ((uintptr_t)X & 15) || ((uintptr_t)Wimg & 15) || M > 0x7fffffffLL / 4)
     return COMBO_EINVAL;
+  if (use_nt3() && !(bias && Cout > 2048)) {
+    const combo_nt3_conv cg{H, W, Cin};
+    return combo_nt3_launch(X, ldx, Wimg, 9LL * Cin, bias, nullptr, Y, ldy, M, Cout, 9 * Cin, relu, g_products, 1, 0, 0, 0, &cg, 0, stream);
+  }
   return launch_nt2<true>(X, ldx, Wimg, bias, Y, ldy, M, Cout, 9 * Cin, relu, ConvGeom2{H, W, Cin}, stream);
 }

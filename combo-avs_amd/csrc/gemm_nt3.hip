@@ -1,0 +1,696 @@
+// gemm_nt3: C[M,N] = A[M,K] . B[N,K]^T (+ bias) (+ ReLU) (masked), fp32 accuracy from 3 bf16 MFMA products (hi.hi + lo.hi +
+// hi.lo, rounded `hi`: ~2^-17 relative per product) - the input-gradient GEMM dX = dY . W of every dense layer, the implicit-GEMM
+// 3x3 convolution's input gradient, the batched mask-logit gradients, and (products = 1) the head's bf16 forward mode.
+//
+// Why v3 (round 4).  gemm_nt2's phases did not overlap.  Ablation on MI355X (tools/bench_nt2.py, COMBO_NT2_DBG bits,
+// 41160 x 1024 -> 256, hot loop): 93 us = 25 (loop skeleton: waits, cursor, address arithmetic) + 30 (MFMA, i.e. the matrix
+// pipe at ~2.2 PF while it runs) + 31 (LDS-DMA issue + landing) + 8 (split) + 3 (LDS reads) + 3 (stores): the SUM of the parts,
+// although two workgroups shared each CU to overlap them - equal tiles keep them in phase.  Inside the training step the
+// kernel ran at 0.18 of its 833 TFLOP/s ceiling and 0.22 of HBM: bound by nothing.  v3 is gemm_f32.hip's skeleton (one
+// persistent workgroup per CU, one wave per SIMD with 512 registers, LDS-DMA ring with counted vmcnt across a raw s_barrier, a
+// wave covers its own latencies) re-timed for a matrix instruction that is 16x faster:
+//   * a stage (BK = 16) is ONE 32x32x16 MFMA triple per 32 x 32 sub-tile = 24 MFMAs of 32 cycles per wave (768 cycles; the
+//     f32 kernel has 4096 cycles per stage to hide the same 6 DMA pieces, 12 ds_read_b128 and 1 barrier);
+//   * phase 0 (hi.hi and lo.hi products, 16 MFMAs): the ds_reads of THIS stage's B `lo` groups and of the NEXT stage's raw A
+//     rows go out first, the DMA pieces of the stage entering the ring are issued between the MFMAs;
+//   * phase 1 (hi.lo products, 8 MFMAs): the next stage's B `hi` groups are read into the registers phase 0 just freed and
+//     the next stage's A rows are split (hi = rne_bf16(x), lo = rne_bf16(x - hi): 6 VALU per pair) between the MFMAs, into
+//     the other half of a two-set register ping-pong (no copies);
+//   * one barrier per stage, at its top: "stage s + 1 has landed for everybody and everybody is done with slot s - 1" (the
+//     slot the DMA of this stage refills), with ST - 3 younger stages left in flight;
+//   * the epilogue's 32 dwordx4 stores per wave are NOT waited for: the vmcnt budget of the next tile's first ST - 3 stages
+//     is raised by the number of stores (they are younger than every ring load those stages need), so the ring never drains
+//     at a tile boundary; operands swapped (D = W . X^T) as in gemm_f32: a lane owns 4 consecutive n of one token.
+// Tile shapes / row split: as gemm_f32.hip (wide 256 x 128, mid 128 x 128, skinny 64 x 64; whole rounds of large tiles + the
+// remaining rows on small ones).
+#include <cstdlib>
+#include <type_traits>
+
+#include "combo_common.h"
+#include "gemm_nt3.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((ext_vector_type(4))) unsigned u4v;
+
+__device__ __forceinline__ unsigned pack_rne(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+template <int OFF>
+__device__ __forceinline__ f4v lds_read128(unsigned addr) {  // inline asm: hipcc drains the LDS-DMA queue before a visible ds_read
+  f4v r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void glds16(const float* g, char* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+constexpr int kBK = 16;
+constexpr int kMaxBiasN = 2048;  // the bias vector lives in LDS (ordinary global loads next to the LDS-DMA stream drain the ring)
+
+__device__ __attribute__((aligned(64))) float g_zero_row3[16];  // zero-initialised: the source of padded conv taps
+
+template <int WM_, int WN_, int TI_, int TJ_, int ST_>
+struct N3Cfg {
+  static constexpr int WM = WM_, WN = WN_, TI = TI_, TJ = TJ_, ST = ST_;
+  static constexpr int NW = WM * WN;  // waves per workgroup: 4 (one per SIMD) or 8 (two per SIMD: one computes while the other
+                                      // sits in an LDS-DMA issue or an LDS wait)
+  static constexpr int BM = WM * TI * 32, BN = WN * TJ * 32;
+  static constexpr int A_BYTES = BM * kBK * 4, B_BYTES = BN * kBK * 4, STAGE = A_BYTES + B_BYTES;
+  static constexpr int A_PIECES = A_BYTES / 1024, PIECES = STAGE / 1024, PPW = PIECES / NW, APW = A_PIECES / NW;
+  static constexpr int RING = ST * STAGE;
+  static constexpr int LDS = RING + kMaxBiasN * 4;
+  static constexpr int STORES = TI * TJ * 4;  // dwordx4 stores per lane and tile
+  static_assert((NW == 4 || NW == 8) && PIECES % NW == 0 && A_PIECES % NW == 0, "the waves share the DMA pieces evenly");
+  static_assert(ST >= 4 && (ST - 3) * PPW + STORES <= 63, "vmcnt is a 6-bit counter");
+  static_assert(LDS <= 160 * 1024, "LDS budget of a CU");
+};
+typedef N3Cfg<8, 1, 1, 4, 6> NWide;     // 8 waves x (32 x 128): 24 KiB stages, 144 KiB ring
+typedef N3Cfg<2, 2, 2, 2, 8> NMid;      // 16 KiB stages, 128 KiB ring
+typedef N3Cfg<2, 2, 1, 1, 16> NSkinny;  //  8 KiB stages, 128 KiB ring = a whole K = 256 panel in flight
+
+struct N3Args {
+  const float* A; long long lda;
+  const float* B; long long ldb;   // pre-split image (combo_presplit_bf16x2_*): per 8 k a 16-B bf16 hi group + a 16-B lo group
+  const float* bias;               // [N] or nullptr
+  const float* mask;               // [M, N] (pitch ldc, batch stride sC) or nullptr: C = mask > 0 ? value : 0
+  float* C; long long ldc;
+  int M, N, K, relu, c_bytes, batch, vec_store, dbg, products;
+  long long sA, sB, sC;
+  combo_nt3_conv cg;
+  unsigned long long* ts;
+};
+
+// P3: three products (fp32-accurate) or one (plain bf16); ABL: ablation bits, COMPILE-TIME (a run-time test per bit costs a scalar
+// branch per use, ~1 000 cycles per stage in total - more than the stage itself): 1 no DMA, 2 no LDS reads, 4 no barrier, 8 no
+// stores, 16 no split, 32 no MFMA; the instances listed in launch_cfg3 exist (COMBO_NT3_DBG, tools/bench_nt2.py)
+template <bool CONV, typename Cfg, bool P3, int ABL>
+__global__ void __launch_bounds__(Cfg::NW * 64, Cfg::NW / 4)
+gemm_nt3_kernel(const N3Args p) {
+  constexpr int NW = Cfg::NW;
+  constexpr int dbg = ABL;
+  constexpr int BM = Cfg::BM, BN = Cfg::BN, TI = Cfg::TI, TJ = Cfg::TJ, ST = Cfg::ST, PPW = Cfg::PPW, APW = Cfg::APW;
+  constexpr int A_BYTES = Cfg::A_BYTES, STAGE = Cfg::STAGE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  combo_ts_begin(p.ts);
+  const float* __restrict__ A = p.A;
+  const float* __restrict__ Bm = p.B;
+  const long long lda = p.lda, ldb = p.ldb;
+  const int M = p.M, N = p.N, K = p.K;
+  const combo_nt3_conv cg = p.cg;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+  const int n_tiles = (N + BN - 1) / BN;
+  const int tpb = ((M + BM - 1) / BM) * n_tiles;  // tiles per batch entry
+  const int tiles = tpb * p.batch;
+  const int G = gridDim.x;
+  const int w = xcd_contiguous(blockIdx.x, G);  // every XCD owns a contiguous tile range: the n tiles of a token tile share an L2
+  const int nst = K / kBK;
+  if (w >= tiles) {  // (grid <= tiles by construction; kept for safety: no workgroup may skip the barriers below)
+    combo_ts_end(p.ts);
+    return;
+  }
+
+  // the bias vector goes to LDS once (zero beyond N), before any LDS-DMA is in flight
+  const unsigned bias_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + (unsigned)Cfg::RING;
+  const int n_pad = min(kMaxBiasN, (N + 3) & ~3);
+  if (p.bias) {
+    float* bl = reinterpret_cast<float*>(smem + Cfg::RING);
+    for (int n = threadIdx.x; n < n_pad; n += NW * 64) bl[n] = n < N ? p.bias[n] : 0.f;
+    __syncthreads();
+  }
+
+  // ---------------- issue cursor: (tile, stage) of the next stage to stream into the ring ----------------
+  const int p_row = lane >> 2, p_chunk = lane & 3;
+  int i_tile = w, i_s = 0, i_slot = 0, issued = 0;
+  int i_tap = 0, i_cin0 = 0;
+  unsigned tap_ok[APW];  // CONV: this lane's A rows -> 9-bit masks of the taps inside the map
+#pragma unroll
+  for (int u = 0; u < APW; ++u) tap_ok[u] = 0u;
+  const float* pa[APW];
+  const float* pb[PPW - APW];
+  int k_mul = 1;  // 0 once the cursor has run past the last tile: the stream goes on with dummy stages (the zero row, k offset 0)
+  // so that EXACTLY ST - 3 younger stages are in flight at every wait and no piece needs a branch; their slots are free by
+  // construction and nobody reads them
+  auto open_tile = [&]() __attribute__((always_inline)) {
+    if (i_tile >= tiles) {
+      k_mul = 0;
+#pragma unroll
+      for (int u = 0; u < APW; ++u) { pa[u] = g_zero_row3 + p_chunk * 4; tap_ok[u] = 0x1ffu; }
+#pragma unroll
+      for (int u = 0; u < PPW - APW; ++u) pb[u] = g_zero_row3 + p_chunk * 4;
+      i_s = 0; i_tap = 0; i_cin0 = 0;
+      return;
+    }
+    const int bi = i_tile / tpb, rem = i_tile - bi * tpb;
+    const float* i_A = A + bi * p.sA;
+    const float* i_B = Bm + bi * p.sB;
+    const int i_m_blk = (rem / n_tiles) * BM;
+    const int i_n_blk = (rem % n_tiles) * BN;
+    i_s = 0; i_tap = 0; i_cin0 = 0;
+#pragma unroll
+    for (int u = 0; u < APW; ++u) {
+      const int r = (wave + NW * u) * 16 + p_row;
+      const int c = p_chunk ^ ((r >> 2) & 3);  // swizzle on the SOURCE chunk, the LDS image stays lane-linear
+      pa[u] = i_A + (long long)min(i_m_blk + r, M - 1) * lda + c * 4;
+    }
+#pragma unroll
+    for (int u = 0; u < PPW - APW; ++u) {
+      const int r = (wave + NW * (u + APW) - Cfg::A_PIECES) * 16 + p_row;
+      const int c = p_chunk ^ ((r >> 2) & 3);
+      pb[u] = i_B + (long long)min(i_n_blk + r, N - 1) * ldb + c * 4;
+    }
+    if (CONV) {
+#pragma unroll
+      for (int u = 0; u < APW; ++u) {
+        const int t = min(i_m_blk + (wave + NW * u) * 16 + p_row, M - 1);
+        const int x = t % cg.W, y = (t / cg.W) % cg.H;
+        unsigned ok = 0u;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+          if (yy >= 0 && yy < cg.H && xx >= 0 && xx < cg.W) ok |= 1u << tap;
+        }
+        tap_ok[u] = ok;
+      }
+    }
+  };
+  // one DMA piece (1 KiB = 16 rows x 64 B, wave-uniform destination) of the stage under the issue cursor
+  auto issue_piece = [&](auto u_tag) __attribute__((always_inline)) {
+    constexpr int u = decltype(u_tag)::value;
+    if (dbg & 1) return;
+    char* st = smem + i_slot * STAGE;
+    const int q = wave + NW * u;  // q < A_PIECES: A rows, else B rows
+    if constexpr (u < APW) {
+      const long long a_off = (CONV ? (long long)((i_tap / 3 - 1) * cg.W + (i_tap % 3 - 1)) * lda + i_cin0 : (long long)(i_s * kBK)) * k_mul;
+      const float* src = pa[u] + a_off;
+      if (CONV) {
+        const int c = p_chunk ^ (((q * 16 + p_row) >> 2) & 3);
+        if (!((tap_ok[u] >> i_tap) & 1u)) src = g_zero_row3 + c * 4;
+      }
+      glds16(src, st + q * 1024);
+    } else {
+      glds16(pb[u - APW] + i_s * kBK * k_mul, st + A_BYTES + (q - Cfg::A_PIECES) * 1024);
+    }
+  };
+  auto issue_finish = [&]() __attribute__((always_inline)) {  // advance the cursor past the stage just issued
+    ++issued;
+    i_slot = i_slot == ST - 1 ? 0 : i_slot + 1;
+    ++i_s;
+    if (CONV) {
+      i_cin0 += kBK;
+      if (i_cin0 == cg.Cin) { i_cin0 = 0; ++i_tap; }
+    }
+    if (i_s == nst) {
+      if (i_tile < tiles) i_tile += G;
+      open_tile();
+    }
+  };
+  auto issue_u = [&](int u) __attribute__((always_inline)) {  // u is a compile-time constant after unrolling
+    if (u == 0) issue_piece(std::integral_constant<int, 0>{});
+    if (u == 1 && PPW > 1) issue_piece(std::integral_constant<int, (PPW > 1 ? 1 : 0)>{});
+    if (u == 2 && PPW > 2) issue_piece(std::integral_constant<int, (PPW > 2 ? 2 : 0)>{});
+    if (u == 3 && PPW > 3) issue_piece(std::integral_constant<int, (PPW > 3 ? 3 : 0)>{});
+    if (u == 4 && PPW > 4) issue_piece(std::integral_constant<int, (PPW > 4 ? 4 : 0)>{});
+    if (u == 5 && PPW > 5) issue_piece(std::integral_constant<int, (PPW > 5 ? 5 : 0)>{});
+    static_assert(PPW <= 6, "add the pieces of a larger stage here");
+    if (u == PPW) issue_finish();
+  };
+  open_tile();
+#pragma unroll 1
+  for (int q = 0; q < ST - 1; ++q) {
+#pragma unroll
+    for (int u = 0; u <= PPW; ++u) issue_u(u);
+  }
+
+  // ---------------- LDS read addresses: lane (row r, k-half g) reads chunks 2g, 2g+1 of its rows ----------------
+  // A rows (fp32): chunk 2g = k 8g..8g+3, chunk 2g+1 = k 8g+4..8g+7.  B rows (pre-split image): chunk 2g = bf16 hi of k 8g..8g+7,
+  // chunk 2g+1 = bf16 lo of the same k.
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int r = lane & 31, g = lane >> 5;
+  const int sw = (r >> 2) & 3;  // a wave's rows are (multiple of 32) + r: they all share the swizzle of r
+  const unsigned a_c0 = lds0 + (unsigned)((wm * TI * 32 + r) * 64 + ((2 * g) ^ sw) * 16);
+  const unsigned a_c1 = lds0 + (unsigned)((wm * TI * 32 + r) * 64 + ((2 * g + 1) ^ sw) * 16);
+  const unsigned b_hi = lds0 + (unsigned)(A_BYTES + (wn * TJ * 32 + r) * 64 + ((2 * g) ^ sw) * 16);
+  const unsigned b_lo = lds0 + (unsigned)(A_BYTES + (wn * TJ * 32 + r) * 64 + ((2 * g + 1) ^ sw) * 16);
+
+  // operand registers: two sets (ping-pong over the stage parity) of split A fragments and B hi groups; one set of B lo groups
+  // and of raw A rows (both live for less than a stage)
+  bf16x8 ah[2][TI], al[2][TI], bh[2][TJ], bl[TJ];
+  f4v ra[TI][2];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+    for (int i = 0; i < TI; ++i) { ah[s2][i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; al[s2][i] = ah[s2][i]; }
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) bh[s2][j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  }
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) bl[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < TI; ++i) ra[i][0] = ra[i][1] = f4v{1.f, 1.f, 1.f, 1.f};
+
+  auto read_b = [&](bf16x8 (&dst)[TJ], unsigned base) __attribute__((always_inline)) {
+    if (dbg & 2) return;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+      const f4v v = j == 0 ? lds_read128<0>(base) : j == 1 ? lds_read128<2048>(base) : j == 2 ? lds_read128<4096>(base) : lds_read128<6144>(base);
+      dst[j] = __builtin_bit_cast(bf16x8, v);
+    }
+  };
+  auto read_a = [&](unsigned so) __attribute__((always_inline)) {
+    if (dbg & 2) return;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      ra[i][0] = i == 0 ? lds_read128<0>(a_c0 + so) : lds_read128<2048>(a_c0 + so);
+      ra[i][1] = i == 0 ? lds_read128<0>(a_c1 + so) : lds_read128<2048>(a_c1 + so);
+    }
+  };
+  // s_waitcnt lgkmcnt(0) tied to the registers the pending ds_reads write (hipcc may not move their uses above it)
+  auto wait_b = [&](bf16x8 (&x)[TJ]) __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (TJ == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) : : "memory");
+    else if constexpr (TJ == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]) : : "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]) : : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto wait_ab = [&](bf16x8 (&x)[TJ]) __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (TI == 2 && TJ == 4)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[1][0]), "+v"(ra[1][1]) : : "memory");
+    else if constexpr (TI == 2 && TJ == 2)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[1][0]), "+v"(ra[1][1]) : : "memory");
+    else if constexpr (TI == 1 && TJ == 4)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(ra[0][0]), "+v"(ra[0][1]) : : "memory");
+    else {
+      static_assert((TI == 2 && TJ == 4) || (TI == 2 && TJ == 2) || (TI == 1 && TJ == 4) || (TI == 1 && TJ == 1), "add the register list of a new wave tile here");
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(ra[0][0]), "+v"(ra[0][1]) : : "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // one quarter of the split of row-tile i (two floats -> one packed bf16 pair of hi and of lo); q = 0..3
+  unsigned hw_[TI][4], lw_[TI][4];
+  auto split_q = [&](int i, int q) __attribute__((always_inline)) {
+    const float v0 = q < 2 ? ra[i][0][2 * q] : ra[i][1][2 * (q - 2)];
+    const float v1 = q < 2 ? ra[i][0][2 * q + 1] : ra[i][1][2 * (q - 2) + 1];
+    if (dbg & 16) { hw_[i][q] = __float_as_uint(v0); lw_[i][q] = __float_as_uint(v1); return; }
+    const unsigned h = pack_rne(v0, v1);  // hi = rne_bf16(x): the dropped lo.lo term is <= 2^-16 |x.w| and unbiased
+    hw_[i][q] = h;
+    lw_[i][q] = pack_rne(v0 - __uint_as_float(h << 16), v1 - __uint_as_float(h & 0xffff0000u));
+  };
+  auto split_commit = [&](bf16x8 (&dh)[TI], bf16x8 (&dl)[TI]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      dh[i] = __builtin_bit_cast(bf16x8, u4v{hw_[i][0], hw_[i][1], hw_[i][2], hw_[i][3]});
+      dl[i] = __builtin_bit_cast(bf16x8, u4v{lw_[i][0], lw_[i][1], lw_[i][2], lw_[i][3]});
+    }
+  };
+
+  f32x16 acc[TI][TJ];
+  f32x16 zero16;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) zero16[q] = 0.f;
+
+  // ---------------- epilogue of one tile: lane (token r, half g) owns n = 8q + 4g + (0..3), q = 0..3, of every sub-tile ----------------
+  struct EpiCtx { int m_blk, n_blk, bi; };
+  auto epilogue = [&](const EpiCtx& ec) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.C + ec.bi * p.sC, 0, p.c_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t m_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.mask ? p.mask + ec.bi * p.sC : p.C), 0, p.c_bytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        __builtin_amdgcn_sched_barrier(0);  // one sub-tile at a time: 16 accumulator registers in flight, not 128
+        const int row = ec.m_blk + (wm * TI + i) * 32 + r;
+        const int nb = ec.n_blk + (wn * TJ + j) * 32 + 4 * g;
+        if (dbg & 8) {  // keep the accumulators alive without storing them
+#pragma unroll
+          for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(acc[i][j][e]));
+          continue;
+        }
+        if (p.vec_store) {
+          f4v bv[4];
+          if (p.bias) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bv[q] = lds_read128<0>(bias_lds + (unsigned)min(nb + 8 * q, n_pad - 4) * 4u);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]) : : "memory");
+          }
+          u4v mv[4];
+          if (p.mask) {  // (these loads are the youngest vector-memory operations: waiting for them drains the ring - masked
+                         //  launches pay one pipeline refill per tile)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int n0 = nb + 8 * q;
+              const unsigned off = n0 < N ? ((unsigned)row * (unsigned)p.ldc + (unsigned)n0) * 4u : 0xfffffff0u;
+              mv[q] = __builtin_amdgcn_raw_buffer_load_b128(m_rsrc, off, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int n0 = nb + 8 * q;
+            f4v v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+            if (p.bias) v += bv[q];
+            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (p.mask) {
+              v.x = __uint_as_float(mv[q].x) > 0.f ? v.x : 0.f; v.y = __uint_as_float(mv[q].y) > 0.f ? v.y : 0.f;
+              v.z = __uint_as_float(mv[q].z) > 0.f ? v.z : 0.f; v.w = __uint_as_float(mv[q].w) > 0.f ? v.w : 0.f;
+            }
+            // rows >= M fall outside the descriptor's range and are dropped; columns >= N are steered there as well
+            const unsigned off = n0 < N ? ((unsigned)row * (unsigned)p.ldc + (unsigned)n0) * 4u : 0xfffffff0u;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), c_rsrc, off, 0, 0);
+          }
+        } else {  // N or ldc not a multiple of 4: scalar stores
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int n = nb + 8 * (e >> 2) + (e & 3);
+            float v = acc[i][j][e];
+            if (p.bias) {
+              float b;
+              asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(b) : "v"(bias_lds + (unsigned)min(n, n_pad - 1) * 4u) : "memory");
+              v += b;
+            }
+            if (p.relu) v = fmaxf(v, 0.f);
+            const unsigned off = n < N ? ((unsigned)row * (unsigned)p.ldc + (unsigned)n) * 4u : 0xfffffff0u;
+            if (p.mask) v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(m_rsrc, off, 0, 0)) > 0.f ? v : 0.f;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), c_rsrc, off, 0, 0);
+          }
+        }
+      }
+  };
+
+  // ---------------- one stage ----------------
+  // PAR: which register set holds this stage's operands (the next stage's go to set PAR ^ 1).  first: first stage of a tile (the
+  // hi.hi products start the accumulators from zero).  `relaxed`: the epilogue stores of the previous tile may still be in
+  // flight behind the ring loads we wait for.
+  constexpr int kYoung = (ST - 3) * PPW;
+  constexpr bool p3 = P3;
+  int c_slot = 0;  // ring slot of the stage being computed
+  auto stage = [&](auto par_tag, bool first, bool relaxed) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(par_tag)::value;
+    const int n_slot = c_slot == ST - 1 ? 0 : c_slot + 1;
+    // stage s + 1 (a real one or a dummy of the stream's tail - nothing below needs to know) has landed once all but the ST - 3
+    // younger stages (and, right after a tile boundary, the previous tile's stores, which are younger than every load waited
+    // for here) are done
+    if (relaxed) wait_vm<kYoung + Cfg::STORES>();
+    else wait_vm<kYoung>();
+    if (!(dbg & 4)) __builtin_amdgcn_s_barrier();
+    // ---- phase 0: B lo of this stage + raw A of the next -> registers; hi.hi and lo.hi products; the ring refill in between
+    read_b(bl, b_lo + (unsigned)(c_slot * STAGE));
+    read_a((unsigned)(n_slot * STAGE));
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int NM0 = 2 * TI * TJ;
+    constexpr int STRIDE = NM0 / (PPW + 1) > 0 ? NM0 / (PPW + 1) : 1;
+    // the hi.hi products of a tile's first stage start the accumulators from zero: two straight-line MFMA sequences, ONE branch
+    auto phase0 = [&](auto first_tag) __attribute__((always_inline)) {
+      constexpr bool FIRST = decltype(first_tag)::value;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < TJ; ++j) {
+            const int idx = (h * TI + i) * TJ + j;
+            if (!(dbg & 32)) {
+              if (h == 0) {
+                if (FIRST) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[PAR][j], ah[PAR][i], zero16, 0, 0, 0);
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[PAR][j], ah[PAR][i], acc[i][j], 0, 0, 0);
+              } else if (p3) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[PAR][j], al[PAR][i], acc[i][j], 0, 0, 0);
+              }
+            } else if (FIRST && h == 0) {
+              acc[i][j] = zero16;
+            }
+            if (idx % STRIDE == 0 && idx / STRIDE <= PPW) {
+              __builtin_amdgcn_sched_barrier(0);
+              issue_u(idx / STRIDE);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+    };
+    if (PAR == 0 && first) phase0(std::true_type{});
+    else phase0(std::false_type{});
+    if constexpr (NM0 / STRIDE <= PPW) {  // (tiles with fewer MFMAs than pieces: the rest of the refill goes out here)
+#pragma unroll
+      for (int u = (NM0 - 1) / STRIDE + 1; u <= PPW; ++u) issue_u(u);
+    }
+    wait_ab(bl);
+    // ---- phase 1: B hi of the next stage -> the other register set; hi.lo products; the next stage's A split in between
+    read_b(bh[PAR ^ 1], b_hi + (unsigned)(n_slot * STAGE));
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int NM1 = TI * TJ, QS = 4 * TI;  // MFMAs of this phase, split quarters to place
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const int idx = i * TJ + j;
+        if (p3 && !(dbg & 32)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[j], ah[PAR][i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int qq = idx * QS / NM1; qq < (idx + 1) * QS / NM1; ++qq) split_q(qq / 4, qq % 4);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    split_commit(ah[PAR ^ 1], al[PAR ^ 1]);
+    wait_b(bh[PAR ^ 1]);
+    c_slot = n_slot;
+  };
+
+  // ---------------- priming: stage 0's operands into register set 0 ----------------
+  wait_vm<(ST - 2) * PPW>();  // stage 0 landed (ST - 1 stages, real or dummy, were issued)
+  __builtin_amdgcn_s_barrier();
+  read_b(bh[0], b_hi);
+  read_a(0u);
+  wait_ab(bh[0]);
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) split_q(i, q);
+  split_commit(ah[0], al[0]);
+
+  const int my_tiles = (tiles - w + G - 1) / G;
+  const bool relax_ok = p.vec_store && !p.mask;
+  typedef std::integral_constant<int, 0> P0;
+  typedef std::integral_constant<int, 1> P1;
+#pragma unroll 1
+  for (int t = 0; t < my_tiles; ++t) {
+    const int tile = w + t * G;
+    const int bi = tile / tpb, rem = tile - bi * tpb;
+    const EpiCtx ec{(rem / n_tiles) * BM, (rem % n_tiles) * BN, bi};
+    // the previous tile's stores are younger than the loads of the stages that were in flight when they were issued: the first
+    // ST - 2 stages of a tile may leave them outstanding (vector stores only: their number is the immediate's)
+    const bool rx = t > 0 && relax_ok;
+    // stages in pairs: even stages compute from register set 0 and prefetch into set 1, odd stages the other way round
+#pragma unroll 1
+    for (int s = 0; s < nst; s += 2) {
+      stage(P0{}, s == 0, rx && s < ST - 2);
+      if (s + 1 < nst) stage(P1{}, false, rx && s + 1 < ST - 2);
+    }
+    if (nst & 1) {  // an odd number of stages: the next tile's first operands were prefetched into set 1 - hand them to set 0
+#pragma unroll
+      for (int i = 0; i < TI; ++i) { ah[0][i] = ah[1][i]; al[0][i] = al[1][i]; }
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) bh[0][j] = bh[1][j];
+    }
+    epilogue(ec);
+  }
+  wait_vm<0>();  // the dummy stages of the stream's tail are still landing: no LDS-DMA may outlive its workgroup's LDS allocation
+  combo_ts_end(p.ts);
+}
+
+int g_force_tile = 0;  // combo_gemm_nt_x3_tile: 0 = planner, 1 wide, 2 mid, 3 skinny (tests, tools)
+
+int n_cu_cached3() {
+  static const int n_cu = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    return cus > 0 ? cus : 256;
+  }();
+  return n_cu;
+}
+
+int dbg_bits3() {
+  static const int d = [] { const char* e = getenv("COMBO_NT3_DBG"); return e ? atoi(e) : 0; }();
+  return d;
+}
+
+template <bool CONV, typename Cfg, bool P3, int ABL>
+int launch_inst3(const N3Args& a, int grid, hipStream_t stream) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt3_kernel<CONV, Cfg, P3, ABL>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  hipLaunchKernelGGL((gemm_nt3_kernel<CONV, Cfg, P3, ABL>), dim3((unsigned)grid), dim3(Cfg::NW * 64), Cfg::LDS, stream, a);
+  return (int)hipGetLastError();
+}
+
+template <bool CONV, typename Cfg>
+int launch_cfg3(N3Args a, hipStream_t stream) {
+  const long long tiles = ((a.M + Cfg::BM - 1LL) / Cfg::BM) * ((a.N + Cfg::BN - 1LL) / Cfg::BN) * a.batch;
+  if (tiles > 0x7fffffffLL) return COMBO_EINVAL;
+  const long long slots = n_cu_cached3();  // one persistent workgroup per CU
+  const int grid = (int)(tiles < slots ? tiles : slots);
+  a.ts = combo_timing_next_slot(a.products == 3 ? COMBO_TS_GEMM_X3 : COMBO_TS_GEMM_BF16, 2.0 * a.M * a.N * a.K * a.batch,
+                                4.0 * a.batch * ((double)a.M * (CONV ? a.K / 9 : a.K) + (double)a.N * a.K + (double)a.M * a.N * (a.mask ? 2 : 1)));
+  if constexpr (!CONV && std::is_same<Cfg, NWide>::value) {  // the ablation instances (COMBO_NT3_DBG, tools/bench_nt2.py)
+    if (a.products == 3) {
+      switch (a.dbg) {
+        case 1: return launch_inst3<CONV, Cfg, true, 1>(a, grid, stream);
+        case 2: return launch_inst3<CONV, Cfg, true, 2>(a, grid, stream);
+        case 4: return launch_inst3<CONV, Cfg, true, 4>(a, grid, stream);
+        case 8: return launch_inst3<CONV, Cfg, true, 8>(a, grid, stream);
+        case 16: return launch_inst3<CONV, Cfg, true, 16>(a, grid, stream);
+        case 32: return launch_inst3<CONV, Cfg, true, 32>(a, grid, stream);
+        case 41: return launch_inst3<CONV, Cfg, true, 41>(a, grid, stream);
+        case 63: return launch_inst3<CONV, Cfg, true, 63>(a, grid, stream);
+        default: break;
+      }
+    }
+  }
+  if (a.products == 3) return launch_inst3<CONV, Cfg, true, 0>(a, grid, stream);
+  return launch_inst3<CONV, Cfg, false, 0>(a, grid, stream);
+}
+
+template <bool CONV>
+int launch_one3(N3Args a, hipStream_t stream, int cfg) {
+  if (cfg == 3) return launch_cfg3<CONV, NSkinny>(a, stream);
+  if (cfg == 2) return launch_cfg3<CONV, NMid>(a, stream);
+  return launch_cfg3<CONV, NWide>(a, stream);
+}
+
+// Tile choice: the load of the busiest CU (tiles are dealt round-robin to one workgroup per CU), with the measured per-MAC
+// cost of the smaller tiles; when the last round of wide tiles is mostly empty the call is split by rows into whole rounds of
+// large tiles + the remaining rows on small ones (as gemm_f32.hip).
+template <bool CONV>
+int launch_nt3(N3Args a, hipStream_t stream) {
+  if (g_force_tile) return launch_one3<CONV>(a, stream, g_force_tile);
+  const long long cus = n_cu_cached3();
+  const int bm[4] = {0, 256, 128, 64}, bn[4] = {0, 128, 128, 64};
+  auto tiles = [&](int c, long long rows) { return ((rows + bm[c] - 1) / bm[c]) * ((a.N + bn[c] - 1LL) / bn[c]) * a.batch; };
+  const double eff[4] = {0.0, 1.0, 1.15, 1.6};
+  auto load = [&](int c, long long rows) { return (double)((tiles(c, rows) + cus - 1) / cus) * bm[c] * bn[c] * eff[c]; };
+  int best = 1;
+  double best_cost = load(1, a.M);
+  for (int c = 2; c <= 3; ++c)
+    if (load(c, a.M) < best_cost) { best = c; best_cost = load(c, a.M); }
+  long long rows_main = a.M;
+  int cfg_rest = 0;
+  if (!CONV && a.batch == 1) {
+    const double penalty = 1.0e6 / a.K;  // a second launch: ~3 us of a CU at this kernel's rate, in units of MACs / K
+    for (int c = 1; c <= 2; ++c) {
+      const long long tn = (a.N + bn[c] - 1LL) / bn[c], tm = (a.M + bm[c] - 1LL) / bm[c];
+      const long long rounds = tm * tn / cus;
+      if (rounds < 1) continue;
+      const long long tm_main = rounds * cus / tn, rm = tm_main * bm[c];
+      if (rm <= 0 || rm >= a.M) continue;
+      for (int rr = c + 1; rr <= 3; ++rr) {
+        const double cost = load(c, rm) + load(rr, a.M - rm) + penalty;
+        if (cost < best_cost * 0.97) { best = c; best_cost = cost; rows_main = rm; cfg_rest = rr; }
+      }
+    }
+  }
+  if (rows_main >= a.M) return launch_one3<CONV>(a, stream, best);
+  N3Args m = a, rs = a;
+  m.M = (int)rows_main;
+  m.c_bytes = (int)(((m.M - 1LL) * a.ldc + a.N) * 4);
+  if (int e = launch_one3<CONV>(m, stream, best)) return e;
+  rs.A = a.A + rows_main * a.lda;
+  rs.C = a.C + rows_main * a.ldc;
+  if (a.mask) rs.mask = a.mask + rows_main * a.ldc;
+  rs.M = (int)(a.M - rows_main);
+  rs.c_bytes = (int)(((rs.M - 1LL) * a.ldc + a.N) * 4);
+  return launch_one3<CONV>(rs, stream, cfg_rest);
+}
+
+}  // namespace
+
+/* Forces the tile shape of the combo_gemm_nt_x3_* / combo_conv3x3_nhwc_x3_* launches that FOLLOW (0 = the planner's choice, 1 =
+ * 256 x 128, 2 = 128 x 128, 3 = 64 x 64): every configuration must give the same result (tests), and tools sweep them.  Returns
+ * the previous value.  Host-side state, read when a launch is issued. */
+extern "C" int combo_gemm_nt_x3_tile(int cfg) {
+  const int prev = g_force_tile;
+  if (cfg >= 0 && cfg <= 3) g_force_tile = cfg;
+  return prev;
+}
+
+int combo_nt3_launch(const float* A, long long lda, const float* Bimg, long long ldb, const float* bias, const float* mask, float* C,
+                     long long ldc, long long M, int N, int K, int relu, int products, int batch, long long sA, long long sB,
+                     long long sC, const combo_nt3_conv* conv, int force_cfg, combo_stream_t stream) {
+  if (!A || !Bimg || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || K % kBK != 0 || lda % 4 != 0 || ldb % 4 != 0 || sA % 4 != 0 ||
+      sB % 4 != 0 || ((uintptr_t)A & 15) || ((uintptr_t)Bimg & 15) || M > 0x7fffffffLL || ((M - 1) * ldc + N) * 4 >= 0x7ffffff0LL ||
+      (bias && N > kMaxBiasN) || (products != 1 && products != 3))
+    return COMBO_EINVAL;
+  const int vec = (N % 4 == 0 && ldc % 4 == 0 && sC % 4 == 0 && !((uintptr_t)C & 15) && (!mask || !((uintptr_t)mask & 15))) ? 1 : 0;
+  N3Args a{A, lda, Bimg, ldb, bias, mask, C, ldc, (int)M, N, K, relu, (int)(((M - 1) * ldc + N) * 4), batch, vec, dbg_bits3(), products,
+           sA, sB, sC, conv ? *conv : combo_nt3_conv{1, 1, K}, nullptr};
+  if (force_cfg) return conv ? launch_one3<true>(a, (hipStream_t)stream, force_cfg) : launch_one3<false>(a, (hipStream_t)stream, force_cfg);
+  return conv ? launch_nt3<true>(a, (hipStream_t)stream) : launch_nt3<false>(a, (hipStream_t)stream);
+}
+
+namespace {
+// out[m, n] = sum_z part[z, m, n], masked (mask > 0 ? . : 0) on request: finishes a split-K input-gradient GEMM; N % 4 == 0,
+// fixed summation order
+__global__ void __launch_bounds__(256)
+nt3_splitk_finish_kernel(const float* __restrict__ part, int splits, long long M, int N, const float* __restrict__ mask,
+                         float* __restrict__ out, long long ldc) {
+  const long long n4 = (long long)M * (N >> 2);
+  const long long i = blockIdx.x * 256LL + threadIdx.x;
+  if (i >= n4) return;
+  const long long mrow = i / (N >> 2);
+  const int c = (int)(i - mrow * (N >> 2)) * 4;
+  float4 a = reinterpret_cast<const float4*>(part)[i];
+  for (int z = 1; z < splits; ++z) {
+    const float4 b = reinterpret_cast<const float4*>(part + (long long)z * M * N)[i];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  if (mask) {
+    const float4 mk = *reinterpret_cast<const float4*>(mask + mrow * ldc + c);
+    a.x = mk.x > 0.f ? a.x : 0.f; a.y = mk.y > 0.f ? a.y : 0.f; a.z = mk.z > 0.f ? a.z : 0.f; a.w = mk.w > 0.f ? a.w : 0.f;
+  }
+  *reinterpret_cast<float4*>(out + mrow * ldc + c) = a;
+}
+}  // namespace
+
+/* Split-K plan of an input-gradient GEMM dX[M, N] = dY[M, K] . W: the number of K slices (1 = do not split).  A long reduction
+ * with few output tiles leaves most CUs idle (the decoder FFN's linear1: 4000 x 2048 -> 256 is 64 tiles of 128 x 128 on 256 CUs,
+ * 63 us where the whole operand set is 39 MB; the backbones' res5 / res4 1x1 layers likewise): the K slices run as the batch
+ * entries of ONE launch into [splits, M, N] partials, a second small launch sums them in a fixed order (and applies the ReLU
+ * mask).  Same arithmetic as the unsplit kernel up to re-association of the K sum. */
+extern "C" int combo_gemm_nt_x3_splitk_plan(int M, int N, int K) {
+  if (K < 512 || N % 4 != 0 || M <= 0) return 1;
+  const long long cus = n_cu_cached3();
+  const long long tiles = ((M + 127LL) / 128) * ((N + 127LL) / 128);  // mid tiles
+  if (tiles * 2 > cus) return 1;
+  int s = (int)(cus / tiles);
+  if (s > 8) s = 8;
+  while (s > 1 && (K % (s * 32) != 0 || K / s < 128)) --s;
+  return s < 1 ? 1 : s;
+}
+
+extern "C" int combo_gemm_nt_x3_splitk_f32(const float* A, long long lda, const float* Bimg, const float* mask, float* C,
+                                           long long ldc, int M, int N, int K, int splits, float* workspace, combo_stream_t stream) {
+  if (splits < 2 || !workspace || K % (splits * 32) != 0 || N % 4 != 0 || ((uintptr_t)workspace & 15) || ((uintptr_t)C & 15) ||
+      (mask && ((uintptr_t)mask & 15)) || ldc % 4 != 0 || (long long)M * N > 0x7fffffffLL / 4)
+    return COMBO_EINVAL;
+  const int Ks = K / splits;
+  // slice z: A columns [z Ks, (z + 1) Ks) (element offset z Ks), image rows keep their pitch K and start z Ks floats in
+  if (int e = combo_nt3_launch(A, lda, Bimg, K, nullptr, nullptr, workspace, N, M, N, Ks, 0, 3, splits, Ks, Ks, (long long)M * N,
+                               nullptr, 0, stream))
+    return e;
+  const long long n4 = (long long)M * (N >> 2);
+  hipLaunchKernelGGL(nt3_splitk_finish_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace,
+                     splits, (long long)M, N, mask, C, ldc);
+  return (int)hipGetLastError();
+}

@@ -148,9 +148,18 @@ def gemm_nt_x3(a, b, bias=None, relu=False, relu_mask=None, img=None):
     if img is None:
         img = presplit(b)
     lib, st = _lib.lib(), _lib.current_stream()
+    if relu_mask is not None:
+        assert bias is None and not relu and relu_mask.shape == (M, N) and relu_mask.is_contiguous()
+    splits = lib.combo_gemm_nt_x3_splitk_plan(M, N, K) if (bias is None and not relu) else 1
+    if splits > 1:  # few output tiles, long K: K slices as the batch entries of one launch + a fixed-order finishing sum
+        ws = torch.empty(splits, M, N, device=a.device, dtype=torch.float32)
+        with _lib.timed("gemm_nt_x3", (M, N, K)):
+            rc = lib.combo_gemm_nt_x3_splitk_f32(a.data_ptr(), a.stride(0), img.data_ptr(), _lib.ptr(relu_mask), out.data_ptr(), N,
+                                                 M, N, K, splits, ws.data_ptr(), st)
+        _lib.check(rc, "combo_gemm_nt_x3_splitk_f32")
+        return out
     with _lib.timed("gemm_nt_x3", (M, N, K)):
         if relu_mask is not None:
-            assert bias is None and not relu and relu_mask.shape == (M, N) and relu_mask.is_contiguous()
             rc = lib.combo_gemm_nt_x3_pre_masked_f32(a.data_ptr(), a.stride(0), img.data_ptr(), relu_mask.data_ptr(),
                                                      out.data_ptr(), N, M, N, K, st)
         else:

@@ -187,6 +187,33 @@ def test_gemm_nt_x3_input_gradient(M, K, N, relu_mask):
     assert rel_err(got, ref) < 1e-5, rel_err(got, ref)
 
 
+@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("M,K,N", [(5000, 256, 384), (777, 48, 200), (20001, 64, 288)])
+def test_gemm_nt_x3_every_tile_configuration_agrees(tile, M, K, N):
+    """csrc/gemm_nt3.hip: wide / mid / skinny tiles forced (combo_gemm_nt_x3_tile) - ragged M and N, an odd number of K stages
+    (K = 48: the register ping-pong hands its sets over at the tile boundary), bias + ReLU and the masked epilogue"""
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd import _lib
+    from combo_avs_amd.ops.linear import gemm_nt_x3
+    torch.manual_seed(tile * 1000 + M)
+    a = torch.randn(M, K, device="cuda")
+    w = torch.randn(N, K, device="cuda") * 0.1
+    b = torch.randn(N, device="cuda")
+    mask = torch.randn(M, N, device="cuda")
+    lib = _lib.lib()
+    prev = lib.combo_gemm_nt_x3_tile(tile)
+    try:
+        got = gemm_nt_x3(a, w, bias=b, relu=True)
+        got_m = gemm_nt_x3(a, w, relu_mask=mask)
+        again = gemm_nt_x3(a, w, bias=b, relu=True)
+    finally:
+        lib.combo_gemm_nt_x3_tile(prev)
+    ref = a.double() @ w.double().t()
+    assert rel_err(got, torch.relu(ref + b.double())) < 1e-5
+    assert rel_err(got_m, ref * (mask > 0)) < 1e-5
+    assert torch.equal(got, again)  # deterministic
+
+
 def test_gemm_nt_x3_strided_token_operand():
     import combo_avs_amd  # noqa: F401
     from combo_avs_amd.ops.linear import gemm_nt_x3

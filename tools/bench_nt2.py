@@ -21,6 +21,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=50)
 ap.add_argument("--shapes", default="all")
 ap.add_argument("--no-lib", action="store_true")
+ap.add_argument("--tile", type=int, default=0, help="force the tile shape (combo_gemm_nt_x3_tile): 1 wide, 2 mid, 3 skinny")
 args = ap.parse_args()
 
 # (M, K, N) of dX = dY[M, K] . W^T-image[N, K]: K = the layer's output features, N = its input features
@@ -32,6 +33,11 @@ if args.shapes == "small":
     SHAPES = [(41160, 256, 256), (41160, 1024, 256), (41160, 256, 1024)]
 if args.shapes == "big":
     SHAPES = SHAPES[:5]
+if args.shapes == "round":  # exactly one round of wide tiles (256 x 128) on 256 CUs: per-stage cost without quantisation effects
+    SHAPES = [(32768, 256, 256), (32768, 1024, 256), (8192, 256, 1024), (32768, 2048, 256)]
+if args.tile:
+    from combo_avs_amd import _lib
+    _lib.lib().combo_gemm_nt_x3_tile(args.tile)
 
 
 def timeit(fn, n):
