@@ -301,7 +301,7 @@ def main():
     ap.add_argument("--head-dtype", default="fp32", choices=["fp32", "bf16"],
                     help="forward GEMMs / convolutions / mask-logit contraction of the head: fp32 = exact fp32 on v_mfma_f32_* (the "
                          "quoted metric: the north-star's 1e-3 bound on the mask logits needs it); bf16 = ONE bf16 product per "
-                         "multiply-add on the head's own kernels (csrc/gemm_nt2.hip), a throughput mode with its own stated "
+                         "multiply-add on the head's own kernels (csrc/gemm_nt3.hip), a throughput mode with its own stated "
                          "tolerance (tests/test_head_gpu.py::test_bf16_forward_mode_stated_tolerance)")
     ap.add_argument("--grad-comm", default="fp32", choices=["fp32", "bf16"],
                     help="dtype of the gradient all-reduce (fp32 = the reference's DDP semantics; bf16 halves the xGMI bytes)")
@@ -529,10 +529,10 @@ def main():
     #   products per fp32 MAC: `achieved` counts the USEFUL 2*M*N*K, `issued` the 3x).
     X3 = 2500.0 / 3  # ceiling of USEFUL flops of the 3-product kernels: 3 bf16 MFMA products per fp32 multiply-add
     KINDS = {0: ("msda_fwd_tap_d32", "hbm", 8000.0, "GB/s", 1e9), 1: ("gemm_nt_f32_kernel", "mfma", 157.3, "TFLOP/s", 1e12),
-             2: ("gemm_nt2_kernel", "mfma", X3, "TFLOP/s", 1e12), 3: ("gemm_tn_grouped_kernel", "hbm", 8000.0, "GB/s", 1e9),
+             2: ("gemm_nt3_kernel", "mfma", X3, "TFLOP/s", 1e12), 3: ("gemm_tn_grouped_kernel", "hbm", 8000.0, "GB/s", 1e9),
              4: ("attn_fwd_kernel", "mfma", 157.3, "TFLOP/s", 1e12), 5: ("attn_bwd_dq/dkv_kernel", "mfma", 157.3, "TFLOP/s", 1e12),
              6: ("msda_bwd", "hbm", 8000.0, "GB/s", 1e9), 7: ("bifuse", "hbm", 8000.0, "GB/s", 1e9),
-             8: ("gemm_nt2_kernel (1 bf16 product: --head-dtype bf16)", "mfma", 2500.0, "TFLOP/s", 1e12)}
+             8: ("gemm_nt3_kernel (1 bf16 product: --head-dtype bf16)", "mfma", 2500.0, "TFLOP/s", 1e12)}
     # HBM traffic per launch: PMC passes of tools/pmc_bench.sh, valid only for the kernels of the commit they were taken at
     pmc, pmc_note = {}, None
     pmc_path = os.path.join(ROOT, "profiles", "r04_pmc.json")

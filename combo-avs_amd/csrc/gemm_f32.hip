@@ -2,7 +2,7 @@
 // (v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate, one rounding per product - bitwise an fmaf chain), and the implicit-GEMM
 // 3x3 convolution on the same loop (CONV = true).
 //
-// Why this kernel exists (round 2): the 3-product bf16 split of gemm_nt2.hip carries ~2^-17 relative error per product
+// Why this kernel exists (round 2): the 3-product bf16 split of gemm_nt3.hip carries ~2^-17 relative error per product
 // against fp32's 2^-24.  Every FORWARD dense layer of the head ends, a few layers later, in `sigmoid(logit) < 0.5` (the
 // attention masks of the decoder, transformer_decoder.py:502-507): a cell whose logit lies within the error band of 0
 // flips, and the flip perturbs that query in all following layers - 0.07 / 0.42 / 0.66 % of the mask logits of prediction

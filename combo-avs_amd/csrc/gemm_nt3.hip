@@ -2,7 +2,7 @@
 // hi.lo, rounded `hi`: ~2^-17 relative per product) - the input-gradient GEMM dX = dY . W of every dense layer, the implicit-GEMM
 // 3x3 convolution's input gradient, the batched mask-logit gradients, and (products = 1) the head's bf16 forward mode.
 //
-// Why v3 (round 4).  gemm_nt2's phases did not overlap.  Ablation on MI355X (tools/bench_nt2.py, COMBO_NT2_DBG bits,
+// Why v3 (round 4).  its predecessor gemm_nt2 (round 3) did not overlap its phases.  Ablation of that kernel on MI355X (COMBO_NT2_DBG bits,
 // 41160 x 1024 -> 256, hot loop): 93 us = 25 (loop skeleton: waits, cursor, address arithmetic) + 30 (MFMA, i.e. the matrix
 // pipe at ~2.2 PF while it runs) + 31 (LDS-DMA issue + landing) + 8 (split) + 3 (LDS reads) + 3 (stores): the SUM of the parts,
 // although two workgroups shared each CU to overlap them - equal tiles keep them in phase.  Inside the training step the
@@ -92,7 +92,7 @@ struct N3Args {
 
 // P3: three products (fp32-accurate) or one (plain bf16); ABL: ablation bits, COMPILE-TIME (a run-time test per bit costs a scalar
 // branch per use, ~1 000 cycles per stage in total - more than the stage itself): 1 no DMA, 2 no LDS reads, 4 no barrier, 8 no
-// stores, 16 no split, 32 no MFMA; the instances listed in launch_cfg3 exist (COMBO_NT3_DBG, tools/bench_nt2.py)
+// stores, 16 no split, 32 no MFMA; the instances listed in launch_cfg3 exist (COMBO_NT3_DBG, tools/bench_nt3.py)
 template <bool CONV, typename Cfg, bool P3, int ABL>
 __global__ void __launch_bounds__(Cfg::NW * 64, Cfg::NW / 4)
 gemm_nt3_kernel(const N3Args p) {
@@ -544,7 +544,7 @@ int launch_cfg3(N3Args a, hipStream_t stream) {
   const int grid = (int)(tiles < slots ? tiles : slots);
   a.ts = combo_timing_next_slot(a.products == 3 ? COMBO_TS_GEMM_X3 : COMBO_TS_GEMM_BF16, 2.0 * a.M * a.N * a.K * a.batch,
                                 4.0 * a.batch * ((double)a.M * (CONV ? a.K / 9 : a.K) + (double)a.N * a.K + (double)a.M * a.N * (a.mask ? 2 : 1)));
-  if constexpr (!CONV && std::is_same<Cfg, NWide>::value) {  // the ablation instances (COMBO_NT3_DBG, tools/bench_nt2.py)
+  if constexpr (!CONV && std::is_same<Cfg, NWide>::value) {  // the ablation instances (COMBO_NT3_DBG, tools/bench_nt3.py)
     if (a.products == 3) {
       switch (a.dbg) {
         case 1: return launch_inst3<CONV, Cfg, true, 1>(a, grid, stream);
@@ -579,7 +579,7 @@ int launch_nt3(N3Args a, hipStream_t stream) {
   const long long cus = n_cu_cached3();
   const int bm[4] = {0, 256, 128, 64}, bn[4] = {0, 128, 128, 64};
   auto tiles = [&](int c, long long rows) { return ((rows + bm[c] - 1) / bm[c]) * ((a.N + bn[c] - 1LL) / bn[c]) * a.batch; };
-  const double eff[4] = {0.0, 1.0, 1.15, 1.6};
+  const double eff[4] = {0.0, 1.0, 1.13, 1.8};  // measured per-MAC cost of a round (tools/bench_nt3.py --shapes round)
   auto load = [&](int c, long long rows) { return (double)((tiles(c, rows) + cus - 1) / cus) * bm[c] * bn[c] * eff[c]; };
   int best = 1;
   double best_cost = load(1, a.M);

@@ -1,0 +1,184 @@
+// Entry points of the 3-product bf16 GEMM family (fp32 accuracy from hi.hi + lo.hi + hi.lo on the bf16 matrix cores) and the weight
+// pre-split they consume.  The kernel itself is csrc/gemm_nt3.hip (round 4); round 3's gemm_nt2 kernel - two workgroups per CU
+// whose phases did not overlap: 0.18 of its MFMA ceiling inside the training step - is gone.
+//   combo_presplit_bf16x2_*          W (any strided [N, K] view, e.g. W^T) -> image: per 8 k a 16-B bf16 `hi` group (hi = rne(x)) and
+//                                    a 16-B bf16 `lo` group (lo = rne(x - hi)), 4 bytes per element, row pitch K floats
+//   combo_gemm_nt_x3_pre_*           C = A . image^T (+ bias) (+ ReLU) (masked) (batched)
+//   combo_conv3x3_nhwc_x3_pre_f32    implicit-GEMM 3x3 convolution over NHWC tokens (the input gradient of a 3x3 convolution with
+//                                    flipped taps; the head's bf16 forward mode)
+//   combo_gemm_nt2_products          1 = plain bf16 (the head's bf16 throughput mode), 3 = the fp32-accurate split (default)
+#include <cstdlib>
+
+#include "combo_common.h"
+#include "gemm_nt3.h"
+
+namespace {
+
+__device__ __forceinline__ unsigned pack_rne(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+constexpr int kBK = 16;
+
+// Weight image: element (n, k) = src[n*ld_row + k*ld_col]; per 8 consecutive k a 16-B group of bf16 `hi`
+// = rne(x) followed by a 16-B group of bf16 `lo` = rne(x - hi): 4 bytes per element, row stride K floats.
+__global__ void __launch_bounds__(256)
+presplit_kernel(const float* __restrict__ src, long long ld_row, long long ld_col, int N, int K, uint4* __restrict__ img,
+                long long batch_stride) {
+  const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  const int kg = K >> 3;
+  if (t >= (long long)N * kg) return;
+  src += blockIdx.y * batch_stride;               // batch entry b: source at src + b*batch_stride, image at img + b*N*K floats
+  img += blockIdx.y * ((long long)N * kg * 2);
+  // neighbouring threads walk the unit-stride direction of the source: k groups for W, rows for a W^T view
+  int n, g8;
+  if (ld_col == 1) { n = (int)(t / kg); g8 = (int)(t - (long long)n * kg); }
+  else { g8 = (int)(t / N); n = (int)(t - (long long)g8 * N); }
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = src[(long long)n * ld_row + (long long)(g8 * 8 + i) * ld_col];
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h[i] = pack_rne(v[2 * i], v[2 * i + 1]);
+    l[i] = pack_rne(v[2 * i] - __uint_as_float(h[i] << 16), v[2 * i + 1] - __uint_as_float(h[i] & 0xffff0000u));
+  }
+  const long long o = ((long long)n * kg + g8) * 2;
+  img[o] = make_uint4(h[0], h[1], h[2], h[3]);
+  img[o + 1] = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+// Grouped form: every weight whose input-gradient GEMM the backward pass will run, split by ONE launch (per 64 problems)
+// instead of one ~5 us launch per weight (148 per training step).  img_ld: floats per image row (>= K): several sources may
+// fill k ranges of one image (the two weights of a column-concatenated layer).
+constexpr int kMaxSplitGroup = 64;
+struct SplitGroupArgs {
+  int count;
+  long long thread_start[kMaxSplitGroup + 1];
+  combo_presplit_problem p[kMaxSplitGroup];
+};
+
+__global__ void __launch_bounds__(256)
+presplit_grouped_kernel(const SplitGroupArgs args) {
+  const long long t0 = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (t0 >= args.thread_start[args.count]) return;
+  int pi = 0;
+  for (int i = 1; i < args.count; ++i)
+    if (t0 >= args.thread_start[i]) pi = i;
+  const combo_presplit_problem& pr = args.p[pi];
+  const long long t = t0 - args.thread_start[pi];
+  const int kg = pr.K >> 3;
+  if (t >= (long long)pr.N * kg) return;  // (a problem's threads are rounded up to whole workgroups)
+  int n, g8;
+  if (pr.ld_col == 1) { n = (int)(t / kg); g8 = (int)(t - (long long)n * kg); }
+  else { g8 = (int)(t / pr.N); n = (int)(t - (long long)g8 * pr.N); }
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = pr.src[(long long)n * pr.ld_row + (long long)(g8 * 8 + i) * pr.ld_col];
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h[i] = pack_rne(v[2 * i], v[2 * i + 1]);
+    l[i] = pack_rne(v[2 * i] - __uint_as_float(h[i] << 16), v[2 * i + 1] - __uint_as_float(h[i] & 0xffff0000u));
+  }
+  uint4* img = reinterpret_cast<uint4*>(pr.img) + (long long)n * (pr.img_ld >> 2) + g8 * 2;
+  img[0] = make_uint4(h[0], h[1], h[2], h[3]);
+  img[1] = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+int g_products = 3;  // combo_gemm_nt2_products: bf16 products per multiply-add of the launches that follow (host state, read at launch)
+
+}  // namespace
+
+/* bf16 products per fp32 multiply-add of the combo_gemm_nt_x3_* / combo_conv3x3_nhwc_x3_* launches that FOLLOW (3 = the
+ * fp32-accurate split, the default; 1 = plain bf16 inputs with fp32 accumulation: the head's bf16 throughput mode, forward GEMMs
+ * only).  Returns the previous value.  Host-side state, read when a launch is issued (a captured graph keeps what was set). */
+extern "C" int combo_gemm_nt2_products(int products) {
+  const int prev = g_products;
+  if (products == 1 || products == 3) g_products = products;
+  return prev;
+}
+
+extern "C" int combo_presplit_bf16x2_f32(const float* src, long long ld_row, long long ld_col, int N, int K, float* img,
+                                         combo_stream_t stream) {
+  if (!src || !img || N <= 0 || K <= 0 || K % 8 != 0 || ((uintptr_t)img & 15)) return COMBO_EINVAL;
+  const long long threads = (long long)N * (K / 8);
+  hipLaunchKernelGGL(presplit_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, ld_row,
+                     ld_col, N, K, reinterpret_cast<uint4*>(img), 0LL);
+  return (int)hipGetLastError();
+}
+
+extern "C" int combo_presplit_bf16x2_grouped_f32(const combo_presplit_problem* problems, int count, combo_stream_t stream) {
+  if (!problems || count <= 0) return COMBO_EINVAL;
+  for (int base = 0; base < count; base += kMaxSplitGroup) {
+    SplitGroupArgs a;
+    a.count = count - base < kMaxSplitGroup ? count - base : kMaxSplitGroup;
+    long long threads = 0;
+    for (int i = 0; i < a.count; ++i) {
+      const combo_presplit_problem& pr = problems[base + i];
+      if (!pr.src || !pr.img || pr.N <= 0 || pr.K <= 0 || pr.K % 8 != 0 || pr.img_ld < pr.K || pr.img_ld % 8 != 0 ||
+          ((uintptr_t)pr.img & 31))
+        return COMBO_EINVAL;
+      a.thread_start[i] = threads;
+      a.p[i] = pr;
+      threads += ((long long)pr.N * (pr.K / 8) + 255) / 256 * 256;  // a workgroup never straddles two problems
+    }
+    a.thread_start[a.count] = threads;
+    hipLaunchKernelGGL(presplit_grouped_kernel, dim3((unsigned)(threads / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+  }
+  return 0;
+}
+
+extern "C" int combo_presplit_bf16x2_batched_f32(const float* src, long long ld_row, long long ld_col, long long batch_stride,
+                                                 int N, int K, int batch, float* img, combo_stream_t stream) {
+  if (!src || !img || N <= 0 || K <= 0 || K % 8 != 0 || batch <= 0 || batch > 65535 || ((uintptr_t)img & 15)) return COMBO_EINVAL;
+  const long long threads = (long long)N * (K / 8);
+  hipLaunchKernelGGL(presplit_kernel, dim3((unsigned)((threads + 255) / 256), (unsigned)batch), dim3(256), 0, (hipStream_t)stream,
+                     src, ld_row, ld_col, N, K, reinterpret_cast<uint4*>(img), batch_stride);
+  return (int)hipGetLastError();
+}
+
+// `batch` independent GEMMs of one shape (the mask-logit contraction mask_embed @ pixel_embed^T per frame and its input
+// gradient): C_b[M,N] = A_b[M,K] . B_b[N,K]^T, operands at base + b * stride (elements).  128 x 128 tiles when M pads better to
+// 128 than to 256.
+extern "C" int combo_gemm_nt_x3_pre_batched_f32(const float* A, long long lda, long long sA, const float* Bimg, long long sB,
+                                                float* C, long long ldc, long long sC, int M, int N, int K, int batch, int relu,
+                                                combo_stream_t stream) {
+  if (!A || !Bimg || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || K % kBK != 0 || lda % 4 != 0 || sA % 4 != 0 ||
+      sB % 4 != 0 || ((uintptr_t)A & 15) || ((uintptr_t)Bimg & 15))
+    return COMBO_EINVAL;
+  const int pad256 = (M + 255) / 256 * 256, pad128 = (M + 127) / 128 * 128;
+  return combo_nt3_launch(A, lda, Bimg, K, nullptr, nullptr, C, ldc, M, N, K, relu, g_products, batch, sA, sB, sC, nullptr,
+                          pad128 < pad256 ? 2 : 1, stream);
+}
+
+extern "C" int combo_gemm_nt_x3_pre_f32(const float* A, long long lda, const float* Bimg, const float* bias, float* C,
+                                        long long ldc, int M, int N, int K, int relu, combo_stream_t stream) {
+  if (!A || !Bimg || !C || M <= 0 || N <= 0 || K <= 0 || K % kBK != 0 || lda % 4 != 0 || ((uintptr_t)A & 15) ||
+      ((uintptr_t)Bimg & 15))
+    return COMBO_EINVAL;
+  return combo_nt3_launch(A, lda, Bimg, K, bias, nullptr, C, ldc, M, N, K, relu, g_products, 1, 0, 0, 0, nullptr, 0, stream);
+}
+
+extern "C" int combo_gemm_nt_x3_pre_masked_f32(const float* A, long long lda, const float* Bimg, const float* mask, float* C,
+                                               long long ldc, int M, int N, int K, combo_stream_t stream) {
+  if (!A || !Bimg || !C || !mask || M <= 0 || N <= 0 || K <= 0 || K % kBK != 0 || lda % 4 != 0 || ((uintptr_t)A & 15) ||
+      ((uintptr_t)Bimg & 15))
+    return COMBO_EINVAL;
+  return combo_nt3_launch(A, lda, Bimg, K, nullptr, mask, C, ldc, M, N, K, 0, g_products, 1, 0, 0, 0, nullptr, 0, stream);
+}
+
+extern "C" int combo_conv3x3_nhwc_x3_pre_f32(const float* X, long long ldx, const float* Wimg, const float* bias, float* Y,
+                                             long long ldy, int B, int H, int W, int Cin, int Cout, int relu,
+                                             combo_stream_t stream) {
+  const long long M = (long long)B * H * W;
+  if (!X || !Wimg || !Y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % kBK != 0 || ldx % 4 != 0 ||
+      ((uintptr_t)X & 15) || ((uintptr_t)Wimg & 15) || M > 0x7fffffffLL / 4)
+    return COMBO_EINVAL;
+  const combo_nt3_conv cg{H, W, Cin};
+  return combo_nt3_launch(X, ldx, Wimg, 9LL * Cin, bias, nullptr, Y, ldy, M, Cout, 9 * Cin, relu, g_products, 1, 0, 0, 0, &cg, 0, stream);
+}

@@ -6,7 +6,7 @@ the largest dense op of the head.  MIOpen's fp32 kernels need
 gradient, weight gradient) at 40 frames; here
   forward  Y  = conv(X, W)        csrc/gemm_f32.hip, CONV = true: exact fp32 MFMA (A rows gathered per tap, zero row for
                                   the padding) - forward values feed the decoder's mask thresholds
-  dX          = conv(dY, W')      csrc/gemm_nt2.hip, CONV = true, W' = taps flipped, channels swapped (3-product bf16 split)
+  dX          = conv(dY, W')      csrc/gemm_nt3.hip, CONV = true, W' = taps flipped, channels swapped (3-product bf16 split)
   dW          = dY^T . im2col(X)  csrc/gemm_tn.hip, CONV = true (3-product split, split-K over the tokens + the fused reduce)
 No im2col buffer exists anywhere.
 """

@@ -3,7 +3,7 @@
   forward   y  = x W^T + b (+ReLU)   csrc/gemm_f32.hip   exact fp32 (v_mfma_f32_32x32x2_f32): forward values end in the
                                                           decoder's `sigmoid(logit) < 0.5` masks, where the 2^-17 error of
                                                           a bf16 split flips near-zero cells
-  dX        = dy W                   csrc/gemm_nt2.hip   3-product bf16 split on the bf16 matrix cores (W^T pre-split from
+  dX        = dy W                   csrc/gemm_nt3.hip   3-product bf16 split on the bf16 matrix cores (W^T pre-split from
                                                           a strided view, no transpose copy; ReLU backward in the epilogue)
   dW, db    = dy^T x, sum dy         csrc/gemm_tn.hip    3-product split, split-K over the tokens; inside `deferred_dw()`
                                                           all weight gradients of a step run as ONE grouped launch
@@ -59,7 +59,7 @@ def gemm_nt_f32(a, w, bias=None, relu=False, out=None):
 
 
 def presplit(b):
-    """bf16 hi/lo image of a 2-D fp32 view [N, K] (any strides: pass `w.t()` for W^T, no copy) for csrc/gemm_nt2.hip."""
+    """bf16 hi/lo image of a 2-D fp32 view [N, K] (any strides: pass `w.t()` for W^T, no copy) for csrc/gemm_nt3.hip."""
     N, K = b.shape
     img = torch.empty(N, K, device=b.device, dtype=torch.float32)
     _lib.check(_lib.lib().combo_presplit_bf16x2_f32(b.data_ptr(), b.stride(0), b.stride(1), N, K, img.data_ptr(),
@@ -83,7 +83,7 @@ def _split_key(b):
 def expect_input_grad(*weights):
     """Forward-pass announcement: the backward pass will run dX = dY . cat(weights, 0) (weights [N_i, K] as stored).  Inside
     grouped_presplit() the pre-split images of ALL announced weights are made by one grouped launch when the first of them is
-    needed (csrc/gemm_nt2.hip presplit_grouped_kernel) instead of one launch per weight and step (148 in the S4 step)."""
+    needed (csrc/gemm_x3.hip presplit_grouped_kernel) instead of one launch per weight and step (148 in the S4 step)."""
     if _split_images is None or not weights[0].is_cuda or any(w.dtype != torch.float32 or w.shape[0] % 8 for w in weights):
         return
     key = tuple(_split_key(w) for w in weights)
@@ -133,7 +133,7 @@ def _expected_image(*weights):
 
 
 def x3_ok(a, n_out):
-    """operands of csrc/gemm_nt2.hip (A rows; the B image is made by `presplit`)"""
+    """operands of csrc/gemm_nt3.hip (A rows; the B image is made by `presplit`)"""
     return (a.is_cuda and a.dtype == torch.float32 and a.dim() == 2 and a.shape[1] % 16 == 0 and a.shape[0] > 0
             and _aligned_rows(a) and a.shape[0] * n_out * 4 < 2 ** 31 - 1)
 
@@ -232,7 +232,7 @@ def gemm_smallm_f32(a, w, bias=None, relu=False):
 
 # ---- the head's bf16 throughput mode ---------------------------------------------------------------------------------------
 # FORWARD_PRECISION = "bf16": every forward GEMM of the head (linear layers, 1x1 / 3x3 convolutions, the mask-logit
-# contraction) runs on csrc/gemm_nt2.hip with ONE bf16 product per multiply-add (bf16 inputs rounded to nearest even, fp32
+# contraction) runs on csrc/gemm_nt3.hip with ONE bf16 product per multiply-add (bf16 inputs rounded to nearest even, fp32
 # accumulation): ~1/16 of the matrix-pipe time of the exact-fp32 instruction.  It is NOT the default: bf16 products move a
 # mask logit by ~3e-3 of its scale, the north-star's 1e-3 bound needs the fp32 path.  Stated tolerance
 # and its test: tests/test_head_gpu.py::test_bf16_forward_mode_stated_tolerance.  Gradient GEMMs keep the 3-product split.
@@ -259,7 +259,7 @@ def forward_image(weight):
 
 
 def gemm_nt_bf16(a, w, bias=None, relu=False, out=None, img=None):
-    """C = a @ w^T (+ bias) (+ ReLU) with ONE bf16 product per multiply-add, fp32 accumulation (csrc/gemm_nt2.hip)"""
+    """C = a @ w^T (+ bias) (+ ReLU) with ONE bf16 product per multiply-add, fp32 accumulation (csrc/gemm_nt3.hip)"""
     M, K = a.shape
     N = w.shape[0]
     if out is None:

@@ -2,7 +2,7 @@
 HIP kernels: the forward contraction of every prediction head is a batched exact-fp32 MFMA GEMM (csrc/gemm_f32.hip, one
 problem per frame: [Q,C] x [HW,C]^T - its output is thresholded at 0 into the next layer's attention mask, so it computes in
 true fp32); the mask itself comes from csrc/maskbits.hip (the same contraction against the DOWNSAMPLED pixel embedding, its MFMA
-result balloted into the bit-packed rows); the two gradient GEMMs run ONCE over the concatenated heads on the 3-product bf16 kernels (csrc/gemm_nt2.hip
+result balloted into the bit-packed rows); the two gradient GEMMs run ONCE over the concatenated heads on the 3-product bf16 kernels (csrc/gemm_nt3.hip
 batched, csrc/gemm_tn.hip grouped, one problem per frame)."""
 import ctypes
 
@@ -16,7 +16,7 @@ def _hip_ok(*ts):
 
 
 def presplit_batched(x, transpose):
-    """bf16 hi/lo image (csrc/gemm_nt2.hip) of a contiguous [B, R, C] tensor: [B, R, C] (K = C) or, transposed, [B, C, R]."""
+    """bf16 hi/lo image (csrc/gemm_nt3.hip) of a contiguous [B, R, C] tensor: [B, R, C] (K = C) or, transposed, [B, C, R]."""
     B, R, C = x.shape
     N, K = (C, R) if transpose else (R, C)
     img = torch.empty(B, N, K, device=x.device, dtype=torch.float32)

@@ -355,7 +355,7 @@ int combo_gemm_tn_smalln_f32(const float* dY, long long ldy, const float* X, lon
                              float* partials, float* db_partials, combo_stream_t stream);
 
 /*   Input-gradient GEMM C[M,N] = A[M,K] . B[N,K]^T (+ bias[N]) (+ ReLU) with the 3-product bf16 split (x.w ~ hi.hi +
- *   hi.lo + lo.hi, hi = rne_bf16, ~2^-17 relative per product) on the bf16 matrix cores (csrc/gemm_nt2.hip): persistent
+ *   hi.lo + lo.hi, hi = rne_bf16, ~2^-17 relative per product) on the bf16 matrix cores (csrc/gemm_nt3.hip): persistent
  *   workgroups with the next tile's first stages in flight under the epilogue stores, LDS-DMA ring with a source-side chunk
  *   swizzle, and the weight operand PRE-SPLIT into bf16 hi/lo groups by combo_presplit_bf16x2_f32 (element (n, k) =
  *   src[n*ld_row + k*ld_col], so for dX = dY . W the image of W^T needs no transpose copy; the image has N rows of K

@@ -1,4 +1,4 @@
-"""CPU: numpy model of the arithmetic of the head's GRADIENT GEMM kernels (csrc/gemm_nt2.hip, gemm_tn.hip) - every fp32
+"""CPU: numpy model of the arithmetic of the head's GRADIENT GEMM kernels (csrc/gemm_nt3.hip, gemm_tn.hip) - every fp32
 operand is split into hi = round_to_nearest_bf16(x) and lo = round_to_nearest_bf16(x - hi), and a product x*w is the sum of
 the three bf16 products hi*hi + hi*lo + lo*hi accumulated in fp32 (the MFMA accumulator).  Pins the error model DESIGN.md
 quotes (operands exact to 2^-17, a single product to 2^-15.5 worst case, ~4e-6 on a K = 256 dot product: ~3x better than

@@ -1,4 +1,4 @@
-"""GPU parity of the implicit-GEMM 3x3 convolution (ops/conv3x3.py on csrc/gemm_f32.hip forward, csrc/gemm_nt2.hip dX, csrc/gemm_tn.hip dW; CONV = true)
+"""GPU parity of the implicit-GEMM 3x3 convolution (ops/conv3x3.py on csrc/gemm_f32.hip forward, csrc/gemm_nt3.hip dX, csrc/gemm_tn.hip dW; CONV = true)
 against a float64 CPU convolution: forward, input gradient, weight gradient, bias gradient; square / non-square / tiny
 maps, ragged token tiles, and the production shape of the FPN output layer (reference: pixel_decoder/msdeformattn.py:281-286)."""
 import pytest

@@ -1,6 +1,6 @@
 """GPU parity of the head's dense-layer kernels against float64 references: the exact-fp32 MFMA forward GEMM
 (csrc/gemm_f32.hip; must sit in fp32's own error class, not the bf16 split's), the 3-product bf16 input-gradient GEMM
-(csrc/gemm_nt2.hip) and weight-gradient GEMM (csrc/gemm_tn.hip): ragged M/N, strided operands, batched form, deferred /
+(csrc/gemm_nt3.hip) and weight-gradient GEMM (csrc/gemm_tn.hip): ragged M/N, strided operands, batched form, deferred /
 grouped weight gradients."""
 import pytest
 import torch
@@ -172,7 +172,7 @@ def test_weight_gradient_gemm_tn_strided_views_and_packed_output():
                                                (20001, 64, 288, False), (16384, 2048, 256, False), (300, 16, 40, False),
                                                (4000, 256, 256, False), (4000, 256, 2048, True), (4000, 512, 256, False)])
 def test_gemm_nt_x3_input_gradient(M, K, N, relu_mask):
-    """dX = dY . W on csrc/gemm_nt2.hip: the weight arrives as a W^T VIEW (pre-split without a transpose copy), optional
+    """dX = dY . W on csrc/gemm_nt3.hip: the weight arrives as a W^T VIEW (pre-split without a transpose copy), optional
     ReLU-mask epilogue; 3-product bf16 split with a rounded `hi` part: < 1e-5 against fp64."""
     import combo_avs_amd  # noqa: F401
     from combo_avs_amd.ops.linear import gemm_nt_x3
@@ -272,7 +272,7 @@ def test_deferred_weight_gradient_with_a_non_deferrable_use_of_the_same_weight()
 @pytest.mark.parametrize("M,C,Hd", [(41160, 256, 1024), (4000, 256, 2048), (700, 256, 512)])
 def test_ffn_relu_gradient_folded_into_the_dx_gemm(M, C, Hd):
     """ops.linear.ffn: linear2(relu(linear1(x))) with the ReLU backward applied in the epilogue of linear2's input-gradient
-    GEMM (csrc/gemm_nt2.hip, mask operand) must give the gradients of the unfused chain bit for bit where both take the
+    GEMM (csrc/gemm_nt3.hip, mask operand) must give the gradients of the unfused chain bit for bit where both take the
     HIP path, and float64's to 2e-5 everywhere ."""
     import combo_avs_amd  # noqa: F401
     from combo_avs_amd.ops import linear as L
@@ -332,7 +332,7 @@ def test_gemm_smallm_weight_streaming(M, K, N, relu, capsys):
 
 def test_grouped_weight_presplit_gives_bitwise_the_same_input_gradients():
     """Inside grouped_presplit() the images of all announced weights are split by one grouped launch (ops.linear.expect_input_grad,
-    csrc/gemm_nt2.hip presplit_grouped_kernel): packed q/k/v slices, a column-concatenated pair and plain layers, compared
+    csrc/gemm_x3.hip presplit_grouped_kernel): packed q/k/v slices, a column-concatenated pair and plain layers, compared
     with the per-weight route outside the context - same split, same GEMM, so bit-identical."""
     from combo_avs_amd.ops import linear as L
     torch.manual_seed(3)

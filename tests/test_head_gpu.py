@@ -398,7 +398,7 @@ def test_fused_criterion_path_equals_unfused(head_run, mode):
 
 def test_bf16_forward_mode_stated_tolerance():
     """The head's bf16 throughput mode (ops.linear.set_forward_precision("bf16"), bench.py --head-dtype bf16): every forward
-    GEMM / convolution / mask-logit contraction of the head on ONE bf16 product per multiply-add (csrc/gemm_nt2.hip, fp32
+    GEMM / convolution / mask-logit contraction of the head on ONE bf16 product per multiply-add (csrc/gemm_nt3.hip, fp32
     accumulation) - the product's own kernels, not torch autocast.  Stated tolerance against the reference's fp32 outputs
     (golden head.npz), which is NOT the north-star's 1e-3 (that is what the default fp32 path is for):
       * prediction head #0 (no thresholded mask upstream): every sampled mask logit within 5e-2 x RMS + 2e-2 x |ref|

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""A/B of a module constant inside the bench step (the COMBO_* environment switches of round 3 are gone):
+    python tools/ab_const.py combo_avs_amd.ops.convwrw.DX_OWN=3 [more assignments] -- [bench.py arguments]
+sets the constants after importing the package, then runs bench.main() in this process."""
+import importlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import combo_avs_amd  # noqa: E402,F401
+
+args = sys.argv[1:]
+rest = []
+if "--" in args:
+    i = args.index("--")
+    args, rest = args[:i], args[i + 1:]
+for a in args:
+    path, val = a.split("=", 1)
+    mod, name = path.rsplit(".", 1)
+    m = importlib.import_module(mod)
+    old = getattr(m, name)
+    setattr(m, name, type(old)(eval(val)) if not isinstance(old, bool) else val in ("1", "True", "true"))
+    print(f"[ab_const] {path}: {old!r} -> {getattr(m, name)!r}", file=sys.stderr)
+import bench  # noqa: E402
+sys.argv = ["bench.py"] + rest
+bench.main()

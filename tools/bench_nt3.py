@@ -1,11 +1,10 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of the input-gradient GEMM (csrc/gemm_nt2.hip / gemm_nt3.hip: fp32 accuracy from 3 bf16 MFMA products) on the
+"""Micro-benchmark of the input-gradient GEMM (csrc/gemm_nt3.hip: fp32 accuracy from 3 bf16 MFMA products) on the
 dX shapes of the training step, against its two ceilings - 833 TFLOP/s useful (2.5 PF / 3 products) and the HBM time of the
 algorithmic bytes (A read once, C written once, weight image once) - and against the library's fp32 and bf16 GEMMs.
 
-    python tools/bench_nt2.py [--iters N] [--shapes all|small|big] [--no-lib]
-    COMBO_NT2_DBG=<bits>  ablation (1 no DMA, 2 no LDS reads, 4 no barrier, 8 no stores, 16 no split, 32 no MFMA)
-    COMBO_DX_KERNEL=2|3   force gemm_nt2 / gemm_nt3"""
+    python tools/bench_nt3.py [--iters N] [--shapes all|small|big] [--no-lib]
+    COMBO_NT3_DBG=<bits>  ablation instances: one of 1 2 4 8 16 32 41 63 (1 no DMA, 2 no LDS reads, 4 no barrier, 8 no stores, 16 no split, 32 no MFMA)
 import argparse
 import os
 import sys

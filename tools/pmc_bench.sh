@@ -16,7 +16,7 @@ agg=collections.defaultdict(lambda: collections.defaultdict(list))
 if fs:
     for r in csv.DictReader(open(fs[0])):
         n=r["Kernel_Name"]
-        m=re.search(r"(gemm_nt_f32_kernel|gemm_smallm_kernel|gemm_nt2_kernel|gemm_tn_grouped_kernel|gemm_tn_glds_kernel|conv3x3_wgrad_kernel|attn_fwd_kernel|attn_bwd_dq_kernel|attn_bwd_dkv_kernel|msda_fwd_tap_d32|msda_bwd_\w+|bifuse_\w+|add_ln_fwd_kernel|ln_bwd_kernel|presplit_kernel)", n)
+        m=re.search(r"(gemm_nt_f32_kernel|gemm_smallm_kernel|gemm_nt3_kernel|gemm_tn_grouped_kernel|gemm_tn_glds_kernel|conv3x3_wgrad_kernel|attn_fwd_kernel|attn_bwd_dq_kernel|attn_bwd_dkv_kernel|msda_fwd_tap_d32|msda_bwd_\w+|bifuse_\w+|add_ln_fwd_kernel|ln_bwd_kernel|presplit_kernel)", n)
         if m: agg[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k,v in sorted(agg.items()):
     print("PMC", k, {c: [round(sum(x)/len(x),1), len(x)] for c,x in v.items()})

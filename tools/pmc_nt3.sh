@@ -1,10 +1,10 @@
 #!/bin/bash
 # PMC counters of the input-gradient GEMM (separate passes per counter set, as MI355X_MICROARCH.md prescribes).
 cd /tmp && export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_nt2.txt
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_nt3.txt
 : > $OUT
 for c in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE SQ_INSTS_MFMA" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAVES SQ_WAIT_INST_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD" "FETCH_SIZE" "WRITE_SIZE"; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc -o p -- python3 $GRAFT_REPO_ROOT/tools/bench_nt2.py --iters 5 --shapes small --no-lib > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc -o p -- python3 $GRAFT_REPO_ROOT/tools/bench_nt3.py --iters 5 --shapes small --no-lib > /dev/null 2>&1
   python3 - <<PY | tee -a $OUT
 import csv,glob,collections
 fs=glob.glob("/tmp/pmc/*counter_collection.csv")
@@ -14,7 +14,7 @@ if not fs:
 agg=collections.defaultdict(lambda: collections.defaultdict(list))
 order=[]
 for r in csv.DictReader(open(fs[0])):
-    if "gemm_nt2" in r["Kernel_Name"] or "gemm_nt3" in r["Kernel_Name"]:
+    if "gemm_nt3" in r["Kernel_Name"]:
         key=(r["Kernel_Name"][:40], r["Grid_Size"], r.get("LDS_Block_Size",""), r.get("VGPR_Count",""))
         agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k,v in agg.items():
