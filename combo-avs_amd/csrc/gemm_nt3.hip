@@ -2,25 +2,35 @@
 // hi.lo, rounded `hi`: ~2^-17 relative per product) - the input-gradient GEMM dX = dY . W of every dense layer, the implicit-GEMM
 // 3x3 convolution's input gradient, the batched mask-logit gradients, and (products = 1) the head's bf16 forward mode.
 //
-// Why v3 (round 4).  its predecessor gemm_nt2 (round 3) did not overlap its phases.  Ablation of that kernel on MI355X (COMBO_NT2_DBG bits,
-// 41160 x 1024 -> 256, hot loop): 93 us = 25 (loop skeleton: waits, cursor, address arithmetic) + 30 (MFMA, i.e. the matrix
-// pipe at ~2.2 PF while it runs) + 31 (LDS-DMA issue + landing) + 8 (split) + 3 (LDS reads) + 3 (stores): the SUM of the parts,
-// although two workgroups shared each CU to overlap them - equal tiles keep them in phase.  Inside the training step the
-// kernel ran at 0.18 of its 833 TFLOP/s ceiling and 0.22 of HBM: bound by nothing.  v3 is gemm_f32.hip's skeleton (one
-// persistent workgroup per CU, one wave per SIMD with 512 registers, LDS-DMA ring with counted vmcnt across a raw s_barrier, a
-// wave covers its own latencies) re-timed for a matrix instruction that is 16x faster:
-//   * a stage (BK = 16) is ONE 32x32x16 MFMA triple per 32 x 32 sub-tile = 24 MFMAs of 32 cycles per wave (768 cycles; the
-//     f32 kernel has 4096 cycles per stage to hide the same 6 DMA pieces, 12 ds_read_b128 and 1 barrier);
-//   * phase 0 (hi.hi and lo.hi products, 16 MFMAs): the ds_reads of THIS stage's B `lo` groups and of the NEXT stage's raw A
-//     rows go out first, the DMA pieces of the stage entering the ring are issued between the MFMAs;
-//   * phase 1 (hi.lo products, 8 MFMAs): the next stage's B `hi` groups are read into the registers phase 0 just freed and
-//     the next stage's A rows are split (hi = rne_bf16(x), lo = rne_bf16(x - hi): 6 VALU per pair) between the MFMAs, into
-//     the other half of a two-set register ping-pong (no copies);
-//   * one barrier per stage, at its top: "stage s + 1 has landed for everybody and everybody is done with slot s - 1" (the
-//     slot the DMA of this stage refills), with ST - 3 younger stages left in flight;
-//   * the epilogue's 32 dwordx4 stores per wave are NOT waited for: the vmcnt budget of the next tile's first ST - 3 stages
-//     is raised by the number of stores (they are younger than every ring load those stages need), so the ring never drains
-//     at a tile boundary; operands swapped (D = W . X^T) as in gemm_f32: a lane owns 4 consecutive n of one token.
+// Why v3 (round 4).  Its predecessor gemm_nt2 (round 3: two 4-wave workgroups per CU, a ring of 3 stages) did not overlap its
+// phases.  Ablation of that kernel on MI355X (41160 x 1024 -> 256, hot loop): 93 us = 25 (loop skeleton: waits, cursor, address
+// arithmetic) + 30 (MFMA, i.e. the matrix pipe at ~2.2 PF while it runs) + 31 (LDS-DMA issue + landing) + 8 (split) + 3 (LDS reads)
+// + 3 (stores): the SUM of the parts - equal tiles keep the two workgroups of a CU in phase.  Inside the training step it ran at
+// 0.18 of its 833 TFLOP/s ceiling and 0.22 of HBM, and the decoder / res4 / res5 layers (few output tiles, long K) used 1/8 of the
+// chip.  v3 is gemm_f32.hip's skeleton - ONE persistent workgroup per CU, LDS-DMA ring of 6 stages with counted vmcnt across a raw
+// s_barrier, every wave software-pipelined - re-timed for a matrix instruction that is 16x faster than the f32 one:
+//   * a stage (BK = 16) is ONE 32x32x16 MFMA triple per 32 x 32 sub-tile; the wide tile (256 x 128) is worked by 8 waves (two per
+//     SIMD, 32 x 128 each: 12 MFMAs = 384 pipe cycles per wave and stage): while one wave of a SIMD sits in an LDS-DMA issue or an
+//     LDS wait the other one feeds the pipe;
+//   * phase 0 (hi.hi and lo.hi products): the ds_reads of THIS stage's B `lo` groups and of the NEXT stage's raw A rows go out
+//     first, the DMA pieces of the stage entering the ring are issued between the MFMAs;
+//   * phase 1 (hi.lo products): the next stage's B `hi` groups are read into the registers phase 0 just freed and the next
+//     stage's A rows are split (hi = rne_bf16(x), lo = rne_bf16(x - hi): 6 VALU per pair) between the MFMAs, into the other half
+//     of a two-set register ping-pong (no copies);
+//   * one barrier per stage, at its top: "stage s + 1 has landed for everybody and everybody is done with slot s - 1" (the slot
+//     the DMA of this stage refills), with ST - 3 younger stages left in flight;
+//   * NO branch in the stream: past the last tile the cursor goes on issuing dummy stages (the zero row), so exactly ST - 3
+//     younger stages are in flight at every wait and prefetching "the next stage" is always legal; ablation bits and the product
+//     count are template parameters (a run-time test per MFMA cost more than the MFMA);
+//   * the epilogue's dwordx4 stores are NOT waited for: the vmcnt budget of the next tile's first ST - 2 stages is raised by the
+//     number of stores (they are younger than every ring load those stages need), so the ring never drains at a tile boundary;
+//     operands swapped (D = W . X^T) as in gemm_f32: a lane owns 4 consecutive n of one token;
+//   * few output tiles and a long K (4000 x 2048 -> 256, the backbones' res4 / res5 layers): split-K as batch entries of one
+//     launch + a fixed-order finishing sum (combo_gemm_nt_x3_splitk_*): 63 -> 27 us.
+// Measured (tools/bench_nt3.py): one round of wide tiles at K = 1024 (32768 x 1024 -> 256) 55 us = 0.93 PF of bf16 MFMA issue
+// (hipBLASLt's plain bf16 GEMM sustains 1.1 - 1.4 PF under the 1400 W cap); without DMA 37 us, without MFMA 45 us, i.e. the
+// phases overlap now; the training step's input-gradient GEMMs 7.17 -> 6.4 ms.  What is left is tile quantisation (41160 rows
+// x 256 columns are 1.26 rounds of wide tiles) and the 66 decoder launches of 0.5 GFLOP at their ~8 us latency floor.
 // Tile shapes / row split: as gemm_f32.hip (wide 256 x 128, mid 128 x 128, skinny 64 x 64; whole rounds of large tiles + the
 // remaining rows on small ones).
 #include <cstdlib>

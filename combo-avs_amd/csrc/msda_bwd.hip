@@ -503,8 +503,10 @@ int combo_msda_backward_win_f32(const float* grad_out, const float* value, const
   if (!plan_windows(host_shapes, host_start, L, wa, lds_max, rows_total, nw) || rows_total != S) return COMBO_EINVAL;
   const long long grid = (long long)B * M * wa.n_win;
   if (grid > 0x7fffffffLL) return COMBO_EINVAL;
-  // algorithmic bytes: value, grad_out, loc, w read once; the three gradients written once
-  const double bytes = 4.0 * B * (2.0 * ((double)S + Lq) * M * kD + 2.0 * 3.0 * (double)Lq * M * L * P);
+  // algorithmic bytes: value [S] and grad_out [Lq] read once, grad_value [S] written once, loc / w read once and
+  // their gradients written once: 5.53 MB per frame at S = Lq = 1029 (221.3 MB at BT = 40).  (Round 3 charged one more Lq x M x D
+  // term - the forward's output, which the backward pass never touches: 263.4 MB.)
+  const double bytes = 4.0 * B * ((2.0 * (double)S + Lq) * M * kD + 2.0 * 3.0 * (double)Lq * M * L * P);
   unsigned long long* ts = combo_timing_next_slot(COMBO_TS_MSDA_BWD, bytes, bytes);
   static bool attr = false;
   if (!attr) {

@@ -64,11 +64,12 @@ def test_decoder_outputs_match_reference(head_run):
 
 
 def test_attention_masks_match_reference_bit_for_bit_up_to_round_off(head_run):
-    """The thresholded masks themselves: recompute `sigmoid(bilinear_down(logits)) < 0.5` from the product's logits with
-    the mask kernel and from the golden sample positions' sign; cells may differ only where the golden logit lies within
-    fp32 round-off of the threshold (counted)."""
-    from combo_avs_amd.ops import masklogit
+    """The thresholded masks themselves: the sign of the product's logits at the golden sample positions, and the reference rule
+    `sigmoid(bilinear_down(logits)) < 0.5` applied by torch to the product's full-resolution logits against the masks the
+    REFERENCE produced (head.npz `dec/attn_bits*`, as produced, before the row reset); cells may differ only where the
+    (interpolated) logit lies within fp32 round-off of the threshold (counted)."""
     z, head, feats, audio, out = head_run
+    ref_masks = synth.frozen_attn_masks(z)
     masks = [a["pred_masks"] for a in out["aux_outputs"]] + [out["pred_masks"]]
     flips = 0
     for i, m in enumerate(masks):
@@ -80,14 +81,12 @@ def test_attention_masks_match_reference_bit_for_bit_up_to_round_off(head_run):
         rms = float(d["l2"]) / np.sqrt(float(d["numel"]))
         assert np.all(np.abs(ref[differ]) < 1e-5 * rms), (i, np.abs(ref[differ]).max())
         flips += int(differ.sum())
-        # the mask kernel on the product's logits == the reference rule applied by torch on the same logits
-        tgt = [(7, 7), (14, 14), (28, 28)][i % 3]
-        blocked = masklogit.attn_mask(m.detach().contiguous(), tgt, True)
-        down = torch.nn.functional.interpolate(m.detach(), size=tgt, mode="bilinear", align_corners=False)
-        ref_blocked = (down.sigmoid().flatten(2) < 0.5)
-        ref_blocked[ref_blocked.all(-1)] = False
-        near = (down.flatten(2).abs() < 1e-5 * rms)
-        assert bool(((blocked == ref_blocked) | near).all())
+        if i < len(ref_masks):  # head i's mask gates layer i: the reference rule on the product's logits == the reference's mask
+            tgt = [(7, 7), (14, 14), (28, 28)][i % 3]
+            down = torch.nn.functional.interpolate(m.detach(), size=tgt, mode="bilinear", align_corners=False)
+            blocked = (down.sigmoid().flatten(2) < 0.5).cpu()
+            near = (down.flatten(2).abs() < 1e-5 * rms).cpu()
+            assert bool(((blocked == ref_masks[i]) | near).all()), int(((blocked != ref_masks[i]) & ~near).sum())
     assert flips <= 2, flips
 
 
