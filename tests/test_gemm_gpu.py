@@ -214,6 +214,25 @@ def test_gemm_nt_x3_every_tile_configuration_agrees(tile, M, K, N):
     assert torch.equal(got, again)  # deterministic
 
 
+@pytest.mark.parametrize("M,K,N", [(1, 16, 4), (33, 32, 37), (257, 64, 130), (4000, 2048, 256), (1960, 512, 2048)])
+def test_gemm_nt_x3_edges_scalar_stores_single_row_and_split_k(M, K, N):
+    """csrc/gemm_nt3.hip beyond the main road: one row; N not a multiple of 4 (scalar stores, scalar mask loads); shapes the
+    split-K plan takes (few output tiles, long K: partial sums + the fixed-order finishing launch, with and without the mask)"""
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd import _lib
+    from combo_avs_amd.ops.linear import gemm_nt_x3
+    torch.manual_seed(M + N)
+    a = torch.randn(M, K, device="cuda")
+    w = torch.randn(N, K, device="cuda") * 0.1
+    mask = torch.randn(M, N, device="cuda")
+    ref = a.double() @ w.double().t()
+    got, got_m, again = gemm_nt_x3(a, w), gemm_nt_x3(a, w, relu_mask=mask), gemm_nt_x3(a, w)
+    assert rel_err(got, ref) < 1e-5 and rel_err(got_m, ref * (mask > 0)) < 1e-5
+    assert torch.equal(got, again)
+    if (M, K, N) in ((4000, 2048, 256), (1960, 512, 2048)):
+        assert (_lib.lib().combo_gemm_nt_x3_splitk_plan(M, N, K) > 1) == ((M, K, N) == (4000, 2048, 256))
+
+
 def test_gemm_nt_x3_strided_token_operand():
     import combo_avs_amd  # noqa: F401
     from combo_avs_amd.ops.linear import gemm_nt_x3

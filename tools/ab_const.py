@@ -18,7 +18,11 @@ if "--" in args:
 for a in args:
     path, val = a.split("=", 1)
     mod, name = path.rsplit(".", 1)
-    m = importlib.import_module(mod)
+    try:
+        m = importlib.import_module(mod)
+    except ModuleNotFoundError:  # module.Class.attribute
+        mod2, cls = mod.rsplit(".", 1)
+        m = getattr(importlib.import_module(mod2), cls)
     old = getattr(m, name)
     setattr(m, name, type(old)(eval(val)) if not isinstance(old, bool) else val in ("1", "True", "true"))
     print(f"[ab_const] {path}: {old!r} -> {getattr(m, name)!r}", file=sys.stderr)
