@@ -316,6 +316,9 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "infer"],
                     help="train = the BASELINE metric (default); infer = eval-mode forward + fused semantic-inference tail "
                          "(SURVEY 8(f) rank 4: what pred.py times)")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="no device-side timing slots (the instrumented kernels' 2 atomics per workgroup + the fold launch per step): the "
+                         "plain step, without `roofline` / `other_kernels` - measures what the instrumentation costs")
     ap.add_argument("--dump-slots", default="", help="comma-separated timing-slot kinds (csrc/combo_common.h COMBO_TS_*): print every "
                                                      "instrumented launch of those kinds (work, bytes, average duration) to stderr")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
@@ -416,7 +419,7 @@ def main():
     n_slots = 4096
     ts_buf = torch.zeros(n_slots, 256, dtype=torch.int64, device=dev)  # csrc/combo_common.h: 16 sub-slots of 16 words
     ts_buf[:, 0::16] = -1  # ~0ull: earliest-start words
-    slot_timing = not args.no_graph  # the instrumented kernels time themselves into ts_buf (graph replays or eager launches)
+    slot_timing = not args.no_graph and not args.no_kernel_timing  # the instrumented kernels time themselves into ts_buf
     graphed = None
     if args.no_graph:
         def step(b):
@@ -434,7 +437,8 @@ def main():
         trace("model built")
         train_step(model, opt, batch)  # eager: MIOpen find / lazy init
         trace("eager step done")
-        _clib.check(_clib.lib().combo_timing_set_buffer(ts_buf.data_ptr(), n_slots), "combo_timing_set_buffer")
+        if slot_timing:
+            _clib.check(_clib.lib().combo_timing_set_buffer(ts_buf.data_ptr(), n_slots), "combo_timing_set_buffer")
         try:
             graphed(batch)  # captures
             trace("captured + first replayed step done")
@@ -442,19 +446,21 @@ def main():
         except Exception as exc:  # noqa: BLE001 - a failed capture must not cost the run: fall back to eager launches
             print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eager", file=sys.stderr, flush=True)
             graphed.graphs.clear()
-            _clib.lib().combo_timing_set_buffer(ts_buf.data_ptr(), n_slots)  # slots handed out to the failed capture: start over
+            if slot_timing:
+                _clib.lib().combo_timing_set_buffer(ts_buf.data_ptr(), n_slots)  # slots handed out to the failed capture: start over
 
             def step(b):
                 return train_step(model, opt, b)
         # timing buffer set but the steps launch eagerly (AVSS batches, a failed capture): the step's i-th instrumented launch
         # takes slot i in EVERY step (combo_timing_rewind), as a graph node does by construction
-        eager_slots = not graphed.graphs
+        eager_slots = slot_timing and not graphed.graphs
         for i in range(max(args.warmup - 1, 0)):
             if eager_slots:
                 _clib.lib().combo_timing_rewind()
             step(batches[i % len(batches)])
             trace("warm-up step done")
-        _clib.lib().combo_timing_fold(_clib.current_stream())
+        if slot_timing:
+            _clib.lib().combo_timing_fold(_clib.current_stream())
         sync()
         ts_buf[:, 2:4] = 0  # count only the launches of the timed region
         sync()

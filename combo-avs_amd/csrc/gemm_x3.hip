@@ -152,8 +152,10 @@ extern "C" int combo_gemm_nt_x3_pre_batched_f32(const float* A, long long lda, l
       sB % 4 != 0 || ((uintptr_t)A & 15) || ((uintptr_t)Bimg & 15))
     return COMBO_EINVAL;
   const int pad256 = (M + 255) / 256 * 256, pad128 = (M + 127) / 128 * 128;
+  // M = 100 queries per frame pads to 128, not 256: 128 x 128 tiles; otherwise the planner weighs tile rounds (M = 1000 rows of 10
+  // heads x 40 frames: 320 wide tiles are 2 rounds on 256 CUs, 640 mid tiles 3 cheaper ones)
   return combo_nt3_launch(A, lda, Bimg, K, nullptr, nullptr, C, ldc, M, N, K, relu, g_products, batch, sA, sB, sC, nullptr,
-                          pad128 < pad256 ? 2 : 1, stream);
+                          pad128 < pad256 ? 2 : 0, stream);
 }
 
 extern "C" int combo_gemm_nt_x3_pre_f32(const float* A, long long lda, const float* Bimg, const float* bias, float* C,
