@@ -227,7 +227,8 @@ def test_gemm_nt_x3_edges_scalar_stores_single_row_and_split_k(M, K, N):
     mask = torch.randn(M, N, device="cuda")
     ref = a.double() @ w.double().t()
     got, got_m, again = gemm_nt_x3(a, w), gemm_nt_x3(a, w, relu_mask=mask), gemm_nt_x3(a, w)
-    assert rel_err(got, ref) < 1e-5 and rel_err(got_m, ref * (mask > 0)) < 1e-5
+    # (relative to the UNMASKED result's norm: the one-row case keeps two small values, 2^-17 of the products they came from)
+    assert rel_err(got, ref) < 1e-5 and float((got_m.double() - ref * (mask > 0)).norm() / ref.norm()) < 1e-5
     assert torch.equal(got, again)
     if (M, K, N) in ((4000, 2048, 256), (1960, 512, 2048)):
         assert (_lib.lib().combo_gemm_nt_x3_splitk_plan(M, N, K) > 1) == ((M, K, N) == (4000, 2048, 256))
