@@ -114,6 +114,8 @@ _SIGNATURES = {
     "combo_lsap_small_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "combo_attention_forward_f32": [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_int, c_void_p] + [c_int] * 5 + [c_float, c_void_p, c_void_p, c_void_p],
     "combo_attention_backward_f32": [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_int, c_void_p] + [c_int] * 5 + [c_float] + [c_void_p] * 8,
+    "combo_attention_backward_ld_f32": [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_int, c_void_p] + [c_int] * 5 + [c_float]
+                                       + [c_void_p] * 6 + [c_longlong, c_void_p, c_longlong, c_void_p],
     "combo_adamw_f32": [c_void_p] * 4 + [c_longlong, c_void_p] + [c_float] * 7 + [c_void_p],
 }
 _RESTYPES = {"combo_build_arch": ctypes.c_char_p}

@@ -52,7 +52,8 @@ struct AttnArgs {
   // backward
   const float* dout;   // [B, Lq, H*32]
   const float* delta;  // [B, H, Lq]  sum_d dO * O
-  float* dq; float* dk; float* dv;  // [B, Lq, H*32], [B, Lk, H*32], [B, Lk, H*32]
+  float* dq; float* dk; float* dv;  // [B, Lq, H*32], [B, Lk, lddk], [B, Lk, lddv]
+  long long lddk, lddv;             // row pitch (floats) of dk / dv: H*32, or the pitch of a wider buffer whose column block they are
   unsigned long long* ts;
   int dbg;  // COMBO_ATTN_DBG ablation bits (timing experiments only): 1 no DMA in the loop, 2 no softmax, 4 no MFMA, 8 no mask pack
   int heavy_per_pair, heavy_blocks;  // forward job table: 32-query tiles per pair on the matrix cores; blocks of those jobs
@@ -722,8 +723,8 @@ attn_bwd_dkv_kernel(const AttnArgs a) {
     }
   }
   if (k_ok) {
-    float* rk = a.dk + ((long long)b * a.Lk + ki) * (a.H * kD) + h * kD;
-    float* rv = a.dv + ((long long)b * a.Lk + ki) * (a.H * kD) + h * kD;
+    float* rk = a.dk + ((long long)b * a.Lk + ki) * a.lddk + h * kD;
+    float* rv = a.dv + ((long long)b * a.Lk + ki) * a.lddv + h * kD;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       *reinterpret_cast<f4v*>(rk + 8 * j + 4 * g) = f4v{dk[4 * j] * a.scale, dk[4 * j + 1] * a.scale, dk[4 * j + 2] * a.scale, dk[4 * j + 3] * a.scale};
@@ -764,7 +765,7 @@ extern "C" int combo_attention_forward_f32(const float* q, long long ldq, const 
   if (!common_ok(q, ldq, k, ldk, v, ldv, B, H, Lq, Lk, blocked, pitch, blocked_bits, wpitch) || !out || ((uintptr_t)out & 15))
     return COMBO_EINVAL;
   AttnArgs a{q, k, v, ldq, ldk, ldv, blocked, pitch, blocked_bits, wpitch, B, H, Lq, Lk, scale, out, lse, nullptr, nullptr, nullptr, nullptr, nullptr,
-             combo_timing_next_slot(COMBO_TS_ATTN_FWD, 4.0 * B * H * (double)Lq * Lk * kD)};
+             0, 0, combo_timing_next_slot(COMBO_TS_ATTN_FWD, 4.0 * B * H * (double)Lq * Lk * kD)};
   int lds = 0, grid = 0;
   if (!job_table(a, lds, grid)) return COMBO_EINVAL;
   static int lds_set = 0;
@@ -777,17 +778,22 @@ extern "C" int combo_attention_forward_f32(const float* q, long long ldq, const 
   return (int)hipGetLastError();
 }
 
-extern "C" int combo_attention_backward_f32(const float* q, long long ldq, const float* k, long long ldk, const float* v, long long ldv,
-                                            const unsigned char* blocked, int pitch, const unsigned* blocked_bits, int wpitch, int B,
-                                            int H, int Lq, int Lk, float scale, const float* out, const float* lse, const float* dout,
-                                            float* delta_ws, float* dq, float* dk, float* dv, combo_stream_t stream) {
+/* _ld: dk / dv are written with row pitches lddk / lddv (floats, multiples of 4, >= H*32): the K / V gradients of a layer land in
+ * their column block of one [B*Lk, layers*E] buffer per memory level, which the merged K / V projection of that level
+ * (ops/linear.py memory_kv) contracts in ONE input-gradient GEMM - no concatenation, no accumulation adds. */
+extern "C" int combo_attention_backward_ld_f32(const float* q, long long ldq, const float* k, long long ldk, const float* v,
+                                               long long ldv, const unsigned char* blocked, int pitch, const unsigned* blocked_bits,
+                                               int wpitch, int B, int H, int Lq, int Lk, float scale, const float* out,
+                                               const float* lse, const float* dout, float* delta_ws, float* dq, float* dk,
+                                               long long lddk, float* dv, long long lddv, combo_stream_t stream) {
   if (!common_ok(q, ldq, k, ldk, v, ldv, B, H, Lq, Lk, blocked, pitch, blocked_bits, wpitch) || !out || !lse || !dout || !delta_ws || !dq || !dk || !dv ||
-      (((uintptr_t)out | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15))
+      (((uintptr_t)out | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) || lddk < H * kD || lddv < H * kD ||
+      lddk % 4 != 0 || lddv % 4 != 0)
     return COMBO_EINVAL;
   const long long n = (long long)B * Lq * H;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dout, out, B, H, Lq, delta_ws);
   AttnArgs a{q, k, v, ldq, ldk, ldv, blocked, pitch, blocked_bits, wpitch, B, H, Lq, Lk, scale, nullptr, const_cast<float*>(lse), dout, delta_ws, dq, dk, dv,
-             combo_timing_next_slot(COMBO_TS_ATTN_BWD, 6.0 * B * H * (double)Lq * Lk * kD)};
+             lddk, lddv, combo_timing_next_slot(COMBO_TS_ATTN_BWD, 6.0 * B * H * (double)Lq * Lk * kD)};
   {
     int lds = 0, grid = 0;
     if (!job_table(a, lds, grid)) return COMBO_EINVAL;
@@ -804,4 +810,12 @@ extern "C" int combo_attention_backward_f32(const float* q, long long ldq, const
   const int lds_kv = 8 * kTileBytes + 2 * kQChunk * 4 + 4 * kQChunk * 4;
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(B * H, (n_kt + 3) / 4), dim3(256), lds_kv, (hipStream_t)stream, a);
   return (int)hipGetLastError();
+}
+
+extern "C" int combo_attention_backward_f32(const float* q, long long ldq, const float* k, long long ldk, const float* v, long long ldv,
+                                            const unsigned char* blocked, int pitch, const unsigned* blocked_bits, int wpitch, int B,
+                                            int H, int Lq, int Lk, float scale, const float* out, const float* lse, const float* dout,
+                                            float* delta_ws, float* dq, float* dk, float* dv, combo_stream_t stream) {
+  return combo_attention_backward_ld_f32(q, ldq, k, ldk, v, ldv, blocked, pitch, blocked_bits, wpitch, B, H, Lq, Lk, scale, out, lse, dout,
+                                         delta_ws, dq, dk, (long long)H * kD, dv, (long long)H * kD, stream);
 }

@@ -16,7 +16,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from ..registry import TRANSFORMER_DECODER_REGISTRY
-from ..ops.linear import Linear, ffn, in_proj, linear
+from ..ops.linear import Linear, ffn, in_proj, in_proj_q, linear, memory_kv
 from .layers import MLP, position_embedding_sine
 
 
@@ -44,16 +44,21 @@ class _MHAParams(nn.Module):
         nn.init.xavier_uniform_(self.in_proj_weight)
         nn.init.constant_(self.out_proj.bias, 0.0)
 
-    def forward(self, query, key, value, blocked=None):
-        """batch-first: query [B,Lq,E], key/value [B,Lk,E]; blocked: uint8 [B,Lq,pitch] (1 = masked out, rows padded to a
-        multiple of 4 bytes, ops.masklogit.attn_mask_padded) or None."""
+    def forward(self, query, key, value, blocked=None, kv=None):
+        """batch-first: query [B,Lq,E], key/value [B,Lk,E]; blocked: an ops.masklogit.PackedMask / uint8 [B,Lq,pitch] (1 = masked
+        out, rows padded to a multiple of 4 bytes) or None.  kv: this layer's (k, v) row views [B*Lk, E] out of
+        ops.linear.memory_kv (the projections of all layers that share the memory, computed together) instead of key / value."""
         from ..ops.attention import attention
         E, H = self.embed_dim, self.num_heads
         B, Lq, _ = query.shape
-        Lk = key.shape[1]
         # (these weights are used once per forward: their dW GEMMs may be deferred into the grouped launch, ops/linear.py)
+        if kv is not None:
+            q = in_proj_q(query, self.in_proj_weight, self.in_proj_bias, defer=True)
+            o = attention(q.reshape(B * Lq, E), kv[0], kv[1], blocked, B, H)  # csrc/attention.hip
+            return self.out_proj(o.view(B, Lq, E))
+        Lk = key.shape[1]
         q, k, v = in_proj(query, key, value, self.in_proj_weight, self.in_proj_bias, same_qk=query is key, defer=True)
-        o = attention(q.reshape(B * Lq, E), k.reshape(B * Lk, E), v.reshape(B * Lk, E), blocked, B, H)  # csrc/attention.hip
+        o = attention(q.reshape(B * Lq, E), k.reshape(B * Lk, E), v.reshape(B * Lk, E), blocked, B, H)
         return self.out_proj(o.view(B, Lq, E))
 
 
@@ -91,14 +96,15 @@ class CrossAttentionLayer(nn.Module):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
 
-    def forward(self, tgt, memory, blocked, pos, query_pos, memory_k=None, fan=None):
-        """memory_k: `memory + pos`, computed once per level by the caller (three layers share a level's memory);
+    def forward(self, tgt, memory, blocked, pos, query_pos, memory_k=None, fan=None, kv=None):
+        """memory_k: `memory + pos`, computed once per level by the caller (three layers share a level's memory); kv: this
+        layer's projected (k, v) when the caller projected the memory for all layers of the level (then memory / pos are unused);
         fan = (residual, query = tgt + query_pos) handles on the previous FFN layer's output; returns
         (residual, value, query-key = out + query_pos) handles on this layer's output for the self-attention layer."""
-        if memory_k is None:
+        if memory_k is None and kv is None:
             memory_k = memory + pos
         t_res, t_q = fan if fan is not None else (tgt, tgt + query_pos)
-        tgt2 = self.multihead_attn(t_q, memory_k, memory, blocked)  # :99-118
+        tgt2 = self.multihead_attn(t_q, memory_k, memory, blocked, kv=kv)  # :99-118
         return self.norm(t_res, tgt2, fanout=2, pos=query_pos)  # LN(tgt + tgt2) in one pass (csrc/layernorm.hip)
 
 
@@ -226,6 +232,11 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
             s = add_channel_vector(self.input_proj[i](x[i]).flatten(2), self.level_embed.weight[i], 1)  # (ops/colsum.py)
             src.append(s.transpose(1, 2))  # [BT,hw,C]
         src_k = [s_ + p_ for s_, p_ in zip(src, pos)]  # key input of the cross-attention layers of a level: once, not per layer
+        # ... and so are the k / v projections: layers l, l + 3, l + 6 read level l - one pair of GEMMs per level computes them
+        # for all three (ops/linear.py memory_kv; their gradients come back through one [tokens, 3 x 256] buffer per level)
+        nl = self.num_feature_levels
+        attn = [layer.multihead_attn for layer in self.transformer_cross_attention_layers]
+        kv = memory_kv(src_k, src, [[(a.in_proj_weight, a.in_proj_bias) for a in attn[l::nl]] for l in range(nl)], defer=True)
         query_embed = self.query_embed.weight.unsqueeze(0)  # [1,Q,C]
         output = self.query_feat.weight.unsqueeze(0).expand(bt, -1, -1)
         if self.queries_fuse_type == "add":
@@ -257,7 +268,8 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
             lvl = i % self.num_feature_levels
             last = i == self.num_layers - 1
             # `blocked` already has the fully-blocked-row reset of :458 applied (fused in the mask kernel)
-            fan = self.transformer_cross_attention_layers[i](output, src[lvl], blocked, pos[lvl], query_embed, src_k[lvl], fan=fan)
+            fan = self.transformer_cross_attention_layers[i](output, src[lvl], blocked, pos[lvl], query_embed, src_k[lvl], fan=fan,
+                                                             kv=kv[lvl][i // nl])
             fan = self.transformer_self_attention_layers[i](None, query_embed, fan=fan)
             out = self.transformer_ffn_layers[i](None, fan=fan, query_pos=query_embed, last=last)
             if last:

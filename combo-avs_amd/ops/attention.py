@@ -17,9 +17,16 @@ def _rows_ok(t):
             and t.data_ptr() % 16 == 0)
 
 
+# K / V that are column blocks of a merged per-level projection (ops/linear.py memory_kv): key = data_ptr of the k block ->
+# (gradient holder, block index).  The backward pass then writes dk / dv straight into the holder's [rows, blocks * E] buffers
+# (csrc/attention.hip strided outputs) instead of into tensors of its own.
+kv_gradient_slots = {}
+
+
 class _Attention(Function):
     @staticmethod
     def forward(ctx, q, k, v, blocked, B, H, bits=None):
+        ctx.kv_slot = kv_gradient_slots.get(k.data_ptr()) if k.stride(0) != k.shape[1] else None
         Lq, Lk = q.shape[0] // B, k.shape[0] // B
         E = H * 32
         assert _rows_ok(q) and _rows_ok(k) and _rows_ok(v) and q.shape[1] == E and k.shape[1] == E and v.shape[1] == E
@@ -51,14 +58,19 @@ class _Attention(Function):
         E = H * 32
         dout = dout.contiguous()
         dq = torch.empty(B * Lq, E, device=q.device, dtype=torch.float32)
-        dk = torch.empty(B * Lk, E, device=q.device, dtype=torch.float32)
-        dv = torch.empty(B * Lk, E, device=q.device, dtype=torch.float32)
+        slot = ctx.kv_slot
+        if slot is not None and slot[0].matches(k, v, slot[1]):
+            dk, dv = slot[0].blocks(slot[1])  # column blocks of the level's shared gradient buffers
+        else:
+            dk = torch.empty(B * Lk, E, device=q.device, dtype=torch.float32)
+            dv = torch.empty(B * Lk, E, device=q.device, dtype=torch.float32)
         delta = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32)
-        _lib.check(_lib.lib().combo_attention_backward_f32(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
-                                                           _lib.ptr(blocked), pitch, _lib.ptr(bits), wpitch, B, H, Lq, Lk, scale,
-                                                           out.data_ptr(), lse.data_ptr(),
-                                                           dout.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(),
-                                                           dv.data_ptr(), _lib.current_stream()), "combo_attention_backward_f32")
+        _lib.check(_lib.lib().combo_attention_backward_ld_f32(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
+                                                              _lib.ptr(blocked), pitch, _lib.ptr(bits), wpitch, B, H, Lq, Lk, scale,
+                                                              out.data_ptr(), lse.data_ptr(),
+                                                              dout.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dk.stride(0),
+                                                              dv.data_ptr(), dv.stride(0), _lib.current_stream()),
+                   "combo_attention_backward_ld_f32")
         return dq, dk, dv, None, None, None, None
 
 

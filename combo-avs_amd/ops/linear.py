@@ -390,14 +390,15 @@ class deferred_dw:
     after the grouped reduce.  The gradients must be read after the context closes (trainer.FlatAdamW.backward does that)."""
 
     def __enter__(self):
-        global _dw_queue, _ln_queue, _dw_index
+        global _dw_queue, _ln_queue, _dw_index, _packed_grads
         self.prev, _dw_queue = _dw_queue, []
         self.prev_ln, _ln_queue = _ln_queue, []
         self.prev_index, _dw_index = _dw_index, {}
+        self.prev_packed, _packed_grads = _packed_grads, {}
         return self
 
     def __exit__(self, *exc):
-        global _dw_queue, _ln_queue, _dw_index
+        global _dw_queue, _ln_queue, _dw_index, _packed_grads
         q, _dw_queue = _dw_queue, self.prev
         ql, _ln_queue = _ln_queue, self.prev_ln
         _dw_index = self.prev_index
@@ -406,6 +407,9 @@ class deferred_dw:
         if exc[0] is None and ql:
             _flush_ln(ql)
         post, _after_flush[:] = _after_flush[:], []
+        if exc[0] is None:
+            _finish_packed_grads()
+        _packed_grads = self.prev_packed
         if exc[0] is None:
             for fn in post:
                 fn()
@@ -668,6 +672,185 @@ class _InProj(Function):
             for i, (dy, x) in enumerate(((dq, xq), (dk, xk), (dv, xv))):
                 _dw_into(dy, x, dW[i * E:(i + 1) * E], db[i * E:(i + 1) * E], defer=ctx.defer)
         return dxq, dxk, dxv, dW, db, None, None
+
+
+# ---- cross-attention with the K / V projections of a memory level merged over the layers that attend to it --------------------
+# transformer_decoder.py:99-118 runs, for decoder layers l, l + 3, l + 6, the K and V projection of the SAME memory (level l)
+# with three weights each: 18 skinny GEMMs per forward pass (M = 40 x 49 .. 784 tokens, N = 256), 18 input-gradient GEMMs whose
+# results autograd adds up (12 accumulation kernels over up to 32 MB each) and 6 extra row-major copies of the memory.
+# memory_kv computes K for the three layers with ONE GEMM (N = 3 x 256: 3 x the tiles on the small levels) and V with another,
+# the attention backward of a layer writes dk / dv into its column block of one [tokens, 3 x 256] buffer (csrc/attention.hip
+# strided outputs), and ONE input-gradient GEMM per operand (K = 768) contracts the whole buffer: nothing is concatenated and
+# nothing accumulated.  The packed [3E, E] weight gradient of a layer is then filled by TWO nodes (rows 0:E by the layer's q
+# projection, rows E:3E by the level's node) - _packed_grad.
+_packed_grads = {}  # packed in_proj weight address -> (dW [3E, E], db [3E], who created it) inside a deferred_dw() context
+
+
+def _packed_grad(W, who):
+    """-> (dW, db, first): gradient tensors of a packed projection that two nodes fill.  Inside deferred_dw() (gradients are
+    read after the context closes) the first caller creates them - dW is the registered flat-buffer view when there is one - and
+    hands them to autograd, the second fills its rows and returns no gradient: autograd never adds anything.  Outside, every
+    node returns a zero-padded tensor of its own and autograd adds the two (safe with any reader)."""
+    if _dw_queue is None:
+        return torch.zeros_like(W), torch.zeros(W.shape[0], device=W.device, dtype=W.dtype), True
+    ent = _packed_grads.pop(W.data_ptr(), None)
+    if ent is not None:
+        return ent[0], ent[1], False
+    dW, db = grad_buffer_like(W), torch.empty(W.shape[0], device=W.device, dtype=W.dtype)
+    _packed_grads[W.data_ptr()] = (dW, db, who)
+    return dW, db, True
+
+
+def _finish_packed_grads():
+    """deferred_dw() closes: a packed gradient only ONE of its two nodes reached (the other's output fed no loss) gets zeros
+    in the rows nobody wrote"""
+    for dW, db, who in _packed_grads.values():
+        E = dW.shape[1]
+        rows = slice(E, None) if who == "q" else slice(0, E)
+        dW[rows].zero_()
+        db[rows].zero_()
+    _packed_grads.clear()
+
+
+class _KVGrads:
+    """dK / dV of one memory level: [rows, layers * E] each, allocated when the first attention backward asks for its block"""
+
+    def __init__(self, rows, blocks, E, k_ptr, v_ptr, device):
+        self.rows, self.n, self.E, self.k_ptr, self.v_ptr, self.device = rows, blocks, E, k_ptr, v_ptr, device
+        self.dK = self.dV = None
+
+    def matches(self, k, v, j):
+        """k / v are exactly block j of the merged projections (not copies, not other tensors at a recycled address)"""
+        return (k.data_ptr() == self.k_ptr + 4 * j * self.E and v.data_ptr() == self.v_ptr + 4 * j * self.E
+                and tuple(k.shape) == (self.rows, self.E) and tuple(v.shape) == (self.rows, self.E)
+                and k.stride(0) == self.n * self.E and v.stride(0) == self.n * self.E)
+
+    def buffers(self):
+        if self.dK is None:
+            self.dK = torch.empty(self.rows, self.n * self.E, device=self.device, dtype=torch.float32)
+            self.dV = torch.empty(self.rows, self.n * self.E, device=self.device, dtype=torch.float32)
+        return self.dK, self.dV
+
+    def blocks(self, j):
+        dK, dV = self.buffers()
+        E = self.E
+        return dK[:, j * E:(j + 1) * E], dV[:, j * E:(j + 1) * E]
+
+
+class _MemoryKV(Function):
+    @staticmethod
+    def forward(ctx, mem_k, mem_v, defer, Wk, bk, Wv, bv, *Wb):
+        """mem_k / mem_v [rows, E]: key input (memory + position) and value input (memory) of one level; Wk / Wv [n E, E], bk /
+        bv [n E]: the k / v rows of the n layers' packed projections, concatenated (copies, not differentiated); Wb = W_0, b_0,
+        W_1, b_1, ...: the packed [3E, E] / [3E] parameters themselves -> k_0, v_0, k_1, v_1, ...: [rows, E] column blocks."""
+        from . import attention as A
+        Ws = Wb[0::2]
+        n, E = len(Ws), Ws[0].shape[1]
+        K_all = forward_gemm(mem_k, Wk, bk, False)
+        V_all = forward_gemm(mem_v, Wv, bv, False)
+        if ctx.needs_input_grad[0]:
+            expect_input_grad(*(W[E:2 * E] for W in Ws))  # the dX image is filled from the layers' slices: no concatenated weight
+        if ctx.needs_input_grad[1]:
+            expect_input_grad(*(W[2 * E:] for W in Ws))
+        ctx.save_for_backward(mem_k, mem_v, *Ws)
+        ctx.defer, ctx.n = defer, n
+        ctx.holder = holder = _KVGrads(mem_k.shape[0], n, E, K_all.data_ptr(), V_all.data_ptr(), mem_k.device)
+        outs = []
+        for j in range(n):
+            k_j, v_j = K_all[:, j * E:(j + 1) * E], V_all[:, j * E:(j + 1) * E]
+            if any(ctx.needs_input_grad):
+                A.kv_gradient_slots[k_j.data_ptr()] = (holder, j)
+            outs += [k_j, v_j]
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *grads):
+        from . import attention as A
+        mem_k, mem_v, *Ws = ctx.saved_tensors
+        n, holder = ctx.n, ctx.holder
+        E = Ws[0].shape[1]
+        dK, dV = holder.buffers()
+        for j in range(n):
+            A.kv_gradient_slots.pop(holder.k_ptr + 4 * j * E, None)
+            for g, buf in ((grads[2 * j], dK), (grads[2 * j + 1], dV)):
+                dst = buf[:, j * E:(j + 1) * E]
+                if g is None:
+                    dst.zero_()  # (a layer whose attention output reached no loss)
+                elif g.data_ptr() != dst.data_ptr() or g.stride() != dst.stride():
+                    dst.copy_(g)  # a gradient that was not written in place by the strided attention backward
+        dxk = input_grad_gemm(dK, tuple(W[E:2 * E] for W in Ws)) if ctx.needs_input_grad[0] else None
+        dxv = input_grad_gemm(dV, tuple(W[2 * E:] for W in Ws)) if ctx.needs_input_grad[1] else None
+        out = [dxk, dxv, None, None, None, None, None]
+        for j, W in enumerate(Ws):
+            if not ctx.needs_input_grad[7 + 2 * j]:
+                out += [None, None]
+                continue
+            dW, db, first = _packed_grad(W, "kv")
+            _dw_into(dK[:, j * E:(j + 1) * E], mem_k, dW[E:2 * E], db[E:2 * E], defer=ctx.defer)
+            _dw_into(dV[:, j * E:(j + 1) * E], mem_v, dW[2 * E:], db[2 * E:], defer=ctx.defer)
+            out += [dW, db] if first else [None, None]
+        return tuple(out)
+
+
+def memory_kv(mem_k, mem_v, level_params, defer=False):
+    """The k / v projections of every cross-attention layer, one pair of GEMMs per memory level.
+    mem_k / mem_v: per level, the key input (memory + position) and the value input (memory), [B, hw, E];
+    level_params: per level, [(in_proj_weight [3E, E], in_proj_bias [3E])] of the layers that attend to that level, in layer order
+    -> per level, [(k, v)] as ROW VIEWS [B * hw, E] (row pitch layers * E) for ops.attention.attention."""
+    E = mem_k[0].shape[-1]
+    with torch.no_grad():  # k rows of level 0's layers, v rows of level 0's layers, k rows of level 1's, ...: ONE copy kernel each
+        Wcat = torch.cat([W[r * E:(r + 1) * E] for params in level_params for r in (1, 2) for W, _ in params], 0)
+        bcat = torch.cat([b[r * E:(r + 1) * E] for params in level_params for r in (1, 2) for _, b in params], 0)
+    if FORWARD_PRECISION == "bf16" and _fwd_images is not None:
+        _fwd_images.setdefault("pinned", []).append(Wcat)  # (bf16 images are cached by weight address for the step)
+    out, off = [], 0
+    for xk, xv, params in zip(mem_k, mem_v, level_params):
+        n = len(params)
+        if n == 0:  # fewer decoder layers than memory levels
+            out.append([])
+            continue
+        flat = [t for pair in params for t in pair]
+        rk, rv = slice(off, off + n * E), slice(off + n * E, off + 2 * n * E)
+        off += 2 * n * E
+        o = _MemoryKV.apply(xk.reshape(-1, E), xv.reshape(-1, E), defer, Wcat[rk], bcat[rk], Wcat[rv], bcat[rv], *flat)
+        out.append([(o[2 * j], o[2 * j + 1]) for j in range(n)])
+    return out
+
+
+class _InProjQ(Function):
+    """q = x W[:E]^T + b[:E] of a packed nn.MultiheadAttention projection whose k / v rows are computed by memory_kv"""
+
+    @staticmethod
+    def forward(ctx, x2d, W, b, defer=False):
+        E = W.shape[1]
+        ctx.defer = defer
+        q = forward_gemm(x2d, W[:E], b[:E], False)
+        if ctx.needs_input_grad[0]:
+            expect_input_grad(W[:E])
+        ctx.save_for_backward(x2d, W)
+        return q
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dq):
+        x2d, W = ctx.saved_tensors
+        E = W.shape[1]
+        dq = dq.contiguous()
+        dx = input_grad_gemm(dq, W[:E]) if ctx.needs_input_grad[0] else None
+        dW = db = None
+        if ctx.needs_input_grad[1]:
+            dW, db, first = _packed_grad(W, "q")
+            _dw_into(dq, x2d, dW[:E], db[:E], defer=ctx.defer)
+            if not first:
+                dW = db = None
+        return dx, dW, db, None
+
+
+def in_proj_q(xq, weight, bias, defer=False):
+    """the q third of the packed projection ([..., E] -> [..., E]); k and v come from memory_kv"""
+    E = weight.shape[1]
+    return _InProjQ.apply(xq.reshape(-1, E), weight, bias, defer).view(*xq.shape[:-1], E)
 
 
 def in_proj(xq, xk, xv, weight, bias, same_qk=False, defer=False):

@@ -483,6 +483,13 @@ int combo_attention_backward_f32(const float* q, long long ldq, const float* k, 
                                  const unsigned char* blocked, int pitch, const unsigned* blocked_bits, int wpitch, int B, int H,
                                  int Lq, int Lk, float scale, const float* out, const float* lse, const float* dout,
                                  float* delta_ws, float* dq, float* dk, float* dv, combo_stream_t stream);
+/*   _ld: dk / dv written with row pitches lddk / lddv (floats; multiples of 4, >= H*32): column blocks of a wider buffer - the K / V
+ *   gradients of the decoder layers that share a memory level (ops/linear.py memory_kv). */
+int combo_attention_backward_ld_f32(const float* q, long long ldq, const float* k, long long ldk, const float* v, long long ldv,
+                                    const unsigned char* blocked, int pitch, const unsigned* blocked_bits, int wpitch, int B, int H,
+                                    int Lq, int Lk, float scale, const float* out, const float* lse, const float* dout,
+                                    float* delta_ws, float* dq, float* dk, long long lddk, float* dv, long long lddv,
+                                    combo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a14  Hungarian-matcher cost matrices, all (decoder output x frame) problems at once
