@@ -98,6 +98,10 @@ _SIGNATURES = {
     "combo_wall_clock_khz": [],
     "combo_gemm_nt_x3_pre_f32": [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_void_p],
     "combo_conv3x3_nhwc_x3_pre_f32": [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_longlong] + [c_int] * 6 + [c_void_p],
+    "combo_gemm_nt_x3_epi_f32": [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_longlong] + [c_int] * 5 + [c_void_p, c_void_p],
+    "combo_conv3x3_x3_splitk_plan": [c_longlong, c_int, c_int],
+    "combo_conv3x3_nhwc_x3_epi_f32": [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_longlong] + [c_int] * 7 + [c_void_p, c_void_p],
+    "combo_conv_nhwc_x3_epi_f32": [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_longlong] + [c_int] * 9 + [c_void_p, c_void_p],
     "combo_gemm_tn_splits": [c_int, c_int, c_int],
     "combo_gemm_tn_x3_f32": [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "combo_gemm_tn_x3_grouped_f32": [c_void_p, c_int, c_void_p],

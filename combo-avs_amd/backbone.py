@@ -121,21 +121,42 @@ class Bottleneck(nn.Module):
             out = self.conv3(out)
             sc = self.shortcut(x) if self.shortcut is not None else x
             return F.relu_(out + sc)
-        # folded path: convolutions run WITHOUT bias, bias (+ residual) + ReLU is one fused pass (csrc/biasact.hip)
-        from .ops.biasact import bias_act
+        # folded path, fp32: bias (+ residual) + ReLU ride in the convolution's GEMM epilogue where the layer runs on the head's
+        # kernels (ops/convwrw.py conv_bias_act), else one fused pass after the library's convolution (csrc/biasact.hip)
         xr = x if x_res is None else x_res
         f1, f2, f3 = next(folded), next(folded), next(folded)
+        if x.dtype == torch.float32:
+            from .ops import convwrw
+            cba = convwrw.conv_bias_act
+            c1, c2, c3 = self.conv1, self.conv2, self.conv3
+            # a ReLU whose output feeds ONE convolution: its gradient mask rides in the epilogue of that convolution's
+            # input-gradient GEMM instead of a pass of its own (conv1 -> conv2 when conv2's dX is an own kernel, conv2 -> conv3)
+            k2 = convwrw.weight_kind(f2[0], c2.stride, c2.padding) if (x.is_cuda and torch.is_grad_enabled() and f2[0].requires_grad) else 0
+            k3 = convwrw.weight_kind(f3[0], c3.stride, c3.padding) if (x.is_cuda and torch.is_grad_enabled() and f3[0].requires_grad) else 0
+            fold1 = convwrw.ENABLED and k2 == 3 and bool(convwrw.DX_OWN & 1) and f2[3] is not None
+            fold2 = convwrw.ENABLED and k3 == 1
+            out = cba(x, f1[0], f1[2], c1.stride, c1.padding, f1[3], grad_masked=fold1)
+            out = cba(out, f2[0], f2[2], c2.stride, c2.padding, f2[3], grad_masked=fold2, mask_dx=fold1)
+            if self.shortcut is not None:
+                fs = next(folded)
+                sc = cba(xr, fs[0], None, self.shortcut.stride, self.shortcut.padding, fs[3])
+                return cba(out, f3[0], self._merged_shift(f3[2], fs[2]), c3.stride, c3.padding, f3[3], residual=sc, fanout=fanout, mask_dx=fold2)
+            return cba(out, f3[0], f3[2], c3.stride, c3.padding, f3[3], residual=xr, fanout=fanout, mask_dx=fold2)
+        from .ops.biasact import bias_act
         out = bias_act(self.conv1(x, f1, bias=False), f1[2])
-        c2 = self.conv2(out, f2, bias=False)
-        # conv2's ReLU feeds only conv3: its gradient mask rides in the epilogue of conv3's input-gradient GEMM
-        from .ops import convwrw
-        fold_relu = c2.dtype == torch.float32 and convwrw.kind(c2, f3[0], 1, 0) == 1
-        out = bias_act(c2, f2[2], grad_masked=fold_relu)
-        out = self.conv3(out, f3, bias=False, mask_dx=fold_relu)
+        out = bias_act(self.conv2(out, f2, bias=False), f2[2])
+        out = self.conv3(out, f3, bias=False)
         if self.shortcut is not None:
             fs = next(folded)
             return bias_act(out, f3[2] + fs[2], self.shortcut(xr, fs, bias=False), fanout=fanout)
         return bias_act(out, f3[2], xr, fanout=fanout)
+
+    def _merged_shift(self, a, b):
+        """FrozenBN shifts of conv3 and of the shortcut as one bias vector (constants: computed once)"""
+        key = (a.data_ptr(), b.data_ptr())
+        if getattr(self, "_shift_key", None) != key:
+            self._shift_key, self._shift_sum = key, (a + b).detach()
+        return self._shift_sum
 
 
 class BasicStem(nn.Module):
@@ -168,10 +189,17 @@ class ResNet(nn.Module):
             self._strides[name], self._channels[name] = 4 * 2 ** i, cout
         self.size_divisibility = 0
         self._bn_cache = {}
-        self.register_load_state_dict_post_hook(lambda module, incompatible: module._bn_cache.clear())
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._drop_constants())
+
+    def _drop_constants(self):
+        """forget everything derived from the frozen statistics (they were loaded or moved)"""
+        self._bn_cache.clear()
+        for m in self.modules():
+            if isinstance(m, Bottleneck):
+                m._shift_key = None
 
     def _apply(self, fn, *args, **kwargs):
-        self._bn_cache.clear()  # .to() / .cuda() moved the frozen statistics
+        self._drop_constants()  # .to() / .cuda() moved the frozen statistics
         return super()._apply(fn, *args, **kwargs)
 
     def _conv_list(self):
@@ -198,7 +226,14 @@ class ResNet(nn.Module):
         convs = self._conv_list()
         scales, shifts, shifts32 = self._frozen_affine(convs, dtype)
         folded_w = _FoldAll.apply(dtype, scales, *[c.weight for c in convs])
-        folded = iter(zip(folded_w, shifts, shifts32))
+        images = [None] * len(convs)
+        if dtype == torch.float32 and x.is_cuda and torch.is_grad_enabled() and folded_w[0].requires_grad:
+            from .ops import convwrw
+            if convwrw.ENABLED and (convwrw.FWD_X3 or convwrw.DX_OWN):
+                # bf16 hi/lo images of every weight the head's 3-product kernels will read (forward and input gradient)
+                with torch.no_grad():
+                    images = convwrw.weight_images([w.detach() for w in folded_w], [(c.stride, c.padding) for c in convs])
+        folded = iter(zip(folded_w, shifts, shifts32, images))
         with torch.autocast("cuda", enabled=False):
             x = self.stem(x.to(dtype).contiguous(memory_format=torch.channels_last), folded)
             out = {}
@@ -247,6 +282,35 @@ class VGGish(nn.Module):
                 raise NotImplementedError("wav->log-mel preprocessing / PCA post-processing are offline steps (disabled in all shipped configs)")
 
     def forward(self, x):
-        x = self.features(x)
+        if x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and not torch.is_autocast_enabled():
+            x = self._features_own(x)
+        else:
+            x = self.features(x)
         x = x.permute(0, 2, 3, 1).reshape(x.size(0), -1)  # vggish.py:21-25
         return self.embeddings(x)
+
+    def _features_own(self, x):
+        """the frozen extractor's forward (no gradient): the 3x3 convolutions with >= 64 input channels + bias + ReLU as ONE
+        launch each of the head's 3-product implicit-GEMM kernel (ops/convwrw.py) on channels_last maps.  Besides the ReLU pass it
+        saves, the result is reproducible from run to run - the library's kernel for the last convolution (512 -> 512 on 12 x 8,
+        3 840 tokens) accumulates with atomics, and a 1e-7 wobble of the audio token is enough to flip a decoder mask cell."""
+        from .ops import convwrw
+        mods = list(self.features)
+        convs = [m for m in mods if isinstance(m, nn.Conv2d)]
+        own = [c.in_channels % 64 == 0 and c.out_channels % 64 == 0 and c.kernel_size == (3, 3) and c.stride == (1, 1)
+               and c.padding == (1, 1) and c.bias is not None for c in convs]
+        images = convwrw.weight_images([c.weight.detach() for c, o in zip(convs, own) if o], [((1, 1), (1, 1))] * sum(own)) if any(own) else []
+        images = iter(images)
+        x = x.contiguous(memory_format=torch.channels_last)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.Conv2d) and own[convs.index(m)] and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
+                x = convwrw._x3_forward(x, 3, next(images)[0], m.bias.detach(), None, True)
+                i += 2
+                continue
+            if isinstance(m, nn.Conv2d) and own[convs.index(m)]:
+                next(images)
+            x = m(x)
+            i += 1
+        return x

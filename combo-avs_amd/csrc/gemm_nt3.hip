@@ -92,9 +92,10 @@ struct N3Args {
   const float* A; long long lda;
   const float* B; long long ldb;   // pre-split image (combo_presplit_bf16x2_*): per 8 k a 16-B bf16 hi group + a 16-B lo group
   const float* bias;               // [N] or nullptr
-  const float* mask;               // [M, N] (pitch ldc, batch stride sC) or nullptr: C = mask > 0 ? value : 0
+  const float* mask;               // [M, N] (pitch ldc, batch stride sC) or nullptr: C = mask > 0 ? value : 0 (aux_add: C += mask,
+                                   // before the ReLU - the residual branch of a bottleneck block)
   float* C; long long ldc;
-  int M, N, K, relu, c_bytes, batch, vec_store, dbg, products;
+  int M, N, K, relu, c_bytes, batch, vec_store, dbg, products, aux_add;
   long long sA, sB, sC;
   combo_nt3_conv cg;
   unsigned long long* ts;
@@ -117,6 +118,8 @@ gemm_nt3_kernel(const N3Args p) {
   const long long lda = p.lda, ldb = p.ldb;
   const int M = p.M, N = p.N, K = p.K;
   const combo_nt3_conv cg = p.cg;
+  const int cs = CONV && cg.stride == 2 ? 2 : 1;                          // CONV: the output map (M = batch x ho x wo tokens)
+  const int ho = (cg.H + cs - 1) / cs, wo = (cg.W + cs - 1) / cs;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
@@ -167,12 +170,17 @@ gemm_nt3_kernel(const N3Args p) {
     const float* i_B = Bm + bi * p.sB;
     const int i_m_blk = (rem / n_tiles) * BM;
     const int i_n_blk = (rem % n_tiles) * BN;
-    i_s = 0; i_tap = 0; i_cin0 = 0;
+    i_s = 0; i_tap = CONV ? bi * cg.tap_step : 0; i_cin0 = 0;  // (split 3x3 convolution: batch entry bi owns taps bi * tap_step ...)
 #pragma unroll
     for (int u = 0; u < APW; ++u) {
       const int r = (wave + NW * u) * 16 + p_row;
       const int c = p_chunk ^ ((r >> 2) & 3);  // swizzle on the SOURCE chunk, the LDS image stays lane-linear
-      pa[u] = i_A + (long long)min(i_m_blk + r, M - 1) * lda + c * 4;
+      long long row = min(i_m_blk + r, M - 1);
+      if (CONV && cg.stride == 2) {  // output token -> the input token under its centre tap
+        const int t = (int)row, xo = t % wo, yo = (t / wo) % ho, b = t / (wo * ho);
+        row = ((long long)b * cg.H + 2 * yo) * cg.W + 2 * xo;
+      }
+      pa[u] = i_A + row * lda + c * 4;
     }
 #pragma unroll
     for (int u = 0; u < PPW - APW; ++u) {
@@ -184,11 +192,11 @@ gemm_nt3_kernel(const N3Args p) {
 #pragma unroll
       for (int u = 0; u < APW; ++u) {
         const int t = min(i_m_blk + (wave + NW * u) * 16 + p_row, M - 1);
-        const int x = t % cg.W, y = (t / cg.W) % cg.H;
+        const int x = (t % wo) * cs, y = ((t / wo) % ho) * cs;  // centre tap in the input map
         unsigned ok = 0u;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-          const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+          const int yy = y + tap / 3 - cg.pad, xx = x + tap % 3 - cg.pad;
           if (yy >= 0 && yy < cg.H && xx >= 0 && xx < cg.W) ok |= 1u << tap;
         }
         tap_ok[u] = ok;
@@ -202,7 +210,7 @@ gemm_nt3_kernel(const N3Args p) {
     char* st = smem + i_slot * STAGE;
     const int q = wave + NW * u;  // q < A_PIECES: A rows, else B rows
     if constexpr (u < APW) {
-      const long long a_off = (CONV ? (long long)((i_tap / 3 - 1) * cg.W + (i_tap % 3 - 1)) * lda + i_cin0 : (long long)(i_s * kBK)) * k_mul;
+      const long long a_off = (CONV ? (long long)((i_tap / 3 - cg.pad) * cg.W + (i_tap % 3 - cg.pad)) * lda + i_cin0 : (long long)(i_s * kBK)) * k_mul;
       const float* src = pa[u] + a_off;
       if (CONV) {
         const int c = p_chunk ^ (((q * 16 + p_row) >> 2) & 3);
@@ -371,8 +379,9 @@ gemm_nt3_kernel(const N3Args p) {
             const int n0 = nb + 8 * q;
             f4v v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
             if (p.bias) v += bv[q];
+            if (p.aux_add) v += __builtin_bit_cast(f4v, mv[q]);
             if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            if (p.mask) {
+            if (p.mask && !p.aux_add) {
               v.x = __uint_as_float(mv[q].x) > 0.f ? v.x : 0.f; v.y = __uint_as_float(mv[q].y) > 0.f ? v.y : 0.f;
               v.z = __uint_as_float(mv[q].z) > 0.f ? v.z : 0.f; v.w = __uint_as_float(mv[q].w) > 0.f ? v.w : 0.f;
             }
@@ -390,9 +399,12 @@ gemm_nt3_kernel(const N3Args p) {
               asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(b) : "v"(bias_lds + (unsigned)min(n, n_pad - 1) * 4u) : "memory");
               v += b;
             }
-            if (p.relu) v = fmaxf(v, 0.f);
             const unsigned off = n < N ? ((unsigned)row * (unsigned)p.ldc + (unsigned)n) * 4u : 0xfffffff0u;
-            if (p.mask) v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(m_rsrc, off, 0, 0)) > 0.f ? v : 0.f;
+            float mval = 0.f;
+            if (p.mask) mval = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(m_rsrc, off, 0, 0));
+            if (p.aux_add) v += mval;
+            if (p.relu) v = fmaxf(v, 0.f);
+            if (p.mask && !p.aux_add) v = mval > 0.f ? v : 0.f;
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), c_rsrc, off, 0, 0);
           }
         }
@@ -553,7 +565,7 @@ int launch_cfg3(N3Args a, hipStream_t stream) {
   const long long slots = n_cu_cached3();  // one persistent workgroup per CU
   const int grid = (int)(tiles < slots ? tiles : slots);
   a.ts = combo_timing_next_slot(a.products == 3 ? COMBO_TS_GEMM_X3 : COMBO_TS_GEMM_BF16, 2.0 * a.M * a.N * a.K * a.batch,
-                                4.0 * a.batch * ((double)a.M * (CONV ? a.K / 9 : a.K) + (double)a.N * a.K + (double)a.M * a.N * (a.mask ? 2 : 1)));
+                                4.0 * a.batch * ((double)a.M * (CONV ? a.cg.Cin : a.K) + (double)a.N * a.K + (double)a.M * a.N * (a.mask ? 2 : 1)));
   if constexpr (!CONV && std::is_same<Cfg, NWide>::value) {  // the ablation instances (COMBO_NT3_DBG, tools/bench_nt3.py)
     if (a.products == 3) {
       switch (a.dbg) {
@@ -637,24 +649,25 @@ extern "C" int combo_gemm_nt_x3_tile(int cfg) {
 
 int combo_nt3_launch(const float* A, long long lda, const float* Bimg, long long ldb, const float* bias, const float* mask, float* C,
                      long long ldc, long long M, int N, int K, int relu, int products, int batch, long long sA, long long sB,
-                     long long sC, const combo_nt3_conv* conv, int force_cfg, combo_stream_t stream) {
+                     long long sC, const combo_nt3_conv* conv, int force_cfg, combo_stream_t stream, int aux_add) {
   if (!A || !Bimg || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || K % kBK != 0 || lda % 4 != 0 || ldb % 4 != 0 || sA % 4 != 0 ||
       sB % 4 != 0 || ((uintptr_t)A & 15) || ((uintptr_t)Bimg & 15) || M > 0x7fffffffLL || ((M - 1) * ldc + N) * 4 >= 0x7ffffff0LL ||
       (bias && N > kMaxBiasN) || (products != 1 && products != 3))
     return COMBO_EINVAL;
   const int vec = (N % 4 == 0 && ldc % 4 == 0 && sC % 4 == 0 && !((uintptr_t)C & 15) && (!mask || !((uintptr_t)mask & 15))) ? 1 : 0;
+  if (aux_add && !mask) return COMBO_EINVAL;
   N3Args a{A, lda, Bimg, ldb, bias, mask, C, ldc, (int)M, N, K, relu, (int)(((M - 1) * ldc + N) * 4), batch, vec, dbg_bits3(), products,
-           sA, sB, sC, conv ? *conv : combo_nt3_conv{1, 1, K}, nullptr};
+           aux_add ? 1 : 0, sA, sB, sC, conv ? *conv : combo_nt3_conv{1, 1, K, 0, 1, 1}, nullptr};
   if (force_cfg) return conv ? launch_one3<true>(a, (hipStream_t)stream, force_cfg) : launch_one3<false>(a, (hipStream_t)stream, force_cfg);
   return conv ? launch_nt3<true>(a, (hipStream_t)stream) : launch_nt3<false>(a, (hipStream_t)stream);
 }
 
 namespace {
-// out[m, n] = sum_z part[z, m, n], masked (mask > 0 ? . : 0) on request: finishes a split-K input-gradient GEMM; N % 4 == 0,
-// fixed summation order
+// out[m, n] = epilogue(sum_z part[z, m, n]): + bias[n], + aux (aux_add), ReLU, aux > 0 ? . : 0 (mask without aux_add) - the
+// epilogue of the unsplit kernel; finishes a split-K GEMM / convolution; N % 4 == 0, fixed summation order
 __global__ void __launch_bounds__(256)
 nt3_splitk_finish_kernel(const float* __restrict__ part, int splits, long long M, int N, const float* __restrict__ mask,
-                         float* __restrict__ out, long long ldc) {
+                         float* __restrict__ out, long long ldc, const float* __restrict__ bias, int relu, int aux_add) {
   const long long n4 = (long long)M * (N >> 2);
   const long long i = blockIdx.x * 256LL + threadIdx.x;
   if (i >= n4) return;
@@ -665,8 +678,15 @@ nt3_splitk_finish_kernel(const float* __restrict__ part, int splits, long long M
     const float4 b = reinterpret_cast<const float4*>(part + (long long)z * M * N)[i];
     a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
   }
-  if (mask) {
-    const float4 mk = *reinterpret_cast<const float4*>(mask + mrow * ldc + c);
+  if (bias) {
+    const float4 bv = *reinterpret_cast<const float4*>(bias + c);
+    a.x += bv.x; a.y += bv.y; a.z += bv.z; a.w += bv.w;
+  }
+  float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (mask) mk = *reinterpret_cast<const float4*>(mask + mrow * ldc + c);
+  if (aux_add) { a.x += mk.x; a.y += mk.y; a.z += mk.z; a.w += mk.w; }
+  if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+  if (mask && !aux_add) {
     a.x = mk.x > 0.f ? a.x : 0.f; a.y = mk.y > 0.f ? a.y : 0.f; a.z = mk.z > 0.f ? a.z : 0.f; a.w = mk.w > 0.f ? a.w : 0.f;
   }
   *reinterpret_cast<float4*>(out + mrow * ldc + c) = a;
@@ -689,18 +709,83 @@ extern "C" int combo_gemm_nt_x3_splitk_plan(int M, int N, int K) {
   return s < 1 ? 1 : s;
 }
 
-extern "C" int combo_gemm_nt_x3_splitk_f32(const float* A, long long lda, const float* Bimg, const float* mask, float* C,
-                                           long long ldc, int M, int N, int K, int splits, float* workspace, combo_stream_t stream) {
+static int nt3_split_launch(const float* A, long long lda, const float* Bimg, const float* bias, const float* aux, int aux_add,
+                            float* C, long long ldc, long long M, int N, int K, int relu, int splits, float* workspace,
+                            const combo_nt3_conv* conv, combo_stream_t stream) {
   if (splits < 2 || !workspace || K % (splits * 32) != 0 || N % 4 != 0 || ((uintptr_t)workspace & 15) || ((uintptr_t)C & 15) ||
-      (mask && ((uintptr_t)mask & 15)) || ldc % 4 != 0 || (long long)M * N > 0x7fffffffLL / 4)
+      (aux && ((uintptr_t)aux & 15)) || (bias && ((uintptr_t)bias & 15)) || (aux_add && !aux) || ldc % 4 != 0 || M * N > 0x7fffffffLL / 4)
     return COMBO_EINVAL;
   const int Ks = K / splits;
-  // slice z: A columns [z Ks, (z + 1) Ks) (element offset z Ks), image rows keep their pitch K and start z Ks floats in
-  if (int e = combo_nt3_launch(A, lda, Bimg, K, nullptr, nullptr, workspace, N, M, N, Ks, 0, 3, splits, Ks, Ks, (long long)M * N,
-                               nullptr, 0, stream))
+  // slice z: A columns [z Ks, (z + 1) Ks) (element offset z Ks; a convolution: taps z * tap_step ...), image rows keep their pitch K
+  // and start z Ks floats in
+  if (int e = combo_nt3_launch(A, lda, Bimg, K, nullptr, nullptr, workspace, N, M, N, Ks, 0, 3, splits, conv ? 0 : Ks, Ks, M * N,
+                               conv, 0, stream, 0))
     return e;
-  const long long n4 = (long long)M * (N >> 2);
+  const long long n4 = M * (N >> 2);
   hipLaunchKernelGGL(nt3_splitk_finish_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace,
-                     splits, (long long)M, N, mask, C, ldc);
+                     splits, M, N, aux, C, ldc, bias, relu, aux_add);
   return (int)hipGetLastError();
+}
+
+extern "C" int combo_gemm_nt_x3_splitk_f32(const float* A, long long lda, const float* Bimg, const float* mask, float* C,
+                                           long long ldc, int M, int N, int K, int splits, float* workspace, combo_stream_t stream) {
+  return nt3_split_launch(A, lda, Bimg, nullptr, mask, 0, C, ldc, M, N, K, 0, splits, workspace, nullptr, stream);
+}
+
+/* C = epilogue(A[M, K] . image[N, K]^T) with the 3-product split: v = acc (+ bias[n]) (+ aux[m, n] when aux_mode == 1: the
+ * residual branch), ReLU when relu, v = aux[m, n] > 0 ? v : 0 when aux_mode == 2 (the ReLU gradient of the layer that produced
+ * the operand); aux has C's pitch.  splits > 1 (combo_gemm_nt_x3_splitk_plan): K slices as batch entries into workspace
+ * [splits, M, N], the epilogue rides in the finishing sum.  The forward pass of the ResNet backbones' 1x1 convolutions
+ * (FrozenBN folded into the weights; detectron2's BottleneckBlock, cited at models/maskformer_model.py:138,145 of the reference). */
+extern "C" int combo_gemm_nt_x3_epi_f32(const float* A, long long lda, const float* Bimg, const float* bias, const float* aux,
+                                        int aux_mode, float* C, long long ldc, int M, int N, int K, int relu, int splits,
+                                        float* workspace, combo_stream_t stream) {
+  if (aux_mode < 0 || aux_mode > 2 || (aux_mode != 0) != (aux != nullptr)) return COMBO_EINVAL;
+  if (splits > 1) return nt3_split_launch(A, lda, Bimg, bias, aux, aux_mode == 1, C, ldc, M, N, K, relu, splits, workspace, nullptr, stream);
+  return combo_nt3_launch(A, lda, Bimg, K, bias, aux, C, ldc, M, N, K, relu, 3, 1, 0, 0, 0, nullptr, 0, stream, aux_mode == 1);
+}
+
+/* Tap split of a 3x3 implicit-GEMM convolution over M tokens: 1 (do not split), 3 (one kernel row per slice) or 9 (one tap per
+ * slice) - few output tiles (res4 / res5: 7 840 / 1 960 tokens at 40 frames) leave most CUs idle otherwise. */
+extern "C" int combo_conv3x3_x3_splitk_plan(long long M, int Cout, int Cin) {
+  if (M <= 0 || Cout % 4 != 0 || Cin % 32 != 0) return 1;
+  const long long cus = n_cu_cached3();
+  const long long tiles = ((M + 127) / 128) * ((Cout + 127LL) / 128);
+  if (tiles * 2 > cus) return 1;
+  // unit: one tap of 128 channels on a 128 x 128 tile (~3 us of a CU); the finishing pass costs a launch + splits reads of [M, Cout]
+  int best = 1;
+  double best_cost = 1e30;
+  for (int s = 1; s <= 9; s *= 3) {
+    const double rounds = (double)((tiles * s + cus - 1) / cus);
+    const double cost = rounds * (9 / s) * (Cin / 128.0) + (s > 1 ? 1.0 + 0.5 * s * ((double)M * Cout / 2.0e6) : 0.0);
+    if (cost < best_cost) { best_cost = cost; best = s; }
+  }
+  return best;
+}
+
+/* Y = epilogue(conv(X, W)) over NHWC tokens, 3-product split: ksize 3 (zero padding 1) or 1 (padding 0), stride 1 or 2 (output
+ * map ceil(H / 2) x ceil(W / 2): the stride-2 3x3 and shortcut convolutions of a ResNet stage's first block); image =
+ * combo_presplit_bf16x2_* of W as [Cout, (ky, kx, cin)]; epilogue and splits (3x3: 1, 3 or 9 = combo_conv3x3_x3_splitk_plan over
+ * the OUTPUT tokens; 1x1: 1) as combo_gemm_nt_x3_epi_f32; aux / Y rows are output tokens. */
+extern "C" int combo_conv_nhwc_x3_epi_f32(const float* X, long long ldx, const float* Wimg, const float* bias, const float* aux,
+                                          int aux_mode, float* Y, long long ldy, int B, int H, int W, int Cin, int Cout, int ksize,
+                                          int stride, int relu, int splits, float* workspace, combo_stream_t stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return COMBO_EINVAL;
+  const int ho = (H + stride - 1) / stride, wo = (W + stride - 1) / stride, taps = ksize * ksize;
+  const long long M = (long long)B * ho * wo;
+  if (!X || !Wimg || !Y || Cin <= 0 || Cout <= 0 || Cin % kBK != 0 || ldx % 4 != 0 || ((uintptr_t)X & 15) || ((uintptr_t)Wimg & 15) ||
+      M > 0x7fffffffLL / 4 || (long long)B * H * W > 0x7fffffffLL / 4 || aux_mode < 0 || aux_mode > 2 ||
+      (aux_mode != 0) != (aux != nullptr) || splits < 1 || taps % splits != 0)
+    return COMBO_EINVAL;
+  combo_nt3_conv cg{H, W, Cin, taps / splits, stride, ksize == 3 ? 1 : 0};
+  if (splits > 1)
+    return nt3_split_launch(X, ldx, Wimg, bias, aux, aux_mode == 1, Y, ldy, M, Cout, taps * Cin, relu, splits, workspace, &cg, stream);
+  return combo_nt3_launch(X, ldx, Wimg, (long long)taps * Cin, bias, aux, Y, ldy, M, Cout, taps * Cin, relu, 3, 1, 0, 0, 0, &cg, 0, stream,
+                          aux_mode == 1);
+}
+
+extern "C" int combo_conv3x3_nhwc_x3_epi_f32(const float* X, long long ldx, const float* Wimg, const float* bias, const float* aux,
+                                             int aux_mode, float* Y, long long ldy, int B, int H, int W, int Cin, int Cout, int relu,
+                                             int splits, float* workspace, combo_stream_t stream) {
+  return combo_conv_nhwc_x3_epi_f32(X, ldx, Wimg, bias, aux, aux_mode, Y, ldy, B, H, W, Cin, Cout, 3, 1, relu, splits, workspace, stream);
 }

@@ -181,6 +181,6 @@ extern "C" int combo_conv3x3_nhwc_x3_pre_f32(const float* X, long long ldx, cons
   if (!X || !Wimg || !Y || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % kBK != 0 || ldx % 4 != 0 ||
       ((uintptr_t)X & 15) || ((uintptr_t)Wimg & 15) || M > 0x7fffffffLL / 4)
     return COMBO_EINVAL;
-  const combo_nt3_conv cg{H, W, Cin};
+  const combo_nt3_conv cg{H, W, Cin, 0, 1, 1};
   return combo_nt3_launch(X, ldx, Wimg, 9LL * Cin, bias, nullptr, Y, ldy, M, Cout, 9 * Cin, relu, g_products, 1, 0, 0, 0, &cg, 0, stream);
 }

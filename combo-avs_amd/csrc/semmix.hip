@@ -46,31 +46,44 @@ template <> struct Ld8<__hip_bfloat16> {
   }
 };
 
-// grid (C/8/64.., chunks, B): thread = 8 channels; loops over the pixels of its chunk; atomics onto acc[B,C]
+// grid (C / 64, B): a workgroup owns 64 channels of one frame - thread = (octet of 8 channels, one of 32 pixel slices), a wave reads
+// 256 contiguous bytes of 8 pixels per step; the 32 slice sums meet in LDS and are added in slice order: no atomics, the result
+// is bit-reproducible (the previous version accumulated 16 chunk sums per frame with float atomics - the only source of run-to-run
+// differences left in the forward pass, 6e-8 on the gate input, enough to flip a decoder mask cell between two steps)
 template <typename T, bool DOT>
 __global__ void __launch_bounds__(256)
-sem_reduce(const T* __restrict__ p, const float* __restrict__ dout, int HW, int C, int chunk, float* __restrict__ acc) {
-  const int c8 = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
-  if (c8 >= C) return;
-  const int b = blockIdx.z;
-  const int i0 = blockIdx.y * chunk, i1 = min(HW, i0 + chunk);
+sem_reduce(const T* __restrict__ p, const float* __restrict__ dout, int HW, int C, float* __restrict__ acc) {
+  __shared__ float red[32][65];
+  const int oct = threadIdx.x & 7, slice = threadIdx.x >> 3;
+  const int c8 = (blockIdx.x * 8 + oct) * 8;
+  const int b = blockIdx.y;
   float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int i = i0; i < i1; ++i) {
-    const long long o = ((long long)b * HW + i) * C + c8;
-    float v[8];
-    Ld8<T>::load(p + o, v);
-    if (DOT) {
-      float d[8];
-      Ld8<float>::load(dout + o, d);
+  if (c8 < C) {
+    for (int i = slice; i < HW; i += 32) {
+      const long long o = ((long long)b * HW + i) * C + c8;
+      float v[8];
+      Ld8<T>::load(p + o, v);
+      if (DOT) {
+        float d[8];
+        Ld8<float>::load(dout + o, d);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) s[k] += v[k] * d[k];
-    } else {
+        for (int k = 0; k < 8; ++k) s[k] += v[k] * d[k];
+      } else {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) s[k] += v[k];
+        for (int k = 0; k < 8; ++k) s[k] += v[k];
+      }
     }
   }
 #pragma unroll
-  for (int k = 0; k < 8; ++k) __hip_atomic_fetch_add(acc + (long long)b * C + c8 + k, s[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int k = 0; k < 8; ++k) red[slice][oct * 8 + k] = s[k];
+  __syncthreads();
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (threadIdx.x < 64 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < 32; ++sl) t += red[sl][threadIdx.x];
+    acc[(long long)b * C + c] = t;
+  }
 }
 
 template <typename T>
@@ -119,12 +132,11 @@ template <typename T>
 int run(int op, const void* a, const void* b, const float* s, const float* g, int B, int HW, int C, void* o1, void* o2,
         hipStream_t st) {
   const long long n8 = (long long)B * HW * C / 8;
-  const int chunk = (HW + 15) / 16;
-  const dim3 rgrid((C / 8 + 255) / 256, (HW + chunk - 1) / chunk, B);
+  const dim3 rgrid((C + 63) / 64, B);
   switch (op) {
-    case 0: hipLaunchKernelGGL((sem_reduce<T, false>), rgrid, dim3(256), 0, st, (const T*)a, nullptr, HW, C, chunk, (float*)o1); break;
+    case 0: hipLaunchKernelGGL((sem_reduce<T, false>), rgrid, dim3(256), 0, st, (const T*)a, nullptr, HW, C, (float*)o1); break;
     case 1: hipLaunchKernelGGL((sem_mix_fwd<T>), dim3(ew_grid(n8)), dim3(256), 0, st, (const T*)a, (const T*)b, s, n8, HW, C, (float*)o1); break;
-    case 2: hipLaunchKernelGGL((sem_reduce<T, true>), rgrid, dim3(256), 0, st, (const T*)a, (const float*)b, HW, C, chunk, (float*)o1); break;
+    case 2: hipLaunchKernelGGL((sem_reduce<T, true>), rgrid, dim3(256), 0, st, (const T*)a, (const float*)b, HW, C, (float*)o1); break;
     case 3: hipLaunchKernelGGL((sem_mix_bwd<T>), dim3(ew_grid(n8)), dim3(256), 0, st, (const float*)a, s, g, n8, HW, C, (T*)o1, (T*)o2); break;
     default: return COMBO_EINVAL;
   }
@@ -133,8 +145,8 @@ int run(int op, const void* a, const void* b, const float* s, const float* g, in
 
 }  // namespace
 
-// op: 0 = gap sum (a = p, o1 = acc[B,C] zeroed), 1 = mix fwd (a = f, b = p, s -> o1 = out fp32),
-//     2 = dot (a = p, b = dout -> o1 = ds[B,C] zeroed), 3 = mix bwd (a = dout, s, g = dgap -> o1 = df, o2 = dp)
+// op: 0 = gap sum (a = p, o1 = acc[B,C], overwritten), 1 = mix fwd (a = f, b = p, s -> o1 = out fp32),
+//     2 = dot (a = p, b = dout -> o1 = ds[B,C], overwritten), 3 = mix bwd (a = dout, s, g = dgap -> o1 = df, o2 = dp)
 extern "C" int combo_sem_mix(int op, int is_bf16, const void* a, const void* b, const float* s, const float* g, int B, int HW,
                              int C, void* o1, void* o2, combo_stream_t stream) {
   if (!a || !o1 || B <= 0 || HW <= 0 || C <= 0 || (C & 7)) return COMBO_EINVAL;

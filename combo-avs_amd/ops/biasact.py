@@ -18,12 +18,15 @@ def fusable(y, residual=None):
 
 class _BiasAct(Function):
     @staticmethod
-    def forward(ctx, y, bias, residual, relu, fanout=False, grad_masked=False):
+    def forward(ctx, y, bias, residual, relu, fanout=False, grad_masked=False, precomputed=False):
+        """precomputed: y already IS relu(conv + bias (+ residual)) - the producing GEMM applied the epilogue (ops/convwrw.py) -
+        and this node only routes the gradients (ReLU mask, residual branch, fan-out sum)"""
         N, C, H, W = y.shape
-        fn = _lib.lib().combo_bias_act_f32 if y.dtype == torch.float32 else _lib.lib().combo_bias_act_bf16
-        _lib.check(fn(y.data_ptr(), bias.float().data_ptr() if bias.dtype != torch.float32 else bias.data_ptr(), _lib.ptr(residual),
-                      N * H * W, C, 1 if relu else 0, _lib.current_stream()), "combo_bias_act")
-        ctx.mark_dirty(y)
+        if not precomputed:
+            fn = _lib.lib().combo_bias_act_f32 if y.dtype == torch.float32 else _lib.lib().combo_bias_act_bf16
+            _lib.check(fn(y.data_ptr(), bias.float().data_ptr() if bias.dtype != torch.float32 else bias.data_ptr(), _lib.ptr(residual),
+                          N * H * W, C, 1 if relu else 0, _lib.current_stream()), "combo_bias_act")
+            ctx.mark_dirty(y)
         # grad_masked: the single consumer hands back a gradient that is already multiplied by [y > 0] (ops/convwrw.py)
         ctx.relu, ctx.has_res, ctx.fanout = relu and not grad_masked, residual is not None, fanout
         if ctx.relu:
@@ -55,14 +58,15 @@ class _BiasAct(Function):
                 _lib.check(fn(dy.data_ptr(), y.data_ptr(), dy.numel(), dx.data_ptr(), _lib.current_stream()), "combo_relu_grad")
         elif dy2 is not None:
             dx = dy + dy2
-        return dx, None, (dx if ctx.has_res else None), None, None, None
+        return dx, None, (dx if ctx.has_res else None), None, None, None, None
 
 
-def bias_act(y, bias, residual=None, relu=True, fanout=False, grad_masked=False):
+def bias_act(y, bias, residual=None, relu=True, fanout=False, grad_masked=False, precomputed=False):
     """y: convolution output WITHOUT bias (modified in place); bias: fp32 [C]; residual: same shape as y or None.
     fanout: return the result twice (two autograd outputs over the same memory) for a consumer pair, see _BiasAct.forward."""
     if fusable(y, residual):
-        return _BiasAct.apply(y, bias, residual, relu, fanout, grad_masked)
+        return _BiasAct.apply(y, bias, residual, relu, fanout, grad_masked, precomputed)
+    assert not precomputed
     out = y + bias.to(y.dtype)[None, :, None, None]
     if residual is not None:
         out = out + residual

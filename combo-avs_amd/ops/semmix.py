@@ -25,7 +25,7 @@ class _Gap(Function):
     def forward(ctx, p):
         p, B, HW, C = _cl(p)
         _lib.require_cuda(p, channels_last=True)
-        acc = torch.zeros(B, C, device=p.device, dtype=torch.float32)
+        acc = torch.empty(B, C, device=p.device, dtype=torch.float32)  # (written, not accumulated: csrc/semmix.hip sem_reduce)
         _call(0, p.dtype == torch.bfloat16, p, None, None, None, B, HW, C, acc)
         ctx.shape, ctx.dtype = p.shape, p.dtype
         return acc / HW
@@ -58,7 +58,7 @@ class _Mix(Function):
         p, s = ctx.saved_tensors
         dout, B, HW, C = _cl(dout.float())
         is_bf16 = p.dtype == torch.bfloat16
-        ds = torch.zeros(B, C, device=p.device, dtype=torch.float32)
+        ds = torch.empty(B, C, device=p.device, dtype=torch.float32)
         _call(2, is_bf16, p, dout, None, None, B, HW, C, ds)
         df = torch.empty_like(p)
         dp = torch.empty_like(p)

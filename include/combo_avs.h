@@ -398,6 +398,28 @@ int combo_gemm_nt_x3_pre_batched_f32(const float* A, long long lda, long long sA
 int combo_conv3x3_nhwc_x3_pre_f32(const float* X, long long ldx, const float* Wimg, const float* bias, float* Y,
                                   long long ldy, int B, int H, int W, int Cin, int Cout, int relu, combo_stream_t stream);
 
+/*   The same two kernels with the bottleneck-block epilogue: the FORWARD pass of the ResNet-50 backbones' stride-1 convolutions
+ *   (detectron2 BottleneckBlock / FrozenBatchNorm2d - not under /root/reference, built at models/maskformer_model.py:138,145;
+ *   SURVEY section 8 row f2), FrozenBN folded into the weights: v = acc (+ bias[n]) (+ aux[m, n] when aux_mode == 1: the
+ *   identity / shortcut branch) -> ReLU when relu -> v = aux[m, n] > 0 ? v : 0 when aux_mode == 2 (input gradients: the ReLU
+ *   gradient of the layer that produced the operand); aux has the output's pitch; aux_mode 0: aux must be NULL.
+ *   splits > 1: K slices (a convolution: kernel rows / taps) as the batch entries of one launch into workspace [splits, M, N],
+ *   the epilogue rides in the fixed-order finishing sum.  Plans: combo_gemm_nt_x3_splitk_plan, combo_conv3x3_x3_splitk_plan
+ *   (1, 3 or 9). */
+int combo_gemm_nt_x3_epi_f32(const float* A, long long lda, const float* Bimg, const float* bias, const float* aux, int aux_mode,
+                             float* C, long long ldc, int M, int N, int K, int relu, int splits, float* workspace,
+                             combo_stream_t stream);
+int combo_conv3x3_x3_splitk_plan(long long M, int Cout, int Cin);
+int combo_conv3x3_nhwc_x3_epi_f32(const float* X, long long ldx, const float* Wimg, const float* bias, const float* aux,
+                                  int aux_mode, float* Y, long long ldy, int B, int H, int W, int Cin, int Cout, int relu,
+                                  int splits, float* workspace, combo_stream_t stream);
+/*   General form: ksize 3 (zero padding 1) or 1 (padding 0), stride 1 or 2 (output map ceil(H / 2) x ceil(W / 2); Y / aux rows
+ *   and the split plan count OUTPUT tokens): the forward pass of the stride-2 3x3 and shortcut convolutions of a ResNet stage's
+ *   first block (the library's kernels for them accumulate with atomics: not reproducible from run to run). */
+int combo_conv_nhwc_x3_epi_f32(const float* X, long long ldx, const float* Wimg, const float* bias, const float* aux, int aux_mode,
+                               float* Y, long long ldy, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int relu,
+                               int splits, float* workspace, combo_stream_t stream);
+
 /*   Weight gradient of that convolution, split-K over the tokens like combo_gemm_tn_x3_f32: partial z is written at
  *   out_partials + z*Cout*9*Cin in [Cout, 3, 3, Cin] order; finish with combo_splitk_reduce_f32.  `splits` as for
  *   combo_gemm_tn_x3_f32 with (M, N, K) = (B*H*W, Cout, 9*Cin).  Cin % 128 == 0, Cout % 4 == 0, Cout >= 64,

@@ -1,0 +1,193 @@
+"""GPU parity of the ResNet backbones' stride-1 convolutions on the head's 3-product kernels (ops/convwrw.py: forward with the
+fused bias / residual / ReLU epilogue, input gradients with the fused ReLU-gradient mask, tap-split 3x3 launches, grouped weight
+images) against the library's fp32 convolution (detectron2 BottleneckBlock semantics)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _cl(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def test_weight_images_equal_the_single_weight_presplit():
+    """the grouped per-tap problems of ops.convwrw.weight_images write the same bits as combo_presplit_bf16x2_f32 of the
+    explicitly permuted / flipped weight matrix"""
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.ops import convwrw
+    from combo_avs_amd.ops import linear as L
+    g = torch.Generator().manual_seed(0)
+    ws = [torch.randn(256, 64, 1, 1, generator=g).cuda(), torch.randn(64, 64, 3, 3, generator=g).cuda(),
+          torch.randn(128, 256, 3, 3, generator=g).cuda(), torch.randn(64, 3, 7, 7, generator=g).cuda(),
+          torch.randn(512, 256, 1, 1, generator=g).cuda()]
+    geo = [((1, 1), (0, 0)), ((1, 1), (1, 1)), ((1, 1), (1, 1)), ((2, 2), (3, 3)), ((2, 2), (0, 0))]
+    imgs = convwrw.weight_images(ws, geo)
+    assert imgs[3] is None  # the 7x7 stem stays with the library
+    assert imgs[4][1] is None  # the stride-2 shortcut: forward image only (its backward is the library's)
+    assert torch.equal(imgs[4][0].view(torch.int32), L.presplit(ws[4].view(512, 256)).view(torch.int32))
+    for w, im in zip(ws[:3], imgs[:3]):
+        cout, cin, k, _ = w.shape
+        fwd = L.presplit(w.permute(0, 2, 3, 1).reshape(cout, k * k * cin).contiguous())
+        dx = L.presplit(w.flip(2, 3).permute(1, 2, 3, 0).reshape(cin, k * k * cout).contiguous())
+        assert torch.equal(im[0].view(torch.int32), fwd.view(torch.int32))
+        assert torch.equal(im[1].view(torch.int32), dx.view(torch.int32))
+
+
+CASES = [  # B, H, cin, cout, k, residual
+    (40, 56, 64, 256, 1, True),     # res2 conv3 + identity
+    (40, 56, 256, 64, 1, False),    # res2 conv1 (64 output channels: skinny tiles)
+    (40, 14, 1024, 256, 1, False),  # res4 conv1: split-K (few tiles, long K)
+    (40, 7, 512, 2048, 1, True),    # res5 conv3
+    (5, 56, 64, 64, 3, False),      # res2 conv2: 64 channels, library weight gradient
+    (40, 14, 256, 256, 3, False),   # res4 conv2: tap split
+    (40, 7, 512, 512, 3, False),    # res5 conv2: tap split
+    (3, 28, 128, 128, 3, False),    # res3 conv2 at a ragged token count
+]
+
+
+@pytest.mark.parametrize("B,H,cin,cout,k,with_res", CASES)
+def test_conv_bias_act_on_the_3product_kernel_matches_the_library(B, H, cin, cout, k, with_res):
+    """forward: relu(conv + bias (+ residual)) within 2e-5 of the output range of an fp64 evaluation (the library's fp32 kernel is
+    held to the same bound); gradients (input, weight, residual) against the library path of the same module: relative L2 <= 1e-2.
+    An output within round-off of zero may sit on the other side of the ReLU (~1e-5 of the entries): that moves one entry of the
+    residual gradient, one ROW of the input gradient and a little of every weight-gradient entry, hence the entry-wise bounds:
+    < 0.1 % (residual) / < 1 % (input) of the entries off by more than 1e-3 RMS, none for the weight gradient (measured: one
+    flip among 2 352 tokens of a 3x3 layer = 9 input-gradient rows = 5.6e-3 relative L2, 0.38 % of the entries)."""
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.ops import convwrw
+    g = torch.Generator().manual_seed(B * 100 + cin + k)
+    x = _cl(torch.randn(B, cin, H, H, generator=g).relu_().cuda())
+    w = (torch.randn(cout, cin, k, k, generator=g) * (cin * k * k) ** -0.5).cuda()
+    b = torch.randn(cout, generator=g).cuda() * 0.3
+    res = _cl(torch.randn(B, cout, H, H, generator=g).cuda()) if with_res else None
+    probe = _cl(torch.randn(B, cout, H, H, generator=g).cuda())
+    ref64 = F.conv2d(x.double(), w.double(), b.double(), 1, k // 2)
+    if with_res:
+        ref64 = ref64 + res.double()
+    ref64 = ref64.relu_()
+    out = {}
+    for mode in ("own", "library"):
+        xx, ww = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        rr = res.clone().requires_grad_(True) if with_res else None
+        images = convwrw.weight_images([ww.detach()], [((1, 1), (k // 2, k // 2))])[0] if mode == "own" else None
+        assert (images is not None) == (mode == "own")
+        prev = convwrw.DX_OWN
+        convwrw.DX_OWN = 3 if mode == "own" else 0
+        try:
+            y = convwrw.conv_bias_act(xx * 1.0, ww, b, 1, k // 2, images, residual=rr)
+            grads = torch.autograd.grad((y * probe).sum(), [xx, ww] + ([rr] if with_res else []))
+        finally:
+            convwrw.DX_OWN = prev
+        out[mode] = (y.detach(), grads)
+    scale = float(ref64.abs().max())
+    for mode in out:
+        assert float((out[mode][0].double() - ref64).abs().max()) <= 2e-5 * scale, mode
+    for name, a, r in zip(("dx", "dw", "dres"), out["own"][1], out["library"][1]):
+        rel = float((a - r).norm() / r.norm())
+        rms = float(r.pow(2).mean().sqrt())
+        frac = float(((a - r).abs() > 1e-3 * rms).float().mean())
+        assert rel <= 1e-2 and frac < {"dx": 1e-2, "dw": 1.0, "dres": 1e-3}[name], (name, rel, frac)
+
+
+def test_relu_gradient_mask_folded_into_the_3x3_input_gradient():
+    """mask_dx: dX of the own 3x3 input-gradient kernel already multiplied by [x > 0] equals the unmasked result times the mask"""
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.ops import convwrw
+    g = torch.Generator().manual_seed(7)
+    x = _cl(torch.randn(8, 256, 14, 14, generator=g).relu_().cuda())
+    w = (torch.randn(256, 256, 3, 3, generator=g) * 0.02).cuda().requires_grad_(True)
+    probe = _cl(torch.randn(8, 256, 14, 14, generator=g).cuda())
+    images = convwrw.weight_images([w.detach()], [((1, 1), (1, 1))])[0]
+    got = []
+    for mask_dx in (False, True):
+        xx = x.clone().requires_grad_(True)
+        y = convwrw._ConvWrw.apply(xx, w, 3, mask_dx, images)
+        got.append(torch.autograd.grad((y * probe).sum(), xx)[0])
+    assert torch.equal(got[1], got[0] * (x > 0))
+
+
+def test_resnet_features_and_gradients_own_forward_vs_library():
+    """the whole fp32 ResNet-50 at 8 frames: res2..res5 features of the 3-product forward within 1e-4 of the feature range of the
+    library forward (50 layers deep), parameter gradients within 5 % relative L2 per tensor (measured: up to 2.2 %) (ReLU sign flips at round-off level
+    move individual entries; the sums they feed stay)"""
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.backbone import ResNet
+    from combo_avs_amd.ops import convwrw
+    torch.manual_seed(0)
+    net = ResNet(50).cuda()
+    for m in net.modules():
+        if hasattr(m, "running_var"):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.uniform_(0.8, 1.2)
+            m.bias.normal_(0, 0.1)
+    net._drop_constants()
+    x = torch.randn(8, 3, 224, 224, device="cuda")
+    res = {}
+    for mode in (True, False):
+        prev = convwrw.FWD_X3, convwrw.DX_OWN
+        convwrw.FWD_X3, convwrw.DX_OWN = mode, (3 if mode else 2)
+        try:
+            feats = net(x)
+            loss = sum((f * torch.sin(torch.arange(f.numel(), device="cuda").view_as(f) * 0.37)).sum() for f in feats.values())
+            params = [p for p in net.parameters() if p.requires_grad]
+            grads = torch.autograd.grad(loss, params)
+        finally:
+            convwrw.FWD_X3, convwrw.DX_OWN = prev
+        res[mode] = ({k: v.detach() for k, v in feats.items()}, grads)
+    for k in res[True][0]:
+        a, r = res[True][0][k], res[False][0][k]
+        assert float((a - r).abs().max()) <= 1e-4 * float(r.abs().max()), k
+    names = [n for n, p in net.named_parameters() if p.requires_grad]
+    for n, a, r in zip(names, res[True][1], res[False][1]):
+        rel = float((a - r).norm() / r.norm().clamp_min(1e-30))
+        assert rel <= 5e-2, (n, rel)
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,k", [(40, 28, 28, 256, 256, 3), (40, 14, 14, 1024, 2048, 1), (3, 15, 9, 128, 128, 3),
+                                                (2, 7, 5, 256, 512, 1), (10, 56, 56, 128, 128, 3)])
+def test_stride2_forward_on_the_own_kernel(B, H, W, cin, cout, k):
+    """the first block of res3 / res4 / res5: 3x3 / stride 2 / pad 1 and the 1x1 / stride 2 shortcut (odd map sizes included),
+    forward + bias + ReLU within 2e-5 of the output range of an fp64 evaluation; bit-identical from call to call; the backward
+    pass is the library's (compared against autograd of F.conv2d)"""
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.ops import convwrw
+    g = torch.Generator().manual_seed(H * 10 + k)
+    x = _cl(torch.randn(B, cin, H, W, generator=g).cuda())
+    w = (torch.randn(cout, cin, k, k, generator=g) * (cin * k * k) ** -0.5).cuda().requires_grad_(True)
+    b = torch.randn(cout, generator=g).cuda() * 0.3
+    geo = ((2, 2), (k // 2, k // 2))
+    assert convwrw.weight_kind(w, *geo) == 20 + k
+    images = convwrw.weight_images([w.detach()], [geo])[0]
+    assert images[1] is None
+    xx = x.clone().requires_grad_(True)
+    y = convwrw.conv_bias_act(xx, w, b, 2, k // 2, images)
+    ref = F.conv2d(x.double(), w.detach().double(), b.double(), 2, k // 2).relu_()
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+    assert float((y.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    y2 = convwrw.conv_bias_act(x.clone().requires_grad_(True), w, b, 2, k // 2, images)
+    assert torch.equal(y, y2)
+    probe = torch.randn(y.shape, generator=g).cuda()
+    dx, dw = torch.autograd.grad((y * probe).sum(), (xx, w))
+    x3 = x.clone().requires_grad_(True)
+    dx_ref, dw_ref = torch.autograd.grad((F.conv2d(x3, w, b, 2, k // 2).relu() * probe).sum(), (x3, w))
+    for a, r in ((dx, dx_ref), (dw, dw_ref)):
+        assert float((a - r).norm() / r.norm()) <= 1e-2
+
+
+def test_vggish_forward_on_the_own_kernels_matches_the_library_and_repeats_bit_for_bit():
+    """audio_backbone/torchvggish/vggish.py:9-27 of the reference: the no-grad forward with the five wide convolutions on the own
+    kernel against nn.Sequential (the library) within 1e-5 of the embedding range; two calls give identical bits"""
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.backbone import VGGish
+    torch.manual_seed(0)
+    net = VGGish().cuda().eval()
+    x = torch.randn(40, 1, 96, 64, device="cuda")
+    with torch.no_grad():
+        a = net(x)
+        b = net(x)
+        ref = net.embeddings(net.features(x).permute(0, 2, 3, 1).reshape(40, -1))
+    assert torch.equal(a, b)
+    assert float((a - ref).abs().max()) <= 1e-5 * float(ref.abs().max())

@@ -45,13 +45,34 @@ def _check_pair(i, ref_l, got_l, report, ref_p, got_p, rel_l2=GC.REL_L2, frac=GC
         (float(d.max()), float((d > 1e-5).float().mean()))
 
 
+FLIP_REL_L2, FLIP_FRAC = 5e-2, 1.0  # un-frozen R50 step: one attention-mask cell on the other side of its threshold moves the
+# gradients of the decoder layers around it by 0.3 - 1 % (seen: layer 7 at 3.7e-3 / 45 % of the entries).  The forward pass is not
+# bit-reproducible from run to run: the library's kernels for res5.0's stride-2 convolutions and VGGish's last convolution
+# accumulate with atomics (tools/probe_forward_bits.py: 1e-6 relative on res5, two EAGER steps differ the same way), so a flip
+# between an eager and a replayed step is rare but legitimate.  The strict bound is applied with the discrete choices frozen.
+
+
 def test_graphed_step_equals_eager_step(rig):
     model, opt, batches, state = rig
     graphed, out = GC.eager_and_graphed(model, opt, batches)
     for i, (ref_l, got_l, report, ref_p, got_p, _, _) in enumerate(out):
-        _check_pair(i, ref_l, got_l, report, ref_p, got_p)
+        _check_pair(i, ref_l, got_l, report, ref_p, got_p, rel_l2=FLIP_REL_L2, frac=FLIP_FRAC)
     assert len(graphed.graphs) == 1  # both batches share one signature -> one capture, second batch via static buffers
     assert any(abs(out[1][1][k] - out[0][0][k]) > 1e-4 for k in out[1][1])  # the second batch really went through
+
+
+def test_graphed_step_equals_eager_step_frozen_choices(rig):
+    """the strict per-parameter bound (5e-3 relative L2, 25 % of the entries; the backbones' library gradients 2e-2 / 80 %) with
+    the discrete choices of a recorded step injected into both runs: no mask cell, matching or sampled point can differ"""
+    model, opt, batches, state = rig
+    GC.freeze_choices(model, opt, batches[0])
+    try:
+        graphed, out = GC.eager_and_graphed(model, opt, batches[:1])
+    finally:
+        GC.unfreeze_choices(model)
+    ref_l, got_l, report, ref_p, got_p, _, _ = out[0]
+    _check_pair(0, ref_l, got_l, report, ref_p, got_p)
+    assert len(graphed.graphs) == 1
 
 
 def test_graphed_step_equals_eager_step_pvt_recipe():
