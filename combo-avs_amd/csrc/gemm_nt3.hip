@@ -87,6 +87,7 @@ struct N3Cfg {
 typedef N3Cfg<8, 1, 1, 4, 6> NWide;     // 8 waves x (32 x 128): 24 KiB stages, 144 KiB ring
 typedef N3Cfg<2, 2, 2, 2, 8> NMid;      // 16 KiB stages, 128 KiB ring
 typedef N3Cfg<2, 2, 1, 1, 16> NSkinny;  //  8 KiB stages, 128 KiB ring = a whole K = 256 panel in flight
+typedef N3Cfg<4, 1, 2, 2, 7> NTall;     // 4 waves x (64 x 64) stacked: 256 x 64 tiles for 64-wide outputs (res2's 64-channel layers)
 
 struct N3Args {
   const float* A; long long lda;
@@ -587,6 +588,7 @@ int launch_cfg3(N3Args a, hipStream_t stream) {
 
 template <bool CONV>
 int launch_one3(N3Args a, hipStream_t stream, int cfg) {
+  if (cfg == 4) return launch_cfg3<CONV, NTall>(a, stream);
   if (cfg == 3) return launch_cfg3<CONV, NSkinny>(a, stream);
   if (cfg == 2) return launch_cfg3<CONV, NMid>(a, stream);
   return launch_cfg3<CONV, NWide>(a, stream);
@@ -599,13 +601,13 @@ template <bool CONV>
 int launch_nt3(N3Args a, hipStream_t stream) {
   if (g_force_tile) return launch_one3<CONV>(a, stream, g_force_tile);
   const long long cus = n_cu_cached3();
-  const int bm[4] = {0, 256, 128, 64}, bn[4] = {0, 128, 128, 64};
+  const int bm[5] = {0, 256, 128, 64, 256}, bn[5] = {0, 128, 128, 64, 64};
   auto tiles = [&](int c, long long rows) { return ((rows + bm[c] - 1) / bm[c]) * ((a.N + bn[c] - 1LL) / bn[c]) * a.batch; };
-  const double eff[4] = {0.0, 1.0, 1.13, 1.8};  // measured per-MAC cost of a round (tools/bench_nt3.py --shapes round)
+  const double eff[5] = {0.0, 1.0, 1.13, 1.8, 1.25};  // measured per-MAC cost of a round (tools/bench_nt3.py --shapes round)
   auto load = [&](int c, long long rows) { return (double)((tiles(c, rows) + cus - 1) / cus) * bm[c] * bn[c] * eff[c]; };
   int best = 1;
   double best_cost = load(1, a.M);
-  for (int c = 2; c <= 3; ++c)
+  for (int c = 2; c <= 4; ++c)
     if (load(c, a.M) < best_cost) { best = c; best_cost = load(c, a.M); }
   long long rows_main = a.M;
   int cfg_rest = 0;
@@ -639,11 +641,11 @@ int launch_nt3(N3Args a, hipStream_t stream) {
 }  // namespace
 
 /* Forces the tile shape of the combo_gemm_nt_x3_* / combo_conv3x3_nhwc_x3_* launches that FOLLOW (0 = the planner's choice, 1 =
- * 256 x 128, 2 = 128 x 128, 3 = 64 x 64): every configuration must give the same result (tests), and tools sweep them.  Returns
+ * 256 x 128, 2 = 128 x 128, 3 = 64 x 64, 4 = 256 x 64): every configuration must give the same result (tests), and tools sweep them.  Returns
  * the previous value.  Host-side state, read when a launch is issued. */
 extern "C" int combo_gemm_nt_x3_tile(int cfg) {
   const int prev = g_force_tile;
-  if (cfg >= 0 && cfg <= 3) g_force_tile = cfg;
+  if (cfg >= 0 && cfg <= 4) g_force_tile = cfg;
   return prev;
 }
 

@@ -18,7 +18,7 @@ def _rows_ok(t):
 
 
 # K / V that are column blocks of a merged per-level projection (ops/linear.py memory_kv): key = data_ptr of the k block ->
-# (gradient holder, block index).  The backward pass then writes dk / dv straight into the holder's [rows, blocks * E] buffers
+# (weak reference to the gradient holder - the projection's autograd node owns it -, block index).  The backward pass then writes dk / dv straight into the holder's [rows, blocks * E] buffers
 # (csrc/attention.hip strided outputs) instead of into tensors of its own.
 kv_gradient_slots = {}
 
@@ -26,7 +26,9 @@ kv_gradient_slots = {}
 class _Attention(Function):
     @staticmethod
     def forward(ctx, q, k, v, blocked, B, H, bits=None):
-        ctx.kv_slot = kv_gradient_slots.get(k.data_ptr()) if k.stride(0) != k.shape[1] else None
+        slot = kv_gradient_slots.get(k.data_ptr()) if k.stride(0) != k.shape[1] else None
+        holder = slot[0]() if slot is not None else None
+        ctx.kv_slot = (holder, slot[1]) if holder is not None else None
         Lq, Lk = q.shape[0] // B, k.shape[0] // B
         E = H * 32
         assert _rows_ok(q) and _rows_ok(k) and _rows_ok(v) and q.shape[1] == E and k.shape[1] == E and v.shape[1] == E

@@ -14,6 +14,7 @@ not take (K not a multiple of 16, misaligned views; the class head's 3-wide grad
 launches per step, counted in DESIGN section 5.
 """
 import ctypes
+import weakref
 import os as _os
 
 import torch
@@ -756,10 +757,13 @@ class _MemoryKV(Function):
         ctx.defer, ctx.n = defer, n
         ctx.holder = holder = _KVGrads(mem_k.shape[0], n, E, K_all.data_ptr(), V_all.data_ptr(), mem_k.device)
         outs = []
+        slots = A.kv_gradient_slots
+        for key in [key for key, (ref, _) in slots.items() if ref() is None]:
+            del slots[key]  # holders of forward passes that never ran backward (their autograd graph is gone)
         for j in range(n):
             k_j, v_j = K_all[:, j * E:(j + 1) * E], V_all[:, j * E:(j + 1) * E]
             if any(ctx.needs_input_grad):
-                A.kv_gradient_slots[k_j.data_ptr()] = (holder, j)
+                slots[k_j.data_ptr()] = (weakref.ref(holder), j)
             outs += [k_j, v_j]
         return tuple(outs)
 

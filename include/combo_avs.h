@@ -310,7 +310,7 @@ int combo_gemm_nt2_products(int products);
 int combo_gemm_nt_x3_splitk_plan(int M, int N, int K);  /* K slices of a few-tile, long-K input-gradient GEMM (1 = none) */
 int combo_gemm_nt_x3_splitk_f32(const float* A, long long lda, const float* Bimg, const float* mask, float* C, long long ldc,
                                 int M, int N, int K, int splits, float* workspace /* [splits, M, N] */, combo_stream_t stream);
-int combo_gemm_nt_x3_tile(int cfg);  /* 0 planner (default), 1 / 2 / 3: force 256x128 / 128x128 / 64x64 tiles (tests, tools); returns the previous value */
+int combo_gemm_nt_x3_tile(int cfg);  /* 0 planner (default), 1 / 2 / 3 / 4: force 256x128 / 128x128 / 64x64 / 256x64 tiles (tests, tools); returns the previous value */
 int combo_gemm_nt_splitk_plan(int M, int N, int K);
 int combo_gemm_nt_splitk_f32(const float* A, long long lda, const float* B, long long ldb, const float* bias, float* C,
                              long long ldc, int M, int N, int K, int relu, int splits, float* workspace, combo_stream_t stream);

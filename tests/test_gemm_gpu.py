@@ -110,9 +110,9 @@ def test_gemm_nt_f32_strided_operands_column_block_output_and_batched_form():
     assert (o[bt] == 7).all()
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
 def test_gemm_nt_f32_every_tile_configuration_agrees(tile, monkeypatch):
-    """wide / mid / skinny tiles forced through the C ABI's A/B switch in a child process (the switch is read once)."""
+    """wide / mid / skinny / tall tiles forced through the C ABI's A/B switch in a child process (the switch is read once)."""
     import os
     import subprocess
     import sys
@@ -187,10 +187,10 @@ def test_gemm_nt_x3_input_gradient(M, K, N, relu_mask):
     assert rel_err(got, ref) < 1e-5, rel_err(got, ref)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
 @pytest.mark.parametrize("M,K,N", [(5000, 256, 384), (777, 48, 200), (20001, 64, 288)])
 def test_gemm_nt_x3_every_tile_configuration_agrees(tile, M, K, N):
-    """csrc/gemm_nt3.hip: wide / mid / skinny tiles forced (combo_gemm_nt_x3_tile) - ragged M and N, an odd number of K stages
+    """csrc/gemm_nt3.hip: wide / mid / skinny / tall tiles forced (combo_gemm_nt_x3_tile) - ragged M and N, an odd number of K stages
     (K = 48: the register ping-pong hands its sets over at the tile boundary), bias + ReLU and the masked epilogue"""
     import combo_avs_amd  # noqa: F401
     from combo_avs_amd import _lib

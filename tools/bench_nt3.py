@@ -20,7 +20,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=50)
 ap.add_argument("--shapes", default="all")
 ap.add_argument("--no-lib", action="store_true")
-ap.add_argument("--tile", type=int, default=0, help="force the tile shape (combo_gemm_nt_x3_tile): 1 wide, 2 mid, 3 skinny")
+ap.add_argument("--tile", type=int, default=0, help="force the tile shape (combo_gemm_nt_x3_tile): 1 wide, 2 mid, 3 skinny, 4 tall")
 args = ap.parse_args()
 
 # (M, K, N) of dX = dY[M, K] . W^T-image[N, K]: K = the layer's output features, N = its input features
