@@ -99,6 +99,7 @@ _SIGNATURES = {
     "combo_gemm_nt_x3_pre_f32": [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_void_p],
     "combo_conv3x3_nhwc_x3_pre_f32": [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_longlong] + [c_int] * 6 + [c_void_p],
     "combo_gemm_nt_x3_epi_f32": [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_longlong] + [c_int] * 5 + [c_void_p, c_void_p],
+    "combo_gemm_nt_x3_epi2_f32": [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong] + [c_int] * 5 + [c_void_p, c_void_p],
     "combo_conv3x3_x3_splitk_plan": [c_longlong, c_int, c_int],
     "combo_conv3x3_nhwc_x3_epi_f32": [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_longlong] + [c_int] * 7 + [c_void_p, c_void_p],
     "combo_conv_nhwc_x3_epi_f32": [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_longlong] + [c_int] * 9 + [c_void_p, c_void_p],

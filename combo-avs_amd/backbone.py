@@ -133,8 +133,8 @@ class Bottleneck(nn.Module):
             # input-gradient GEMM instead of a pass of its own (conv1 -> conv2 when conv2's dX is an own kernel, conv2 -> conv3)
             k2 = convwrw.weight_kind(f2[0], c2.stride, c2.padding) if (x.is_cuda and torch.is_grad_enabled() and f2[0].requires_grad) else 0
             k3 = convwrw.weight_kind(f3[0], c3.stride, c3.padding) if (x.is_cuda and torch.is_grad_enabled() and f3[0].requires_grad) else 0
-            fold1 = convwrw.ENABLED and k2 == 3 and bool(convwrw.DX_OWN & 1) and f2[3] is not None
-            fold2 = convwrw.ENABLED and k3 == 1
+            fold1 = convwrw.ENABLED and convwrw.MASK_3X3 and k2 == 3 and bool(convwrw.DX_OWN & 1) and f2[3] is not None
+            fold2 = convwrw.ENABLED and convwrw.MASK_1X1 and k3 == 1
             out = cba(x, f1[0], f1[2], c1.stride, c1.padding, f1[3], grad_masked=fold1)
             out = cba(out, f2[0], f2[2], c2.stride, c2.padding, f2[3], grad_masked=fold2, mask_dx=fold1)
             if self.shortcut is not None:
@@ -227,9 +227,10 @@ class ResNet(nn.Module):
         scales, shifts, shifts32 = self._frozen_affine(convs, dtype)
         folded_w = _FoldAll.apply(dtype, scales, *[c.weight for c in convs])
         images = [None] * len(convs)
-        if dtype == torch.float32 and x.is_cuda and torch.is_grad_enabled() and folded_w[0].requires_grad:
+        if dtype == torch.float32 and x.is_cuda:
             from .ops import convwrw
-            if convwrw.ENABLED and (convwrw.FWD_X3 or convwrw.DX_OWN):
+            training = torch.is_grad_enabled() and folded_w[0].requires_grad
+            if convwrw.ENABLED and (convwrw.FWD_X3 or (convwrw.DX_OWN and training)):
                 # bf16 hi/lo images of every weight the head's 3-product kernels will read (forward and input gradient)
                 with torch.no_grad():
                     images = convwrw.weight_images([w.detach() for w in folded_w], [(c.stride, c.padding) for c in convs])

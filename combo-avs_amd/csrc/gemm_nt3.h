@@ -11,8 +11,8 @@ struct combo_nt3_conv {
 };
 
 // C_b[M,N] = A_b[M,K] . Bimg_b[N,K]^T (+ bias) (+ ReLU) (mask_b > 0 ? . : 0), `batch` problems at base + b * stride (elements; the
-// mask shares C's pitch and stride; aux_add: C += mask before the ReLU instead); products: 3 = fp32-accurate split, 1 = plain bf16; conv != nullptr: implicit-GEMM 3x3
+// mask shares C's pitch and stride; add: C += add before the ReLU, same layout); products: 3 = fp32-accurate split, 1 = plain bf16; conv != nullptr: implicit-GEMM 3x3
 // convolution (A = NHWC tokens, K = 9 * Cin); force_cfg: 0 auto, 1 wide (256 x 128), 2 mid (128 x 128), 3 skinny (64 x 64), 4 tall (256 x 64).
 int combo_nt3_launch(const float* A, long long lda, const float* Bimg, long long ldb, const float* bias, const float* mask, float* C,
                      long long ldc, long long M, int N, int K, int relu, int products, int batch, long long sA, long long sB,
-                     long long sC, const combo_nt3_conv* conv, int force_cfg, combo_stream_t stream, int aux_add = 0);
+                     long long sC, const combo_nt3_conv* conv, int force_cfg, combo_stream_t stream, const float* add = nullptr);

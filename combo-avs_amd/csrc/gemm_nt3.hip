@@ -93,10 +93,11 @@ struct N3Args {
   const float* A; long long lda;
   const float* B; long long ldb;   // pre-split image (combo_presplit_bf16x2_*): per 8 k a 16-B bf16 hi group + a 16-B lo group
   const float* bias;               // [N] or nullptr
-  const float* mask;               // [M, N] (pitch ldc, batch stride sC) or nullptr: C = mask > 0 ? value : 0 (aux_add: C += mask,
-                                   // before the ReLU - the residual branch of a bottleneck block)
+  const float* mask;               // [M, N] (pitch ldc, batch stride sC) or nullptr: C = mask > 0 ? value : 0, applied last
+  const float* add;                // [M, N] (same pitch / stride) or nullptr: C += add before the ReLU (the residual branch of a
+                                   // bottleneck block; the other gradient arriving at a block input)
   float* C; long long ldc;
-  int M, N, K, relu, c_bytes, batch, vec_store, dbg, products, aux_add;
+  int M, N, K, relu, c_bytes, batch, vec_store, dbg, products;
   long long sA, sB, sC;
   combo_nt3_conv cg;
   unsigned long long* ts;
@@ -346,6 +347,8 @@ gemm_nt3_kernel(const N3Args p) {
     const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.C + ec.bi * p.sC, 0, p.c_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t m_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.mask ? p.mask + ec.bi * p.sC : p.C), 0, p.c_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t d_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.add ? p.add + ec.bi * p.sC : p.C), 0, p.c_bytes, 0x00020000);
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -365,30 +368,51 @@ gemm_nt3_kernel(const N3Args p) {
             for (int q = 0; q < 4; ++q) bv[q] = lds_read128<0>(bias_lds + (unsigned)min(nb + 8 * q, n_pad - 4) * 4u);
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]) : : "memory");
           }
+          // add / mask: one register set, used twice (the wide tiles have no registers to spare).  These loads are the youngest
+          // vector-memory operations: waiting for them drains the ring - such launches pay one pipeline refill per tile.
+          f4v v[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            v[q] = f4v{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+            if (p.bias) v[q] += bv[q];
+          }
           u4v mv[4];
-          if (p.mask) {  // (these loads are the youngest vector-memory operations: waiting for them drains the ring - masked
-                         //  launches pay one pipeline refill per tile)
+          if (p.add) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int n0 = nb + 8 * q;
+              const unsigned off = n0 < N ? ((unsigned)row * (unsigned)p.ldc + (unsigned)n0) * 4u : 0xfffffff0u;
+              mv[q] = __builtin_amdgcn_raw_buffer_load_b128(d_rsrc, off, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] += __builtin_bit_cast(f4v, mv[q]);
+          }
+          if (p.relu) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              v[q].x = fmaxf(v[q].x, 0.f); v[q].y = fmaxf(v[q].y, 0.f); v[q].z = fmaxf(v[q].z, 0.f); v[q].w = fmaxf(v[q].w, 0.f);
+            }
+          }
+          if (p.mask) {
+            __builtin_amdgcn_sched_barrier(0);  // (the mask loads reuse the registers of the add loads: keep them behind)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const int n0 = nb + 8 * q;
               const unsigned off = n0 < N ? ((unsigned)row * (unsigned)p.ldc + (unsigned)n0) * 4u : 0xfffffff0u;
               mv[q] = __builtin_amdgcn_raw_buffer_load_b128(m_rsrc, off, 0, 0);
             }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              v[q].x = __uint_as_float(mv[q].x) > 0.f ? v[q].x : 0.f; v[q].y = __uint_as_float(mv[q].y) > 0.f ? v[q].y : 0.f;
+              v[q].z = __uint_as_float(mv[q].z) > 0.f ? v[q].z : 0.f; v[q].w = __uint_as_float(mv[q].w) > 0.f ? v[q].w : 0.f;
+            }
           }
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int n0 = nb + 8 * q;
-            f4v v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-            if (p.bias) v += bv[q];
-            if (p.aux_add) v += __builtin_bit_cast(f4v, mv[q]);
-            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            if (p.mask && !p.aux_add) {
-              v.x = __uint_as_float(mv[q].x) > 0.f ? v.x : 0.f; v.y = __uint_as_float(mv[q].y) > 0.f ? v.y : 0.f;
-              v.z = __uint_as_float(mv[q].z) > 0.f ? v.z : 0.f; v.w = __uint_as_float(mv[q].w) > 0.f ? v.w : 0.f;
-            }
             // rows >= M fall outside the descriptor's range and are dropped; columns >= N are steered there as well
             const unsigned off = n0 < N ? ((unsigned)row * (unsigned)p.ldc + (unsigned)n0) * 4u : 0xfffffff0u;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), c_rsrc, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v[q]), c_rsrc, off, 0, 0);
           }
         } else {  // N or ldc not a multiple of 4: scalar stores
 #pragma unroll
@@ -401,11 +425,9 @@ gemm_nt3_kernel(const N3Args p) {
               v += b;
             }
             const unsigned off = n < N ? ((unsigned)row * (unsigned)p.ldc + (unsigned)n) * 4u : 0xfffffff0u;
-            float mval = 0.f;
-            if (p.mask) mval = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(m_rsrc, off, 0, 0));
-            if (p.aux_add) v += mval;
+            if (p.add) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(d_rsrc, off, 0, 0));
             if (p.relu) v = fmaxf(v, 0.f);
-            if (p.mask && !p.aux_add) v = mval > 0.f ? v : 0.f;
+            if (p.mask) v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(m_rsrc, off, 0, 0)) > 0.f ? v : 0.f;
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), c_rsrc, off, 0, 0);
           }
         }
@@ -501,7 +523,7 @@ gemm_nt3_kernel(const N3Args p) {
   split_commit(ah[0], al[0]);
 
   const int my_tiles = (tiles - w + G - 1) / G;
-  const bool relax_ok = p.vec_store && !p.mask;
+  const bool relax_ok = p.vec_store && !p.mask && !p.add;
   typedef std::integral_constant<int, 0> P0;
   typedef std::integral_constant<int, 1> P1;
 #pragma unroll 1
@@ -566,7 +588,7 @@ int launch_cfg3(N3Args a, hipStream_t stream) {
   const long long slots = n_cu_cached3();  // one persistent workgroup per CU
   const int grid = (int)(tiles < slots ? tiles : slots);
   a.ts = combo_timing_next_slot(a.products == 3 ? COMBO_TS_GEMM_X3 : COMBO_TS_GEMM_BF16, 2.0 * a.M * a.N * a.K * a.batch,
-                                4.0 * a.batch * ((double)a.M * (CONV ? a.cg.Cin : a.K) + (double)a.N * a.K + (double)a.M * a.N * (a.mask ? 2 : 1)));
+                                4.0 * a.batch * ((double)a.M * (CONV ? a.cg.Cin : a.K) + (double)a.N * a.K + (double)a.M * a.N * (1 + (a.mask ? 1 : 0) + (a.add ? 1 : 0))));
   if constexpr (!CONV && std::is_same<Cfg, NWide>::value) {  // the ablation instances (COMBO_NT3_DBG, tools/bench_nt3.py)
     if (a.products == 3) {
       switch (a.dbg) {
@@ -633,6 +655,7 @@ int launch_nt3(N3Args a, hipStream_t stream) {
   rs.A = a.A + rows_main * a.lda;
   rs.C = a.C + rows_main * a.ldc;
   if (a.mask) rs.mask = a.mask + rows_main * a.ldc;
+  if (a.add) rs.add = a.add + rows_main * a.ldc;
   rs.M = (int)(a.M - rows_main);
   rs.c_bytes = (int)(((rs.M - 1LL) * a.ldc + a.N) * 4);
   return launch_one3<CONV>(rs, stream, cfg_rest);
@@ -651,25 +674,24 @@ extern "C" int combo_gemm_nt_x3_tile(int cfg) {
 
 int combo_nt3_launch(const float* A, long long lda, const float* Bimg, long long ldb, const float* bias, const float* mask, float* C,
                      long long ldc, long long M, int N, int K, int relu, int products, int batch, long long sA, long long sB,
-                     long long sC, const combo_nt3_conv* conv, int force_cfg, combo_stream_t stream, int aux_add) {
+                     long long sC, const combo_nt3_conv* conv, int force_cfg, combo_stream_t stream, const float* add) {
   if (!A || !Bimg || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || K % kBK != 0 || lda % 4 != 0 || ldb % 4 != 0 || sA % 4 != 0 ||
       sB % 4 != 0 || ((uintptr_t)A & 15) || ((uintptr_t)Bimg & 15) || M > 0x7fffffffLL || ((M - 1) * ldc + N) * 4 >= 0x7ffffff0LL ||
       (bias && N > kMaxBiasN) || (products != 1 && products != 3))
     return COMBO_EINVAL;
-  const int vec = (N % 4 == 0 && ldc % 4 == 0 && sC % 4 == 0 && !((uintptr_t)C & 15) && (!mask || !((uintptr_t)mask & 15))) ? 1 : 0;
-  if (aux_add && !mask) return COMBO_EINVAL;
-  N3Args a{A, lda, Bimg, ldb, bias, mask, C, ldc, (int)M, N, K, relu, (int)(((M - 1) * ldc + N) * 4), batch, vec, dbg_bits3(), products,
-           aux_add ? 1 : 0, sA, sB, sC, conv ? *conv : combo_nt3_conv{1, 1, K, 0, 1, 1}, nullptr};
+  const int vec = (N % 4 == 0 && ldc % 4 == 0 && sC % 4 == 0 && !((uintptr_t)C & 15) && (!mask || !((uintptr_t)mask & 15)) && (!add || !((uintptr_t)add & 15))) ? 1 : 0;
+  N3Args a{A, lda, Bimg, ldb, bias, mask, add, C, ldc, (int)M, N, K, relu, (int)(((M - 1) * ldc + N) * 4), batch, vec, dbg_bits3(), products,
+           sA, sB, sC, conv ? *conv : combo_nt3_conv{1, 1, K, 0, 1, 1}, nullptr};
   if (force_cfg) return conv ? launch_one3<true>(a, (hipStream_t)stream, force_cfg) : launch_one3<false>(a, (hipStream_t)stream, force_cfg);
   return conv ? launch_nt3<true>(a, (hipStream_t)stream) : launch_nt3<false>(a, (hipStream_t)stream);
 }
 
 namespace {
-// out[m, n] = epilogue(sum_z part[z, m, n]): + bias[n], + aux (aux_add), ReLU, aux > 0 ? . : 0 (mask without aux_add) - the
+// out[m, n] = epilogue(sum_z part[z, m, n]): + bias[n], + add[m, n], ReLU, mask[m, n] > 0 ? . : 0 - the
 // epilogue of the unsplit kernel; finishes a split-K GEMM / convolution; N % 4 == 0, fixed summation order
 __global__ void __launch_bounds__(256)
 nt3_splitk_finish_kernel(const float* __restrict__ part, int splits, long long M, int N, const float* __restrict__ mask,
-                         float* __restrict__ out, long long ldc, const float* __restrict__ bias, int relu, int aux_add) {
+                         float* __restrict__ out, long long ldc, const float* __restrict__ bias, int relu, const float* __restrict__ add) {
   const long long n4 = (long long)M * (N >> 2);
   const long long i = blockIdx.x * 256LL + threadIdx.x;
   if (i >= n4) return;
@@ -684,11 +706,13 @@ nt3_splitk_finish_kernel(const float* __restrict__ part, int splits, long long M
     const float4 bv = *reinterpret_cast<const float4*>(bias + c);
     a.x += bv.x; a.y += bv.y; a.z += bv.z; a.w += bv.w;
   }
-  float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
-  if (mask) mk = *reinterpret_cast<const float4*>(mask + mrow * ldc + c);
-  if (aux_add) { a.x += mk.x; a.y += mk.y; a.z += mk.z; a.w += mk.w; }
+  if (add) {
+    const float4 dv = *reinterpret_cast<const float4*>(add + mrow * ldc + c);
+    a.x += dv.x; a.y += dv.y; a.z += dv.z; a.w += dv.w;
+  }
   if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
-  if (mask && !aux_add) {
+  if (mask) {
+    const float4 mk = *reinterpret_cast<const float4*>(mask + mrow * ldc + c);
     a.x = mk.x > 0.f ? a.x : 0.f; a.y = mk.y > 0.f ? a.y : 0.f; a.z = mk.z > 0.f ? a.z : 0.f; a.w = mk.w > 0.f ? a.w : 0.f;
   }
   *reinterpret_cast<float4*>(out + mrow * ldc + c) = a;
@@ -711,40 +735,50 @@ extern "C" int combo_gemm_nt_x3_splitk_plan(int M, int N, int K) {
   return s < 1 ? 1 : s;
 }
 
-static int nt3_split_launch(const float* A, long long lda, const float* Bimg, const float* bias, const float* aux, int aux_add,
+static int nt3_split_launch(const float* A, long long lda, const float* Bimg, const float* bias, const float* add, const float* mask,
                             float* C, long long ldc, long long M, int N, int K, int relu, int splits, float* workspace,
                             const combo_nt3_conv* conv, combo_stream_t stream) {
   if (splits < 2 || !workspace || K % (splits * 32) != 0 || N % 4 != 0 || ((uintptr_t)workspace & 15) || ((uintptr_t)C & 15) ||
-      (aux && ((uintptr_t)aux & 15)) || (bias && ((uintptr_t)bias & 15)) || (aux_add && !aux) || ldc % 4 != 0 || M * N > 0x7fffffffLL / 4)
+      (add && ((uintptr_t)add & 15)) || (mask && ((uintptr_t)mask & 15)) || (bias && ((uintptr_t)bias & 15)) || ldc % 4 != 0 ||
+      M * N > 0x7fffffffLL / 4)
     return COMBO_EINVAL;
   const int Ks = K / splits;
   // slice z: A columns [z Ks, (z + 1) Ks) (element offset z Ks; a convolution: taps z * tap_step ...), image rows keep their pitch K
   // and start z Ks floats in
   if (int e = combo_nt3_launch(A, lda, Bimg, K, nullptr, nullptr, workspace, N, M, N, Ks, 0, 3, splits, conv ? 0 : Ks, Ks, M * N,
-                               conv, 0, stream, 0))
+                               conv, 0, stream, nullptr))
     return e;
   const long long n4 = M * (N >> 2);
   hipLaunchKernelGGL(nt3_splitk_finish_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace,
-                     splits, M, N, aux, C, ldc, bias, relu, aux_add);
+                     splits, M, N, mask, C, ldc, bias, relu, add);
   return (int)hipGetLastError();
 }
 
 extern "C" int combo_gemm_nt_x3_splitk_f32(const float* A, long long lda, const float* Bimg, const float* mask, float* C,
                                            long long ldc, int M, int N, int K, int splits, float* workspace, combo_stream_t stream) {
-  return nt3_split_launch(A, lda, Bimg, nullptr, mask, 0, C, ldc, M, N, K, 0, splits, workspace, nullptr, stream);
+  return nt3_split_launch(A, lda, Bimg, nullptr, nullptr, mask, C, ldc, M, N, K, 0, splits, workspace, nullptr, stream);
 }
 
-/* C = epilogue(A[M, K] . image[N, K]^T) with the 3-product split: v = acc (+ bias[n]) (+ aux[m, n] when aux_mode == 1: the
- * residual branch), ReLU when relu, v = aux[m, n] > 0 ? v : 0 when aux_mode == 2 (the ReLU gradient of the layer that produced
- * the operand); aux has C's pitch.  splits > 1 (combo_gemm_nt_x3_splitk_plan): K slices as batch entries into workspace
- * [splits, M, N], the epilogue rides in the finishing sum.  The forward pass of the ResNet backbones' 1x1 convolutions
- * (FrozenBN folded into the weights; detectron2's BottleneckBlock, cited at models/maskformer_model.py:138,145 of the reference). */
+/* C = epilogue(A[M, K] . image[N, K]^T) with the 3-product split: v = acc (+ bias[n]) (+ add[m, n]: the residual branch / the other
+ * gradient arriving at the operand's producer), ReLU when relu, v = mask[m, n] > 0 ? v : 0 last (the ReLU gradient of the layer
+ * that produced the operand); add and mask have C's pitch, either may be NULL.  splits > 1 (combo_gemm_nt_x3_splitk_plan): K
+ * slices as batch entries into workspace [splits, M, N], the epilogue rides in the finishing sum.  The forward pass and the
+ * input gradients of the ResNet backbones' 1x1 convolutions (FrozenBN folded into the weights; detectron2's BottleneckBlock, cited
+ * at models/maskformer_model.py:138,145 of the reference). */
+extern "C" int combo_gemm_nt_x3_epi2_f32(const float* A, long long lda, const float* Bimg, const float* bias, const float* add,
+                                         const float* mask, float* C, long long ldc, int M, int N, int K, int relu, int splits,
+                                         float* workspace, combo_stream_t stream) {
+  if (splits > 1) return nt3_split_launch(A, lda, Bimg, bias, add, mask, C, ldc, M, N, K, relu, splits, workspace, nullptr, stream);
+  return combo_nt3_launch(A, lda, Bimg, K, bias, mask, C, ldc, M, N, K, relu, 3, 1, 0, 0, 0, nullptr, 0, stream, add);
+}
+
+/* The same with ONE auxiliary tensor: aux_mode 0 none (aux NULL), 1 add, 2 mask. */
 extern "C" int combo_gemm_nt_x3_epi_f32(const float* A, long long lda, const float* Bimg, const float* bias, const float* aux,
                                         int aux_mode, float* C, long long ldc, int M, int N, int K, int relu, int splits,
                                         float* workspace, combo_stream_t stream) {
   if (aux_mode < 0 || aux_mode > 2 || (aux_mode != 0) != (aux != nullptr)) return COMBO_EINVAL;
-  if (splits > 1) return nt3_split_launch(A, lda, Bimg, bias, aux, aux_mode == 1, C, ldc, M, N, K, relu, splits, workspace, nullptr, stream);
-  return combo_nt3_launch(A, lda, Bimg, K, bias, aux, C, ldc, M, N, K, relu, 3, 1, 0, 0, 0, nullptr, 0, stream, aux_mode == 1);
+  return combo_gemm_nt_x3_epi2_f32(A, lda, Bimg, bias, aux_mode == 1 ? aux : nullptr, aux_mode == 2 ? aux : nullptr, C, ldc, M, N, K, relu,
+                                   splits, workspace, stream);
 }
 
 /* Tap split of a 3x3 implicit-GEMM convolution over M tokens: 1 (do not split), 3 (one kernel row per slice) or 9 (one tap per
@@ -781,9 +815,10 @@ extern "C" int combo_conv_nhwc_x3_epi_f32(const float* X, long long ldx, const f
     return COMBO_EINVAL;
   combo_nt3_conv cg{H, W, Cin, taps / splits, stride, ksize == 3 ? 1 : 0};
   if (splits > 1)
-    return nt3_split_launch(X, ldx, Wimg, bias, aux, aux_mode == 1, Y, ldy, M, Cout, taps * Cin, relu, splits, workspace, &cg, stream);
-  return combo_nt3_launch(X, ldx, Wimg, (long long)taps * Cin, bias, aux, Y, ldy, M, Cout, taps * Cin, relu, 3, 1, 0, 0, 0, &cg, 0, stream,
-                          aux_mode == 1);
+    return nt3_split_launch(X, ldx, Wimg, bias, aux_mode == 1 ? aux : nullptr, aux_mode == 2 ? aux : nullptr, Y, ldy, M, Cout, taps * Cin,
+                            relu, splits, workspace, &cg, stream);
+  return combo_nt3_launch(X, ldx, Wimg, (long long)taps * Cin, bias, aux_mode == 2 ? aux : nullptr, Y, ldy, M, Cout, taps * Cin, relu, 3, 1,
+                          0, 0, 0, &cg, 0, stream, aux_mode == 1 ? aux : nullptr);
 }
 
 extern "C" int combo_conv3x3_nhwc_x3_epi_f32(const float* X, long long ldx, const float* Wimg, const float* bias, const float* aux,

@@ -32,6 +32,9 @@ ENABLED = True   # weight gradients of the stride-1 1x1 / 3x3 convolutions on th
 DX_OWN = 3
 FWD_X3 = True    # forward on the 3-product kernels with the fused bias / residual / ReLU epilogue (needs weight_images)
 DX_MIN_C = 64
+# ReLU-gradient mask of conv1's output in the epilogue of the 3x3 convolution's own input-gradient kernel (needs DX_OWN bit 0)
+MASK_3X3 = True
+MASK_1X1 = True  # the same for conv2's output in conv3's (1x1) input-gradient GEMM
 
 
 def kind(x, w, stride, padding):
@@ -220,12 +223,26 @@ class _ConvWrw(Function):
         return dx, dw, None, None, None, None, None, None
 
 
+def _forward_ok(x, w, residual):
+    return (ENABLED and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and not torch.is_autocast_enabled() and x.dim() == 4
+            and x.is_contiguous(memory_format=torch.channels_last)
+            and (residual is None or (residual.dtype == torch.float32 and residual.shape[1] == w.shape[0]
+                                      and residual.is_contiguous(memory_format=torch.channels_last))))
+
+
 def conv_bias_act(x, w, bias, stride, padding, images=None, residual=None, relu=True, fanout=False, grad_masked=False, mask_dx=False):
     """relu(conv2d(x, w) + bias (+ residual)) of a FrozenBN-folded backbone convolution (bias: fp32 [cout] or None = no epilogue
     at all).  With `images` (weight_images) the whole expression is ONE launch of the 3-product kernel; otherwise the library's
     convolution followed by the fused bias / ReLU pass (ops/biasact.py).  fanout / grad_masked / mask_dx: see
     ops.biasact.bias_act and _ConvWrw.forward."""
     from .biasact import bias_act, fusable
+    if images is not None and FWD_X3 and not (torch.is_grad_enabled() and (w.requires_grad or x.requires_grad)) and _forward_ok(x, w, residual):
+        # no gradient (evaluation): the same kernel without an autograd node - the features of an evaluation forward are
+        # bit-identical to the training forward's
+        k = weight_kind(w, stride, padding, x.shape)
+        if k:
+            y = _x3_forward(x, k, images[0], bias, residual, relu and bias is not None)
+            return (y, y) if (fanout and bias is not None) else y
     k = kind(x, w, stride, padding)
     if k and images is not None and FWD_X3 and (residual is None or (residual.dtype == torch.float32 and residual.shape[1] == w.shape[0]
                                                                      and residual.is_contiguous(memory_format=torch.channels_last))):

@@ -139,34 +139,25 @@ def x3_ok(a, n_out):
             and _aligned_rows(a) and a.shape[0] * n_out * 4 < 2 ** 31 - 1)
 
 
-def gemm_nt_x3(a, b, bias=None, relu=False, relu_mask=None, img=None):
-    """C[M,N] = a[M,K] @ b[N,K]^T (+ bias) (+ ReLU) with the 3-product bf16 split (~2^-17 relative per product): the
+def gemm_nt_x3(a, b, bias=None, relu=False, relu_mask=None, img=None, add=None):
+    """C[M,N] = a[M,K] @ b[N,K]^T (+ bias) (+ add) (+ ReLU) with the 3-product bf16 split (~2^-17 relative per product): the
     input-gradient GEMM dX = dY . W (b = `weight.t()`, any strided 2-D view).  relu_mask [M,N]: C = relu_mask > 0 ? C : 0
-    (the ReLU backward of the layer that produced the operand, folded into the epilogue)."""
+    (the ReLU backward of the layer that produced the operand, folded into the epilogue); add [M,N]: another gradient arriving
+    at the same tensor, summed in the epilogue (before the mask)."""
     M, K = a.shape
     N = b.shape[0]
     out = torch.empty(M, N, device=a.device, dtype=torch.float32)
     if img is None:
         img = presplit(b)
     lib, st = _lib.lib(), _lib.current_stream()
-    if relu_mask is not None:
-        assert bias is None and not relu and relu_mask.shape == (M, N) and relu_mask.is_contiguous()
-    splits = lib.combo_gemm_nt_x3_splitk_plan(M, N, K) if (bias is None and not relu) else 1
-    if splits > 1:  # few output tiles, long K: K slices as the batch entries of one launch + a fixed-order finishing sum
-        ws = torch.empty(splits, M, N, device=a.device, dtype=torch.float32)
-        with _lib.timed("gemm_nt_x3", (M, N, K)):
-            rc = lib.combo_gemm_nt_x3_splitk_f32(a.data_ptr(), a.stride(0), img.data_ptr(), _lib.ptr(relu_mask), out.data_ptr(), N,
-                                                 M, N, K, splits, ws.data_ptr(), st)
-        _lib.check(rc, "combo_gemm_nt_x3_splitk_f32")
-        return out
+    for t in (relu_mask, add):
+        assert t is None or (t.shape == (M, N) and t.is_contiguous() and t.dtype == torch.float32)
+    splits = lib.combo_gemm_nt_x3_splitk_plan(M, N, K)
+    ws = torch.empty(splits, M, N, device=a.device, dtype=torch.float32) if splits > 1 else None
     with _lib.timed("gemm_nt_x3", (M, N, K)):
-        if relu_mask is not None:
-            rc = lib.combo_gemm_nt_x3_pre_masked_f32(a.data_ptr(), a.stride(0), img.data_ptr(), relu_mask.data_ptr(),
-                                                     out.data_ptr(), N, M, N, K, st)
-        else:
-            rc = lib.combo_gemm_nt_x3_pre_f32(a.data_ptr(), a.stride(0), img.data_ptr(), _lib.ptr(bias), out.data_ptr(), N, M, N, K,
-                                              1 if relu else 0, st)
-    _lib.check(rc, "combo_gemm_nt_x3_pre_f32")
+        rc = lib.combo_gemm_nt_x3_epi2_f32(a.data_ptr(), a.stride(0), img.data_ptr(), _lib.ptr(bias), _lib.ptr(add), _lib.ptr(relu_mask),
+                                           out.data_ptr(), N, M, N, K, 1 if relu else 0, splits, _lib.ptr(ws), st)
+    _lib.check(rc, "combo_gemm_nt_x3_epi2_f32")
     return out
 
 

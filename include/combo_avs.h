@@ -409,6 +409,12 @@ int combo_conv3x3_nhwc_x3_pre_f32(const float* X, long long ldx, const float* Wi
 int combo_gemm_nt_x3_epi_f32(const float* A, long long lda, const float* Bimg, const float* bias, const float* aux, int aux_mode,
                              float* C, long long ldc, int M, int N, int K, int relu, int splits, float* workspace,
                              combo_stream_t stream);
+/*   ... with both auxiliary tensors: v = acc (+ bias) (+ add[m, n]) -> ReLU -> mask[m, n] > 0 ? v : 0 (either may be NULL): the input
+ *   gradient of a bottleneck block's first convolution takes the identity branch's gradient (add) and the ReLU gradient of the
+ *   block input (mask) in its epilogue - no separate add + ReLU-gradient pass over the block input's gradient. */
+int combo_gemm_nt_x3_epi2_f32(const float* A, long long lda, const float* Bimg, const float* bias, const float* add, const float* mask,
+                              float* C, long long ldc, int M, int N, int K, int relu, int splits, float* workspace,
+                              combo_stream_t stream);
 int combo_conv3x3_x3_splitk_plan(long long M, int Cout, int Cin);
 int combo_conv3x3_nhwc_x3_epi_f32(const float* X, long long ldx, const float* Wimg, const float* bias, const float* aux,
                                   int aux_mode, float* Y, long long ldy, int B, int H, int W, int Cin, int Cout, int relu,
