@@ -50,10 +50,10 @@ presplit_kernel(const float* __restrict__ src, long long ld_row, long long ld_co
   img[o + 1] = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
-// Grouped form: every weight whose input-gradient GEMM the backward pass will run, split by ONE launch (per 64 problems)
+// Grouped form: every weight whose input-gradient GEMM the backward pass will run, split by ONE launch (per 56 problems)
 // instead of one ~5 us launch per weight (148 per training step).  img_ld: floats per image row (>= K): several sources may
 // fill k ranges of one image (the two weights of a column-concatenated layer).
-constexpr int kMaxSplitGroup = 64;
+constexpr int kMaxSplitGroup = 56;  // (the argument block of a launch stays below 4 KiB)
 struct SplitGroupArgs {
   int count;
   long long thread_start[kMaxSplitGroup + 1];
@@ -71,21 +71,28 @@ presplit_grouped_kernel(const SplitGroupArgs args) {
   const long long t = t0 - args.thread_start[pi];
   const int kg = pr.K >> 3;
   if (t >= (long long)pr.N * kg) return;  // (a problem's threads are rounded up to whole workgroups)
+  // neighbouring threads walk the direction in which the source is denser: the k groups of a row or the rows of a k group
+  const long long row_step = pr.ld_row < 0 ? -pr.ld_row : pr.ld_row, grp_step = 8 * (pr.ld_col < 0 ? -pr.ld_col : pr.ld_col);
   int n, g8;
-  if (pr.ld_col == 1) { n = (int)(t / kg); g8 = (int)(t - (long long)n * kg); }
+  if (grp_step <= row_step) { n = (int)(t / kg); g8 = (int)(t - (long long)n * kg); }
   else { g8 = (int)(t / pr.N); n = (int)(t - (long long)g8 * pr.N); }
-  float v[8];
+  const int taps = pr.taps > 1 ? pr.taps : 1;
+  const float* src = pr.src + (long long)n * pr.ld_row + (long long)(g8 * 8) * pr.ld_col;
+  for (int tap = 0; tap < taps; ++tap) {
+    float v[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] = pr.src[(long long)n * pr.ld_row + (long long)(g8 * 8 + i) * pr.ld_col];
-  unsigned h[4], l[4];
+    for (int i = 0; i < 8; ++i) v[i] = src[(long long)i * pr.ld_col + tap];
+    unsigned h[4], l[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    h[i] = pack_rne(v[2 * i], v[2 * i + 1]);
-    l[i] = pack_rne(v[2 * i] - __uint_as_float(h[i] << 16), v[2 * i + 1] - __uint_as_float(h[i] & 0xffff0000u));
+    for (int i = 0; i < 4; ++i) {
+      h[i] = pack_rne(v[2 * i], v[2 * i + 1]);
+      l[i] = pack_rne(v[2 * i] - __uint_as_float(h[i] << 16), v[2 * i + 1] - __uint_as_float(h[i] & 0xffff0000u));
+    }
+    const int col_tap = pr.flip ? taps - 1 - tap : tap;
+    uint4* img = reinterpret_cast<uint4*>(pr.img) + (long long)n * (pr.img_ld >> 2) + ((long long)col_tap * kg + g8) * 2;
+    img[0] = make_uint4(h[0], h[1], h[2], h[3]);
+    img[1] = make_uint4(l[0], l[1], l[2], l[3]);
   }
-  uint4* img = reinterpret_cast<uint4*>(pr.img) + (long long)n * (pr.img_ld >> 2) + g8 * 2;
-  img[0] = make_uint4(h[0], h[1], h[2], h[3]);
-  img[1] = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
 int g_products = 3;  // combo_gemm_nt2_products: bf16 products per multiply-add of the launches that follow (host state, read at launch)
@@ -118,8 +125,8 @@ extern "C" int combo_presplit_bf16x2_grouped_f32(const combo_presplit_problem* p
     long long threads = 0;
     for (int i = 0; i < a.count; ++i) {
       const combo_presplit_problem& pr = problems[base + i];
-      if (!pr.src || !pr.img || pr.N <= 0 || pr.K <= 0 || pr.K % 8 != 0 || pr.img_ld < pr.K || pr.img_ld % 8 != 0 ||
-          ((uintptr_t)pr.img & 31))
+      if (!pr.src || !pr.img || pr.N <= 0 || pr.K <= 0 || pr.K % 8 != 0 || pr.taps < 0 || pr.taps > 9 ||
+          pr.img_ld < (long long)pr.K * (pr.taps > 1 ? pr.taps : 1) || pr.img_ld % 8 != 0 || ((uintptr_t)pr.img & 31))
         return COMBO_EINVAL;
       a.thread_start[i] = threads;
       a.p[i] = pr;

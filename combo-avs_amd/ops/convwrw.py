@@ -71,7 +71,7 @@ def weight_images(weights, geometry):
     """bf16 hi/lo images (combo_presplit_bf16x2_*) of the folded weights of one backbone, all by grouped launches:
     weights [cout, cin, k, k] fp32, geometry [(stride, padding)] -> per weight None (layer not handled) or
     (forward image [cout, k*k*cin] with K ordered (ky, kx, cin), input-gradient image [cin, k*k*cout] with the taps flipped).
-    A 3x3 weight in NCHW order is 9 strided problems per image (one per tap)."""
+    A 3x3 weight in NCHW order is ONE problem per image whose threads read the 9 contiguous taps of 8 (cout, cin) pairs."""
     kinds = [weight_kind(w, s, p) if (w.is_cuda and w.dtype == torch.float32) else 0 for w, (s, p) in zip(weights, geometry)]
     total = sum((2 if k < 20 else 1) * w.numel() for w, k in zip(weights, kinds) if k)
     if total == 0:
@@ -100,14 +100,19 @@ def weight_images(weights, geometry):
             cout, cin, k = w.shape[:3]
             s0, s1, s2, s3 = w.stride()
             fwd, dx = imgs
-            for ky in range(k):
+            if (s2, s3) == (k, 1) or k == 1:  # the taps of a (cout, cin) pair are contiguous: one problem per image
+                plist.append(L._SplitProblem(w.data_ptr(), fwd.data_ptr(), s0, s1, k * k * cin, cout, cin, k * k, 0))
+                if dx is not None:  # dX[t] = sum_tap' dY[t + shift(tap')] . W[.., tap flipped]
+                    plist.append(L._SplitProblem(w.data_ptr(), dx.data_ptr(), s1, s0, k * k * cout, cin, cout, k * k, 1))
+                continue
+            for ky in range(k):  # any other layout (channels_last weights): one strided problem per tap
                 for kx in range(k):
                     tap = ky * k + kx
                     src = w.data_ptr() + 4 * (ky * s2 + kx * s3)
-                    plist.append(L._SplitProblem(src, fwd.data_ptr() + 4 * tap * cin, s0, s1, k * k * cin, cout, cin))
+                    plist.append(L._SplitProblem(src, fwd.data_ptr() + 4 * tap * cin, s0, s1, k * k * cin, cout, cin, 0, 0))
                     if dx is not None:
-                        flip = (k - 1 - ky) * k + (k - 1 - kx)  # dX[t] = sum_tap' dY[t + shift(tap')] . W[.., tap flipped]
-                        plist.append(L._SplitProblem(src, dx.data_ptr() + 4 * flip * cout, s1, s0, k * k * cout, cin, cout))
+                        flip = (k - 1 - ky) * k + (k - 1 - kx)
+                        plist.append(L._SplitProblem(src, dx.data_ptr() + 4 * flip * cout, s1, s0, k * k * cout, cin, cout, 0, 0))
         pr = (L._SplitProblem * len(plist))(*plist)
         if len(_problem_cache) > 64:
             _problem_cache.clear()

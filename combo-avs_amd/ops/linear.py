@@ -70,7 +70,7 @@ def presplit(b):
 
 class _SplitProblem(ctypes.Structure):  # combo_presplit_problem (include/combo_avs.h)
     _fields_ = [("src", ctypes.c_void_p), ("img", ctypes.c_void_p), ("ld_row", ctypes.c_longlong), ("ld_col", ctypes.c_longlong),
-                ("img_ld", ctypes.c_longlong), ("N", ctypes.c_int), ("K", ctypes.c_int)]
+                ("img_ld", ctypes.c_longlong), ("N", ctypes.c_int), ("K", ctypes.c_int), ("taps", ctypes.c_int), ("flip", ctypes.c_int)]
 
 
 _split_images = None  # key -> image, while a grouped_presplit() context is open: weights announced by the forward pass

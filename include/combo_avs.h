@@ -379,11 +379,16 @@ int combo_presplit_bf16x2_batched_f32(const float* src, long long ld_row, long l
                                       int K, int batch, float* img, combo_stream_t stream);
 /*   Grouped pre-split: element (n, k) of problem i = src[n*ld_row + k*ld_col] lands in image row n (img_ld floats per row,
  *   >= K, a multiple of 8; img 32-byte aligned - an offset of k0 floats into a wider image concatenates sources along k).
- *   One launch per 64 problems: all weights whose input-gradient GEMMs the backward pass of a step runs. */
+ *   One launch per 56 problems: all weights whose input-gradient GEMMs the backward pass of a step runs. */
+/*   taps > 1 (9: a 3x3 convolution weight): element (n, k, tap) = src[n*ld_row + k*ld_col + tap] (the taps of one (n, k) pair
+ *   are contiguous: an NCHW-ordered [Cout, Cin, 3, 3] tensor read as n = cout, k = cin for the forward image or n = cin, k = cout
+ *   for the input-gradient image) lands in image row n at column (flip ? taps - 1 - tap : tap) * K + k; img_ld >= taps * K.
+ *   One thread reads the taps x 8 values of a (row, 8-k group): contiguous runs of the source either way. */
 typedef struct {
   const float* src; float* img;
   long long ld_row, ld_col, img_ld;
   int N, K;
+  int taps, flip;  /* 0 / 1 taps: a plain matrix */
 } combo_presplit_problem;
 int combo_presplit_bf16x2_grouped_f32(const combo_presplit_problem* problems, int count, combo_stream_t stream);
 int combo_gemm_nt_x3_pre_batched_f32(const float* A, long long lda, long long sA, const float* Bimg, long long sB, float* C,
