@@ -4,7 +4,7 @@ dX shapes of the training step, against its two ceilings - 833 TFLOP/s useful (2
 algorithmic bytes (A read once, C written once, weight image once) - and against the library's fp32 and bf16 GEMMs.
 
     python tools/bench_nt3.py [--iters N] [--shapes all|small|big] [--no-lib]
-    COMBO_NT3_DBG=<bits>  ablation instances: one of 1 2 4 8 16 32 41 63 (1 no DMA, 2 no LDS reads, 4 no barrier, 8 no stores, 16 no split, 32 no MFMA)
+    COMBO_NT3_DBG=<bits>  ablation instances: one of 1 2 4 8 16 32 41 63 (1 no DMA, 2 no LDS reads, 4 no barrier, 8 no stores, 16 no split, 32 no MFMA)"""
 import argparse
 import os
 import sys
