@@ -244,10 +244,12 @@ class ResNet(nn.Module):
             x_res = None
             for i, (name, blk) in enumerate(blocks):
                 fan = dtype == torch.float32 and i + 1 < len(blocks) and torch.is_grad_enabled()
-                y = blk(x, folded, x_res, fan)
-                x, x_res = y if fan else (y, None)
-                if name in self._out_features and (i + 1 == len(blocks) or blocks[i + 1][0] != name):
-                    out[name] = x
+                is_out = name in self._out_features and (i + 1 == len(blocks) or blocks[i + 1][0] != name)
+                # (a stage's last block has a third consumer - the head: a third alias, summed in the same ReLU-gradient pass)
+                y = blk(x, folded, x_res, (3 if is_out else 2) if fan else False)
+                x, x_res = (y[0], y[1]) if fan else (y, None)
+                if is_out:
+                    out[name] = y[2] if fan else x
         return out
 
     def output_shape(self):

@@ -83,6 +83,20 @@ relu_grad2_f32_kernel(const float* __restrict__ dy1, const float* __restrict__ d
                                                  v.w > 0.f ? a.w + b.w : 0.f);
 }
 
+// ... and with three consumers (the last block of a ResNet stage: next stage's first convolution, its shortcut branch, the head)
+__global__ void __launch_bounds__(256)
+relu_grad3_f32_kernel(const float* __restrict__ dy1, const float* __restrict__ dy2, const float* __restrict__ dy3,
+                      const float* __restrict__ y, long long n4, float* __restrict__ dx) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4 a = reinterpret_cast<const float4*>(dy1)[i];
+  const float4 b = reinterpret_cast<const float4*>(dy2)[i];
+  const float4 c = reinterpret_cast<const float4*>(dy3)[i];
+  const float4 v = reinterpret_cast<const float4*>(y)[i];
+  reinterpret_cast<float4*>(dx)[i] = make_float4(v.x > 0.f ? a.x + b.x + c.x : 0.f, v.y > 0.f ? a.y + b.y + c.y : 0.f,
+                                                 v.z > 0.f ? a.z + b.z + c.z : 0.f, v.w > 0.f ? a.w + b.w + c.w : 0.f);
+}
+
 // fp32 variant of bias_act_kernel (the reference's S4 recipe runs the backbones in fp32: SOLVER.AMP.ENABLED False); 4 channels per thread
 __global__ void __launch_bounds__(256)
 bias_act_f32_kernel(float* __restrict__ y, const float* __restrict__ bias, const float* __restrict__ res, long long n4, int C4, int relu) {
@@ -125,6 +139,17 @@ int combo_relu_grad2_f32(const float* dy1, const float* dy2, const float* y, lon
     return COMBO_EINVAL;
   const long long n4 = n / 4;
   hipLaunchKernelGGL(relu_grad2_f32_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy1, dy2, y, n4, dx);
+  return (int)hipGetLastError();
+}
+
+int combo_relu_grad3_f32(const float* dy1, const float* dy2, const float* dy3, const float* y, long long n, float* dx,
+                         combo_stream_t stream) {
+  if (!dy1 || !dy2 || !dy3 || !y || !dx || n <= 0 || n % 4 != 0 ||
+      (((uintptr_t)dy1 | (uintptr_t)dy2 | (uintptr_t)dy3 | (uintptr_t)y | (uintptr_t)dx) & 15))
+    return COMBO_EINVAL;
+  const long long n4 = n / 4;
+  hipLaunchKernelGGL(relu_grad3_f32_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy1, dy2, dy3, y, n4,
+                     dx);
   return (int)hipGetLastError();
 }
 

@@ -118,7 +118,7 @@ sem_mix_bwd(const float* __restrict__ dout, const float* __restrict__ s, const f
     Ld8<float>::load(dgap + b * C + c, gv);
 #pragma unroll
     for (int k = 0; k < 8; ++k) r[k] = d[k] * sv[k] + gv[k];
-    Ld8<T>::store(df + o, d);
+    if (df) Ld8<T>::store(df + o, d);  // (fp32: the caller hands dout itself on as df - no copy)
     Ld8<T>::store(dp + o, r);
   }
 }
@@ -146,10 +146,10 @@ int run(int op, const void* a, const void* b, const float* s, const float* g, in
 }  // namespace
 
 // op: 0 = gap sum (a = p, o1 = acc[B,C], overwritten), 1 = mix fwd (a = f, b = p, s -> o1 = out fp32),
-//     2 = dot (a = p, b = dout -> o1 = ds[B,C], overwritten), 3 = mix bwd (a = dout, s, g = dgap -> o1 = df, o2 = dp)
+//     2 = dot (a = p, b = dout -> o1 = ds[B,C], overwritten), 3 = mix bwd (a = dout, s, g = dgap -> o1 = df (may be NULL: df = dout is the caller's), o2 = dp)
 extern "C" int combo_sem_mix(int op, int is_bf16, const void* a, const void* b, const float* s, const float* g, int B, int HW,
                              int C, void* o1, void* o2, combo_stream_t stream) {
-  if (!a || !o1 || B <= 0 || HW <= 0 || C <= 0 || (C & 7)) return COMBO_EINVAL;
+  if (!a || (!o1 && op != 3) || (op == 3 && !o2) || B <= 0 || HW <= 0 || C <= 0 || (C & 7)) return COMBO_EINVAL;
   return is_bf16 ? run<__hip_bfloat16>(op, a, b, s, g, B, HW, C, o1, o2, (hipStream_t)stream)
                  : run<float>(op, a, b, s, g, B, HW, C, o1, o2, (hipStream_t)stream);
 }

@@ -14,6 +14,10 @@ class channel_weighted_block(nn.Module):
         self.fc1 = nn.Linear(in_features=dim, out_features=int(dim / 16))
         self.fc2 = nn.Linear(in_features=int(dim / 16), out_features=dim)
 
+    def gate(self, y):
+        """[B, C] pooled features -> [B, C] channel weights"""
+        return torch.sigmoid(L.linear(L.linear(y, self.fc1.weight, self.fc1.bias, relu=True), self.fc2.weight, self.fc2.bias))
+
     def forward(self, x):
         b, c, _, _ = x.size()
         y = K.global_avg_pool(x)  # [B,C] fp32
@@ -26,5 +30,9 @@ def sem_mix(features, pre_sam_features, scale_factor_modules):
     out = {}
     for (key, blk) in zip(features.keys(), scale_factor_modules):
         p = pre_sam_features[key]
-        out[key] = K.mix(features[key], p, blk(p).view(p.shape[0], p.shape[1]))
+        if p.is_cuda and isinstance(blk, channel_weighted_block):
+            # pool + gate + mix as one autograd node: the pool's gradient rides in the mix-backward kernel (ops/semmix.py _GateMix)
+            out[key] = K.gate_mix(features[key], p, blk.gate, tuple(blk.parameters()))
+        else:
+            out[key] = K.mix(features[key], p, blk(p).view(p.shape[0], p.shape[1]))
     return out

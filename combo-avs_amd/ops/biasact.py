@@ -32,38 +32,46 @@ class _BiasAct(Function):
         if ctx.relu:
             ctx.save_for_backward(y)
         if fanout:
-            # the SAME values as two autograd outputs (the second is a view): a consumer pair - next block's first convolution and
-            # its identity / shortcut branch - then hands back two separate gradients, added inside the ReLU-gradient pass
-            return y, y.view_as(y)
+            # the SAME values as two (fanout = True / 2) or three autograd outputs (views): the consumers - next block's first
+            # convolution, its identity / shortcut branch, and for a stage's last block the head - then hand back separate
+            # gradients, added inside the ReLU-gradient pass
+            return (y,) + tuple(y.view_as(y) for _ in range(max(int(fanout), 2) - 1))
         return y
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, dy, dy2=None):
-        if dy is None:
-            dy, dy2 = dy2, None
+    def backward(ctx, *dys):
+        got = [g for g in dys if g is not None]
+        dy = got[0]
         dx = dy
         if ctx.relu:
             (y,) = ctx.saved_tensors
-            dy = dy.contiguous(memory_format=torch.channels_last)
+            f32 = all(g.dtype == torch.float32 for g in got)
+            got = [g.contiguous(memory_format=torch.channels_last) for g in got]
+            dy = got[0]
             dx = torch.empty_like(dy)
-            if dy2 is not None and dy.dtype == torch.float32 and dy2.dtype == torch.float32:
-                dy2 = dy2.contiguous(memory_format=torch.channels_last)
-                _lib.check(_lib.lib().combo_relu_grad2_f32(dy.data_ptr(), dy2.data_ptr(), y.data_ptr(), dy.numel(), dx.data_ptr(),
-                                                           _lib.current_stream()), "combo_relu_grad2_f32")
+            lib, st = _lib.lib(), _lib.current_stream()
+            if len(got) == 3 and f32:
+                _lib.check(lib.combo_relu_grad3_f32(got[0].data_ptr(), got[1].data_ptr(), got[2].data_ptr(), y.data_ptr(), dy.numel(),
+                                                    dx.data_ptr(), st), "combo_relu_grad3_f32")
+            elif len(got) == 2 and f32:
+                _lib.check(lib.combo_relu_grad2_f32(got[0].data_ptr(), got[1].data_ptr(), y.data_ptr(), dy.numel(), dx.data_ptr(), st),
+                           "combo_relu_grad2_f32")
             else:
-                if dy2 is not None:
-                    dy = (dy + dy2).contiguous(memory_format=torch.channels_last)
-                fn = _lib.lib().combo_relu_grad_f32 if dy.dtype == torch.float32 else _lib.lib().combo_relu_grad_bf16
-                _lib.check(fn(dy.data_ptr(), y.data_ptr(), dy.numel(), dx.data_ptr(), _lib.current_stream()), "combo_relu_grad")
-        elif dy2 is not None:
-            dx = dy + dy2
+                for g in got[1:]:
+                    dy = (dy + g).contiguous(memory_format=torch.channels_last)
+                fn = lib.combo_relu_grad_f32 if dy.dtype == torch.float32 else lib.combo_relu_grad_bf16
+                _lib.check(fn(dy.data_ptr(), y.data_ptr(), dy.numel(), dx.data_ptr(), st), "combo_relu_grad")
+        else:
+            for g in got[1:]:
+                dx = dx + g
         return dx, None, (dx if ctx.has_res else None), None, None, None, None
 
 
 def bias_act(y, bias, residual=None, relu=True, fanout=False, grad_masked=False, precomputed=False):
     """y: convolution output WITHOUT bias (modified in place); bias: fp32 [C]; residual: same shape as y or None.
-    fanout: return the result twice (two autograd outputs over the same memory) for a consumer pair, see _BiasAct.forward."""
+    fanout: return the result twice (True / 2) or three times (two / three autograd outputs over the same memory) for its
+    consumers, see _BiasAct.forward."""
     if fusable(y, residual):
         return _BiasAct.apply(y, bias, residual, relu, fanout, grad_masked, precomputed)
     assert not precomputed
@@ -71,4 +79,4 @@ def bias_act(y, bias, residual=None, relu=True, fanout=False, grad_masked=False,
     if residual is not None:
         out = out + residual
     out = torch.relu_(out) if relu else out
-    return (out, out) if fanout else out
+    return (out,) * max(int(fanout), 2) if fanout else out

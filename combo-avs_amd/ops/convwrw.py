@@ -247,7 +247,7 @@ def conv_bias_act(x, w, bias, stride, padding, images=None, residual=None, relu=
         k = weight_kind(w, stride, padding, x.shape)
         if k:
             y = _x3_forward(x, k, images[0], bias, residual, relu and bias is not None)
-            return (y, y) if (fanout and bias is not None) else y
+            return (y,) * max(int(fanout), 2) if (fanout and bias is not None) else y
     k = kind(x, w, stride, padding)
     if k and images is not None and FWD_X3 and (residual is None or (residual.dtype == torch.float32 and residual.shape[1] == w.shape[0]
                                                                      and residual.is_contiguous(memory_format=torch.channels_last))):

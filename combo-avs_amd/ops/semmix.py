@@ -15,7 +15,7 @@ def _cl(x):
 
 def _call(op, is_bf16, a, b, s, g, B, HW, C, o1, o2=None):
     _lib.check(_lib.lib().combo_sem_mix(op, 1 if is_bf16 else 0, a.data_ptr(), _lib.ptr(b), _lib.ptr(s), _lib.ptr(g), B, HW, C,
-                                        o1.data_ptr(), _lib.ptr(o2), _lib.current_stream()), "combo_sem_mix")
+                                        _lib.ptr(o1), _lib.ptr(o2), _lib.current_stream()), "combo_sem_mix")
 
 
 class _Gap(Function):
@@ -65,6 +65,63 @@ class _Mix(Function):
         zero = torch.zeros(B, C, device=p.device, dtype=torch.float32)
         _call(3, is_bf16, dout, None, s, zero, B, HW, C, df, dp)
         return df, dp, ds
+
+
+class _GateMix(Function):
+    """out = f + gate(mean_HW(p)) * p as ONE autograd node (models/utils/misc.py:112-131 + maskformer_model.py:345-352).  As
+    separate nodes (pool, gate, mix) the gradient of p arrived in two pieces - dout * s from the mix and the pool's broadcast
+    gradient - which autograd added with a full-map kernel per level; here the pool's gradient [B, C] rides in the mix-backward
+    kernel (its `dgap` operand) and, in fp32, df IS dout (no copy).  `gate` is a callable [B, C] -> [B, C] built from ordinary
+    autograd ops (the two small dense layers + sigmoid): its graph is recorded inside forward and differentiated inside
+    backward; gate_params are its parameters (listed so that autograd routes their gradients)."""
+
+    @staticmethod
+    def forward(ctx, f, p, gate, *gate_params):
+        f, B, HW, C = _cl(f)
+        p, _, _, _ = _cl(p)
+        _lib.require_cuda(f, p, channels_last=True)
+        acc = torch.empty(B, C, device=p.device, dtype=torch.float32)
+        _call(0, p.dtype == torch.bfloat16, p, None, None, None, B, HW, C, acc)
+        with torch.enable_grad():
+            gap = (acc / HW).requires_grad_(True)
+            s = gate(gap)
+        s_val = s.detach().contiguous().float()
+        out = torch.empty(f.shape, device=f.device, dtype=torch.float32, memory_format=torch.channels_last)
+        _call(1, f.dtype == torch.bfloat16, f, p, s_val, None, B, HW, C, out)
+        ctx.save_for_backward(p, s_val)
+        ctx.inner = (gap, s)
+        ctx.f_dtype, ctx.n_params = f.dtype, len(gate_params)
+        ctx.params = gate_params
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        p, s_val = ctx.saved_tensors
+        gap, s = ctx.inner
+        ctx.inner = None
+        dout, B, HW, C = _cl(dout.float())
+        is_bf16 = p.dtype == torch.bfloat16
+        ds = torch.empty(B, C, device=p.device, dtype=torch.float32)
+        _call(2, is_bf16, p, dout, None, None, B, HW, C, ds)
+        need = [t for t in ctx.params if t.requires_grad]
+        with torch.enable_grad():
+            grads = torch.autograd.grad(s, [gap] + need, ds.to(s.dtype))
+        dgap = (grads[0].float() / HW).contiguous()
+        it = iter(grads[1:])
+        dparams = [next(it) if t.requires_grad else None for t in ctx.params]
+        dp = torch.empty_like(p)
+        if ctx.f_dtype == torch.float32 and not is_bf16:
+            df = dout  # d out / d f = 1
+            _call(3, False, dout, None, s_val, dgap, B, HW, C, None, dp)
+        else:
+            df = torch.empty_like(p)
+            _call(3, is_bf16, dout, None, s_val, dgap, B, HW, C, df, dp)
+        return (df, dp, None) + tuple(dparams)
+
+
+def gate_mix(f, p, gate, gate_params):
+    return _GateMix.apply(f, p, gate, *gate_params)
 
 
 def global_avg_pool(p):

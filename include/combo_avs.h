@@ -139,6 +139,9 @@ int combo_bias_act_f32(float* y, const float* bias, const float* residual, long 
 int combo_relu_grad_f32(const float* dy, const float* y, long long n, float* dx, combo_stream_t stream);
 /*   dx = (dy1 + dy2) * (y > 0): a block output with two consumers that hand their gradients over separately (backbone.py) */
 int combo_relu_grad2_f32(const float* dy1, const float* dy2, const float* y, long long n, float* dx, combo_stream_t stream);
+/* ... of a block output with three consumers (the last block of a ResNet stage also feeds the head): dx = (dy1 + dy2 + dy3) . [y > 0] */
+int combo_relu_grad3_f32(const float* dy1, const float* dy2, const float* dy3, const float* y, long long n, float* dx,
+                         combo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * PVTv2 depth-wise 3x3 convolution on token-major bf16 activations (models/modeling/backbone/pvtv2.py:377-388, DWConv:

@@ -191,3 +191,32 @@ def test_vggish_forward_on_the_own_kernels_matches_the_library_and_repeats_bit_f
         ref = net.embeddings(net.features(x).permute(0, 2, 3, 1).reshape(40, -1))
     assert torch.equal(a, b)
     assert float((a - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
+def test_three_way_fanout_sums_all_consumers_in_the_relu_gradient_pass():
+    """ops.biasact.bias_act(fanout=3): a stage's last block hands its output to the next stage's first convolution, its shortcut
+    and the head as three aliases; dx = (dy1 + dy2 + dy3) . [y > 0] in one pass (combo_relu_grad3_f32) equals autograd on the
+    plain expression"""
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.ops.biasact import bias_act
+    g = torch.Generator().manual_seed(11)
+    z = _cl(torch.randn(4, 64, 9, 7, generator=g).cuda())
+    b = torch.randn(64, generator=g).cuda()
+    res = _cl(torch.randn(4, 64, 9, 7, generator=g).cuda())
+    w = [_cl(torch.randn(4, 64, 9, 7, generator=g).cuda()) for _ in range(3)]
+    zz, rr = z.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    a, b2, c = bias_act(zz * 1.0, b, rr, fanout=3)
+    assert a.data_ptr() == b2.data_ptr() == c.data_ptr()
+    got = torch.autograd.grad((a * w[0]).sum() + (b2 * w[1]).sum() + (c * w[2]).sum(), (zz, rr))
+    z2, r2 = z.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    y = torch.relu(z2 + b[None, :, None, None] + r2)
+    ref = torch.autograd.grad((y * (w[0] + w[1] + w[2])).sum(), (z2, r2))
+    for x, r in zip(got, ref):
+        torch.testing.assert_close(x, r, rtol=1e-6, atol=1e-6)
+    # two of three consumers without a gradient: still the masked sum of what arrives
+    zz = z.clone().requires_grad_(True)
+    a, b2, c = bias_act(zz * 1.0, b, None, fanout=3)
+    got = torch.autograd.grad((b2 * w[1]).sum(), zz)[0]
+    z2 = z.clone().requires_grad_(True)
+    ref = torch.autograd.grad((torch.relu(z2 + b[None, :, None, None]) * w[1]).sum(), z2)[0]
+    torch.testing.assert_close(got, ref, rtol=1e-6, atol=1e-6)

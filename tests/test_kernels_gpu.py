@@ -84,20 +84,24 @@ def test_sem_mix_forward_backward(dtype):
         out = sem_mix({"res2": f.cuda()}, {"res2": p.cuda()}, [blk])["res2"]
         np.testing.assert_allclose(out.detach().cpu().numpy(), z["sem256/mixed"], rtol=1e-5, atol=1e-5)
     fq, pq = f.to(dtype).float(), p.to(dtype).float()  # the values the kernel actually sees
-    P = {"m.0." + k: v.detach().cpu().double() for k, v in blk.state_dict().items()}
+    P = {"m.0." + k: v.detach().cpu().double().requires_grad_(True) for k, v in blk.state_dict().items()}
     fr, pr = fq.double().requires_grad_(True), pq.double().requires_grad_(True)
     ref = O.sem_mix(P, "m.", {"res2": fr}, {"res2": pr})["res2"]
     g = synth.synth_tensor("sem256.g", tuple(ref.shape), 0)
-    rf, rp = torch.autograd.grad(ref, (fr, pr), g.double())
+    names = [k for k, _ in blk.named_parameters()]
+    rf, rp, *r_params = torch.autograd.grad(ref, (fr, pr) + tuple(P["m.0." + k] for k in names), g.double())
     fg = f.cuda().to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     pg = p.cuda().to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     out = sem_mix({"res2": fg}, {"res2": pg}, [blk])["res2"]
     assert out.dtype == torch.float32
     torch.testing.assert_close(out.cpu().double(), ref.detach(), rtol=1e-5, atol=1e-5)
-    gf, gp = torch.autograd.grad(out, (fg, pg), g.cuda())
+    gf, gp, *g_params = torch.autograd.grad(out, (fg, pg) + tuple(blk.parameters()), g.cuda())
     tol = dict(rtol=1e-2, atol=2e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(gf.cpu().double(), rf, **tol)
     torch.testing.assert_close(gp.cpu().double(), rp, **tol)
+    # the gate's parameters: their gradients come out of the graph recorded INSIDE the fused pool + gate + mix node (ops/semmix.py)
+    for k, a, r in zip(names, g_params, r_params):
+        assert float((a.cpu().double() - r).norm() / r.norm()) < (2e-2 if dtype == torch.bfloat16 else 1e-4), k
 
 
 def test_fused_inference_tail_vs_oracle():
