@@ -627,9 +627,11 @@ def main():
                                       f"{dist.get_backend()} all-reduce (forced one-rank process group)" if world == 1 else
                                       f"{dist.get_backend()} all-reduce of the flat gradient buffer"),
                        "global_batch_clips": args.clips * world, "frames_per_clip": T, "parallelism": f"dp{world}",
-                       "precision": ("bf16 backbones (host PyTorch), " if args.dtype == "bf16" else "fp32 backbones, ")
+                       "precision": ("bf16 backbones (host PyTorch), " if args.dtype == "bf16" else
+                                     "fp32 backbones (stride-1 / forward convolutions on the own kernels: every fp32 product as 3 bf16 MFMA "
+                                     "products with fp32 accumulation, max error 5e-6 of a layer's output range; DESIGN section 2), ")
                                     + ("head forward GEMMs on ONE bf16 product per multiply-add (own kernels; NOT the quoted metric)"
-                                       if args.head_dtype == "bf16" else "fp32 head + HIP kernels")},
+                                       if args.head_dtype == "bf16" else "head forward in exact fp32 (fp32 MFMA), gradients with the 3-product split")},
             "roofline": roof,
             "other_kernels": kernels,
         }
