@@ -44,6 +44,8 @@ CASES = [  # B, H, cin, cout, k, residual
     (40, 14, 256, 256, 3, False),   # res4 conv2: tap split
     (40, 7, 512, 512, 3, False),    # res5 conv2: tap split
     (3, 28, 128, 128, 3, False),    # res3 conv2 at a ragged token count
+    (10, 7, 512, 2048, 1, True),    # res5 conv3 at 10 frames: split-K with the residual added by the finishing sum
+    (10, 14, 1024, 256, 1, False),  # res4 conv1 at 10 frames: split-K, bias + ReLU in the finishing sum
 ]
 
 
