@@ -112,6 +112,7 @@ _SIGNATURES = {
     "combo_add_layernorm_forward_f32": [c_void_p] * 4 + [c_float, c_longlong, c_int] + [c_void_p] * 5 + [c_longlong, c_void_p, c_void_p],
     "combo_layernorm_backward_f32": [c_void_p] * 5 + [c_longlong, c_int] + [c_void_p] * 6,
     "combo_splitk_reduce_f32": [c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
+    "combo_splitk_reduce_nchw_f32": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "combo_uncertain_points_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p],
     "combo_mask_loss_forward_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p],
     "combo_mask_loss_backward_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int] + [c_void_p] * 4 + [c_int, c_void_p, c_void_p],

@@ -441,6 +441,23 @@ splitk_reduce_kernel(const float* __restrict__ part, int splits, long long n, fl
   }
 }
 
+// The same sum for a 3x3 convolution's weight gradient, written in the parameter's own (NCHW) order: partials are
+// [splits][Cout][taps][Cin] (the implicit GEMM's K order), out is [Cout][Cin][taps].  A thread owns one (cout, cin) pair and its
+// `taps` consecutive outputs; neighbouring threads read neighbouring cin - no permute copy after the reduce.
+__global__ void __launch_bounds__(256)
+splitk_reduce_nchw_kernel(const float* __restrict__ part, int splits, int cout, int taps, int cin, float* __restrict__ out) {
+  const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (t >= (long long)cout * cin) return;
+  const int co = (int)(t / cin), ci = (int)(t - (long long)co * cin);
+  const long long n = (long long)cout * taps * cin;
+  for (int tap = 0; tap < taps; ++tap) {
+    const long long src = ((long long)co * taps + tap) * cin + ci;
+    float a = part[src];
+    for (int z = 1; z < splits; ++z) a += part[z * n + src];
+    out[t * taps + tap] = a;
+  }
+}
+
 struct ReduceGroupArgs {
   int count;
   long long thread_start[kMaxGroup + 1];
@@ -492,6 +509,14 @@ int combo_splitk_reduce_f32(const float* partials, int splits, long long n, floa
   const long long threads = (n >> 2) + (nb > 0 ? nb : 0);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      partials, splits, n, out, db_partials, nb > 0 ? nb : 0, db);
+  return (int)hipGetLastError();
+}
+
+int combo_splitk_reduce_nchw_f32(const float* partials, int splits, int Cout, int taps, int Cin, float* out, combo_stream_t stream) {
+  if (!partials || !out || splits <= 0 || Cout <= 0 || taps <= 0 || Cin <= 0) return COMBO_EINVAL;
+  const long long threads = (long long)Cout * Cin;
+  hipLaunchKernelGGL(splitk_reduce_nchw_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partials,
+                     splits, Cout, taps, Cin, out);
   return (int)hipGetLastError();
 }
 

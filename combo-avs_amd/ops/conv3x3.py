@@ -62,7 +62,8 @@ def _conv_tokens(x_tok, wm, bias, B, H, W, cin, cout, exact, relu=False):
 
 
 def _wgrad_tokens(dy_tok, x_tok, B, H, W, cin, cout):
-    """-> dW as [cout, 3, 3, cin]"""
+    """-> dW in the parameter's own order [cout, cin, 3, 3] (contiguous): the split-K partials come out of the implicit GEMM as
+    [cout, 3, 3, cin]; the finishing sum writes them permuted (csrc/gemm_tn.hip splitk_reduce_nchw_kernel)"""
     lib = _lib.lib()
     M, K = B * H * W, 9 * cin
     splits = lib.combo_gemm_tn_splits(M, cout, K)
@@ -74,12 +75,9 @@ def _wgrad_tokens(dy_tok, x_tok, B, H, W, cin, cout):
         rc = lib.combo_conv3x3_wgrad_x3_f32(dy_tok.data_ptr(), dy_tok.stride(0), x_tok.data_ptr(), x_tok.stride(0),
                                             part.data_ptr(), B, H, W, cin, cout, splits, st)
     _lib.check(rc, "combo_conv3x3_wgrad_x3_f32")
-    if splits == 1:
-        return part[0].view(cout, 3, 3, cin)
-    dw = torch.empty(cout, K, device=x_tok.device, dtype=torch.float32)
-    _lib.check(lib.combo_splitk_reduce_f32(part.data_ptr(), splits, cout * K, dw.data_ptr(), None, 0, None, st),
-               "combo_splitk_reduce_f32")
-    return dw.view(cout, 3, 3, cin)
+    dw = torch.empty(cout, cin, 3, 3, device=x_tok.device, dtype=torch.float32)
+    _lib.check(lib.combo_splitk_reduce_nchw_f32(part.data_ptr(), splits, cout, 9, cin, dw.data_ptr(), st), "combo_splitk_reduce_nchw_f32")
+    return dw
 
 
 def _tokens(x):
@@ -114,9 +112,7 @@ class _Conv3x3(Function):
             wt = weight.flip(2, 3).permute(1, 2, 3, 0).reshape(cin, 9 * cout)
             dx = _conv_tokens(dy_tok, wt, None, B, H, W, cout, cin, exact=False).view(B, H, W, cin).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
-            dw = _wgrad_tokens(dy_tok, _tokens(x), B, H, W, cin, cout).permute(0, 3, 1, 2)
-            if dw.shape != weight.shape or not dw.is_contiguous():
-                dw = dw.contiguous()
+            dw = _wgrad_tokens(dy_tok, _tokens(x), B, H, W, cin, cout)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy_tok.sum(0)
         return dx, dw, db

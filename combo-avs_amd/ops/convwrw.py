@@ -219,9 +219,7 @@ class _ConvWrw(Function):
                 g, _ = L.weight_grad(w.view(cout, cin), dy_tok, x_tok, False, True)  # joins the grouped launch when it can
                 dw = g.view(cout, cin, 1, 1)
             elif cin % 128 == 0 and cout % 128 == 0:
-                dw = C3._wgrad_tokens(dy_tok, x_tok, B, H, W, cin, cout).permute(0, 3, 1, 2)
-                if not dw.is_contiguous():
-                    dw = dw.contiguous()
+                dw = C3._wgrad_tokens(dy_tok, x_tok, B, H, W, cin, cout)
             else:  # the 64-channel 3x3 layers of res2: the library's weight gradient
                 dw = torch.ops.aten.convolution_backward(dy, x, w, None, (1, 1), (pad, pad), (1, 1), False, (0, 0), 1,
                                                          (False, True, False))[1]

@@ -499,6 +499,9 @@ int combo_layernorm_backward_f32(const float* dy, const float* z, const float* m
  *   (nn.MultiheadAttention's packed in_proj_weight gradient). */
 int combo_splitk_reduce_f32(const float* partials, int splits, long long n, float* out, const float* db_partials, int nb,
                             float* db, combo_stream_t stream);
+/*   ... of a 3x3 convolution's weight gradient (combo_conv3x3_wgrad_x3_f32 partials, [splits][Cout][taps][Cin]) written in the
+ *   parameter's own NCHW order [Cout][Cin][taps]: no permute copy between the reduce and autograd. */
+int combo_splitk_reduce_nchw_f32(const float* partials, int splits, int Cout, int taps, int Cin, float* out, combo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a12  masked multi-head attention of the decoder layers, head_dim = 32 (csrc/attention.hip)
