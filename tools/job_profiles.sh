@@ -1,5 +1,5 @@
 mkdir -p gpurun_out
-export COMBO_COMMIT=1a6ce2d
+export COMBO_COMMIT=3e99ec4
 bash tools/final_profile.sh --profile-only > gpurun_out/final_profile.log 2>&1
 bash tools/pmc_bench.sh > gpurun_out/pmc_bench.log 2>&1
 tail -3 gpurun_out/pmc_bench.log | cut -c1-400
