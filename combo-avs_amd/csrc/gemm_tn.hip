@@ -442,20 +442,26 @@ splitk_reduce_kernel(const float* __restrict__ part, int splits, long long n, fl
 }
 
 // The same sum for a 3x3 convolution's weight gradient, written in the parameter's own (NCHW) order: partials are
-// [splits][Cout][taps][Cin] (the implicit GEMM's K order), out is [Cout][Cin][taps].  A thread owns one (cout, cin) pair and its
-// `taps` consecutive outputs; neighbouring threads read neighbouring cin - no permute copy after the reduce.
+// [splits][Cout][taps][Cin] (the implicit GEMM's K order), out is [Cout][Cin][taps].  A thread sums one float4 of the partial
+// layout (4 consecutive cin of one (cout, tap): coalesced reads, the loop depth of the plain reduce) and scatters its 4 results
+// `taps` floats apart - no permute copy after the reduce.  Cin % 4 == 0.
 __global__ void __launch_bounds__(256)
 splitk_reduce_nchw_kernel(const float* __restrict__ part, int splits, int cout, int taps, int cin, float* __restrict__ out) {
-  const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (t >= (long long)cout * cin) return;
-  const int co = (int)(t / cin), ci = (int)(t - (long long)co * cin);
   const long long n = (long long)cout * taps * cin;
-  for (int tap = 0; tap < taps; ++tap) {
-    const long long src = ((long long)co * taps + tap) * cin + ci;
-    float a = part[src];
-    for (int z = 1; z < splits; ++z) a += part[z * n + src];
-    out[t * taps + tap] = a;
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;  // float4 index into [Cout][taps][Cin]
+  if (i >= (n >> 2)) return;
+  float4 a = reinterpret_cast<const float4*>(part)[i];
+  for (int z = 1; z < splits; ++z) {
+    const float4 b = reinterpret_cast<const float4*>(part + (long long)z * n)[i];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
   }
+  const long long e = i * 4;
+  const int ci = (int)(e % cin);
+  const long long ct = e / cin;  // co * taps + tap
+  const int tap = (int)(ct % taps);
+  const long long co = ct / taps;
+  float* o = out + (co * cin + ci) * taps + tap;
+  o[0] = a.x; o[taps] = a.y; o[2 * taps] = a.z; o[3 * taps] = a.w;
 }
 
 struct ReduceGroupArgs {
@@ -513,8 +519,8 @@ int combo_splitk_reduce_f32(const float* partials, int splits, long long n, floa
 }
 
 int combo_splitk_reduce_nchw_f32(const float* partials, int splits, int Cout, int taps, int Cin, float* out, combo_stream_t stream) {
-  if (!partials || !out || splits <= 0 || Cout <= 0 || taps <= 0 || Cin <= 0) return COMBO_EINVAL;
-  const long long threads = (long long)Cout * Cin;
+  if (!partials || !out || splits <= 0 || Cout <= 0 || taps <= 0 || Cin <= 0 || Cin % 4 != 0 || ((uintptr_t)partials & 15)) return COMBO_EINVAL;
+  const long long threads = (long long)Cout * taps * Cin / 4;
   hipLaunchKernelGGL(splitk_reduce_nchw_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partials,
                      splits, Cout, taps, Cin, out);
   return (int)hipGetLastError();
