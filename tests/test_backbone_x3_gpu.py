@@ -222,3 +222,39 @@ def test_three_way_fanout_sums_all_consumers_in_the_relu_gradient_pass():
     z2 = z.clone().requires_grad_(True)
     ref = torch.autograd.grad((torch.relu(z2 + b[None, :, None, None]) * w[1]).sum(), z2)[0]
     torch.testing.assert_close(got, ref, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("ks,stride", [(3, 1), (3, 2), (1, 1), (1, 2)])
+@pytest.mark.parametrize("cin,cout", [(64, 64), (80, 132), (128, 50)])
+@pytest.mark.parametrize("aux_mode", [0, 1, 2])
+def test_conv_entry_point_through_the_c_abi_every_epilogue_and_split(ks, stride, cin, cout, aux_mode):
+    """combo_conv_nhwc_x3_epi_f32 called directly: 3x3 / 1x1, stride 1 / 2, odd map sizes, channel counts that are not multiples
+    of the tile (cout = 50: the scalar-store path), bias + ReLU, aux as residual (1) or as ReLU-gradient mask (2), un-split and
+    every legal tap split - against an fp64 evaluation (2e-5 of the output range)"""
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd import _lib
+    from combo_avs_amd.ops import linear as L
+    g = torch.Generator().manual_seed(ks * 100 + stride * 10 + cin + aux_mode)
+    B, H, W = 3, 9, 7
+    ho, wo = (H + stride - 1) // stride, (W + stride - 1) // stride
+    x = torch.randn(B, H, W, cin, generator=g).cuda()                 # NHWC tokens
+    w = (torch.randn(cout, cin, ks, ks, generator=g) * (cin * ks * ks) ** -0.5).cuda()
+    b = torch.randn(cout, generator=g).cuda()
+    aux = torch.randn(B * ho * wo, cout, generator=g).cuda()
+    img = L.presplit(w.permute(0, 2, 3, 1).reshape(cout, ks * ks * cin).contiguous())
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), stride, ks // 2).permute(0, 2, 3, 1).reshape(-1, cout)
+    if aux_mode == 1:
+        ref = ref + aux.double()
+    ref = ref.relu()
+    if aux_mode == 2:
+        ref = ref * (aux.double() > 0)
+    lib, st = _lib.lib(), _lib.current_stream()
+    M = B * ho * wo
+    for splits in ((1, 3, 9) if ks == 3 and cin % 32 == 0 and cout % 4 == 0 else (1,)):
+        y = torch.full((M, cout), float("nan"), device="cuda")
+        ws = torch.empty(splits, M, cout, device="cuda") if splits > 1 else None
+        rc = lib.combo_conv_nhwc_x3_epi_f32(x.data_ptr(), cin, img.data_ptr(), b.data_ptr(), aux.data_ptr() if aux_mode else None, aux_mode,
+                                            y.data_ptr(), cout, B, H, W, cin, cout, ks, stride, 1, splits, _lib.ptr(ws), st)
+        assert rc == 0, (rc, splits)
+        err = float((y.double() - ref).abs().max())
+        assert err <= 2e-5 * float(ref.abs().max()) + 1e-6, (splits, err)
