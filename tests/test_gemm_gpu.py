@@ -386,3 +386,33 @@ def test_grouped_weight_presplit_gives_bitwise_the_same_input_gradients():
     assert L._split_images is None
     for r, g in zip(ref, got):
         assert torch.equal(r, g)
+
+
+@pytest.mark.parametrize("M,K,N", [(3000, 512, 256), (777, 128, 52), (41160, 64, 256)])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+def test_gemm_nt_x3_epilogue_with_add_and_mask_together(M, K, N, tile):
+    """combo_gemm_nt_x3_epi2_f32: bias + add + ReLU + mask in one epilogue (the add and mask tensors share one register set in the
+    kernel), every tile configuration, with and without split-K, N not a multiple of 4 (scalar stores)"""
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd import _lib
+    from combo_avs_amd.ops.linear import presplit
+    torch.manual_seed(M + N + tile)
+    a = torch.randn(M, K, device="cuda")
+    w = torch.randn(N, K, device="cuda") * K ** -0.5
+    b = torch.randn(N, device="cuda")
+    add = torch.randn(M, N, device="cuda")
+    mask = torch.randn(M, N, device="cuda")
+    img = presplit(w)
+    ref = (torch.relu(a.double() @ w.double().t() + b.double() + add.double())) * (mask.double() > 0)
+    lib, st = _lib.lib(), _lib.current_stream()
+    prev = lib.combo_gemm_nt_x3_tile(tile)
+    try:
+        for splits in ((1, 2, 4) if (N % 4 == 0 and K % 128 == 0 and K >= 512) else (1,)):
+            y = torch.full((M, N), float("nan"), device="cuda")
+            ws = torch.empty(splits, M, N, device="cuda") if splits > 1 else None
+            rc = lib.combo_gemm_nt_x3_epi2_f32(a.data_ptr(), K, img.data_ptr(), b.data_ptr(), add.data_ptr(), mask.data_ptr(), y.data_ptr(), N,
+                                               M, N, K, 1, splits, _lib.ptr(ws), st)
+            assert rc == 0, (rc, splits)
+            assert rel_err(y, ref) < 1e-5, (splits, rel_err(y, ref))
+    finally:
+        lib.combo_gemm_nt_x3_tile(prev)
