@@ -36,9 +36,9 @@ def _conv_tokens(x_tok, wm, bias, B, H, W, cin, cout, exact, relu=False):
     assert B * H * W * cout * 4 < 2 ** 31 - 1  # (the kernels address Y with 32-bit byte offsets)
     lib, st = _lib.lib(), _lib.current_stream()
     from . import linear as L
-    if exact and L.FORWARD_PRECISION == "bf16":  # the head's bf16 throughput mode: one bf16 product per multiply-add
+    if exact and L.FORWARD_PRECISION != "fp32":  # the head's bf16 throughput mode: one bf16 product per multiply-add
         img = L.forward_image(wm)
-        prev = lib.combo_gemm_nt2_products(1)
+        prev = lib.combo_gemm_nt2_products(L.forward_products())
         try:
             with _lib.timed("conv3x3_bf16", (B * H * W, cout, 9 * cin)):
                 rc = lib.combo_conv3x3_nhwc_x3_pre_f32(x_tok.data_ptr(), x_tok.stride(0), img.data_ptr(), _lib.ptr(bias), y.data_ptr(),

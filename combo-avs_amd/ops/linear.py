@@ -234,9 +234,14 @@ _fwd_images = None  # {weight view key: bf16 hi/lo image [N, K]} of the current 
 
 def set_forward_precision(mode):
     global FORWARD_PRECISION
-    if mode not in ("fp32", "bf16"):
+    if mode not in ("fp32", "bf16", "x3"):
         raise ValueError(mode)
     FORWARD_PRECISION = mode
+
+
+def forward_products():
+    """bf16 products per multiply-add of the head's forward GEMMs in the current mode ("bf16": 1; "x3": the fp32-grade split)"""
+    return 1 if FORWARD_PRECISION == "bf16" else 3
 
 
 def forward_image(weight):
@@ -259,7 +264,7 @@ def gemm_nt_bf16(a, w, bias=None, relu=False, out=None, img=None):
     if img is None:
         img = forward_image(w)
     lib, st = _lib.lib(), _lib.current_stream()
-    prev = lib.combo_gemm_nt2_products(1)
+    prev = lib.combo_gemm_nt2_products(forward_products())
     try:
         with _lib.timed("gemm_nt_bf16", (M, N, K)):
             rc = lib.combo_gemm_nt_x3_pre_f32(a.data_ptr(), a.stride(0), img.data_ptr(), _lib.ptr(bias), out.data_ptr(), out.stride(0),
@@ -271,7 +276,7 @@ def gemm_nt_bf16(a, w, bias=None, relu=False, out=None, img=None):
 
 
 def _bf16_ok(x2d, weight, out):
-    return (FORWARD_PRECISION == "bf16" and x3_ok(x2d, weight.shape[0]) and weight.dtype == torch.float32 and weight.dim() == 2
+    return (FORWARD_PRECISION != "fp32" and x3_ok(x2d, weight.shape[0]) and weight.dtype == torch.float32 and weight.dim() == 2
             and weight.shape[1] % 16 == 0 and weight.shape[0] % 4 == 0 and x2d.shape[0] > 64
             and (out is None or (out.stride(1) == 1 and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0)))
 
@@ -797,7 +802,7 @@ def memory_kv(mem_k, mem_v, level_params, defer=False):
     with torch.no_grad():  # k rows of level 0's layers, v rows of level 0's layers, k rows of level 1's, ...: ONE copy kernel each
         Wcat = torch.cat([W[r * E:(r + 1) * E] for params in level_params for r in (1, 2) for W, _ in params], 0)
         bcat = torch.cat([b[r * E:(r + 1) * E] for params in level_params for r in (1, 2) for _, b in params], 0)
-    if FORWARD_PRECISION == "bf16" and _fwd_images is not None:
+    if FORWARD_PRECISION != "fp32" and _fwd_images is not None:
         _fwd_images.setdefault("pinned", []).append(Wcat)  # (bf16 images are cached by weight address for the step)
     out, off = [], 0
     for xk, xv, params in zip(mem_k, mem_v, level_params):

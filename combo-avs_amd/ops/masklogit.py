@@ -83,10 +83,10 @@ def mask_logits_all_into(mask_embeds, mf_tok, out):
     mask_embeds: list of [BT, Q, C]; out [heads, BT, Q, HW]"""
     from . import linear as L
     mf = mf_tok.detach()
-    if L.FORWARD_PRECISION == "bf16":  # the head's bf16 throughput mode: per head, one bf16 product per multiply-add
+    if L.FORWARD_PRECISION != "fp32":  # the head's bf16 throughput mode: per head, one bf16 product per multiply-add
         img = presplit_batched(mf, transpose=False)
         lib = _lib.lib()
-        prev = lib.combo_gemm_nt2_products(1)
+        prev = lib.combo_gemm_nt2_products(L.forward_products())
         try:
             for h, m in enumerate(mask_embeds):
                 gemm_nt_batched(m.detach().contiguous(), img, out[h])

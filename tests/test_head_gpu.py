@@ -395,6 +395,56 @@ def test_fused_criterion_path_equals_unfused(head_run, mode):
         assert (a - b).abs().max() <= 2e-4 * b.abs().max() + 1e-8, float((a - b).abs().max() / b.abs().max())
 
 
+def test_x3_forward_mode_stated_tolerance():
+    """The head's 3-product forward mode (ops.linear.set_forward_precision("x3"), bench.py --head-dtype x3): the forward GEMMs /
+    convolutions / mask-logit contraction of the head on csrc/gemm_nt3.hip with the fp32-grade 3-product bf16 split (max error
+    ~5e-6 per layer) instead of the exact fp32 matrix instruction.  NOT the default: a cell of a decoder attention mask whose
+    logit lies within that error of 0 flips and re-routes its query for the rest of the decoder - the north-star bound then holds
+    for all but a few entries instead of for all of them (the default path: 0 outliers).  Stated tolerance against the
+    reference's fp32 outputs (golden head.npz):
+      * prediction head #0 (no thresholded mask upstream): EVERY sampled mask logit within 1e-3 x RMS + 1e-3 x |ref|;
+      * all 10 heads: >= 98 % of the sampled mask logits within that bound (measured: heads 0 - 6 all of them, head 7 99.93 %,
+        head 8 99.4 %, head 9 98.85 % - the same picture as round 1's 3-product forward), relative L2 error of every head <= 2e-3
+        (measured <= 8.2e-4), max error 2.4e-2 RMS;
+      * class logits: >= 99.5 % within 1e-3 x RMS + 1e-3 x |ref| (measured: 14 of 15 000 beyond)."""
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.ops import linear as L
+    z = np.load(os.path.join(G, "head.npz"))
+    spec = json.loads(str(z["spec"]))
+    head, cfg = build_head()
+    head.load_state_dict(synth.synth_state_dict(spec, 0))
+    head = head.cuda().eval()
+    feats, audio = gen_inputs.head_inputs()
+    feats = {k: v.cuda() for k, v in feats.items()}
+    L.set_forward_precision("x3")
+    try:
+        with torch.no_grad(), L.grouped_presplit():
+            out = head(dict(feats), audio.cuda())
+        torch.cuda.synchronize()
+    finally:
+        L.set_forward_precision("fp32")
+    masks = [a["pred_masks"] for a in out["aux_outputs"]] + [out["pred_masks"]]
+    report = []
+    for i, m in enumerate(masks):
+        d = synth.unpack(f"dec/pred_masks{i}", z)
+        idx = synth.digest_indices(m.numel(), 4096, f"dec/pred_masks{i}")
+        got = m.reshape(-1).cpu().numpy()[idx].astype(np.float64)
+        ref = np.asarray(d["sample"]).astype(np.float64)
+        rms = float(np.sqrt((ref ** 2).mean()))
+        err = np.abs(got - ref)
+        beyond = float((err > 1e-3 * rms + 1e-3 * np.abs(ref)).mean())
+        l2 = float(np.sqrt((err ** 2).sum() / (ref ** 2).sum()))
+        report.append((i, round(beyond, 5), round(l2, 6), round(float(err.max() / rms), 5)))
+    logits = torch.stack([a["pred_logits"] for a in out["aux_outputs"]] + [out["pred_logits"]]).cpu().numpy()
+    ref = z["dec/pred_logits"]
+    bad = np.abs(logits - ref) > 1e-3 * np.sqrt((ref ** 2).mean()) + 1e-3 * np.abs(ref)
+    if os.environ.get("COMBO_TEST_VERBOSE") == "1":
+        print("[x3 mode] head: (frac beyond the north-star bound, rel L2, max err / RMS)", report, "class logits beyond:", int(bad.sum()), "of", bad.size)
+    assert report[0][1] == 0.0, report
+    assert all(r[1] <= 0.02 and r[2] <= 2e-3 for r in report), report
+    assert bad.mean() <= 5e-3, float(bad.mean())
+
+
 def test_bf16_forward_mode_stated_tolerance():
     """The head's bf16 throughput mode (ops.linear.set_forward_precision("bf16"), bench.py --head-dtype bf16): every forward
     GEMM / convolution / mask-logit contraction of the head on ONE bf16 product per multiply-add (csrc/gemm_nt3.hip, fp32
