@@ -506,13 +506,17 @@ def main():
                 print(f"[slot {sl}] kind {kind.value} work {work.value:.4g} bytes {nbytes.value:.4g} avg_us {float(tsv[sl, 2]) / khz * 1e3 / n_l:.1f}", file=sys.stderr)
             if khz > 0 and n_l > 0:
                 d = per_kind.setdefault(kind.value, {"us": 0.0, "launches": 0, "work": 0.0, "bytes": 0.0, "nodes": 0, "big_us": 0.0,
-                                                     "big_work": 0.0, "big_launches": 0})
+                                                     "big_work": 0.0, "big_launches": 0, "floor_us": 0.0})
                 us = float(tsv[sl, 2]) / khz * 1e3
                 d["us"] += us
                 d["launches"] += n_l
                 d["work"] += work.value * n_l
                 d["bytes"] += nbytes.value * n_l
                 d["nodes"] += 1
+                # the launch's own roofline: the longer of its matrix-pipe time and its HBM time at the peaks (GEMM kinds)
+                ceil = {1: 157.3e12, 2: 2500.0e12 / 3, 8: 2500.0e12}.get(kind.value)
+                if ceil:
+                    d["floor_us"] += n_l * max(work.value / ceil, nbytes.value / 8e12) * 1e6
                 if work.value >= 2e9:  # launches of >= 2 GFLOP (GB for the HBM-bound kinds): the layers that can fill the chip
                     d["big_us"] += us
                     d["big_work"] += work.value * n_l
@@ -585,6 +589,10 @@ def main():
             r["large_launches"] = {"min_gflop": 2, "launches_per_step": d["big_launches"] // max(args.steps, 1),
                                    "ms_per_step": round(d["big_us"] / max(args.steps, 1) / 1e3, 3), "achieved": round(big, 1),
                                    "frac": round(big / peak, 4)}
+        if d.get("floor_us"):
+            # every launch against ITS binding roofline (a third of the 3-product launches are HBM-bound 64 .. 256-channel layers:
+            # `frac` prices them against the matrix pipe)
+            r["frac_of_binding_roofline"] = round(d["floor_us"] / d["us"], 4)
         if kind in (1, 2, 3) and d["bytes"] > 0:  # the GEMM families also report the other side of their roofline
             useful = d["work"] / secs / 1e12
             r["hbm"] = {"algorithmic_bytes_per_step": d["bytes"] / max(args.steps, 1), "achieved_gbs": round(d["bytes"] / secs / 1e9, 1),
