@@ -170,9 +170,17 @@ def other_workloads(timeout_s=420):
     dtype, launch}].  Bounded: a hard timeout per child; a failed child is reported, not fatal."""
     import subprocess
     out = []
-    for name in ("pvt_ms3_t10", "pvt_avss_512"):
-        cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
-               "--no-other-workloads"]
+    runs = [("pvt_ms3_t10", ["--config", "pvt_ms3_t10", "--steps", "5", "--warmup", "2"]),
+            ("pvt_avss_512", ["--config", "pvt_avss_512", "--steps", "5", "--warmup", "2"]),
+            # the price of the 3-product backbone forward (`dtype_detail`): the default workload with the backbones' forward
+            # convolutions on the library's exact-fp32 kernels (ops.convwrw.FWD_X3 = False), everything else unchanged
+            ("r50_s4_library_backbone_forward", ["--config", "r50_s4", "--library-backbone-forward", "--steps", "10", "--warmup", "3"])]
+    notes = {"pvt_avss_512": "the reference trains AVSS under fp16 autocast (configs/avs_ss/PVT-AVSS-SemanticSegmentation.yaml:41-42: "
+                             "SOLVER.AMP.ENABLED True); here: bf16 autocast backbones + the fp32 head - no golden vector covers an AMP run",
+             "r50_s4_library_backbone_forward": "BASELINE configs[1] with the R50 / VGGish forward convolutions on the library's fp32 kernels "
+                                                "instead of the own 3-product kernels: the A/B beside `value`"}
+    for name, extra in runs:
+        cmd = [sys.executable, os.path.abspath(__file__)] + extra + ["--no-cpu-baseline", "--no-other-workloads"]
         t0 = time.perf_counter()
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
@@ -184,6 +192,8 @@ def other_workloads(timeout_s=420):
             out.append({"name": name, "workload": j["config"]["workload"], "ms_per_step": j["ms_per_step"], "frames_per_s": j["value"],
                         "steps": j["steps"], "warmup": j["warmup"], "dtype": j["dtype"], "launch": j["config"]["launch"][:60],
                         "precision": j["config"]["precision"], "wall_s": round(time.perf_counter() - t0, 1)})
+            if name in notes:
+                out[-1]["note"] = notes[name]
         except subprocess.TimeoutExpired:
             out.append({"name": name, "error": f"did not finish within {timeout_s} s"})
     return out
@@ -258,6 +268,33 @@ def csrc_digest():
     return h.hexdigest()
 
 
+def device_identity(index):
+    """what distinguishes one physical GPU from another on this node: the device's UUID (when this torch exposes it) and its PCI
+    domain:bus:device address"""
+    p = torch.cuda.get_device_properties(index)
+    uuid = getattr(p, "uuid", None)
+    pci = "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0))
+    return {"device_index": int(index), "name": p.name, "uuid": str(uuid) if uuid is not None else None, "pci": pci}
+
+
+def device_census(rank, local_rank, dev):
+    """Every rank reports {rank, local device index, UUID / PCI address}; all ranks get the table and ALL of them fail when two
+    ranks sit on one physical device - an N-GPU number must come from N distinct GPUs (train_net.py:284-291 launches one
+    process per GPU).  COMBO_SINGLE_DEVICE=1 (the functional N-rank run on a 1-GPU box) waives the check and says so."""
+    me = dict(device_identity(dev.index), rank=rank, local_rank=local_rank, pid=os.getpid())
+    table = [None] * dist.get_world_size()
+    dist.all_gather_object(table, me)
+    return census_verdict(table, os.environ.get("COMBO_SINGLE_DEVICE") == "1")
+
+
+def census_verdict(table, shared):
+    keys = [(t["uuid"] or "", t["pci"]) for t in table]
+    if len(set(keys)) != len(keys) and not shared:
+        raise RuntimeError("bench.py: %d ranks but only %d distinct devices: %s (COMBO_SINGLE_DEVICE=1 allows a functional run on a "
+                           "shared device)" % (len(keys), len(set(keys)), table))
+    return {"ranks": table, "distinct_devices": len(set(keys)), "shared_device_run": bool(shared)}
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` (N > 1) outside a launcher: this parent - which has made NO GPU call (device_count() does not
     initialise HIP on this image) - starts the N ranks as a child process group through torch.distributed.run, the same
@@ -312,6 +349,9 @@ def main():
                          "flag, skips them as well)")
     ap.add_argument("--backbone", default="r50", choices=["r50", "pvt"],
                     help="r50 = BASELINE configs[1] (default, the quoted metric); pvt = COMBO-PVTv2-B5 (configs 4-5 family)")
+    ap.add_argument("--library-backbone-forward", action="store_true",
+                    help="forward convolutions of the R50 / VGGish backbones on the library's exact-fp32 kernels instead of the own "
+                         "3-product kernels (ops.convwrw.FWD_X3 = False): the A/B entry of `other_workloads`, NOT the quoted metric")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of the captured hipGraph step")
     ap.add_argument("--mode", default="train", choices=["train", "infer"],
                     help="train = the BASELINE metric (default); infer = eval-mode forward + fused semantic-inference tail "
@@ -357,11 +397,18 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    rank_table = None
+    if dist.is_initialized():
+        rank_table = device_census(rank, local_rank, dev)
+
     import combo_avs_amd  # noqa: F401
     from combo_avs_amd import combo_cfg, msda
     from combo_avs_amd.meta_arch import build_model
     from combo_avs_amd.trainer import FlatAdamW, GraphedTrainStep, train_step
 
+    if args.library_backbone_forward:
+        from combo_avs_amd.ops import convwrw as _cw
+        _cw.FWD_X3 = False
     if args.head_dtype == "x3":
         from combo_avs_amd.ops import linear as _lin
         _lin.set_forward_precision("x3")
@@ -456,7 +503,7 @@ def main():
                 return train_step(model, opt, b)
         # timing buffer set but the steps launch eagerly (AVSS batches, a failed capture): the step's i-th instrumented launch
         # takes slot i in EVERY step (combo_timing_rewind), as a graph node does by construction
-        eager_slots = slot_timing and not graphed.graphs
+        eager_slots = slot_timing and (graphed.eager_only or not graphed.graphs)
         for i in range(max(args.warmup - 1, 0)):
             if eager_slots:
                 _clib.lib().combo_timing_rewind()
@@ -467,10 +514,14 @@ def main():
         sync()
         ts_buf[:, 2:4] = 0  # count only the launches of the timed region
         sync()
+    # what config.launch reports: did the timed steps run eagerly (flag, failed capture, GraphedTrainStep's memset-self-test fallback,
+    # an AVSS batch)?  Independent of the instrumentation; eager_slots = "rewind the timing slots per step" needs both.
+    ran_eager = args.no_graph or graphed is None or graphed.eager_only or not graphed.graphs
+    eager_slots = slot_timing and ran_eager
+    opt.comm_events = [] if dist.is_initialized() else None  # (start, end) events around every gradient all-reduce of the timed steps
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     marks[0].record()
-    eager_slots = slot_timing and not graphed.graphs
     for i in range(args.steps):
         if eager_slots:
             _clib.lib().combo_timing_rewind()
@@ -532,6 +583,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    comm = None
+    if dist.is_initialized():
+        evs = opt.comm_events or []
+        opt.comm_events = None
+        ms = sum(a.elapsed_time(b) for a, b in evs)
+        t = torch.tensor([ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        comm = {"all_reduce_ms_per_step": round(float(t.item()) / max(args.steps, 1), 3), "collectives_per_step": len(evs) // max(args.steps, 1),
+                "bytes_per_step": int(opt.flat_grad.numel() * (2 if args.grad_comm == "bf16" else 4)),
+                "timing": "HIP events on the stream each collective runs on (pre-divide / copy kernels of the bf16 mode included), max "
+                          "over ranks; with COMBO_DP_OVERLAP the head region's collective overlaps the backbones' backward graph"}
     frames = args.clips * T * world * args.steps
     value = frames / elapsed
     bt = args.clips * T
@@ -619,11 +681,20 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "ms_per_step_median": round(median_ms, 3) if median_ms else None,
             "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if (args.dtype == "bf16" or args.head_dtype == "bf16") else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if (args.dtype == "bf16" or args.head_dtype == "bf16") else "f32",
+            "dtype_detail": ("bf16 autocast backbones (host PyTorch); " if args.dtype == "bf16" else
+                             "R50 / VGGish forward convolutions: library fp32 kernels (exact fp32); " if args.library_backbone_forward else
+                             "R50 / VGGish forward + input-gradient convolutions: bf16x3 (every fp32 product as 3 bf16 MFMA products, fp32 "
+                             "accumulation, ~2^-17 per product); ")
+                            + ("head forward: ONE bf16 product per multiply-add; " if args.head_dtype == "bf16" else
+                               "head forward: bf16x3; " if args.head_dtype == "x3" else
+                               "head forward (GEMMs, 3x3 convolution, attention, mask logits): exact fp32 on v_mfma_f32_*; ")
+                            + "all gradient GEMMs (dX, dW): bf16x3; LayerNorm / softmax / losses / optimiser: fp32 VALU",
+            "data": "synthetic",
             "config": {"workload": f"{wl['name']}: bs={args.clips} clips x {T} frames x {H}x{W} per GPU, K={wl['K']}, full train step "
                                    "(fwd + 39-term loss + bwd + all-reduce + clip + AdamW), random-init weights",
                        "name": args.config,
-                       "launch": "eager" if (args.no_graph or eager_slots) else (
+                       "launch": "eager" if ran_eager else (
                            "2 hipGraphs (fwd + loss + head bwd | backbone bwd; the head's gradient all-reduce overlaps the second; AdamW eager)"
                            if dist.is_initialized() and os.environ.get("COMBO_DP_OVERLAP", "1") == "1" else
                            "hipGraph (fwd+loss+bwd captured; all-reduce + AdamW eager)"),
@@ -649,6 +720,13 @@ def main():
             "roofline": roof,
             "other_kernels": kernels,
         }
+        if dist.is_initialized():
+            out["rccl_world_size"] = dist.get_world_size()
+            out["ranks"] = rank_table["ranks"]
+            out["distinct_devices"] = rank_table["distinct_devices"]
+            if rank_table["shared_device_run"]:
+                out["shared_device_run"] = True  # COMBO_SINGLE_DEVICE=1: a functional N-rank run, NOT an N-GPU number
+            out["all_reduce"] = comm
         if world == 1 and not args.no_cpu_baseline and args.config == "r50_s4":
             out["cpu_baseline"] = cpu_baseline()
         if (world == 1 and not args.no_other_workloads and not args.no_cpu_baseline and args.config == "r50_s4"

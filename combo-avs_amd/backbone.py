@@ -131,8 +131,13 @@ class Bottleneck(nn.Module):
             c1, c2, c3 = self.conv1, self.conv2, self.conv3
             # a ReLU whose output feeds ONE convolution: its gradient mask rides in the epilogue of that convolution's
             # input-gradient GEMM instead of a pass of its own (conv1 -> conv2 when conv2's dX is an own kernel, conv2 -> conv3)
-            k2 = convwrw.weight_kind(f2[0], c2.stride, c2.padding) if (x.is_cuda and torch.is_grad_enabled() and f2[0].requires_grad) else 0
-            k3 = convwrw.weight_kind(f3[0], c3.stride, c3.padding) if (x.is_cuda and torch.is_grad_enabled() and f3[0].requires_grad) else 0
+            # (the kind conv_bias_act will pick for conv2 / conv3, from the activation shapes they will see: conv1 keeps the map,
+            # conv2 strides it - a res5 3x3 on a 1 x 1 map, say, is NOT taken by the own kernels)
+            ok = x.is_cuda and torch.is_grad_enabled() and not torch.is_autocast_enabled() and x.is_contiguous(memory_format=torch.channels_last)
+            B_, _, H_, W_ = x.shape
+            s2 = c2.stride[0] if isinstance(c2.stride, (tuple, list)) else c2.stride
+            k2 = convwrw.weight_kind(f2[0], c2.stride, c2.padding, (B_, f2[0].shape[1], H_, W_)) if (ok and f2[0].requires_grad) else 0
+            k3 = convwrw.weight_kind(f3[0], c3.stride, c3.padding, (B_, f3[0].shape[1], (H_ - 1) // s2 + 1, (W_ - 1) // s2 + 1)) if (ok and f3[0].requires_grad) else 0
             fold1 = convwrw.ENABLED and convwrw.MASK_3X3 and k2 == 3 and bool(convwrw.DX_OWN & 1) and f2[3] is not None
             fold2 = convwrw.ENABLED and convwrw.MASK_1X1 and k3 == 1
             out = cba(x, f1[0], f1[2], c1.stride, c1.padding, f1[3], grad_masked=fold1)

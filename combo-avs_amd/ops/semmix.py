@@ -76,40 +76,46 @@ class _GateMix(Function):
     backward; gate_params are its parameters (listed so that autograd routes their gradients)."""
 
     @staticmethod
-    def forward(ctx, f, p, gate, *gate_params):
+    def forward(ctx, f, p, gate, record, *gate_params):
         f, B, HW, C = _cl(f)
         p, _, _, _ = _cl(p)
         _lib.require_cuda(f, p, channels_last=True)
         acc = torch.empty(B, C, device=p.device, dtype=torch.float32)
         _call(0, p.dtype == torch.bfloat16, p, None, None, None, B, HW, C, acc)
-        with torch.enable_grad():
-            gap = (acc / HW).requires_grad_(True)
-            s = gate(gap)
+        # record (decided by gate_mix, where the caller's grad mode is still visible): False under no_grad / inference_mode
+        # (evaluation, bench --mode infer) - then no inner graph is built or kept
+        if record:
+            with torch.enable_grad():
+                gap = (acc / HW).requires_grad_(True)
+                s = gate(gap)
+        else:
+            with torch.no_grad():
+                gap, s = None, gate(acc / HW)
         s_val = s.detach().contiguous().float()
         out = torch.empty(f.shape, device=f.device, dtype=torch.float32, memory_format=torch.channels_last)
         _call(1, f.dtype == torch.bfloat16, f, p, s_val, None, B, HW, C, out)
-        ctx.save_for_backward(p, s_val)
-        ctx.inner = (gap, s)
-        ctx.f_dtype, ctx.n_params = f.dtype, len(gate_params)
-        ctx.params = gate_params
+        if record:
+            ctx.save_for_backward(p, s_val, *gate_params)  # the parameters travel through save_for_backward (version checks, hooks)
+            ctx.inner = (gap, s)
+        ctx.f_dtype = f.dtype
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dout):
-        p, s_val = ctx.saved_tensors
+        p, s_val, *params = ctx.saved_tensors
         gap, s = ctx.inner
         ctx.inner = None
         dout, B, HW, C = _cl(dout.float())
         is_bf16 = p.dtype == torch.bfloat16
         ds = torch.empty(B, C, device=p.device, dtype=torch.float32)
         _call(2, is_bf16, p, dout, None, None, B, HW, C, ds)
-        need = [t for t in ctx.params if t.requires_grad]
+        need = [t for t in params if t.requires_grad]
         with torch.enable_grad():
             grads = torch.autograd.grad(s, [gap] + need, ds.to(s.dtype))
         dgap = (grads[0].float() / HW).contiguous()
         it = iter(grads[1:])
-        dparams = [next(it) if t.requires_grad else None for t in ctx.params]
+        dparams = [next(it) if t.requires_grad else None for t in params]
         dp = torch.empty_like(p)
         if ctx.f_dtype == torch.float32 and not is_bf16:
             df = dout  # d out / d f = 1
@@ -117,11 +123,12 @@ class _GateMix(Function):
         else:
             df = torch.empty_like(p)
             _call(3, is_bf16, dout, None, s_val, dgap, B, HW, C, df, dp)
-        return (df, dp, None) + tuple(dparams)
+        return (df, dp, None, None) + tuple(dparams)
 
 
 def gate_mix(f, p, gate, gate_params):
-    return _GateMix.apply(f, p, gate, *gate_params)
+    record = torch.is_grad_enabled() and any(t.requires_grad for t in (f, p, *gate_params))
+    return _GateMix.apply(f, p, gate, record, *gate_params)
 
 
 def global_avg_pool(p):

@@ -103,6 +103,7 @@ class FlatAdamW:
         if self.n_early == len(entries):
             self.split = total
         self._comm_stream = None
+        self.comm_events = None  # a list: all_reduce_grads appends (start, end) events around every collective (bench.py)
         self.unused = ()  # indices (into self.params) of parameters the last backward pass produced no gradient for
 
     def zero_grad(self):
@@ -211,6 +212,10 @@ class FlatAdamW:
         g = self.flat_grad[lo:hi]
 
         def run():
+            ev = None
+            if self.comm_events is not None and g.is_cuda:  # bench.py: events on the stream the collective runs on
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             if self.grad_comm_dtype != g.dtype:
                 buf = (g / world).to(self.grad_comm_dtype)  # pre-divide: keeps the sum inside bf16's range
                 dist.all_reduce(buf)
@@ -218,6 +223,9 @@ class FlatAdamW:
             else:
                 dist.all_reduce(g)
                 g.div_(world)
+            if ev is not None:
+                ev[1].record()
+                self.comm_events.append(ev)
         if overlap and g.is_cuda:
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream(device=g.device)
@@ -471,7 +479,11 @@ class GraphedTrainStep:
                 if os.environ.get("COMBO_GRAPH_STRICT") == "1":
                     raise RuntimeError(msg)
                 import logging
+                import sys
                 logging.getLogger(__name__).warning("%s  Falling back to the eager (un-captured) training step.", msg)
+                # an application without logging configured must still see that its step is NOT captured (slower): once, on stderr
+                print("[combo_avs_amd] GraphedTrainStep: hipGraph memset self-test failed - running the EAGER (un-captured) training "
+                      "step (COMBO_GRAPH_STRICT=1 raises instead); see GraphedTrainStep.eager_only", file=sys.stderr, flush=True)
                 self.eager_only = True
 
     def _num_masks(self, batched_inputs, dev):

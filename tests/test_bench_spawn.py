@@ -44,3 +44,20 @@ def test_refuses_more_ranks_than_devices():
                        env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 2 and "--gpus 2 but only" in r.stderr
     assert '"metric"' not in r.stdout
+
+
+def test_census_refuses_ranks_that_share_a_device():
+    """bench.census_verdict: the table every rank gathers (rank, device UUID / PCI address) must hold N distinct devices"""
+    import pytest
+    import bench
+    a = {"rank": 0, "uuid": "GPU-aa", "pci": "0000:05:00"}
+    b = {"rank": 1, "uuid": "GPU-bb", "pci": "0000:15:00"}
+    ok = bench.census_verdict([a, b], shared=False)
+    assert ok["distinct_devices"] == 2 and not ok["shared_device_run"]
+    with pytest.raises(RuntimeError, match="distinct devices"):
+        bench.census_verdict([a, dict(a, rank=1)], shared=False)
+    waived = bench.census_verdict([a, dict(a, rank=1)], shared=True)
+    assert waived["distinct_devices"] == 1 and waived["shared_device_run"]
+    # no UUID exposed by this torch: the PCI address alone decides
+    c, d = {"rank": 0, "uuid": None, "pci": "0000:05:00"}, {"rank": 1, "uuid": None, "pci": "0000:25:00"}
+    assert bench.census_verdict([c, d], shared=False)["distinct_devices"] == 2

@@ -28,6 +28,26 @@ def test_two_ranks_sharing_the_gpu_run_the_bench_flow():
     assert len(lines) == 1, r.stdout[-1000:]  # rank 0 only
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and out["config"]["global_batch_clips"] == 4
+    # the line proves what ran: every rank's device identity, the process group's size, the measured all-reduce time
+    assert out["rccl_world_size"] == 2 and [r_["rank"] for r_ in out["ranks"]] == [0, 1]
+    assert all(r_["pci"] and r_["name"] and r_["pid"] > 0 for r_ in out["ranks"]) and out["ranks"][0]["pid"] != out["ranks"][1]["pid"]
+    assert out["distinct_devices"] == 1 and out["shared_device_run"] is True  # two ranks on ONE GPU: allowed only by COMBO_SINGLE_DEVICE=1
+    ar = out["all_reduce"]
+    assert ar["all_reduce_ms_per_step"] > 0 and ar["collectives_per_step"] >= 1 and ar["bytes_per_step"] > 300e6, ar
+
+
+def test_two_ranks_on_one_device_are_refused_without_the_waiver():
+    """An N-rank run whose ranks share a physical device must not produce an "N-GPU" line: without COMBO_SINGLE_DEVICE=1 every
+    rank raises after the device census (all_gather_object of UUID / PCI address)."""
+    env = dict(os.environ, COMBO_DIST_BACKEND="gloo", COMBO_MIOPEN_BENCHMARK="0", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT,
+               HIP_VISIBLE_DEVICES="0,0")
+    env.pop("COMBO_SINGLE_DEVICE", None)
+    # LOCAL_RANK 0 and 1 both map to physical device 0: set_device(local_rank) would fail on a 1-GPU box, so both ranks are
+    # given local rank 0 by a wrapper environment - torch.distributed.run sets LOCAL_RANK itself, hence the census is what refuses
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29635", os.path.join(ROOT, "tests", "dp_census_child.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode != 0 and "distinct devices" in r.stderr, r.stderr[-2000:]
 
 
 def _json_line(stdout):

@@ -1,5 +1,6 @@
 mkdir -p gpurun_out
-export COMBO_COMMIT=3e99ec4
+# the commit the counters are stamped with: git here; on the GPU box (no .git) the file tools/grun.sh wrote before the snapshot
+export COMBO_COMMIT=$(git rev-parse --short HEAD 2>/dev/null || cat .combo_commit 2>/dev/null || echo unknown)
 bash tools/final_profile.sh --profile-only > gpurun_out/final_profile.log 2>&1
 bash tools/pmc_bench.sh > gpurun_out/pmc_bench.log 2>&1
 tail -3 gpurun_out/pmc_bench.log | cut -c1-400
