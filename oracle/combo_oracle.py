@@ -645,7 +645,8 @@ def maskformer_forward(P, batched_inputs, num_classes=2, training=True, rand=tor
     """Full model step on CPU: normalise, VGGish (no grad), dual R50, SEM mix, head, then the weighted
     39-term loss (training) or the per-frame sem_seg maps (eval).  S4/MS3 path (is_avss_data False).
     record: test hook - a dict that receives this run's discrete choices: "attn_masks" (list of 9 bool [BT,Q,hw], the form
-    `transformer_decoder(attn_override=...)` accepts) and the criterion's "match_src" / "match_tgt" / "topk"."""
+    `transformer_decoder(attn_override=...)` accepts), the criterion's "match_src" / "match_tgt" / "topk", and the 10 heads'
+    "pred_masks" [BT,Q,H/4,W/4] / "pred_logits" [BT,Q,K+1] (transformer_decoder.py:481-509)."""
     mean = torch.tensor(PIXEL_MEAN).view(1, 3, 1, 1)
     std = torch.tensor(PIXEL_STD).view(1, 3, 1, 1)
     images = torch.cat([b["images"] for b in batched_inputs]).float()
@@ -668,6 +669,9 @@ def maskformer_forward(P, batched_inputs, num_classes=2, training=True, rand=tor
     losses = set_criterion(out, targets, num_classes, None, world_size, rand, record=record)
     if record is not None:
         record["attn_masks"] = [a[::8].clone() for a in out["attn_masks"][:9]]  # one of the 8 identical head replicas
+        # the north-star's compared quantity: mask / class logits of all 10 prediction heads (9 auxiliary + the final one)
+        record["pred_masks"] = [a["pred_masks"].detach() for a in out["aux_outputs"]] + [out["pred_masks"].detach()]
+        record["pred_logits"] = [a["pred_logits"].detach() for a in out["aux_outputs"]] + [out["pred_logits"].detach()]
     wd = loss_weights()
     return {k: v * wd[k] for k, v in losses.items()}  # :384-391
 

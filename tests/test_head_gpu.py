@@ -203,14 +203,23 @@ def head_run_frozen(head_run):
     return z, head, feats, audio, out
 
 
+# The bounds of the two gradient classes.  They are constants so that loosening one is a visible diff:
+ELEMENTWISE = dict(rtol=2e-3, atol_rms=2e-3, frac_bad=0.002)   # every gradient NOT upstream of the deformable encoder's sampling
+ENERGY_FORM = dict(rel_l2=1e-2, cap_rms=0.3)                   # PIXEL_BOUNDARY tensors: relative L2 only (+ <= 25 % beyond 2e-3)
+
+
+@pytest.mark.parametrize("group", ["elementwise_2e-3", "pixel_boundary_tensors_relative_L2_1e-2_only"])
 @pytest.mark.parametrize("mode", ["s4", "all", "ss"])
-def test_criterion_gradients_with_the_references_choices_frozen(head_run_frozen, mode):
+def test_criterion_gradients_with_the_references_choices_frozen(head_run_frozen, mode, group):
     """Gradients of the weighted 39-term loss against the reference's with the reference's own discrete choices injected on
     the HIP path: the 9 attention masks (decoder.attn_mask_override), the Hungarian pairs of all 10 outputs and the top-k sets
     of the importance sampling (criterion.frozen_choices).  What is left is arithmetic: NO outlier budget beyond 0.2 % at
     2e-3 for every gradient that does not pass through the deformable encoder's bilinear taps, and an energy bound for the
     five that do (synth.check_digest_l2; the CPU oracle measures rel. L2 <= 2.7e-3, worst entry 0.11 RMS on the same vectors -
-    tests/test_oracle_golden.py - the bound here leaves 4x for the 3-product bf16 gradient GEMMs)."""
+    tests/test_oracle_golden.py - the bound here leaves 4x for the 3-product bf16 gradient GEMMs).
+    group "pixel_boundary_tensors_relative_L2_1e-2_only": the tensors held ONLY to the energy form - a bilinear tap crossing a
+    pixel under a 1e-7 change of a sampling location moves the value-map gradient between neighbouring pixels; the same
+    happens CPU-vs-CPU (oracle vs reference, tests/test_oracle_golden.py).  Looser than the element-wise class by design."""
     z, head, feats, audio, out = head_run_frozen
     zc = np.load(os.path.join(G, "criterion.npz"))
     crit, wd = make_criterion(mode)
@@ -240,14 +249,25 @@ def test_criterion_gradients_with_the_references_choices_frozen(head_run_frozen,
     for n, g in zip(names, grads):
         d = synth.unpack(f"{mode}/grad/{n}", zc)
         scale = float(d["l2"]) / max(np.sqrt(float(d["numel"])), 1.0)
+        energy = n in PIXEL_BOUNDARY or synth.upstream_of_sampling(n)
+        if energy != group.startswith("pixel_boundary"):
+            continue
         try:
-            if n in PIXEL_BOUNDARY or synth.upstream_of_sampling(n):
-                synth.check_digest_l2(g.cpu(), d, f"{mode}/grad/{n}", rel_l2=1e-2, cap_rms=0.3)
+            if energy:
+                synth.check_digest_l2(g.cpu(), d, f"{mode}/grad/{n}", **ENERGY_FORM)
             else:
-                synth.check_digest(g.cpu(), d, f"{mode}/grad/{n}", rtol=2e-3, atol=2e-3 * scale + 1e-9, frac_bad=0.002)
+                synth.check_digest(g.cpu(), d, f"{mode}/grad/{n}", rtol=ELEMENTWISE["rtol"], atol=ELEMENTWISE["atol_rms"] * scale + 1e-9,
+                                   frac_bad=ELEMENTWISE["frac_bad"])
         except AssertionError as e:
             worst.append(str(e))
     assert not worst, worst
+
+
+def test_gradient_bounds_have_not_been_loosened():
+    """the two classes' bounds as reviewed in round 4 (VERDICT weak 3): a change here must be argued in DESIGN section 2"""
+    assert ELEMENTWISE == dict(rtol=2e-3, atol_rms=2e-3, frac_bad=0.002) and ENERGY_FORM == dict(rel_l2=1e-2, cap_rms=0.3)
+    import inspect
+    assert inspect.signature(synth.check_digest_l2).parameters["frac_2e3_cap"].default == 0.25
 
 
 def test_fast_matching_path_agrees_with_replay(head_run):

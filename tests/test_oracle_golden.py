@@ -206,8 +206,9 @@ def test_criterion_losses_and_grads(head_run, mode):
 PIXEL_BOUNDARY = synth.PIXEL_BOUNDARY  # (tests/golden/synth.py)
 
 
+@pytest.mark.parametrize("group", ["elementwise_2e-3", "pixel_boundary_tensors_relative_L2_1e-2_only"])
 @pytest.mark.parametrize("mode", ["s4", "all", "ss"])
-def test_criterion_grads_with_the_references_discrete_choices_frozen(head_run, mode):
+def test_criterion_grads_with_the_references_discrete_choices_frozen(head_run, mode, group):
     """The same gradient comparison with the reference's own discrete choices injected - the 9 attention masks
     (`dec/attn_bits*`), the Hungarian pairs of all 10 outputs (`*/match_all_*`) and the top-k sets of the importance sampling
     (`*/topk_bits`).  What remains is floating-point re-association: NO outlier budget at 2e-3 for the gradients that do not
@@ -246,7 +247,9 @@ def test_criterion_grads_with_the_references_discrete_choices_frozen(head_run, m
             scale = float(d["l2"]) / max(np.sqrt(float(d["numel"])), 1.0)
             # measured (oracle vs reference): 0.000 % outliers for every tensor that is not downstream of the deformable
             # encoder's sampling; relative L2 error <= 2.7e-3 and worst entry <= 0.11 RMS for those that are (PIXEL_BOUNDARY)
-            if n in PIXEL_BOUNDARY:
+            if (n in PIXEL_BOUNDARY) != group.startswith("pixel_boundary"):
+                continue
+            if n in PIXEL_BOUNDARY:  # CPU oracle vs CPU reference: the same pixel-boundary effect, hence the same looser class
                 synth.check_digest_l2(g, d, f"{mode}/grad/{n}", rel_l2=1e-2, cap_rms=0.3)
             else:
                 synth.check_digest(g, d, f"{mode}/grad/{n}", rtol=2e-3, atol=2e-3 * scale + 1e-9, frac_bad=0.002)
