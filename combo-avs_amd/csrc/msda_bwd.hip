@@ -27,17 +27,20 @@
 // (geometry + one 4-byte LDS atomic per tap).  (A single window-wide scale 2^30 / sum |a| was measured: 2.3e-5 absolute error
 // at Lq = 1029 - the 7x7 rows collect 300+ adds at a resolution set by a bound 50x above their weight; row scales: 6e-7.)
 //
-// A wave handles 64 samples (16 queries x 4 points) per iteration:
-//   A  lane = sample: tap geometry, kept in REGISTERS; the 16 grad_out rows of the iteration arrive by LDS-DMA meanwhile
-//   B  gather, lane = (query of 16, tap of 4), one step per point: the lane's 32-channel dot product <value row, grad_out
-//      row>, quad DPP sums with per-tap coefficients -> d/dw, d/dloc of 16 samples per step, stored per (query, point)
-//   C  scatter, lane = (sample of the query's 4, channel pair of 16), one step per query and tap: one ds_add_u64 per
-//      (sample, tap); the {tap weight, accumulator row} records of 32 samples at a time pass through 1 KiB of LDS per wave
+// A wave handles 64 samples (16 queries x 4 points) per iteration, lane = sample in EVERY phase (round 5):
+//   A  tap geometry, kept in REGISTERS; the 16 grad_out rows of the iteration arrive by LDS-DMA meanwhile
+//   B  gather: the lane's own four 32-channel dot products <value tap row, grad_out row> -> d/dw, d/dloc of its sample
+//   C  scatter: 16 steps, in step t the lane adds its four taps for the channel pair of the lane t places along its row of 16
+//      (DPP row rotation): a 16-lane LDS service group always covers 16 distinct bank pairs - conflict-free ds_add_u64
 // (v1 of this file - 12-wave workgroups, one per CU, 56-byte LDS records per sample, 8-lane gather - ran 320 us per layer
-//  against 303 us for the two-kernel path: ~33 issued instructions per sample, 25 us of un-overlapped prologue per workgroup.)
+//  against 303 us for the two-kernel path: ~33 issued instructions per sample, 25 us of un-overlapped prologue per workgroup.
+//  Round 3/4: lane = (query, tap) gather with 6 ds_bpermute per step + quad DPP sums, lane = (sample of 4, channel pair) scatter
+//  fed through 1 KiB of {weight, row} records per wave: 64 + 112 LDS instructions per 64 samples, 257 us per layer in the step.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+
+#include <type_traits>
 
 #include "combo_common.h"
 
@@ -49,7 +52,7 @@ constexpr int kMaxLv = 8;
 constexpr int kMaxWin = 64;
 constexpr int kLds = 160 * 1024;
 constexpr int kNWmax = 16;
-constexpr int kWaveLds = 2048 + 1024;  // per wave: 16 grad_out rows (2 KiB) + the scatter records of 32 samples (1 KiB)
+constexpr int kWaveLds = 2048;  // per wave: the 16 grad_out rows of its iteration (2 KiB)
 
 struct WinArgs {
   int n_win;
@@ -114,7 +117,6 @@ msda_bwd_win_d32(const float* __restrict__ gout, const float* __restrict__ value
   float* red = reinterpret_cast<float*>(wsum + ((R + 1 + 3) & ~3));                    // [NW][36] + chmx[36]
   float* chmx = red + NW * 36;
   float* gbuf = chmx + 36 + wave * (kWaveLds / 4);                                     // [16 queries][32]: grad_out rows of the iteration
-  float4* rec = reinterpret_cast<float4*>(gbuf + 512);                                 // [32 samples][2]: {ws, row * 128} x 4 taps
 
   // ---- stage the level's value rows with LDS-DMA (whole-level windows); clear the accumulators --------------------------------
   {
@@ -273,11 +275,9 @@ msda_bwd_win_d32(const float* __restrict__ gout, const float* __restrict__ value
   __syncthreads();
 
   // ---- the pass over the samples --------------------------------------------------------------------------------------------------------
-  const int cp = lane & 15, u4 = lane >> 4;   // phase C: channel pair, sample of the query's 4
-  const int qi = lane >> 2, kt = lane & 3;    // phase B: query of the iteration's 16, tap
+  const int cp = lane & 15;  // phase C: the lane's own channel pair (step t works on the pair of the lane t places along its row)
   const float inv0 = [&] { const float mm = chmx[2 * cp]; return mm > 0.f ? 1.f / mm : (mm == mm ? 0.f : mm); }();
   const float inv1 = [&] { const float mm = chmx[2 * cp + 1]; return mm > 0.f ? 1.f / mm : (mm == mm ? 0.f : mm); }();
-  char* acc_lane = reinterpret_cast<char*>(acc) + cp * 8;
   // (the next iteration's sample is in flight during the current one; the counted vmcnt waits for the grad_out rows retire
   //  the loads in order, so a deeper prefetch would be drained by them anyway)
   float2 xy_n0;
@@ -321,89 +321,90 @@ msda_bwd_win_d32(const float* __restrict__ gout, const float* __restrict__ value
     }
     __builtin_amdgcn_wave_barrier();
 
-    // -- phase B: gather.  Step j = point j of the 16 queries; lane (qi, kt) owns tap kt of sample 4 qi + j.
+    // -- phase B: gather, lane = sample (as in phase A: nothing crosses lanes).  The lane reads its query's grad_out row (the 4
+    //    samples of a query sit in 4 neighbouring lanes: the same LDS address, a broadcast) and the slab rows of its four taps,
+    //    forms the four 32-channel products <value_tap, grad_out[q]> and combines them into d/dw, d/dx, d/dy of ITS sample
+    //    (.cuh:148-163).  (Round 3's form - lane = (query, tap), the sample's parameters fetched with 6 ds_bpermute per step and
+    //    the taps summed over quads by DPP - issued 64 LDS instructions per 64 samples; this one 40 and no cross-lane traffic.)
     if (own_mask) {
-      float4 gq[8];  // this lane's query row of grad_out, all 32 channels
+      const int ql = lane >> 2;  // this lane's query among the iteration's 16
+      float4 gq[8];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) gq[c] = *reinterpret_cast<const float4*>(gbuf + qi * kD + c * 4);
-      const unsigned r01 = (unsigned)grow[0] | ((unsigned)grow[1] << 16), r23 = (unsigned)grow[2] | ((unsigned)grow[3] << 16);
-      float keep_w = 0.f, keep_x = 0.f, keep_y = 0.f;  // lane kt == j keeps the results of point j
-#pragma unroll 1
-      for (int j = 0; j < 4; ++j) {
-        const int src = 4 * qi + j;
-        const float lh = bperm(par.x, src), lw = bperm(par.y, src), aW = bperm(par.z, src), aH = bperm(par.w, src);
-        const unsigned ra = bperm_u(r01, src), rb = bperm_u(r23, src);
-        const unsigned pair = (kt & 2) ? rb : ra;
-        const int row = (int)((kt & 1) ? (pair >> 16) : (pair & 0xffffu));  // slab row of this lane's tap (NR: the zero row)
-        float d = 0.f;
-        if (row < NR) {
-          float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
-          const float* vr = slab + row * kD;
-          const int sw7 = row & 7;  // LDS slab: chunk c sits at position c ^ (row & 7)
+      for (int c = 0; c < 8; ++c) gq[c] = *reinterpret_cast<const float4*>(gbuf + ql * kD + c * 4);
+      float dk[4];
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {  // two halves of the 128-byte row: 16 registers of value in flight, not 32
-            float4 v[4];
+      for (int k = 0; k < 4; ++k) {
+        const int row = grow[k];  // NR: the zero row (tap outside the map, or a sample owned elsewhere)
+        const float* vr = slab + row * kD;
+        const int sw7 = row & 7;  // LDS slab: chunk c sits at position c ^ (row & 7)
+        float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = *reinterpret_cast<const float4*>(vr + (((4 * h + c) ^ sw7) * 4));
+        for (int h = 0; h < 2; ++h) {  // two halves of the 128-byte row: 16 registers of value in flight, not 32
+          float4 v[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              d0 = fmaf(v[c].x, gq[4 * h + c].x, d0); d1 = fmaf(v[c].y, gq[4 * h + c].y, d1);
-              d2 = fmaf(v[c].z, gq[4 * h + c].z, d2); d3 = fmaf(v[c].w, gq[4 * h + c].w, d3);
-            }
+          for (int c = 0; c < 4; ++c) v[c] = *reinterpret_cast<const float4*>(vr + (((4 * h + c) ^ sw7) * 4));
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            d0 = fmaf(v[c].x, gq[4 * h + c].x, d0); d1 = fmaf(v[c].y, gq[4 * h + c].y, d1);
+            d2 = fmaf(v[c].z, gq[4 * h + c].z, d2); d3 = fmaf(v[c].w, gq[4 * h + c].w, d3);
           }
-          d = (d0 + d1) + (d2 + d3);
         }
-        // per-tap coefficients: d/dw = sum_k bw_k d_k; d/dx = a W sum_k bx_k d_k; d/dy = a H sum_k by_k d_k  (.cuh:148-163)
-        const float wy = (kt & 2) ? lh : 1.f - lh, wx = (kt & 1) ? lw : 1.f - lw;
-        float sw = wy * wx * d;
-        float sx = ((kt & 1) ? wy : -wy) * d * aW;
-        float sy = ((kt & 2) ? wx : -wx) * d * aH;
-        sw += dppf<0xB1>(sw); sx += dppf<0xB1>(sx); sy += dppf<0xB1>(sy);  // quad_perm [1,0,3,2]
-        sw += dppf<0x4E>(sw); sx += dppf<0x4E>(sx); sy += dppf<0x4E>(sy);  // quad_perm [2,3,0,1]
-        if (kt == j) { keep_w = sw; keep_x = sx; keep_y = sy; }
+        dk[k] = (d0 + d1) + (d2 + d3);
       }
-      // lane (qi, kt) stores point kt of query qbase + qi when the sample is owned here
-      if ((own_mask >> (4 * qi + kt)) & 1ull) {
-        const long long e = (((long long)b * Lq + qbase + qi) * M + m) * LP + lv * P + kt;
-        gaw[e] = keep_w;
-        *reinterpret_cast<float2*>(gloc + e * 2) = make_float2(keep_x, keep_y);
+      if (owner) {
+        const float lh = par.x, lw = par.y, hh = 1.f - lh, hw = 1.f - lw;
+        // d/dw = sum_k w_k d_k; d/dx = a W sum_k (+-)wy_k d_k; d/dy = a H sum_k (+-)wx_k d_k  (taps: 0 top-left, 1 top-right, 2 bottom-left, 3 bottom-right)
+        const float sw = (hh * hw * dk[0] + hh * lw * dk[1]) + (lh * hw * dk[2] + lh * lw * dk[3]);
+        const float sx = ((hh * dk[1] - hh * dk[0]) + (lh * dk[3] - lh * dk[2])) * par.z;
+        const float sy = ((hw * dk[2] - hw * dk[0]) + (lw * dk[3] - lw * dk[1])) * par.w;
+        const int i = ibase + lane;  // (live: owner implies it)
+        const int q = i / P, pp = i - q * P;
+        const long long e = (((long long)b * Lq + q) * M + m) * LP + lv * P + pp;
+        gaw[e] = sw;
+        *reinterpret_cast<float2*>(gloc + e * 2) = make_float2(sx, sy);
       }
     }
 
-    // -- phase C: scatter.  Records of 32 samples at a time through the wave's 1 KiB record buffer; lane (u4, cp) adds the four
-    //    taps of sample 4 q + u4 for channel pair cp: a ds_add_u64 wave instruction covers 4 rows x 128 B.
+    // -- phase C: scatter, lane = sample.  16 steps; in step t the lane adds its four taps for channel pair cp_t = the pair of the
+    //    lane t places further in its row of 16 lanes (a DPP row rotation, also applied to the pair's 1 / max|grad_out| factors):
+    //    within every 16-lane group the pairs are distinct, i.e. the group's 16 ds_add_u64 fall into 16 different 8-byte bank
+    //    pairs whatever rows they hit - conflict-free at the LDS's 4 x 16-lane service order.  (Round 3's form - lane = (sample of
+    //    the query's 4, channel pair) - passed {weight, row} records of 32 samples at a time through LDS: 36 more LDS instructions
+    //    per 64 samples and two wave barriers per half.)
+    if (touch_mask) {
+      float ws[4];
+      int ab[4];
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      if (((touch_mask >> (32 * half)) & 0xffffffffull) == 0ull) continue;  // wave-uniform
-      if ((lane >> 5) == half) {
-        const int sl = lane & 31;
-        rec[sl * 2] = make_float4(wt[0] * rowscale[arow[0]], __int_as_float(arow[0] * 128), wt[1] * rowscale[arow[1]],
-                                  __int_as_float(arow[1] * 128));
-        rec[sl * 2 + 1] = make_float4(wt[2] * rowscale[arow[2]], __int_as_float(arow[2] * 128), wt[3] * rowscale[arow[3]],
-                                      __int_as_float(arow[3] * 128));
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-      for (int q8 = 0; q8 < 8; ++q8) {
-        if (((touch_mask >> (32 * half + 4 * q8)) & 0xfull) == 0ull) continue;  // wave-uniform: none of the query's 4 samples
-        const float2 g2 = *reinterpret_cast<const float2*>(gbuf + (half * 8 + q8) * kD + 2 * cp);
-        const float g0 = g2.x * inv0, g1 = g2.y * inv1;  // normalised to [-1, 1] per channel
-        const float4 ra = rec[(q8 * 4 + u4) * 2], rb = rec[(q8 * 4 + u4) * 2 + 1];
-        const float wsk[4] = {ra.x, ra.z, rb.x, rb.z};
-        const int ark[4] = {__float_as_int(ra.y), __float_as_int(ra.w), __float_as_int(rb.y), __float_as_int(rb.w)};
+      for (int k = 0; k < 4; ++k) { ws[k] = wt[k] * rowscale[arow[k]]; ab[k] = arow[k] * 128; }
+      const float* gl = gbuf + (lane >> 2) * kD;
+      auto step = [&](auto t_tag) __attribute__((always_inline)) {
+        constexpr int T = decltype(t_tag)::value;
+        int cb = cp * 8;
+        float i0 = inv0, i1 = inv1;
+        if constexpr (T > 0) {
+          cb = __builtin_amdgcn_update_dpp(0, cb, 0x120 + T, 0xf, 0xf, true);  // row_ror:T
+          i0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(inv0), 0x120 + T, 0xf, 0xf, true));
+          i1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(inv1), 0x120 + T, 0xf, 0xf, true));
+        }
+        const float2 g2 = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(gl) + cb);
+        const float g0 = g2.x * i0, g1 = g2.y * i1;  // normalised to [-1, 1] per channel
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const int v0 = cvt_rpi(wsk[k] * g0), v1 = cvt_rpi(wsk[k] * g1);
+          const int v0 = cvt_rpi(ws[k] * g0), v1 = cvt_rpi(ws[k] * g1);
           const unsigned long long x = ((unsigned long long)(unsigned)(v1 + (v0 >> 31)) << 32) | (unsigned)v0;
-          __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(acc_lane + ark[k]), x, __ATOMIC_RELAXED,
+          __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(acc) + ab[k] + cb), x, __ATOMIC_RELAXED,
                                  __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      };
+      step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+      step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+      step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
+      step(std::integral_constant<int, 9>{}); step(std::integral_constant<int, 10>{}); step(std::integral_constant<int, 11>{});
+      step(std::integral_constant<int, 12>{}); step(std::integral_constant<int, 13>{}); step(std::integral_constant<int, 14>{});
+      step(std::integral_constant<int, 15>{});
     }
+    // the next iteration's LDS-DMA rewrites gbuf: every lane's reads of it must have returned (they have: their results were
+    // consumed above) and the wave is one instruction stream - nothing to wait for
   }
   __syncthreads();
 

@@ -40,7 +40,7 @@ def test_two_ranks_on_one_device_are_refused_without_the_waiver():
     """An N-rank run whose ranks share a physical device must not produce an "N-GPU" line: without COMBO_SINGLE_DEVICE=1 every
     rank raises after the device census (all_gather_object of UUID / PCI address)."""
     env = dict(os.environ, COMBO_DIST_BACKEND="gloo", COMBO_MIOPEN_BENCHMARK="0", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT,
-               HIP_VISIBLE_DEVICES="0,0")
+               )
     env.pop("COMBO_SINGLE_DEVICE", None)
     # LOCAL_RANK 0 and 1 both map to physical device 0: set_device(local_rank) would fail on a 1-GPU box, so both ranks are
     # given local rank 0 by a wrapper environment - torch.distributed.run sets LOCAL_RANK itself, hence the census is what refuses
