@@ -190,7 +190,7 @@ def other_workloads(timeout_s=420):
                 continue
             j = json.loads(lines[-1])
             out.append({"name": name, "workload": j["config"]["workload"], "ms_per_step": j["ms_per_step"], "frames_per_s": j["value"],
-                        "steps": j["steps"], "warmup": j["warmup"], "dtype": j["dtype"], "launch": j["config"]["launch"][:60],
+                        "steps": j["steps"], "warmup": j["warmup"], "dtype": j["dtype"], "launch": j["config"]["launch"][:200],
                         "precision": j["config"]["precision"], "wall_s": round(time.perf_counter() - t0, 1)})
             if name in notes:
                 out[-1]["note"] = notes[name]
@@ -492,6 +492,10 @@ def main():
         try:
             graphed(batch)  # captures
             trace("captured + first replayed step done")
+            if wl["avss"]:  # instance counts per frame differ from batch to batch: one graph per signature, all captured before
+                for b_ in batches[1:]:  # the timed region (they share one memory pool, trainer.GraphedTrainStep._capture)
+                    graphed(b_)
+                trace("%d graphs captured" % len(graphed.graphs))
             step = graphed
         except Exception as exc:  # noqa: BLE001 - a failed capture must not cost the run: fall back to eager launches
             print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eager", file=sys.stderr, flush=True)
@@ -697,7 +701,9 @@ def main():
                        "launch": "eager" if ran_eager else (
                            "2 hipGraphs (fwd + loss + head bwd | backbone bwd; the head's gradient all-reduce overlaps the second; AdamW eager)"
                            if dist.is_initialized() and os.environ.get("COMBO_DP_OVERLAP", "1") == "1" else
-                           "hipGraph (fwd+loss+bwd captured; all-reduce + AdamW eager)"),
+                           "hipGraph (fwd+loss+bwd captured; all-reduce + AdamW eager)"
+                           + (f"; {len(graphed.graphs)} graphs = one per (instance counts per frame, flag values) signature of the {len(batches)} "
+                              "rotated batches, sharing one memory pool" if graphed is not None and len(graphed.graphs) > 1 else "")),
                        "instrumentation": "the instrumented kernels' timing atomics (2 per workgroup) and one fold launch per step run "
                                           "inside the timed region" if slot_timing else "HIP events around the MSDeformAttn core",
                        "arithmetic": "forward GEMMs / convolutions / attention of the head in exact fp32 on v_mfma_f32_* (peak 157.3 "

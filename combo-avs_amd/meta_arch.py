@@ -160,8 +160,12 @@ class MaskFormer(nn.Module):
         with torch.no_grad(), amp:
             audio_feature = self.audio_backbone(audio_log_mels).float()  # :327-328
         audio_feature = audio_feature.unsqueeze(1)
+        avss_index = getattr(self, "avss_static_index", None) if self.is_avss_data else None
         if self.is_avss_data:
-            audio_feature = audio_feature[vid_flag.bool()]
+            # maskformer_model.py:330-331: the audio rows of the frames that exist.  Boolean indexing reads the flag VALUES on the
+            # host (a synchronisation: not capturable); trainer.GraphedTrainStep reads them once per step before the graph
+            # launch, keys its graphs by them and hands over the same selection as constant index tensors
+            audio_feature = audio_feature.index_select(0, avss_index[0]) if avss_index is not None else audio_feature[vid_flag.bool()]
         if self.use_pre_sam:
             pre = torch.cat([b["pre_masks"].to(dev, non_blocking=True) for b in batched_inputs], dim=0)
             pre = self._pad(pre.sub(self.pixel_mean).div_(self.pixel_std) if pre.dtype == torch.uint8
@@ -201,7 +205,7 @@ class MaskFormer(nn.Module):
             gt_instances = [inst for b in batched_inputs for inst in b["instances"]]
             targets = self.prepare_targets(gt_instances, images)
             if self.is_avss_data:
-                losses = self.criterion(outputs, targets, vid_flag, gt_flag)
+                losses = self.criterion(outputs, targets, vid_flag, gt_flag, gt_index=None if avss_index is None else avss_index[1])
             else:
                 losses = self.criterion(outputs, targets)
             if getattr(losses, "families", None):

@@ -389,6 +389,8 @@ class SetCriterion(nn.Module):
 class SetCriterion_SS(SetCriterion):
     """AVSS variant: frames are chosen by gt_temporal_mask_flag (criterion_ss.py:246-257)."""
 
-    def forward(self, outputs, targets, vid_temporal_mask_flag, gt_temporal_mask_flag):
-        index = torch.where(gt_temporal_mask_flag == 1)[0].to(outputs["pred_logits"].device)
+    def forward(self, outputs, targets, vid_temporal_mask_flag, gt_temporal_mask_flag, gt_index=None):
+        """gt_index: the rows `torch.where(gt_temporal_mask_flag == 1)[0]` as a ready device tensor (a captured step: the flag
+        values were read on the host before the graph launch, trainer.GraphedTrainStep)"""
+        index = gt_index if gt_index is not None else torch.where(gt_temporal_mask_flag == 1)[0].to(outputs["pred_logits"].device)
         return self._losses(self._select(outputs, index), targets)

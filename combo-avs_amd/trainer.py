@@ -466,6 +466,7 @@ class GraphedTrainStep:
         self.model, self.opt = model, optimizer
         self.warmup_iters, self.max_graphs = warmup_iters, max_graphs
         self.graphs = {}
+        self._pool = None  # the memory pool all captured signatures share (they replay one after the other)
         # eager_only: the step is NOT captured (every call runs trainer.train_step) because this process replays hipGraph
         # memset nodes wrongly - callers that report a graphed number (bench.py) read this flag
         self.eager_only = False
@@ -492,14 +493,24 @@ class GraphedTrainStep:
             for inst in b["instances"]:
                 t = inst["gt_classes"] if isinstance(inst, dict) else inst.gt_classes
                 n += int(t.shape[0])
-        if self.model.is_avss_data:
-            return None  # frame selection depends on flag VALUES: AVSS batches run eagerly
         num = torch.tensor([float(n)], device=dev)
         world = 1
         if dist.is_available() and dist.is_initialized():
             dist.all_reduce(num)
             world = dist.get_world_size()
         return torch.clamp(num / world, min=1)
+
+    def _avss_flags(self, batched_inputs):
+        """AVSS batches: the VALUES of vid_temporal_mask_flag / gt_temporal_mask_flag select frames (maskformer_model.py:330-331,
+        criterion_ss.py:246-257) - read here, on the host, once per step (free when the dataset mapper's CPU tensors arrive as
+        they are; ONE device->host copy when the flags already sit on the GPU).  They become part of the graph key and, as
+        constant index tensors, of the captured step.  -> ((vid flags), (gt flags)) as python ints, or None."""
+        if not self.model.is_avss_data:
+            return None
+        vid = torch.cat([b["vid_temporal_mask_flag"].reshape(-1) for b in batched_inputs])
+        gt = torch.cat([b["gt_temporal_mask_flag"].reshape(-1) for b in batched_inputs])
+        both = torch.stack([vid.float(), gt.float()]).cpu()
+        return tuple(int(v) for v in both[0].tolist()), tuple(int(v == 1) for v in both[1].tolist())
 
     def _fwd_bwd(self, batch):
         from .ops.linear import grouped_presplit
@@ -529,13 +540,16 @@ class GraphedTrainStep:
         cut_grads = self.opt.backward_early(total, cut)
         return {k: v.detach() for k, v in loss_dict.items()}, cut_grads
 
-    def _capture(self, batched_inputs, num_masks):
+    def _capture(self, batched_inputs, num_masks, flags=None):
         from .ops import bifuse
         dev = num_masks.device
         static_batch = _clone_batch(batched_inputs)
         static_num = num_masks.clone()
         crit = self.model.criterion
         crit.num_masks_override = static_num
+        if flags is not None:  # AVSS: the selections the flag values stand for, as constants of this graph
+            self.model.avss_static_index = (torch.tensor([i for i, v in enumerate(flags[0]) if v], dtype=torch.long, device=dev),
+                                            torch.tensor([i for i, v in enumerate(flags[1]) if v], dtype=torch.long, device=dev))
         counter = bifuse.step_counter(dev)
         from .ops.linear import grouped_presplit
         cut = self._cut_backward()
@@ -553,12 +567,16 @@ class GraphedTrainStep:
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
             graph = torch.cuda.CUDAGraph()
+            # graphs of different input signatures (AVSS: instance counts per frame vary from batch to batch) replay one after
+            # the other, never concurrently: they share ONE memory pool - the second capture reuses the activations' blocks of
+            # the first instead of reserving its own 100+ GB
+            pool_kw = {} if self._pool is None else {"pool": self._pool}
             # thread_local: RCCL's watchdog thread may poll events while this thread captures; that must not
             # invalidate the capture (the default "global" mode would)
             if cut:
                 graph_b = torch.cuda.CUDAGraph()
                 with grouped_presplit():  # spans both captures: the second graph's input-gradient GEMMs use images split in the first
-                    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    with torch.cuda.graph(graph, capture_error_mode="thread_local", **pool_kw):
                         counter.add_(1)
                         static_losses, cut_grads = self._fwd_early(static_batch)
                     with torch.cuda.graph(graph_b, pool=graph.pool(), capture_error_mode="thread_local"):
@@ -566,24 +584,31 @@ class GraphedTrainStep:
                     del cut_grads
                 graph = (graph, graph_b)
             else:
-                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                with torch.cuda.graph(graph, capture_error_mode="thread_local", **pool_kw):
                     counter.add_(1)
                     static_losses = self._fwd_bwd(static_batch)
+            if self._pool is None:
+                self._pool = (graph[0] if isinstance(graph, tuple) else graph).pool()
         finally:
             crit.num_masks_override = None
+            self.model.avss_static_index = None
         return graph, static_batch, static_num, static_losses
 
     def __call__(self, batched_inputs):
         tensors, rest = _input_leaves(batched_inputs)
         dev = self.model.device
         num_masks = self._num_masks(batched_inputs, dev)
-        if self.eager_only or num_masks is None or not all(t.is_cuda for t in tensors):
+        # (AVSS flag tensors may stay on the CPU, as the dataset mapper hands them over: their values travel in the key)
+        flag_keys = ("vid_temporal_mask_flag", "gt_temporal_mask_flag")
+        flag_ids = {id(b[k]) for b in batched_inputs for k in flag_keys if k in b} if self.model.is_avss_data else set()
+        if self.eager_only or num_masks is None or not all(t.is_cuda for t in tensors if id(t) not in flag_ids):
             return train_step(self.model, self.opt, batched_inputs)
-        key = (tuple((tuple(t.shape), t.dtype) for t in tensors), rest, self.model.training)
+        flags = self._avss_flags(batched_inputs)
+        key = (tuple((tuple(t.shape), t.dtype) for t in tensors), rest, self.model.training, flags)
         if key not in self.graphs:
             if len(self.graphs) >= self.max_graphs:
                 return train_step(self.model, self.opt, batched_inputs)
-            self.graphs[key] = self._capture(batched_inputs, num_masks)
+            self.graphs[key] = self._capture(batched_inputs, num_masks, flags)
         graph, static_batch, static_num, static_losses = self.graphs[key]
         static_tensors, _ = _input_leaves(static_batch)
         src = [t for t, s in zip(tensors, static_tensors) if t.data_ptr() != s.data_ptr()]

@@ -333,6 +333,67 @@ def test_avss_recipe_k71_ten_frames_trains(capsys):
     assert all(torch.isfinite(v) for v in losses.values())
 
 
+def test_avss_step_is_captured_per_signature_and_matches_the_eager_step():
+    """BASELINE configs[3] family, captured: the AVSS step's frame selection depends on flag VALUES (maskformer_model.py:330-331,
+    criterion_ss.py:246-257); GraphedTrainStep reads them on the host, keys its graphs by (shapes, instance counts per frame, flag
+    values) and bakes the selection into the graph as index tensors.  Two batches with different instance counts -> two graphs
+    that share one memory pool; a third batch with a 5-frame clip's flags -> a third graph.  The replayed losses equal the eager
+    step's on the same weights (fixed parameters: lr 0; the bilateral-fusion dropout is off)."""
+    sys.path.insert(0, ROOT)
+    import combo_avs_amd  # noqa: F401
+    from bench import synth_batch
+    from combo_avs_amd import combo_cfg
+    from combo_avs_amd.meta_arch import build_model
+    from combo_avs_amd.trainer import FlatAdamW, GraphedTrainStep, train_step
+    cfg = combo_cfg(os.path.join(ROOT, "configs/avs_ss/COMBO_PVTV2B5_bs8_90k.yaml"))
+    torch.manual_seed(0)
+    model = build_model(cfg).cuda().train()
+    model.backbone_dtype = torch.bfloat16
+    model.sem_seg_head.fusion_module.b_attn.attn_list[0].dropout = 0.0
+    from combo_avs_amd.backbone_pvt import DropPath
+    for m_ in model.modules():  # stochastic depth of the PVT backbones off: eager and replayed steps must be comparable
+        if isinstance(m_, DropPath):
+            m_.p = 0.0
+    opt = FlatAdamW(model, base_lr=0.0, weight_decay=0.0, backbone_multiplier=0.1, clip_value=0.01)
+    b1 = synth_batch(1, 10, 224, 224, "cuda", seed=5, K=71, gt="all", avss=True)
+    b2 = synth_batch(1, 10, 224, 224, "cuda", seed=6, K=71, gt="all", avss=True)
+    assert [i["gt_classes"].numel() for i in b1[0]["instances"]] != [i["gt_classes"].numel() for i in b2[0]["instances"]]
+    b3 = synth_batch(1, 10, 224, 224, "cuda", seed=5, K=71, gt="all", avss=True)
+    b3[0]["vid_temporal_mask_flag"] = b3[0]["vid_temporal_mask_flag"].cpu()  # as the dataset mapper hands them over: CPU tensors
+    b3[0]["gt_temporal_mask_flag"] = b3[0]["gt_temporal_mask_flag"].cpu()
+    b3[0]["vid_temporal_mask_flag"][5:] = 0
+    b3[0]["gt_temporal_mask_flag"][5:] = 0
+    for k in ("instances", "images", "pre_masks"):
+        b3[0][k] = b3[0][k][:5]
+    crit = model.criterion
+    pts = {}
+
+    def fixed_points(n, p):  # the same random points in the eager and the replayed step of a batch
+        key = (n, p)
+        if key not in pts:
+            pts[key] = torch.rand(n, p, 2, generator=torch.Generator().manual_seed(7)).cuda()
+        return pts[key]
+    crit.point_source = fixed_points
+    try:
+        ref = []
+        for b in (b1, b2, b3):
+            ref.append({k: float(v) for k, v in train_step(model, opt, b).items()})
+        g = GraphedTrainStep(model, opt)
+        got = []
+        for b in (b1, b2, b3, b1, b3):
+            got.append({k: float(v) for k, v in g(b).items()})
+        torch.cuda.synchronize()
+    finally:
+        crit.point_source = None
+    assert len(g.graphs) == 3 and not g.eager_only, len(g.graphs)
+    pools = {(gr[0] if isinstance(gr[0], torch.cuda.CUDAGraph) else gr[0][0]).pool() for gr in g.graphs.values()}
+    assert len(pools) == 1, pools
+    for want, have in zip(ref + [ref[0], ref[2]], got):
+        assert len(have) == 39
+        for k in want:
+            assert abs(have[k] - want[k]) <= 2e-2 * abs(want[k]) + 2e-3, (k, have[k], want[k])  # bf16 backbones: atomics-free but re-associated library GEMMs
+
+
 def test_ms3_ten_frame_clips_train_graphed():
     """BASELINE configs[4] family: COMBO-PVTv2-B5 MS3 with 10-frame clips (synthetic T; every frame annotated), bf16 backbones,
     eager step then two graph replays."""
