@@ -124,8 +124,12 @@ _SIGNATURES = {
     "combo_attention_backward_ld_f32": [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_int, c_void_p] + [c_int] * 5 + [c_float]
                                        + [c_void_p] * 6 + [c_longlong, c_void_p, c_longlong, c_void_p],
     "combo_adamw_f32": [c_void_p] * 4 + [c_longlong, c_void_p] + [c_float] * 7 + [c_void_p],
+    "combo_sra_attention_ok": [c_int, c_int, c_int],
+    "combo_sra_attention_backward_workspace": [c_int, c_int, c_int, c_int],
+    "combo_sra_attention_forward_bf16": [c_void_p] * 4 + [c_int] * 4 + [c_float, c_void_p],
+    "combo_sra_attention_backward_bf16": [c_void_p] * 9 + [c_int] * 4 + [c_float, c_void_p],
 }
-_RESTYPES = {"combo_build_arch": ctypes.c_char_p}
+_RESTYPES = {"combo_build_arch": ctypes.c_char_p, "combo_sra_attention_backward_workspace": ctypes.c_longlong}
 
 
 def exported_symbols():

@@ -226,9 +226,18 @@ class Attention(nn.Module):
                 x_ = _ln(x_.flatten(2).transpose(1, 2), self.norm, wts)
         else:
             x_ = xs
-        k, v = _linear(x_, self.kv, wts).view(B, -1, 2, h, d).unbind(2)  # (unbind: ONE stack in the backward pass, not two
-        k, v = k.transpose(1, 2), v.transpose(1, 2)                      # zero-filled select gradients and their sum)
-        o = F.scaled_dot_product_attention(q, k, v, dropout_p=self.attn_drop.p if self.training else 0.0, scale=self.scale)
+        kv = _linear(x_, self.kv, wts)
+        drop = self.attn_drop.p if self.training else 0.0
+        if drop == 0.0:
+            from .ops import sra
+            q_lin = q.transpose(1, 2).reshape(B, N, C)  # (a view of the projection's output: q is its [B, h, N, d] view)
+            if sra.usable(q_lin, kv, h):
+                # own kernels (csrc/sra_attention.hip): few keys, head dimension 64 - the projections' outputs are read where they
+                # lie, the result is written in the [B, N, C] layout the output projection consumes
+                return self.proj_drop(_linear(sra.sra_attention(q_lin, kv, h, self.scale), self.proj, wts))
+        k, v = kv.view(B, -1, 2, h, d).unbind(2)          # (unbind: ONE stack in the backward pass, not two zero-filled select
+        k, v = k.transpose(1, 2), v.transpose(1, 2)      # gradients and their sum)
+        o = F.scaled_dot_product_attention(q, k, v, dropout_p=drop, scale=self.scale)
         return self.proj_drop(_linear(o.transpose(1, 2).reshape(B, N, C), self.proj, wts))
 
 

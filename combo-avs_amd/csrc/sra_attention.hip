@@ -1,0 +1,579 @@
+// Spatial-reduction attention of PVTv2 (reference: models/modeling/backbone/pvtv2.py:60-132, linear = False): softmax(q k^T / sqrt(d)) v
+// with FEW keys per (frame, head) - the token grid reduced by the strided sr x sr convolution: 49 keys at 224 x 224 in every stage,
+// 256 at 512 x 512 - head dimension 64, bf16 operands, fp32 accumulation (what the reference's autocast / our bf16 backbone recipe
+// computes through F.scaled_dot_product_attention; that library path - aotriton's attn_fwd / bwd_kernel_dk_dv / bwd_kernel_dq - was
+// 52 ms of the 742 ms configs[3] step).
+//
+// Layouts (no transposes, no copies around the kernels):
+//   q    [B, N, H * 64]       the q projection's output as it is              (head h = columns 64 h .. 64 h + 63)
+//   kv   [B, Nk, 2, H, 64]    the kv projection's output as it is             (k = [:, :, 0], v = [:, :, 1])
+//   out  [B, N, H * 64]       what the output projection consumes             dq / dkv: the same layouts as q / kv
+//   lse2 [B, H, Npad]         log2 of the softmax denominator of the scaled scores in base 2, Npad = N rounded up to 32
+// The few keys are what shapes the kernels: K and V of a (frame, head) pair fit LDS whole (<= 64 KiB), so there is no online
+// softmax - a wave owns 32 queries and ALL keys:
+//   forward   S^T[keys, 32 q] = K . Q^T on v_mfma_f32_32x32x16_bf16 (in the D layout a lane owns ONE query column: the row
+//             statistics are lane-local + one exchange with lane ^ 32), P^T = exp2(S^T c - max) packed to bf16 IS the B operand
+//             of O^T[64 d, 32 q] += V^T . P^T when the contraction index is enumerated in D-layout order; V^T is staged
+//             transposed in LDS once per workgroup (pitch = keys + 4 halves: the 32 rows of a fragment hit 32 distinct bank pairs).
+//   dq        the same walk: S^T, dP^T = V . dO^T, dS^T = P^T (dP^T - D), dQ^T += K^T . dS^T block by block (P from the saved lse2:
+//             no running maximum, nothing but one 32-key block of S^T / dP^T is live); also writes D = rowsum(dO . O).
+//   dk, dv    a wave owns 64 keys (32 for the 49-key maps) and walks the query tiles of its chunk: S = Q . K^T, dP = dO . V^T (the
+//             operands of the first two products swapped: the D layout now has a lane own one KEY column), dV^T += dO^T . P,
+//             dK^T += Q^T . dS with Q^T / dO^T tiles staged transposed in LDS per tile; fp32 partials per chunk into a workspace,
+//             summed in a fixed order by sra_dkv_finish (bitwise reproducible: no atomics anywhere).
+#include <cstdint>
+
+#include "combo_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef unsigned short bf16_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u4v;
+typedef __attribute__((ext_vector_type(2))) unsigned u2v;
+
+constexpr int kHD = 64;
+
+__device__ __forceinline__ unsigned pack_rne(float a, float b) {  // {lo: bf16(a), hi: bf16(b)}, round to nearest even
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32); }
+
+struct SraArgs {
+  const bf16_t* q;      // [B, N, C]
+  const bf16_t* kv;     // [B, Nk, 2, H, 64]
+  bf16_t* o;            // forward: out; backward: the saved out
+  float* lse2;          // [B, H, Npad]
+  const bf16_t* dout;   // [B, N, C]
+  float* delta;         // [B, H, Npad]   D = rowsum(dO . O)   (written by dq, read by dkv)
+  bf16_t* dq;           // [B, N, C]
+  float* part;          // dkv partials [B * H, chunks, 2, NKP, 64] fp32
+  bf16_t* dkv;          // [B, Nk, 2, H, 64]
+  int B, N, Nk, H, Npad, chunks, tiles_per_chunk;
+  float c;              // softmax scale * log2(e)
+  float scale;
+  unsigned long long* ts;
+};
+
+// K or V of one (frame, head) -> LDS row-major, 128 B per key, 16-byte chunk c of row j at position c ^ ((j >> 1) & 7): the 16 rows
+// a ds_read_b128 service group touches ((j & 1), (j >> 1) & 7 all different) fall into 16 different 4-bank slots.  Rows >= Nk: zeros.
+template <int NT>
+__device__ __forceinline__ void stage_rows(char* dst, const bf16_t* kv, int b, int h, int which, int Nk, int NKP, int H) {
+  const long long C2 = 2LL * H * kHD;
+  for (int idx = threadIdx.x; idx < NKP * 8; idx += NT) {
+    const int j = idx >> 3, c = idx & 7;
+    u4v v = {0u, 0u, 0u, 0u};
+    if (j < Nk) v = *reinterpret_cast<const u4v*>(kv + ((long long)b * Nk + j) * C2 + ((long long)which * H + h) * kHD + c * 8);
+    *reinterpret_cast<u4v*>(dst + j * 128 + ((c ^ ((j >> 1) & 7)) << 4)) = v;
+  }
+}
+// the same tensor TRANSPOSED: [64 d][NKP + 4] bf16 (pitch in bytes 2 NKP + 8); two keys per 4-byte store
+template <int NT>
+__device__ __forceinline__ void stage_transposed(char* dst, const bf16_t* kv, int b, int h, int which, int Nk, int NKP, int H) {
+  const long long C2 = 2LL * H * kHD;
+  const int pitch = 2 * NKP + 8;
+  for (int idx = threadIdx.x; idx < (NKP / 2) * 8; idx += NT) {
+    const int j2 = idx >> 3, c = idx & 7;
+    u4v a = {0u, 0u, 0u, 0u}, bq = {0u, 0u, 0u, 0u};
+    const bf16_t* base = kv + ((long long)b * Nk) * C2 + ((long long)which * H + h) * kHD + c * 8;
+    if (2 * j2 < Nk) a = *reinterpret_cast<const u4v*>(base + (long long)(2 * j2) * C2);
+    if (2 * j2 + 1 < Nk) bq = *reinterpret_cast<const u4v*>(base + (long long)(2 * j2 + 1) * C2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // dword i of a chunk = channels 8 c + 2 i, 8 c + 2 i + 1
+      const unsigned lo = (a[i] & 0xffffu) | (bq[i] << 16), hi = (a[i] >> 16) | (bq[i] & 0xffff0000u);
+      *reinterpret_cast<unsigned*>(dst + (8 * c + 2 * i) * pitch + 4 * j2) = lo;
+      *reinterpret_cast<unsigned*>(dst + (8 * c + 2 * i + 1) * pitch + 4 * j2) = hi;
+    }
+  }
+}
+
+// A / B fragment of a row-major staged matrix: row j, k-slots 16 kk + 8 g .. + 7
+__device__ __forceinline__ bf16x8 frag_rows(const char* base, int j, int kk, int g) {
+  return *reinterpret_cast<const bf16x8*>(base + j * 128 + (((2 * kk + g) ^ ((j >> 1) & 7)) << 4));
+}
+// A fragment of a transposed staged matrix for the contraction over keys in D-layout order: row d, keys k0 + 4 g + {0..3} and
+// k0 + 8 + 4 g + {0..3}  (k0 = 32 blk + 16 half)
+__device__ __forceinline__ bf16x8 frag_transposed(const char* base, int pitch, int d, int k0, int g) {
+  const u2v lo = *reinterpret_cast<const u2v*>(base + d * pitch + (k0 + 4 * g) * 2);
+  const u2v hi = *reinterpret_cast<const u2v*>(base + d * pitch + (k0 + 8 + 4 * g) * 2);
+  return __builtin_bit_cast(bf16x8, (u4v){lo[0], lo[1], hi[0], hi[1]});
+}
+// bf16 B fragment from 8 consecutive D-layout accumulator entries
+__device__ __forceinline__ bf16x8 pack8(const float* p) {
+  return __builtin_bit_cast(bf16x8, (u4v){pack_rne(p[0], p[1]), pack_rne(p[2], p[3]), pack_rne(p[4], p[5]), pack_rne(p[6], p[7])});
+}
+
+// ------------------------------------------------------------------------------------------------------------------ forward
+template <int NB>
+__global__ void __launch_bounds__(256, 2)
+sra_fwd_kernel(const SraArgs p) {
+  constexpr int NKP = 32 * NB, PITCH = 2 * NKP + 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  combo_ts_begin(p.ts);
+  char* Krm = smem;
+  char* VT = smem + NKP * 128;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 31, g = lane >> 5;
+  const int id = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int chunk = id % p.chunks, bh = id / p.chunks;
+  const int h = bh % p.H, b = bh / p.H;
+  const long long C = (long long)p.H * kHD;
+  stage_rows<256>(Krm, p.kv, b, h, 0, p.Nk, NKP, p.H);
+  stage_transposed<256>(VT, p.kv, b, h, 1, p.Nk, NKP, p.H);
+  __syncthreads();
+  const int n_tiles = (p.N + 31) >> 5;
+  const int t_end = min(n_tiles, (chunk + 1) * p.tiles_per_chunk);
+  for (int t = chunk * p.tiles_per_chunk + wave; t < t_end; t += 4) {
+    const int q0 = t * 32, qi = q0 + m;
+    const bf16_t* qrow = p.q + ((long long)b * p.N + min(qi, p.N - 1)) * C + h * kHD + 8 * g;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(qrow + 16 * kk);
+    float mx = -3.0e38f, sum = 0.f;
+    f32x16 oacc[2];
+#pragma unroll
+    for (int d2 = 0; d2 < 2; ++d2)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[d2][e] = 0.f;
+    // one 32-key block of scaled, masked scores S^T (rows = keys, this lane's column = its query)
+    auto scores = [&](int blk, f32x16& sb) __attribute__((always_inline)) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sb[e] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Krm, 32 * blk + m, kk, g), qf[kk], sb, 0, 0, 0);
+      const bool ragged = 32 * blk + 32 > p.Nk;  // (uniform) the block holds padded keys
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float v = sb[e] * p.c;
+        if (ragged && 32 * blk + 8 * (e >> 2) + 4 * g + (e & 3) >= p.Nk) v = -3.0e38f;
+        sb[e] = v;
+      }
+    };
+    // P^T of a block (already exponentiated) into the output accumulators
+    auto apply = [&](int blk, const f32x16& pb) __attribute__((always_inline)) {
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        float pe[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pe[u] = pb[8 * hf + u];
+        const bf16x8 pf = pack8(pe);
+#pragma unroll
+        for (int d2 = 0; d2 < 2; ++d2)
+          oacc[d2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(VT, PITCH, 32 * d2 + m, 32 * blk + 16 * hf, g), pf, oacc[d2], 0, 0, 0);
+      }
+    };
+    if constexpr (NB <= 2) {  // all blocks stay in registers
+      f32x16 s[NB];
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk) {
+        scores(blk, s[blk]);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[blk][e]);
+      }
+      mx = fmaxf(mx, xor32(mx));
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float pe = exp2_fast(s[blk][e] - mx);
+          s[blk][e] = pe;
+          sum += pe;
+        }
+        apply(blk, s[blk]);
+      }
+    } else {  // two passes over the key blocks (the scores are recomputed: 32 more matrix instructions per tile against 128
+              // accumulator registers - two workgroups per CU need <= 256 registers per lane)
+#pragma unroll 1
+      for (int blk = 0; blk < NB; ++blk) {
+        f32x16 sb;
+        scores(blk, sb);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sb[e]);
+      }
+      mx = fmaxf(mx, xor32(mx));
+#pragma unroll 1
+      for (int blk = 0; blk < NB; ++blk) {
+        f32x16 sb;
+        scores(blk, sb);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float pe = exp2_fast(sb[e] - mx);
+          sb[e] = pe;
+          sum += pe;
+        }
+        apply(blk, sb);
+      }
+    }
+    sum += xor32(sum);
+    if (qi < p.N) {
+      const float inv = 1.f / sum;
+      bf16_t* orow = p.o + ((long long)b * p.N + qi) * C + h * kHD + 4 * g;
+#pragma unroll
+      for (int d2 = 0; d2 < 2; ++d2)
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4) {
+          const u2v w = {pack_rne(oacc[d2][4 * j4] * inv, oacc[d2][4 * j4 + 1] * inv), pack_rne(oacc[d2][4 * j4 + 2] * inv, oacc[d2][4 * j4 + 3] * inv)};
+          *reinterpret_cast<u2v*>(orow + 32 * d2 + 8 * j4) = w;
+        }
+      if (g == 0 && p.lse2) p.lse2[((long long)b * p.H + h) * p.Npad + qi] = mx + __log2f(sum);
+    }
+  }
+  combo_ts_end(p.ts);
+}
+
+// ------------------------------------------------------------------------------------------------------------------ backward: dq (+ D)
+template <int NB>
+__global__ void __launch_bounds__(256, 2)
+sra_bwd_dq_kernel(const SraArgs p) {
+  constexpr int NKP = 32 * NB, PITCH = 2 * NKP + 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  combo_ts_begin(p.ts);
+  char* Krm = smem;
+  char* Vrm = smem + NKP * 128;
+  char* KT = smem + 2 * NKP * 128;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 31, g = lane >> 5;
+  const int id = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int chunk = id % p.chunks, bh = id / p.chunks;
+  const int h = bh % p.H, b = bh / p.H;
+  const long long C = (long long)p.H * kHD;
+  stage_rows<256>(Krm, p.kv, b, h, 0, p.Nk, NKP, p.H);
+  stage_rows<256>(Vrm, p.kv, b, h, 1, p.Nk, NKP, p.H);
+  stage_transposed<256>(KT, p.kv, b, h, 0, p.Nk, NKP, p.H);
+  __syncthreads();
+  const int n_tiles = (p.N + 31) >> 5;
+  const int t_end = min(n_tiles, (chunk + 1) * p.tiles_per_chunk);
+  for (int t = chunk * p.tiles_per_chunk + wave; t < t_end; t += 4) {
+    const int q0 = t * 32, qi = q0 + m;
+    const long long roff = ((long long)b * p.N + min(qi, p.N - 1)) * C + h * kHD + 8 * g;
+    bf16x8 qf[4], gf[4];
+    float dsum = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      qf[kk] = *reinterpret_cast<const bf16x8*>(p.q + roff + 16 * kk);
+      gf[kk] = *reinterpret_cast<const bf16x8*>(p.dout + roff + 16 * kk);
+      const u4v ov = *reinterpret_cast<const u4v*>(p.o + roff + 16 * kk), gv = __builtin_bit_cast(u4v, gf[kk]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dsum += bf_lo(ov[i]) * bf_lo(gv[i]) + bf_hi(ov[i]) * bf_hi(gv[i]);
+    }
+    dsum += xor32(dsum);  // D[q] = sum_d dO[q, d] O[q, d] (the two lanes of a query hold 32 channels each)
+    const long long sidx = ((long long)b * p.H + h) * p.Npad + qi;
+    const float l2 = qi < p.N ? p.lse2[sidx] : 3.0e38f;  // a query row beyond N: P = exp2(-inf) = 0
+    if (g == 0) p.delta[sidx] = qi < p.N ? dsum : 0.f;
+    f32x16 qacc[2];
+#pragma unroll
+    for (int d2 = 0; d2 < 2; ++d2)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) qacc[d2][e] = 0.f;
+#pragma unroll(NB <= 2 ? NB : 1)
+    for (int blk = 0; blk < NB; ++blk) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Krm, 32 * blk + m, kk, g), qf[kk], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Vrm, 32 * blk + m, kk, g), gf[kk], dp, 0, 0, 0);
+      }
+      const bool ragged = 32 * blk + 32 > p.Nk;
+      float ds[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float pe = exp2_fast(s[e] * p.c - l2);
+        if (ragged && 32 * blk + 8 * (e >> 2) + 4 * g + (e & 3) >= p.Nk) pe = 0.f;
+        ds[e] = pe * (dp[e] - dsum);
+      }
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const bf16x8 df = pack8(ds + 8 * hf);
+#pragma unroll
+        for (int d2 = 0; d2 < 2; ++d2)
+          qacc[d2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(KT, PITCH, 32 * d2 + m, 32 * blk + 16 * hf, g), df, qacc[d2], 0, 0, 0);
+      }
+    }
+    if (qi < p.N) {
+      bf16_t* drow = p.dq + ((long long)b * p.N + qi) * C + h * kHD + 4 * g;
+#pragma unroll
+      for (int d2 = 0; d2 < 2; ++d2)
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4) {
+          const u2v w = {pack_rne(qacc[d2][4 * j4] * p.scale, qacc[d2][4 * j4 + 1] * p.scale),
+                         pack_rne(qacc[d2][4 * j4 + 2] * p.scale, qacc[d2][4 * j4 + 3] * p.scale)};
+          *reinterpret_cast<u2v*>(drow + 32 * d2 + 8 * j4) = w;
+        }
+    }
+  }
+  combo_ts_end(p.ts);
+}
+
+// ------------------------------------------------------------------------------------------------------------------ backward: dk, dv
+// NB key blocks over NWK waves (KB = NB / NWK blocks each), NWQ = 4 / NWK query sub-streams; every wave writes its own partial
+template <int NB, int NWK>
+__global__ void __launch_bounds__(256, 1)
+sra_bwd_dkv_kernel(const SraArgs p) {
+  constexpr int NKP = 32 * NB, KB = NB / NWK, NWQ = 4 / NWK, TP = 72;  // TP: pitch of the transposed [64 d][32 q] tiles (bytes)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  combo_ts_begin(p.ts);
+  char* Krm = smem;
+  char* Vrm = smem + NKP * 128;
+  char* tiles = smem + 2 * NKP * 128;  // per query sub-stream: Q^T and dO^T tiles, 64 x TP bytes each
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 31, g = lane >> 5;
+  const int wk = wave % NWK, wq = wave / NWK;
+  const int id = xcd_contiguous(blockIdx.x, gridDim.x);
+  const int chunk = id % p.chunks, bh = id / p.chunks;
+  const int h = bh % p.H, b = bh / p.H;
+  const long long C = (long long)p.H * kHD;
+  stage_rows<256>(Krm, p.kv, b, h, 0, p.Nk, NKP, p.H);
+  stage_rows<256>(Vrm, p.kv, b, h, 1, p.Nk, NKP, p.H);
+  __syncthreads();
+  char* QT = tiles + wq * (2 * 64 * TP);
+  char* GT = QT + 64 * TP;
+  f32x16 kacc[KB][2], vacc[KB][2];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+    for (int d2 = 0; d2 < 2; ++d2)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { kacc[kb][d2][e] = 0.f; vacc[kb][d2][e] = 0.f; }
+  const int n_tiles = (p.N + 31) >> 5;
+  const int t_beg = chunk * p.tiles_per_chunk, t_end = min(n_tiles, t_beg + p.tiles_per_chunk);
+  const int n_loop = (t_end - t_beg + NWQ - 1) / NWQ;  // every wave runs the same number of iterations (workgroup barriers inside)
+  for (int it = 0; it < n_loop; ++it) {
+    const int t = t_beg + it * NWQ + wq;
+    const bool live = t < t_end;
+    const int q0 = t * 32, qi = q0 + m;
+    const long long roff = ((long long)b * p.N + min(max(qi, 0), p.N - 1)) * C + h * kHD + 8 * g;
+    bf16x8 qf[4], gf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      qf[kk] = *reinterpret_cast<const bf16x8*>(p.q + roff + 16 * kk);
+      gf[kk] = *reinterpret_cast<const bf16x8*>(p.dout + roff + 16 * kk);
+    }
+    const bool row_ok = live && qi < p.N;
+    // the tile transposed into LDS (wave wk == 0 of the sub-stream writes it: lane (query m, half g) holds channels 16 kk + 8 g ..)
+    __syncthreads();  // everybody is done reading the previous tiles
+    if (wk == 0) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int d = 16 * kk + 8 * g + i;
+          *reinterpret_cast<bf16_t*>(QT + d * TP + 2 * m) = row_ok ? (bf16_t)qf[kk][i] : (bf16_t)0;
+          *reinterpret_cast<bf16_t*>(GT + d * TP + 2 * m) = row_ok ? (bf16_t)gf[kk][i] : (bf16_t)0;
+        }
+    }
+    __syncthreads();
+    if (!live) continue;  // (after both barriers)
+    // per-row statistics of this lane's 16 query rows: 8 (e >> 2) + 4 g + (e & 3)
+    float l2[16], dl[16];
+    {
+      const long long sb = ((long long)b * p.H + h) * p.Npad + q0 + 4 * g;
+#pragma unroll
+      for (int j4 = 0; j4 < 4; ++j4) {
+        const float4 a = *reinterpret_cast<const float4*>(p.lse2 + sb + 8 * j4), d4 = *reinterpret_cast<const float4*>(p.delta + sb + 8 * j4);
+        l2[4 * j4] = a.x; l2[4 * j4 + 1] = a.y; l2[4 * j4 + 2] = a.z; l2[4 * j4 + 3] = a.w;
+        dl[4 * j4] = d4.x; dl[4 * j4 + 1] = d4.y; dl[4 * j4 + 2] = d4.z; dl[4 * j4 + 3] = d4.w;
+      }
+    }
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const int blk = wk * KB + kb;
+      f32x16 s, dp;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {  // rows = queries, columns = keys: the forward's operands swapped
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[kk], frag_rows(Krm, 32 * blk + m, kk, g), s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[kk], frag_rows(Vrm, 32 * blk + m, kk, g), dp, 0, 0, 0);
+      }
+      const bool key_ok = 32 * blk + m < p.Nk;  // this lane's key column
+      float pe[16], ds[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int qr = q0 + 8 * (e >> 2) + 4 * g + (e & 3);
+        float v = exp2_fast(s[e] * p.c - l2[e]);
+        if (!key_ok || qr >= p.N) v = 0.f;
+        pe[e] = v;
+        ds[e] = v * (dp[e] - dl[e]);
+      }
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const bf16x8 pf = pack8(pe + 8 * hf), df = pack8(ds + 8 * hf);
+#pragma unroll
+        for (int d2 = 0; d2 < 2; ++d2) {
+          vacc[kb][d2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(GT, TP, 32 * d2 + m, 16 * hf, g), pf, vacc[kb][d2], 0, 0, 0);
+          kacc[kb][d2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(QT, TP, 32 * d2 + m, 16 * hf, g), df, kacc[kb][d2], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // partials: part[bh][chunk * NWQ + wq][which][key][d] fp32; D layout: lane = key column, 4 consecutive channels per store
+  float* pb = p.part + (((long long)bh * (p.chunks * NWQ) + chunk * NWQ + wq) * 2) * NKP * kHD;
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    const int key = 32 * (wk * KB + kb) + m;
+#pragma unroll
+    for (int d2 = 0; d2 < 2; ++d2)
+#pragma unroll
+      for (int j4 = 0; j4 < 4; ++j4) {
+        const int d = 32 * d2 + 8 * j4 + 4 * g;
+        *reinterpret_cast<float4*>(pb + (long long)key * kHD + d) =
+            make_float4(kacc[kb][d2][4 * j4], kacc[kb][d2][4 * j4 + 1], kacc[kb][d2][4 * j4 + 2], kacc[kb][d2][4 * j4 + 3]);
+        *reinterpret_cast<float4*>(pb + (long long)NKP * kHD + (long long)key * kHD + d) =
+            make_float4(vacc[kb][d2][4 * j4], vacc[kb][d2][4 * j4 + 1], vacc[kb][d2][4 * j4 + 2], vacc[kb][d2][4 * j4 + 3]);
+      }
+  }
+  combo_ts_end(p.ts);
+}
+
+// dkv[b, key, which, h, :] = bf16(sum over the partials in a fixed order (* scale for dk))
+__global__ void __launch_bounds__(256)
+sra_dkv_finish(const float* __restrict__ part, int n_part, int NKP, int B, int Nk, int H, float scale, bf16_t* __restrict__ dkv) {
+  const long long i = blockIdx.x * 256LL + threadIdx.x;  // one thread = 4 channels of (bh, which, key)
+  const long long total = (long long)B * H * 2 * Nk * 16;
+  if (i >= total) return;
+  const int c4 = (int)(i & 15);
+  long long r = i >> 4;
+  const int key = (int)(r % Nk); r /= Nk;
+  const int which = (int)(r & 1); r >>= 1;
+  const int h = (int)(r % H), b = (int)(r / H);
+  const long long bh = (long long)b * H + h;
+  const float* src = part + ((bh * n_part) * 2 + which) * (long long)NKP * kHD + (long long)key * kHD + c4 * 4;
+  float4 a = *reinterpret_cast<const float4*>(src);
+  for (int z = 1; z < n_part; ++z) {
+    const float4 v = *reinterpret_cast<const float4*>(src + (long long)z * 2 * NKP * kHD);
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  const float f = which == 0 ? scale : 1.f;
+  const u2v w = {pack_rne(a.x * f, a.y * f), pack_rne(a.z * f, a.w * f)};
+  *reinterpret_cast<u2v*>(dkv + (((long long)b * Nk + key) * 2 + which) * H * kHD + (long long)h * kHD + c4 * 4) = w;
+}
+
+int n_cu_sra() {
+  static const int n = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    return cus > 0 ? cus : 256;
+  }();
+  return n;
+}
+
+int nb_of(int Nk) { return Nk <= 64 ? 2 : (Nk <= 128 ? 4 : (Nk <= 256 ? 8 : 0)); }
+
+// chunks of query tiles per (frame, head): enough workgroups to fill the chip a few times over, not more than the tiles
+void plan_chunks(int B, int H, int N, int want_wg, int min_tiles, int& chunks, int& tpc) {
+  const int n_tiles = (N + 31) / 32;
+  long long c = ((long long)want_wg + (long long)B * H - 1) / ((long long)B * H);
+  if (c < 1) c = 1;
+  long long per = (n_tiles + c - 1) / c;
+  if (per < min_tiles) per = min_tiles;
+  if (per > n_tiles) per = n_tiles;
+  tpc = (int)per;
+  chunks = (n_tiles + tpc - 1) / tpc;
+}
+
+template <typename K>
+int set_lds(K kern, size_t bytes) {
+  return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+}  // namespace
+
+extern "C" {
+
+/* 1 when the kernels take this geometry (head dimension 64, <= 256 keys); else the caller keeps its library path */
+int combo_sra_attention_ok(int N, int Nk, int head_dim) { return (head_dim == kHD && N > 0 && Nk > 0 && nb_of(Nk) > 0) ? 1 : 0; }
+
+/* fp32 elements of the backward workspace `part` for this problem (dk / dv partials per chunk) */
+long long combo_sra_attention_backward_workspace(int B, int N, int Nk, int H) {
+  const int NB = nb_of(Nk);
+  if (NB == 0 || B <= 0 || N <= 0 || H <= 0) return 0;
+  int chunks, tpc;
+  plan_chunks(B, H, N, 3 * n_cu_sra(), NB == 2 ? 8 : 4, chunks, tpc);
+  const int nwq = NB == 2 ? 2 : (NB == 4 ? 2 : 1);
+  return (long long)B * H * chunks * nwq * 2 * (32LL * NB) * kHD;
+}
+
+int combo_sra_attention_forward_bf16(const void* q, const void* kv, void* out, float* lse2, int B, int N, int Nk, int H, float scale,
+                                     combo_stream_t stream) {
+  const int NB = nb_of(Nk);
+  if (!q || !kv || !out || B <= 0 || N <= 0 || H <= 0 || NB == 0 || ((uintptr_t)q & 15) || ((uintptr_t)kv & 15) || ((uintptr_t)out & 7))
+    return COMBO_EINVAL;
+  SraArgs a{};
+  a.q = (const bf16_t*)q; a.kv = (const bf16_t*)kv; a.o = (bf16_t*)out; a.lse2 = lse2;
+  a.B = B; a.N = N; a.Nk = Nk; a.H = H; a.Npad = (N + 31) & ~31;
+  a.c = scale * 1.4426950408889634f; a.scale = scale;
+  plan_chunks(B, H, N, 4 * n_cu_sra(), 4, a.chunks, a.tiles_per_chunk);
+  const long long grid = (long long)B * H * a.chunks;
+  if (grid > 0x7fffffffLL) return COMBO_EINVAL;
+  a.ts = nullptr;  // (not one of bench.py's instrumented families: its attention kinds are priced against the fp32 matrix peak)
+  const size_t lds = (size_t)32 * NB * 128 + (size_t)64 * (64 * NB + 8);
+  int e = 0;
+#define SRA_FWD(NB_)                                                                                                      \
+  {                                                                                                                       \
+    static bool attr = false;                                                                                             \
+    if (!attr) { e = set_lds(sra_fwd_kernel<NB_>, lds); attr = e == 0; }                                                   \
+    if (e == 0) hipLaunchKernelGGL(sra_fwd_kernel<NB_>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a);     \
+  }
+  if (NB == 2) SRA_FWD(2) else if (NB == 4) SRA_FWD(4) else SRA_FWD(8)
+#undef SRA_FWD
+  return e ? e : (int)hipGetLastError();
+}
+
+/* dq [B, N, H*64], dkv [B, Nk, 2, H, 64] from dout; delta: [B, H, Npad] fp32 workspace (Npad = N rounded up to 32), part:
+ * combo_sra_attention_backward_workspace floats.  Deterministic (no atomics). */
+int combo_sra_attention_backward_bf16(const void* q, const void* kv, const void* out, const void* dout, const float* lse2, float* delta,
+                                      float* part, void* dq, void* dkv, int B, int N, int Nk, int H, float scale, combo_stream_t stream) {
+  const int NB = nb_of(Nk);
+  if (!q || !kv || !out || !dout || !lse2 || !delta || !part || !dq || !dkv || B <= 0 || N <= 0 || H <= 0 || NB == 0 ||
+      ((uintptr_t)q & 15) || ((uintptr_t)kv & 15) || ((uintptr_t)out & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dq & 7) ||
+      ((uintptr_t)dkv & 7) || ((uintptr_t)part & 15) || ((uintptr_t)lse2 & 15) || ((uintptr_t)delta & 15))
+    return COMBO_EINVAL;
+  SraArgs a{};
+  a.q = (const bf16_t*)q; a.kv = (const bf16_t*)kv; a.o = (bf16_t*)const_cast<void*>(out); a.lse2 = const_cast<float*>(lse2);
+  a.dout = (const bf16_t*)dout; a.delta = delta; a.dq = (bf16_t*)dq; a.part = part; a.dkv = (bf16_t*)dkv;
+  a.B = B; a.N = N; a.Nk = Nk; a.H = H; a.Npad = (N + 31) & ~31;
+  a.c = scale * 1.4426950408889634f; a.scale = scale;
+  int e = 0;
+  // ---- dq (+ D)
+  plan_chunks(B, H, N, 4 * n_cu_sra(), 4, a.chunks, a.tiles_per_chunk);
+  long long grid = (long long)B * H * a.chunks;
+  if (grid > 0x7fffffffLL) return COMBO_EINVAL;
+  size_t lds = (size_t)2 * 32 * NB * 128 + (size_t)64 * (64 * NB + 8);
+#define SRA_DQ(NB_)                                                                                                          \
+  {                                                                                                                          \
+    static bool attr = false;                                                                                                \
+    if (!attr) { e = set_lds(sra_bwd_dq_kernel<NB_>, lds); attr = e == 0; }                                                   \
+    if (e == 0) hipLaunchKernelGGL(sra_bwd_dq_kernel<NB_>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a);     \
+  }
+  if (NB == 2) SRA_DQ(2) else if (NB == 4) SRA_DQ(4) else SRA_DQ(8)
+#undef SRA_DQ
+  if (e) return e;
+  // ---- dk, dv partials + the fixed-order finish
+  plan_chunks(B, H, N, 3 * n_cu_sra(), NB == 2 ? 8 : 4, a.chunks, a.tiles_per_chunk);
+  grid = (long long)B * H * a.chunks;
+  const int nwq = NB == 2 ? 2 : (NB == 4 ? 2 : 1);
+  lds = (size_t)2 * 32 * NB * 128 + (size_t)nwq * 2 * 64 * 72;
+#define SRA_DKV(NB_, NWK_)                                                                                                          \
+  {                                                                                                                                 \
+    static bool attr = false;                                                                                                       \
+    if (!attr) { e = set_lds(sra_bwd_dkv_kernel<NB_, NWK_>, lds); attr = e == 0; }                                                   \
+    if (e == 0) hipLaunchKernelGGL((sra_bwd_dkv_kernel<NB_, NWK_>), dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a);   \
+  }
+  if (NB == 2) SRA_DKV(2, 2) else if (NB == 4) SRA_DKV(4, 2) else SRA_DKV(8, 4)
+#undef SRA_DKV
+  if (e) return e;
+  const long long n4 = (long long)B * H * 2 * Nk * 16;
+  hipLaunchKernelGGL(sra_dkv_finish, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part, a.chunks * nwq, 32 * NB, B,
+                     Nk, H, scale, (bf16_t*)dkv);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

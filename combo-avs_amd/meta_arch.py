@@ -147,7 +147,11 @@ class MaskFormer(nn.Module):
 
     def forward(self, batched_inputs):
         dev = self.device
-        if self.is_avss_data:
+        # (a captured AVSS step: the flag values were read before the capture and arrive as constant index tensors - the flag
+        #  tensors themselves, CPU tensors when they come straight from the dataset mapper, are not touched inside the capture)
+        avss_index = getattr(self, "avss_static_index", None) if (self.is_avss_data and self.training) else None
+        vid_flag = gt_flag = None
+        if self.is_avss_data and avss_index is None:
             vid_flag = torch.cat([b["vid_temporal_mask_flag"] for b in batched_inputs], dim=0).to(dev)
             gt_flag = torch.cat([b["gt_temporal_mask_flag"] for b in batched_inputs], dim=0).to(dev)
         images = torch.cat([b["images"].to(dev, non_blocking=True) for b in batched_inputs], dim=0)
@@ -160,7 +164,6 @@ class MaskFormer(nn.Module):
         with torch.no_grad(), amp:
             audio_feature = self.audio_backbone(audio_log_mels).float()  # :327-328
         audio_feature = audio_feature.unsqueeze(1)
-        avss_index = getattr(self, "avss_static_index", None) if self.is_avss_data else None
         if self.is_avss_data:
             # maskformer_model.py:330-331: the audio rows of the frames that exist.  Boolean indexing reads the flag VALUES on the
             # host (a synchronisation: not capturable); trainer.GraphedTrainStep reads them once per step before the graph

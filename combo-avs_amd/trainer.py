@@ -556,8 +556,12 @@ class GraphedTrainStep:
         try:
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
+            # a further signature of the same model (AVSS: other instance counts per frame): libraries and lazy state are warm, and
+            # eager iterations next to the first graph's pool would not fit at 512 x 512 (200 GB of pool + 100 GB of eager
+            # activations) - captured directly, allocating from the shared pool
+            n_warm = self.warmup_iters if self._pool is None else 0
             with torch.cuda.stream(side):
-                for _ in range(self.warmup_iters):  # autotuning / lazy initialisation outside the capture
+                for _ in range(n_warm):  # autotuning / lazy initialisation outside the capture
                     if cut:
                         with grouped_presplit():
                             _, cg = self._fwd_early(static_batch)
@@ -566,6 +570,8 @@ class GraphedTrainStep:
                         self._fwd_bwd(static_batch)
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
+            if torch.cuda.memory_reserved(dev) > 0.3 * torch.cuda.get_device_properties(dev).total_memory:
+                torch.cuda.empty_cache()  # the eager iterations' cached blocks (two streams' worth) back to the runtime: the pool needs them
             graph = torch.cuda.CUDAGraph()
             # graphs of different input signatures (AVSS: instance counts per frame vary from batch to batch) replay one after
             # the other, never concurrently: they share ONE memory pool - the second capture reuses the activations' blocks of

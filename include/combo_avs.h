@@ -504,6 +504,25 @@ int combo_splitk_reduce_f32(const float* partials, int splits, long long n, floa
 int combo_splitk_reduce_nchw_f32(const float* partials, int splits, int Cout, int taps, int Cin, float* out, combo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * f2  Spatial-reduction attention of the PVTv2 backbone (models/modeling/backbone/pvtv2.py:60-132, linear = False):
+ *   softmax(q k^T * scale) v per (frame, head), head dimension 64, FEW keys (the token grid reduced by the strided sr x sr
+ *   convolution: 49 keys at 224 x 224, 256 at 512 x 512; <= 256 here), bf16 operands, fp32 accumulation, no mask, no dropout
+ *   (attn_drop = 0 in every shipped config).  Replaces F.scaled_dot_product_attention of the host-PyTorch backbone, reading the
+ *   projections' outputs where they lie:
+ *     q   [B, N, H*64] bf16    kv [B, Nk, 2, H, 64] bf16 (k = [:, :, 0], v = [:, :, 1])    out [B, N, H*64] bf16
+ *     lse2 [B, H, Npad] fp32 (Npad = N rounded up to 32): log2 of the softmax denominator of the scaled scores (base 2)
+ *   backward: dq [B, N, H*64], dkv [B, Nk, 2, H, 64] (the kv projection's gradient in one tensor); delta [B, H, Npad] and
+ *   part [combo_sra_attention_backward_workspace floats] are workspaces.  No atomics: bitwise reproducible.
+ *   combo_sra_attention_ok: 1 when the geometry is taken (else the caller keeps its own path).
+ * ---------------------------------------------------------------------------------------------- */
+int combo_sra_attention_ok(int N, int Nk, int head_dim);
+long long combo_sra_attention_backward_workspace(int B, int N, int Nk, int H);
+int combo_sra_attention_forward_bf16(const void* q, const void* kv, void* out, float* lse2, int B, int N, int Nk, int H, float scale,
+                                     combo_stream_t stream);
+int combo_sra_attention_backward_bf16(const void* q, const void* kv, const void* out, const void* dout, const float* lse2, float* delta,
+                                      float* part, void* dq, void* dkv, int B, int N, int Nk, int H, float scale, combo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * a12  masked multi-head attention of the decoder layers, head_dim = 32 (csrc/attention.hip)
  *   replaces nn.MultiheadAttention's core `softmax(q k^T * scale + mask) v` as called by CrossAttentionLayer / SelfAttentionLayer
  *   (transformer_decoder/transformer_decoder.py:99-118, 50-58; the packed in_proj / out_proj GEMMs are combo_gemm_nt_f32).
