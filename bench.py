@@ -164,26 +164,31 @@ def cpu_baseline(timeout_s=300):
                 "sample": f"one oracle step did not finish within {timeout_s} s on this host"}
 
 
-def other_workloads(timeout_s=420):
-    """BASELINE configs[4] and configs[3] at their full per-GPU size, 5 timed steps each (after 2 warm-up steps), each in a child
-    process of its own (a fresh HIP context: started as a child, never exec'ed) -> [{name, workload, ms_per_step, frames_per_s,
-    dtype, launch}].  Bounded: a hard timeout per child; a failed child is reported, not fatal."""
+def other_workloads(budget_s=400):
+    """BASELINE configs[4] and configs[3] at their full per-GPU size (5 timed steps each after 2 warm-up steps) and the default
+    workload with the library's backbone forward (the A/B beside `value`), each in a child process of its own (a fresh HIP context:
+    started as a child, never exec'ed) -> [{name, workload, ms_per_step, frames_per_s, dtype, launch}].  Bounded: the children
+    share ONE wall-clock budget (a child gets what is left, at least 45 s; a child that runs out is reported as such, later
+    ones as skipped) - the default `python bench.py` must finish within minutes; a failed child is reported, not fatal."""
     import subprocess
     out = []
-    runs = [("pvt_ms3_t10", ["--config", "pvt_ms3_t10", "--steps", "5", "--warmup", "2"]),
-            ("pvt_avss_512", ["--config", "pvt_avss_512", "--steps", "5", "--warmup", "2"]),
-            # the price of the 3-product backbone forward (`dtype_detail`): the default workload with the backbones' forward
-            # convolutions on the library's exact-fp32 kernels (ops.convwrw.FWD_X3 = False), everything else unchanged
-            ("r50_s4_library_backbone_forward", ["--config", "r50_s4", "--library-backbone-forward", "--steps", "10", "--warmup", "3"])]
+    runs = [("r50_s4_library_backbone_forward", ["--config", "r50_s4", "--library-backbone-forward", "--steps", "10", "--warmup", "3"]),
+            ("pvt_ms3_t10", ["--config", "pvt_ms3_t10", "--steps", "5", "--warmup", "2"]),
+            ("pvt_avss_512", ["--config", "pvt_avss_512", "--steps", "5", "--warmup", "2"])]
     notes = {"pvt_avss_512": "the reference trains AVSS under fp16 autocast (configs/avs_ss/PVT-AVSS-SemanticSegmentation.yaml:41-42: "
                              "SOLVER.AMP.ENABLED True); here: bf16 autocast backbones + the fp32 head - no golden vector covers an AMP run",
              "r50_s4_library_backbone_forward": "BASELINE configs[1] with the R50 / VGGish forward convolutions on the library's fp32 kernels "
                                                 "instead of the own 3-product kernels: the A/B beside `value`"}
+    t_all = time.perf_counter()
     for name, extra in runs:
+        left = budget_s - (time.perf_counter() - t_all)
+        if left < 45:
+            out.append({"name": name, "error": f"skipped: the {budget_s} s budget of the side workloads is spent"})
+            continue
         cmd = [sys.executable, os.path.abspath(__file__)] + extra + ["--no-cpu-baseline", "--no-other-workloads"]
         t0 = time.perf_counter()
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=left, cwd=ROOT)
             lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
             if r.returncode != 0 or not lines:
                 out.append({"name": name, "error": (r.stderr.strip().splitlines() or ["no JSON line"])[-1][:300]})
@@ -195,7 +200,7 @@ def other_workloads(timeout_s=420):
             if name in notes:
                 out[-1]["note"] = notes[name]
         except subprocess.TimeoutExpired:
-            out.append({"name": name, "error": f"did not finish within {timeout_s} s"})
+            out.append({"name": name, "error": f"did not finish within the {left:.0f} s left of the side workloads' budget"})
     return out
 
 
@@ -483,7 +488,8 @@ def main():
         # find pass).  HIP cannot record events inside a captured graph, so the instrumented kernels (GEMMs, MSDeformAttn
         # core, decoder attention) time themselves: every launch gets a slot {min start, done, sum of ticks, launches} of
         # `ts_buf`; graph nodes keep theirs over the replays (csrc/combo_common.h, csrc/timing.hip)
-        graphed = GraphedTrainStep(model, opt)
+        # AVSS: 1 .. 4 instances per frame in the synthetic batches - padded to 4 so that every batch replays the same graph
+        graphed = GraphedTrainStep(model, opt, pad_targets_to=4 if wl["avss"] else None)
         trace("model built")
         train_step(model, opt, batch)  # eager: MIOpen find / lazy init
         trace("eager step done")
@@ -492,10 +498,6 @@ def main():
         try:
             graphed(batch)  # captures
             trace("captured + first replayed step done")
-            if wl["avss"]:  # instance counts per frame differ from batch to batch: one graph per signature, all captured before
-                for b_ in batches[1:]:  # the timed region (they share one memory pool, trainer.GraphedTrainStep._capture)
-                    graphed(b_)
-                trace("%d graphs captured" % len(graphed.graphs))
             step = graphed
         except Exception as exc:  # noqa: BLE001 - a failed capture must not cost the run: fall back to eager launches
             print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eager", file=sys.stderr, flush=True)
@@ -702,8 +704,8 @@ def main():
                            "2 hipGraphs (fwd + loss + head bwd | backbone bwd; the head's gradient all-reduce overlaps the second; AdamW eager)"
                            if dist.is_initialized() and os.environ.get("COMBO_DP_OVERLAP", "1") == "1" else
                            "hipGraph (fwd+loss+bwd captured; all-reduce + AdamW eager)"
-                           + (f"; {len(graphed.graphs)} graphs = one per (instance counts per frame, flag values) signature of the {len(batches)} "
-                              "rotated batches, sharing one memory pool" if graphed is not None and len(graphed.graphs) > 1 else "")),
+                           + ("; per-frame instance lists padded to 4 (real counts in a device tensor): one graph for all batches"
+                              if graphed is not None and graphed.pad_targets_to else "")),
                        "instrumentation": "the instrumented kernels' timing atomics (2 per workgroup) and one fold launch per step run "
                                           "inside the timed region" if slot_timing else "HIP events around the MSDeformAttn core",
                        "arithmetic": "forward GEMMs / convolutions / attention of the head in exact fp32 on v_mfma_f32_* (peak 157.3 "

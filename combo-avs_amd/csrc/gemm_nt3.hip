@@ -59,6 +59,27 @@ __device__ __forceinline__ f4v lds_read128(unsigned addr) {  // inline asm: hipc
 }
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// s_waitcnt vmcnt(n) for a run-time n (the immediate is a 6-bit field): rounds n DOWN to one of a few values - waiting for more
+// than necessary is always correct
+__device__ __forceinline__ void wait_vm_upto(int n) {
+  if (n >= 48) wait_vm<48>();
+  else if (n >= 36) wait_vm<36>();
+  else if (n >= 30) wait_vm<30>();
+  else if (n >= 24) wait_vm<24>();
+  else if (n >= 20) wait_vm<20>();
+  else if (n >= 16) wait_vm<16>();
+  else if (n >= 15) wait_vm<15>();
+  else if (n >= 12) wait_vm<12>();
+  else if (n >= 10) wait_vm<10>();
+  else if (n >= 9) wait_vm<9>();
+  else if (n >= 8) wait_vm<8>();
+  else if (n >= 6) wait_vm<6>();
+  else if (n >= 5) wait_vm<5>();
+  else if (n >= 4) wait_vm<4>();
+  else if (n >= 3) wait_vm<3>();
+  else if (n >= 2) wait_vm<2>();
+  else wait_vm<0>();
+}
 __device__ __forceinline__ void glds16(const float* g, char* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
@@ -106,7 +127,7 @@ struct N3Args {
 // P3: three products (fp32-accurate) or one (plain bf16); ABL: ablation bits, COMPILE-TIME (a run-time test per bit costs a scalar
 // branch per use, ~1 000 cycles per stage in total - more than the stage itself): 1 no DMA, 2 no LDS reads, 4 no barrier, 8 no
 // stores, 16 no split, 32 no MFMA; the instances listed in launch_cfg3 exist (COMBO_NT3_DBG, tools/bench_nt3.py)
-template <bool CONV, typename Cfg, bool P3, int ABL>
+template <bool CONV, typename Cfg, bool P3, int ABL, bool AUX>
 __global__ void __launch_bounds__(Cfg::NW * 64, Cfg::NW / 4)
 gemm_nt3_kernel(const N3Args p) {
   constexpr int NW = Cfg::NW;
@@ -343,6 +364,38 @@ gemm_nt3_kernel(const N3Args p) {
 
   // ---------------- epilogue of one tile: lane (token r, half g) owns n = 8q + 4g + (0..3), q = 0..3, of every sub-tile ----------------
   struct EpiCtx { int m_blk, n_blk, bi; };
+  // Early auxiliary operand (round 5).  The epilogue's `add` / `mask` loads used to be issued in the epilogue, i.e. BEHIND the
+  // ST - 1 stages of the next tile already streaming into the ring (120 KiB per CU for the wide tile): the wait for them was a
+  // wait for the whole ring - one pipeline refill per tile, 5 us against 2.6 us of matrix work at K = 256 (the FFN's masked dX GEMM ran
+  // at 2.2 x its HBM time).  Now ONE of the two operands (add if present, else mask) is requested ST - 1 stages before the tile
+  // ends, in front of the next tile's first stage: by the epilogue it has landed, and the counted waits in between allow its
+  // AUXN loads to stay outstanding (they are younger than every ring load those stages need).  Costs TI * TJ * 16 registers.
+  // (not on the 8-wave convolution instance: its 256-register budget has no room for them - 60 spilled registers - and it keeps
+  //  the in-epilogue loads)
+  // AUX: an instance of its own (the request's addressing costs the plain launches ~40 spilled scalar registers otherwise)
+  constexpr bool AUX_OK = AUX && !(CONV && NW == 8);
+  constexpr int AUXN = AUX_OK ? TI * TJ * 4 : 0;
+  u4v aux[AUX_OK ? TI : 1][AUX_OK ? TJ : 1][4];
+  const bool aux_is_add = p.add != nullptr;
+  const bool aux_early = AUX_OK && p.vec_store && (p.add || p.mask) && !(dbg & 8);
+  auto aux_request = [&](const EpiCtx& ec) __attribute__((always_inline)) {
+    if constexpr (!AUX_OK) return;
+    const float* src = aux_is_add ? p.add : p.mask;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src + ec.bi * p.sC), 0, p.c_bytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const int row = ec.m_blk + (wm * TI + i) * 32 + r;
+        const int nb = ec.n_blk + (wn * TJ + j) * 32 + 4 * g;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n0 = nb + 8 * q;
+          const unsigned off = n0 < N ? ((unsigned)row * (unsigned)p.ldc + (unsigned)n0) * 4u : 0xfffffff0u;
+          aux[AUX_OK ? i : 0][AUX_OK ? j : 0][q] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, off, 0, 0);
+        }
+      }
+  };
   auto epilogue = [&](const EpiCtx& ec) __attribute__((always_inline)) {
     const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.C + ec.bi * p.sC, 0, p.c_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t m_rsrc =
@@ -378,11 +431,16 @@ gemm_nt3_kernel(const N3Args p) {
           }
           u4v mv[4];
           if (p.add) {
+            if (AUX_OK && aux_early) {  // (requested ST - 1 stages ago: aux_request)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int n0 = nb + 8 * q;
-              const unsigned off = n0 < N ? ((unsigned)row * (unsigned)p.ldc + (unsigned)n0) * 4u : 0xfffffff0u;
-              mv[q] = __builtin_amdgcn_raw_buffer_load_b128(d_rsrc, off, 0, 0);
+              for (int q = 0; q < 4; ++q) mv[q] = aux[AUX_OK ? i : 0][AUX_OK ? j : 0][q];
+            } else {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int n0 = nb + 8 * q;
+                const unsigned off = n0 < N ? ((unsigned)row * (unsigned)p.ldc + (unsigned)n0) * 4u : 0xfffffff0u;
+                mv[q] = __builtin_amdgcn_raw_buffer_load_b128(d_rsrc, off, 0, 0);
+              }
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] += __builtin_bit_cast(f4v, mv[q]);
@@ -395,11 +453,16 @@ gemm_nt3_kernel(const N3Args p) {
           }
           if (p.mask) {
             __builtin_amdgcn_sched_barrier(0);  // (the mask loads reuse the registers of the add loads: keep them behind)
+            if (AUX_OK && aux_early && !aux_is_add) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int n0 = nb + 8 * q;
-              const unsigned off = n0 < N ? ((unsigned)row * (unsigned)p.ldc + (unsigned)n0) * 4u : 0xfffffff0u;
-              mv[q] = __builtin_amdgcn_raw_buffer_load_b128(m_rsrc, off, 0, 0);
+              for (int q = 0; q < 4; ++q) mv[q] = aux[AUX_OK ? i : 0][AUX_OK ? j : 0][q];
+            } else {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int n0 = nb + 8 * q;
+                const unsigned off = n0 < N ? ((unsigned)row * (unsigned)p.ldc + (unsigned)n0) * 4u : 0xfffffff0u;
+                mv[q] = __builtin_amdgcn_raw_buffer_load_b128(m_rsrc, off, 0, 0);
+              }
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -441,13 +504,16 @@ gemm_nt3_kernel(const N3Args p) {
   constexpr int kYoung = (ST - 3) * PPW;
   constexpr bool p3 = P3;
   int c_slot = 0;  // ring slot of the stage being computed
-  auto stage = [&](auto par_tag, bool first, bool relaxed) __attribute__((always_inline)) {
+  auto stage = [&](auto par_tag, bool first, bool relaxed, bool auxw) __attribute__((always_inline)) {
     constexpr int PAR = decltype(par_tag)::value;
     const int n_slot = c_slot == ST - 1 ? 0 : c_slot + 1;
     // stage s + 1 (a real one or a dummy of the stream's tail - nothing below needs to know) has landed once all but the ST - 3
     // younger stages (and, right after a tile boundary, the previous tile's stores, which are younger than every load waited
     // for here) are done
-    if (relaxed) wait_vm<kYoung + Cfg::STORES>();
+    // (auxw: the early auxiliary loads of this tile are among the younger loads that may stay outstanding, see aux_request)
+    if (relaxed && auxw) wait_vm<kYoung + Cfg::STORES + AUXN>();
+    else if (relaxed) wait_vm<kYoung + Cfg::STORES>();
+    else if (auxw) wait_vm<kYoung + AUXN>();
     else wait_vm<kYoung>();
     if (!(dbg & 4)) __builtin_amdgcn_s_barrier();
     // ---- phase 0: B lo of this stage + raw A of the next -> registers; hi.hi and lo.hi products; the ring refill in between
@@ -523,7 +589,11 @@ gemm_nt3_kernel(const N3Args p) {
   split_commit(ah[0], al[0]);
 
   const int my_tiles = (tiles - w + G - 1) / G;
-  const bool relax_ok = p.vec_store && !p.mask && !p.add;
+  // (an epilogue that still loads an operand itself - add AND mask, scalar stores - waits for everything anyway)
+  const bool relax_ok = p.vec_store && !(p.mask && p.add);
+  // the auxiliary operand is requested at the top of stage s_aux = nst - (ST - 1), rounded down to an even stage (the stage loop
+  // runs in register-set pairs), 0 for short reductions; (nst - s_aux) stages are issued between the request and the epilogue
+  const int s_aux = aux_early ? (nst > ST - 1 ? (nst - (ST - 1)) & ~1 : 0) : nst + 2;
   typedef std::integral_constant<int, 0> P0;
   typedef std::integral_constant<int, 1> P1;
 #pragma unroll 1
@@ -537,8 +607,10 @@ gemm_nt3_kernel(const N3Args p) {
     // stages in pairs: even stages compute from register set 0 and prefetch into set 1, odd stages the other way round
 #pragma unroll 1
     for (int s = 0; s < nst; s += 2) {
-      stage(P0{}, s == 0, rx && s < ST - 2);
-      if (s + 1 < nst) stage(P1{}, false, rx && s + 1 < ST - 2);
+      if (s == s_aux) aux_request(ec);
+      // aux window: while the request is younger than the stage being waited for (s - s_aux <= ST - 3)
+      stage(P0{}, s == 0, rx && s < ST - 2, s >= s_aux && s - s_aux <= ST - 3);
+      if (s + 1 < nst) stage(P1{}, false, rx && s + 1 < ST - 2, s + 1 >= s_aux && s + 1 - s_aux <= ST - 3);
     }
     if (nst & 1) {  // an odd number of stages: the next tile's first operands were prefetched into set 1 - hand them to set 0
 #pragma unroll
@@ -546,6 +618,7 @@ gemm_nt3_kernel(const N3Args p) {
 #pragma unroll
       for (int j = 0; j < TJ; ++j) bh[0][j] = bh[1][j];
     }
+    if (aux_early) wait_vm_upto((nst - s_aux) * PPW);  // the auxiliary operand has landed; the stages issued since may stay in flight
     epilogue(ec);
   }
   wait_vm<0>();  // the dummy stages of the stream's tail are still landing: no LDS-DMA may outlive its workgroup's LDS allocation
@@ -568,17 +641,27 @@ int dbg_bits3() {
   return d;
 }
 
-template <bool CONV, typename Cfg, bool P3, int ABL>
-int launch_inst3(const N3Args& a, int grid, hipStream_t stream) {
+template <bool CONV, typename Cfg, bool P3, int ABL, bool AUX>
+int launch_inst3x(const N3Args& a, int grid, hipStream_t stream) {
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt3_kernel<CONV, Cfg, P3, ABL>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt3_kernel<CONV, Cfg, P3, ABL, AUX>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  hipLaunchKernelGGL((gemm_nt3_kernel<CONV, Cfg, P3, ABL>), dim3((unsigned)grid), dim3(Cfg::NW * 64), Cfg::LDS, stream, a);
+  hipLaunchKernelGGL((gemm_nt3_kernel<CONV, Cfg, P3, ABL, AUX>), dim3((unsigned)grid), dim3(Cfg::NW * 64), Cfg::LDS, stream, a);
   return (int)hipGetLastError();
+}
+
+template <bool CONV, typename Cfg, bool P3, int ABL>
+int launch_inst3(const N3Args& a, int grid, hipStream_t stream) {
+  // the early-auxiliary-operand instance: launches with a vector-store epilogue that adds or masks (not the ablation builds, not
+  // the 8-wave convolution tile: no registers for it)
+  if constexpr (ABL == 0 && !(CONV && Cfg::NW == 8)) {
+    if (a.vec_store && (a.add || a.mask)) return launch_inst3x<CONV, Cfg, P3, ABL, true>(a, grid, stream);
+  }
+  return launch_inst3x<CONV, Cfg, P3, ABL, false>(a, grid, stream);
 }
 
 template <bool CONV, typename Cfg>

@@ -25,14 +25,27 @@ struct Frag {
   bf16x8 hi, lo;
 };
 
+// Four packs per asm statement, each ending in `s_nop 1`: the fragments feed matrix instructions, and hipcc pads no hazard whose
+// producer sits inside an asm string (a VALU-written VGPR needs 2 wait states before an MFMA reads it as A / B; round 5: the same
+// unpadded pattern in csrc/sra_attention.hip gave stale operands on ~4 % of its tiles, and a scan of this file's ISA showed 7
+// v_cvt_pk -> v_mfma pairs closer than that).
+__device__ __forceinline__ void pack4(const float (&x)[8], unsigned (&r)[4]) {
+  asm("v_cvt_pk_bf16_f32 %0, %4, %5\n\tv_cvt_pk_bf16_f32 %1, %6, %7\n\tv_cvt_pk_bf16_f32 %2, %8, %9\n\tv_cvt_pk_bf16_f32 %3, %10, %11\n\ts_nop 1"
+      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
+      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
+}
+
 __device__ __forceinline__ Frag make_frag(const float (&v)[8]) {
   Frag f;
   unsigned h[4], l[4];
+  pack4(v, h);  // hi = rne_bf16(x): the dropped lo.lo term is <= 2^-16 |x.w| and unbiased
+  float res[8];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    h[t] = pack_rne(v[2 * t], v[2 * t + 1]);  // hi = rne_bf16(x): the dropped lo.lo term is <= 2^-16 |x.w| and unbiased
-    l[t] = pack_rne(v[2 * t] - __uint_as_float(h[t] << 16), v[2 * t + 1] - __uint_as_float(h[t] & 0xffff0000u));
+    res[2 * t] = v[2 * t] - __uint_as_float(h[t] << 16);
+    res[2 * t + 1] = v[2 * t + 1] - __uint_as_float(h[t] & 0xffff0000u);
   }
+  pack4(res, l);
   f.hi = __builtin_bit_cast(bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
   f.lo = __builtin_bit_cast(bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
   return f;

@@ -69,6 +69,12 @@ class SetCriterion(nn.Module):
         self.importance_sample_ratio = importance_sample_ratio
         self.n_frame = n_frame  # hard-coded 5 in the reference (criterion.py:243,284)
         self.point_source = None  # test hook
+        # Padded targets (trainer.GraphedTrainStep(pad_targets_to=G)): every frame's target list arrives padded to the same length
+        # (zero masks, label 0) and the REAL counts live in this device tensor [F] int32 - the step's shapes no longer depend on how
+        # many instances a frame holds, so ONE captured graph serves every batch (AVSS: 1 .. 4 classes per frame).  Matching is
+        # unchanged (the device LSAP takes the counts and ignores the padded columns); padded pairs carry weight 0 in the mask
+        # losses and write their class target into a dummy query.
+        self.padded_counts = None
         # test hook: {"match_src", "match_tgt": int64 [L, Nm], "topk": bool [L, Nm, oversampled points]} - the reference's own
         # Hungarian pairs and importance-sampling top-k sets (tests/golden `*/match_all_*`, `*/topk_bits`) used INSTEAD of the
         # device LSAP's / the selection kernel's, so that a gradient comparison does not hinge on a near-tie
@@ -166,7 +172,10 @@ class SetCriterion(nn.Module):
             # trainer.GraphedTrainStep: the (all-reduced, clamped) value lives in a static device tensor that is refreshed
             # outside the captured hipGraph (a host->device copy / collective cannot be part of the graph)
             return self.num_masks_override
-        num_masks = torch.as_tensor([sum(len(t["labels"]) for t in targets)], dtype=torch.float, device=device)
+        if self.padded_counts is not None:  # padded targets: the real counts (a device tensor)
+            num_masks = self.padded_counts.sum().to(torch.float).reshape(1)
+        else:
+            num_masks = torch.as_tensor([sum(len(t["labels"]) for t in targets)], dtype=torch.float, device=device)
         world = 1
         if dist.is_available() and dist.is_initialized():
             dist.all_reduce(num_masks)
@@ -284,7 +293,22 @@ class SetCriterion(nn.Module):
                 C = self.matcher.batched_cost(logits.view(L * F_, Q, -1), masks.view(L * F_, Q, *masks.shape[-2:]).float(),
                                               lab.repeat(L, 1), gt.repeat(L, 1, 1, 1), mpts)  # [L*F,Q,Gmax]
         frame = torch.cat([torch.full((g,), f, dtype=torch.int64) for f, g in enumerate(G)])
-        if self.frozen_choices is not None:
+        pair_w = None  # padded mode: [F * Gmax] weights of the (frame, slot) pairs (1 = a real target, 0 = padding)
+        if self.padded_counts is not None:
+            if self.frozen_choices is not None or Gmax > self.matcher.LSAP_DEVICE_MAX_G or len(set(G)) != 1:
+                raise ValueError("padded targets: every frame must carry the same (padded) number of targets <= the device LSAP's limit")
+            pc = self.padded_counts.to(torch.int32)
+            _, _, frame = self._static_match_index(tuple(G), L, Gmax, dev)
+            slot_ok = torch.arange(Gmax, device=dev)[None, :] < pc[:, None]  # [F, Gmax]
+            rfc = self.matcher.solve_device(C, pc.repeat(L)).view(L, F_, Gmax)
+            big = torch.where(rfc < 0, torch.full_like(rfc, 1 << 40), rfc)
+            rows, order = torch.sort(big, dim=2)  # the real pairs of a frame first, sorted by query (as scipy returns them)
+            ok = slot_ok[None].expand(L, F_, Gmax)
+            src_q = torch.where(ok, rows, torch.zeros_like(rows)).view(L, F_ * Gmax)
+            tgt_g = order.view(L, F_ * Gmax)
+            pair_w = slot_ok.reshape(-1).to(torch.float32)
+            self.last_indices = (src_q, tgt_g, frame)
+        elif self.frozen_choices is not None:
             src_q = self.frozen_choices["match_src"].to(dev)
             tgt_g = self.frozen_choices["match_tgt"].to(dev)
             frame = self._static_match_index(tuple(G), L, Gmax, dev)[2]  # cached on the device: no copy inside a captured step
@@ -316,9 +340,15 @@ class SetCriterion(nn.Module):
             src_q, tgt_g, frame = src_q.to(dev), tgt_g.to(dev), frame.to(dev)
         num_masks = self._num_masks(targets, dev)
         # ---- classification loss (criterion.py:121-135), per output ---------------------------------------------
-        target_classes = torch.full((L, F_, Q), self.num_classes, dtype=torch.int64, device=dev)
         lidx = torch.arange(L, device=dev)[:, None].expand(L, Nm)
-        target_classes[lidx, frame[None].expand(L, Nm), src_q] = lab[frame[None].expand(L, Nm), tgt_g]
+        if pair_w is None:
+            target_classes = torch.full((L, F_, Q), self.num_classes, dtype=torch.int64, device=dev)
+            target_classes[lidx, frame[None].expand(L, Nm), src_q] = lab[frame[None].expand(L, Nm), tgt_g]
+        else:  # padded pairs write into a dummy query Q that is cut away
+            target_classes = torch.full((L, F_, Q + 1), self.num_classes, dtype=torch.int64, device=dev)
+            q_ce = torch.where(pair_w[None].expand(L, Nm) > 0, src_q, torch.full_like(src_q, Q))
+            target_classes[lidx, frame[None].expand(L, Nm), q_ce] = lab[frame[None].expand(L, Nm), tgt_g]
+            target_classes = target_classes[..., :Q].contiguous()
         nll = F.cross_entropy(logits.reshape(L * F_ * Q, -1), target_classes.view(-1), reduction="none").view(L, -1)
         wgt = self.empty_weight[target_classes].view(L, -1)
         from ..ops.colsum import row_sum  # (no ATen reduction over >= 2 000 inputs inside the captured step: ops/colsum.py)
@@ -337,6 +367,8 @@ class SetCriterion(nn.Module):
             n_mid = len(outputs.get("middles_attn_mask", []))
             bce, dice, dot, nrm = maskloss.mask_and_cosine(xall, n_mid, self.n_frame, mask_index, gt, gt_index, coords)
             bce, dice = bce.view(L, Nm), dice.view(L, Nm)
+            if pair_w is not None:
+                bce, dice = bce * pair_w, dice * pair_w
             lc = None
             if n_mid:
                 nf = self.n_frame
@@ -353,6 +385,8 @@ class SetCriterion(nn.Module):
             self.last_coords = coords
         bce, dice = maskloss.mask_losses(masks32, mask_index, gt, gt_index, coords)
         bce, dice = bce.view(L, Nm), dice.view(L, Nm)
+        if pair_w is not None:
+            bce, dice = bce * pair_w, dice * pair_w
         loss_mask = bce.sum(1) / num_masks
         loss_dice = dice.sum(1) / num_masks
         return self._assemble(loss_ce, loss_mask, loss_dice, outputs)

@@ -462,9 +462,14 @@ class GraphedTrainStep:
     The returned loss dict holds STATIC tensors that the next call overwrites.
     Signatures beyond `max_graphs` fall back to the eager step."""
 
-    def __init__(self, model, optimizer, warmup_iters=2, max_graphs=4):
+    def __init__(self, model, optimizer, warmup_iters=2, max_graphs=4, pad_targets_to=None):
+        """pad_targets_to: G - every frame's instance list is padded to G entries (zero masks) before it enters the step and the
+        real counts travel in a device tensor (modeling.criterion.SetCriterion.padded_counts): batches whose frames hold different
+        numbers of instances (AVSS: 1 .. 4 classes per frame) then share ONE signature, i.e. one captured graph.  A frame with more
+        than G instances runs the eager step."""
         self.model, self.opt = model, optimizer
         self.warmup_iters, self.max_graphs = warmup_iters, max_graphs
+        self.pad_targets_to = pad_targets_to
         self.graphs = {}
         self._pool = None  # the memory pool all captured signatures share (they replay one after the other)
         # eager_only: the step is NOT captured (every call runs trainer.train_step) because this process replays hipGraph
@@ -512,6 +517,29 @@ class GraphedTrainStep:
         both = torch.stack([vid.float(), gt.float()]).cpu()
         return tuple(int(v) for v in both[0].tolist()), tuple(int(v == 1) for v in both[1].tolist())
 
+    def _pad_instances(self, batched_inputs):
+        """-> (batch with every instance list padded to pad_targets_to entries, [real count per frame]) or None when a frame
+        holds more.  New small tensors per step (two per frame), outside the captured graph."""
+        G = self.pad_targets_to
+        out, counts = [], []
+        for b in batched_inputs:
+            nb = dict(b)
+            nb["instances"] = []
+            for inst in b["instances"]:
+                cls = inst["gt_classes"] if isinstance(inst, dict) else inst.gt_classes
+                msk = inst["gt_masks"] if isinstance(inst, dict) else inst.gt_masks
+                msk = getattr(msk, "tensor", msk)
+                n = int(cls.shape[0])
+                if n > G:
+                    return None
+                pc, pm = cls.new_zeros(G), msk.new_zeros((G,) + tuple(msk.shape[1:]))
+                if n:
+                    pc[:n], pm[:n] = cls, msk
+                nb["instances"].append({"gt_classes": pc, "gt_masks": pm})
+                counts.append(n)
+            out.append(nb)
+        return out, counts
+
     def _fwd_bwd(self, batch):
         from .ops.linear import grouped_presplit
         self.model.record_head_inputs = False
@@ -540,26 +568,33 @@ class GraphedTrainStep:
         cut_grads = self.opt.backward_early(total, cut)
         return {k: v.detach() for k, v in loss_dict.items()}, cut_grads
 
-    def _capture(self, batched_inputs, num_masks, flags=None):
+    def _capture(self, batched_inputs, num_masks, flags=None, counts=None):
         from .ops import bifuse
         dev = num_masks.device
         static_batch = _clone_batch(batched_inputs)
         static_num = num_masks.clone()
         crit = self.model.criterion
         crit.num_masks_override = static_num
+        static_counts = None
+        if counts is not None:  # padded targets: the real counts per frame, refreshed before every replay
+            static_counts = torch.tensor(counts, dtype=torch.int32, device=dev)
+            crit.padded_counts = static_counts
+        keep = None
         if flags is not None:  # AVSS: the selections the flag values stand for, as constants of this graph
-            self.model.avss_static_index = (torch.tensor([i for i, v in enumerate(flags[0]) if v], dtype=torch.long, device=dev),
-                                            torch.tensor([i for i, v in enumerate(flags[1]) if v], dtype=torch.long, device=dev))
+            keep = (torch.tensor([i for i, v in enumerate(flags[0]) if v], dtype=torch.long, device=dev),
+                    torch.tensor([i for i, v in enumerate(flags[1]) if v], dtype=torch.long, device=dev))
+            self.model.avss_static_index = keep  # (allocated OUTSIDE the capture: the graph's kernels read them on every replay -
+            # they must live as long as the graph does, hence `keep` in the returned record)
         counter = bifuse.step_counter(dev)
         from .ops.linear import grouped_presplit
         cut = self._cut_backward()
         try:
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
-            # a further signature of the same model (AVSS: other instance counts per frame): libraries and lazy state are warm, and
-            # eager iterations next to the first graph's pool would not fit at 512 x 512 (200 GB of pool + 100 GB of eager
-            # activations) - captured directly, allocating from the shared pool
-            n_warm = self.warmup_iters if self._pool is None else 0
+            # (every signature gets its eager iterations: lazily built index tensors - host -> device copies - must exist before
+            #  the capture.  At 512 x 512 a second signature does not fit next to the first graph's 200 GB pool: the caller falls back
+            #  to the eager step; pad_targets_to makes the instance counts a non-issue)
+            n_warm = self.warmup_iters
             with torch.cuda.stream(side):
                 for _ in range(n_warm):  # autotuning / lazy initialisation outside the capture
                     if cut:
@@ -597,8 +632,9 @@ class GraphedTrainStep:
                 self._pool = (graph[0] if isinstance(graph, tuple) else graph).pool()
         finally:
             crit.num_masks_override = None
+            crit.padded_counts = None
             self.model.avss_static_index = None
-        return graph, static_batch, static_num, static_losses
+        return graph, static_batch, static_num, static_losses, static_counts, keep
 
     def __call__(self, batched_inputs):
         tensors, rest = _input_leaves(batched_inputs)
@@ -610,12 +646,23 @@ class GraphedTrainStep:
         if self.eager_only or num_masks is None or not all(t.is_cuda for t in tensors if id(t) not in flag_ids):
             return train_step(self.model, self.opt, batched_inputs)
         flags = self._avss_flags(batched_inputs)
+        counts = None
+        if self.pad_targets_to:
+            padded = self._pad_instances(batched_inputs)
+            if padded is None:  # a frame with more instances than the padded length
+                return train_step(self.model, self.opt, batched_inputs)
+            batched_inputs, counts = padded
+            tensors, rest = _input_leaves(batched_inputs)
         key = (tuple((tuple(t.shape), t.dtype) for t in tensors), rest, self.model.training, flags)
         if key not in self.graphs:
             if len(self.graphs) >= self.max_graphs:
+                if counts is not None:
+                    raise RuntimeError("GraphedTrainStep: more input signatures than max_graphs with padded targets")
                 return train_step(self.model, self.opt, batched_inputs)
-            self.graphs[key] = self._capture(batched_inputs, num_masks, flags)
-        graph, static_batch, static_num, static_losses = self.graphs[key]
+            self.graphs[key] = self._capture(batched_inputs, num_masks, flags, counts)
+        graph, static_batch, static_num, static_losses, static_counts, _keep = self.graphs[key]
+        if static_counts is not None:
+            static_counts.copy_(torch.tensor(counts, dtype=torch.int32), non_blocking=True)
         static_tensors, _ = _input_leaves(static_batch)
         src = [t for t, s in zip(tensors, static_tensors) if t.data_ptr() != s.data_ptr()]
         dst = [s for t, s in zip(tensors, static_tensors) if t.data_ptr() != s.data_ptr()]
