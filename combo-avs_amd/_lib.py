@@ -64,6 +64,7 @@ _SIGNATURES = {
     "combo_sem_mix": [c_int, c_int] + [c_void_p] * 4 + [c_int] * 3 + [c_void_p] * 3,
     "combo_semantic_inference_f32": [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p, c_void_p],
     "combo_conv3x3_wgrad_x3_f32": [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p] + [c_int] * 6 + [c_void_p],
+    "combo_conv_wgrad_x3_f32": [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p] + [c_int] * 8 + [c_void_p],
     "combo_presplit_bf16x2_f32": [c_void_p, c_longlong, c_longlong, c_int, c_int, c_void_p, c_void_p],
     "combo_presplit_bf16x2_grouped_f32": [c_void_p, c_int, c_void_p],
     "combo_presplit_bf16x2_batched_f32": [c_void_p, c_longlong, c_longlong, c_longlong, c_int, c_int, c_int, c_void_p, c_void_p],

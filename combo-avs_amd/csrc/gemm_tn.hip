@@ -178,16 +178,20 @@ __device__ __forceinline__ void glds16(const float* g, char* l) {
 // tap, or a row of zeros where the tap leaves the map.  Token -> (y, x) by multiply-high with host-made reciprocals.
 __device__ __attribute__((aligned(64))) float g_tn_zero_row[256];
 
+// (round 5) generalised: H, W = the OUTPUT map (the rows of dY), Hin, Win = the input map (the rows of X), stride 1 or 2, kernel
+// size 1 or 3 (padding ksize / 2); a k tile may span several taps (Cin = 64: two taps per 128 columns) - every lane keeps the
+// (tap, channel) of ITS 16-byte column group (Cin % 4 == 0).
 struct TnConvGeom {
   int H, W, Cin;
   unsigned magicW, magicH;  // ceil(2^32 / W), ceil(2^32 / H): the quotient is exact while tokens * max(H, W) < 2^32 (host check)
+  int Hin, Win, stride, ksize;
 };
 
 template <int WN, int kStages, bool CONV = false>
 __device__ __forceinline__ void
 gemm_tn_glds_body(const float* __restrict__ dY, long long ldy, const float* __restrict__ X, long long ldx,
                   float* __restrict__ out, float* __restrict__ db_part, int M, int N, int K, int mchunk, int bx, int by,
-                  int bz, TnConvGeom cg = TnConvGeom{1, 1, 1, 0u, 0u}) {
+                  int bz, TnConvGeom cg = TnConvGeom{1, 1, 1, 0u, 0u, 1, 1, 1, 3}) {
   constexpr int WK = 4 / WN, BN = 128 * WN, BK = 64 * WK;
   constexpr int A_BYTES = kTS * BN * 4, B_BYTES = kTS * BK * 4, STAGE = A_BYTES + B_BYTES;
   constexpr int A_PIECES = A_BYTES / 1024, B_PIECES = B_BYTES / 1024, PIECES = A_PIECES + B_PIECES;  // 1-KiB DMA pieces
@@ -202,12 +206,13 @@ gemm_tn_glds_body(const float* __restrict__ dY, long long ldy, const float* __re
   const int nst = (mend - mbeg + kTS - 1) / kTS;
   const int col = lane & 31, kg = lane >> 5;
 
-  int c_tap = 0, c_dy = 0, c_dx = 0, c_ci0 = 0;
+  int l_dy = 0, l_dx = 0, l_ci = 0;  // CONV: tap offset and input channel of this lane's X column group (constant over the stages)
   if (CONV) {
-    c_tap = k_blk / cg.Cin;
-    c_ci0 = k_blk - c_tap * cg.Cin;
-    c_dy = c_tap / 3 - 1;
-    c_dx = c_tap % 3 - 1;
+    const int cl = min(BK == 128 ? k_blk + (lane & 31) * 4 : k_blk + lane * 4, K - 4);
+    const int tap = cl / cg.Cin, pad = cg.ksize >> 1;
+    l_ci = cl - tap * cg.Cin;
+    l_dy = tap / cg.ksize - pad;
+    l_dx = tap % cg.ksize - pad;
   }
   // ---- per-lane DMA source columns (constant over the stages), clamped inside the matrix ----
   // piece q of a stage (1 KiB = one wave instruction): q < A_PIECES -> dY rows, else X rows
@@ -232,12 +237,13 @@ gemm_tn_glds_body(const float* __restrict__ dY, long long ldy, const float* __re
         c = min(c, K - 4);
         const int m = min(m0 + t, M - 1);
         if (CONV) {
-          const unsigned row = __umulhi((unsigned)m, cg.magicW);          // m / W
+          const unsigned row = __umulhi((unsigned)m, cg.magicW);          // m / W            (output token m = (frame, y, x))
           const int x = m - (int)row * cg.W;
-          const int y = (int)row - (int)__umulhi(row, cg.magicH) * cg.H;  // (m / W) % H
-          const bool ok = (unsigned)(y + c_dy) < (unsigned)cg.H && (unsigned)(x + c_dx) < (unsigned)cg.W;
-          const int ci = c - k_blk + c_ci0;
-          const float* src = ok ? X + (long long)(m + c_dy * cg.W + c_dx) * ldx + ci : g_tn_zero_row + (ci & 255);
+          const unsigned fr = __umulhi(row, cg.magicH);                   // frame
+          const int y = (int)row - (int)fr * cg.H;
+          const int yi = y * cg.stride + l_dy, xi = x * cg.stride + l_dx;  // the input pixel under this lane's tap
+          const bool ok = (unsigned)yi < (unsigned)cg.Hin && (unsigned)xi < (unsigned)cg.Win;
+          const float* src = ok ? X + ((long long)((int)fr * cg.Hin + yi) * cg.Win + xi) * ldx + l_ci : g_tn_zero_row + (l_ci & 255);
           glds16(src, st + A_BYTES + qb * 1024);
         } else {
           glds16(X + (long long)m * ldx + c, st + A_BYTES + qb * 1024);
@@ -605,13 +611,18 @@ int combo_gemm_tn_x3_f32(const float* dY, long long ldy, const float* X, long lo
   return (int)hipGetLastError();
 }
 
-int combo_conv3x3_wgrad_x3_f32(const float* dY, long long ldy, const float* X, long long ldx, float* out_partials, int B,
-                               int H, int W, int Cin, int Cout, int splits, combo_stream_t stream) {
-  const long long M = (long long)B * H * W;
-  const int K = 9 * Cin;
-  if (!dY || !X || !out_partials || B <= 0 || H < 2 || W < 2 || M * (H > W ? H : W) >= (1LL << 32) || M > 0x7fffffffLL / 4 || Cin <= 0 ||
-      Cin % 128 != 0 || Cout < 64 || Cout % 4 != 0 || splits <= 0 || ldy % 4 != 0 || ldx % 4 != 0 || ((uintptr_t)dY & 15) ||
-      ((uintptr_t)X & 15))
+/* Weight gradient of a convolution over NHWC tokens as an implicit TN GEMM: dW[cout, (ky, kx, cin)] = sum over the output tokens
+ * dY[t, cout] . X[input pixel of t under tap (ky, kx), cin]; ksize 1 or 3 (padding ksize / 2), stride 1 or 2 (output map ceil(Hin / 2) x
+ * ceil(Win / 2)), Cin % 4 == 0, Cout >= 64.  Partials [splits, Cout, ksize^2 * Cin]; finish with combo_splitk_reduce_nchw_f32. */
+int combo_conv_wgrad_x3_f32(const float* dY, long long ldy, const float* X, long long ldx, float* out_partials, int B, int Hin, int Win,
+                            int Cin, int Cout, int ksize, int stride, int splits, combo_stream_t stream) {
+  if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || Hin <= 0 || Win <= 0) return COMBO_EINVAL;
+  const int H = (Hin + stride - 1) / stride, W = (Win + stride - 1) / stride;
+  const long long M = (long long)B * H * W, Min = (long long)B * Hin * Win;
+  const int K = ksize * ksize * Cin;
+  if (!dY || !X || !out_partials || B <= 0 || (ksize == 3 && (Hin < 2 || Win < 2)) || M * (H > W ? H : W) >= (1LL << 32) || Min > 0x7fffffffLL / 4 ||
+      M < 256 || Cin <= 0 || Cin % 4 != 0 || K < 64 || Cout < 64 || Cout % 4 != 0 || splits <= 0 || ldy % 4 != 0 || ldx % 4 != 0 ||
+      ((uintptr_t)dY & 15) || ((uintptr_t)X & 15))
     return COMBO_EINVAL;
   int mchunk = (int)((M + splits - 1) / splits);
   mchunk = (mchunk + 15) / 16 * 16;
@@ -625,11 +636,16 @@ int combo_conv3x3_wgrad_x3_f32(const float* dY, long long ldy, const float* X, l
     attr = true;
   }
   const int remap = 1;  // XCD-contiguous tile order
-  TnConvGeom cg{H, W, Cin, (unsigned)(0xffffffffu / (unsigned)W + 1u), (unsigned)(0xffffffffu / (unsigned)H + 1u)};
+  TnConvGeom cg{H, W, Cin, (unsigned)(0xffffffffu / (unsigned)W + 1u), (unsigned)(0xffffffffu / (unsigned)H + 1u), Hin, Win, stride, ksize};
   const dim3 grid((K + 127) / 128, (Cout + 255) / 256, splits);
   hipLaunchKernelGGL(conv3x3_wgrad_kernel, grid, dim3(256), lds, (hipStream_t)stream, dY, ldy, X, ldx, out_partials, (int)M,
                      Cout, K, mchunk, remap, cg);
   return (int)hipGetLastError();
+}
+
+int combo_conv3x3_wgrad_x3_f32(const float* dY, long long ldy, const float* X, long long ldx, float* out_partials, int B,
+                               int H, int W, int Cin, int Cout, int splits, combo_stream_t stream) {
+  return combo_conv_wgrad_x3_f32(dY, ldy, X, ldx, out_partials, B, H, W, Cin, Cout, 3, 1, splits, stream);
 }
 
 int combo_gemm_tn_x3_grouped_f32(const combo_gemm_tn_problem* problems, int count, combo_stream_t stream) {

@@ -61,22 +61,24 @@ def _conv_tokens(x_tok, wm, bias, B, H, W, cin, cout, exact, relu=False):
     return y
 
 
-def _wgrad_tokens(dy_tok, x_tok, B, H, W, cin, cout):
-    """-> dW in the parameter's own order [cout, cin, 3, 3] (contiguous): the split-K partials come out of the implicit GEMM as
-    [cout, 3, 3, cin]; the finishing sum writes them permuted (csrc/gemm_tn.hip splitk_reduce_nchw_kernel)"""
+def _wgrad_tokens(dy_tok, x_tok, B, H, W, cin, cout, ksize=3, stride=1):
+    """-> dW in the parameter's own order [cout, cin, ksize, ksize] (contiguous): the split-K partials come out of the implicit GEMM as
+    [cout, ky, kx, cin]; the finishing sum writes them permuted (csrc/gemm_tn.hip splitk_reduce_nchw_kernel).  H, W: the INPUT map
+    (the rows of x_tok); dy_tok rows are the ceil(H / stride) x ceil(W / stride) output tokens."""
     lib = _lib.lib()
-    M, K = B * H * W, 9 * cin
+    taps = ksize * ksize
+    M, K = B * (-(-H // stride)) * (-(-W // stride)), taps * cin
     splits = lib.combo_gemm_tn_splits(M, cout, K)
     mchunk = (-(-M // splits) + 15) // 16 * 16
     splits = -(-M // mchunk)
     part = torch.empty(splits, cout, K, device=x_tok.device, dtype=torch.float32)
     st = _lib.current_stream()
     with _lib.timed("conv3x3_wgrad_x3", (M, cout, K)):
-        rc = lib.combo_conv3x3_wgrad_x3_f32(dy_tok.data_ptr(), dy_tok.stride(0), x_tok.data_ptr(), x_tok.stride(0),
-                                            part.data_ptr(), B, H, W, cin, cout, splits, st)
-    _lib.check(rc, "combo_conv3x3_wgrad_x3_f32")
-    dw = torch.empty(cout, cin, 3, 3, device=x_tok.device, dtype=torch.float32)
-    _lib.check(lib.combo_splitk_reduce_nchw_f32(part.data_ptr(), splits, cout, 9, cin, dw.data_ptr(), st), "combo_splitk_reduce_nchw_f32")
+        rc = lib.combo_conv_wgrad_x3_f32(dy_tok.data_ptr(), dy_tok.stride(0), x_tok.data_ptr(), x_tok.stride(0),
+                                         part.data_ptr(), B, H, W, cin, cout, ksize, stride, splits, st)
+    _lib.check(rc, "combo_conv_wgrad_x3_f32")
+    dw = torch.empty(cout, cin, ksize, ksize, device=x_tok.device, dtype=torch.float32)
+    _lib.check(lib.combo_splitk_reduce_nchw_f32(part.data_ptr(), splits, cout, taps, cin, dw.data_ptr(), st), "combo_splitk_reduce_nchw_f32")
     return dw
 
 

@@ -35,6 +35,10 @@ DX_MIN_C = 64
 # ReLU-gradient mask of conv1's output in the epilogue of the 3x3 convolution's own input-gradient kernel (needs DX_OWN bit 0)
 MASK_3X3 = True
 MASK_1X1 = True  # the same for conv2's output in conv3's (1x1) input-gradient GEMM
+# (round 5) weight gradients that were the library's until now, on the generalised implicit TN GEMM (csrc/gemm_tn.hip
+# combo_conv_wgrad_x3_f32): the 64-channel 3x3 layers of res2, and the stride-2 3x3 / 1x1 shortcut layers of res3.0 / res4.0 / res5.0
+WGRAD_ANY_C = True
+WGRAD_S2 = True
 
 
 def kind(x, w, stride, padding):
@@ -194,10 +198,13 @@ class _ConvWrw(Function):
         pad = 1 if ctx.k % 10 == 3 else 0
         if not dy.is_contiguous(memory_format=torch.channels_last):
             dy = dy.contiguous(memory_format=torch.channels_last)
-        if ctx.k > 20:  # stride 2: the library's backward
+        if ctx.k > 20:  # stride 2 (the first block of res3 / res4 / res5): input gradient the library's, weight gradient own
             assert not ctx.mask_dx
+            own_dw = WGRAD_S2 and ctx.needs_input_grad[1] and cin % 4 == 0 and cout >= 64 and cout % 4 == 0 and dy.shape[0] * dy.shape[2] * dy.shape[3] >= 256
             dx, dw, _ = torch.ops.aten.convolution_backward(dy, x, w, None, (2, 2), (pad, pad), (1, 1), False, (0, 0), 1,
-                                                            (ctx.needs_input_grad[0], ctx.needs_input_grad[1], False))
+                                                            (ctx.needs_input_grad[0], ctx.needs_input_grad[1] and not own_dw, False))
+            if own_dw:
+                dw = C3._wgrad_tokens(C3._tokens(dy), C3._tokens(x), B, H, W, cin, cout, ksize=3 if ctx.k == 23 else 1, stride=2)
             return dx, dw, None, None, None, None, None, None
         dx = dw = None
         if ctx.needs_input_grad[0] and ctx.k == 3 and (DX_OWN & 1) and ctx.img_dx is not None:
@@ -220,9 +227,9 @@ class _ConvWrw(Function):
             if ctx.k == 1:
                 g, _ = L.weight_grad(w.view(cout, cin), dy_tok, x_tok, False, True)  # joins the grouped launch when it can
                 dw = g.view(cout, cin, 1, 1)
-            elif cin % 128 == 0 and cout % 128 == 0:
-                dw = C3._wgrad_tokens(dy_tok, x_tok, B, H, W, cin, cout)
-            else:  # the 64-channel 3x3 layers of res2: the library's weight gradient
+            elif (cin % 128 == 0 and cout % 128 == 0) or (WGRAD_ANY_C and cin % 4 == 0 and cout >= 64 and cout % 4 == 0):
+                dw = C3._wgrad_tokens(dy_tok, x_tok, B, H, W, cin, cout)  # (round 5: any channel count - res2's 64-channel layers)
+            else:  # the library's weight gradient
                 dw = torch.ops.aten.convolution_backward(dy, x, w, None, (1, 1), (pad, pad), (1, 1), False, (0, 0), 1,
                                                          (False, True, False))[1]
         return dx, dw, None, None, None, None, None, None

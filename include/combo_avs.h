@@ -440,6 +440,11 @@ int combo_conv_nhwc_x3_epi_f32(const float* X, long long ldx, const float* Wimg,
  *   B*H*W*max(H,W) < 2^32. */
 int combo_conv3x3_wgrad_x3_f32(const float* dY, long long ldy, const float* X, long long ldx, float* out_partials, int B,
                                int H, int W, int Cin, int Cout, int splits, combo_stream_t stream);
+/* (round 5) the same implicit TN GEMM for kernel size 1 or 3 (padding ksize / 2), stride 1 or 2 (output map ceil(Hin / 2) x ceil(Win / 2)) and
+ * any Cin % 4 == 0: the weight gradients of the ResNet backbones' 64-channel 3x3 layers and of the stride-2 3x3 / shortcut layers
+ * (d2 BottleneckBlock, built at models/maskformer_model.py:138,145).  dY rows = output tokens, X rows = input tokens. */
+int combo_conv_wgrad_x3_f32(const float* dY, long long ldy, const float* X, long long ldx, float* out_partials, int B, int Hin, int Win,
+                            int Cin, int Cout, int ksize, int stride, int splits, combo_stream_t stream);
 
 /*   Weight gradient dW[N,K] = dY[M,N]^T . X[M,K] (reduction over the M tokens), same 3-way bf16 split, fragments loaded
  *   straight from global memory (no LDS), split-K over M: partial z is written at out_partials + z*N*K and the caller

@@ -289,3 +289,60 @@ def test_mask_logits_of_the_whole_model_stay_within_the_north_star_bound_with_th
         rms = ref[head].pow(2).mean().sqrt()
         share = float(((got[head] - ref[head]).abs() > 1e-3 * rms + 1e-3 * ref[head].abs()).float().mean())
         assert share <= 1e-3, (head, share)
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,ksize,stride", [
+    (2, 56, 56, 64, 64, 3, 1),      # res2's 64-channel 3x3 layers: a 128-column K tile spans two taps, K = 576 is ragged
+    (3, 28, 28, 128, 128, 3, 2),    # res3.0 conv2 (stride 2)
+    (2, 15, 13, 256, 256, 3, 2),    # odd map: output ceil(H / 2) x ceil(W / 2), taps leaving the map on every side
+    (2, 28, 28, 256, 512, 1, 2),    # res3.0 shortcut (1x1, stride 2)
+    (2, 14, 14, 1024, 2048, 1, 2),  # res5.0 shortcut
+    (2, 9, 11, 64, 192, 3, 1),
+])
+def test_generalised_weight_gradient_kernel_vs_fp64(B, H, W, cin, cout, ksize, stride):
+    """combo_conv_wgrad_x3_f32 (round 5: any Cin % 4 == 0, kernel size 1 / 3, stride 1 / 2) against torch's convolution weight
+    gradient evaluated in fp64: the ResNet-50 weight gradients that were the library's until round 4."""
+    from combo_avs_amd.ops import conv3x3 as C3
+    torch.manual_seed(B + H + cin + ksize + stride)
+    pad = ksize // 2
+    x = torch.randn(B, cin, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+    w = torch.randn(cout, cin, ksize, ksize, device="cuda") * 0.05
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    dy = torch.randn(B, cout, Ho, Wo, device="cuda").contiguous(memory_format=torch.channels_last)
+    dw = C3._wgrad_tokens(C3._tokens(dy), C3._tokens(x), B, H, W, cin, cout, ksize=ksize, stride=stride)
+    torch.cuda.synchronize()
+    ref = torch.ops.aten.convolution_backward(dy.double(), x.double(), w.double(), None, (stride, stride), (pad, pad), (1, 1), False, (0, 0), 1,
+                                              (False, True, False))[1]
+    assert dw.shape == ref.shape
+    err = (dw.double() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= 2e-5 * scale, (err, scale)  # 3-product bf16 split: ~2^-17 per product, long reductions average it down
+
+
+def test_resnet_weight_gradients_own_kernels_vs_library_for_every_layer():
+    """every convolution weight gradient of the fp32 ResNet-50 with the round-5 switches on (64-channel and stride-2 layers on the
+    own kernel) against the same backward pass with them off (the library's kernels for those layers)"""
+    from combo_avs_amd.backbone import ResNet
+    from combo_avs_amd.ops import convwrw
+    torch.manual_seed(0)
+    net = ResNet(50).cuda().train()
+    x = torch.randn(2, 3, 96, 96, device="cuda")
+    res = {}
+    for mode in (True, False):
+        prev = convwrw.WGRAD_ANY_C, convwrw.WGRAD_S2
+        convwrw.WGRAD_ANY_C = convwrw.WGRAD_S2 = mode
+        try:
+            feats = net(x)
+            loss = sum(f.float().pow(2).mean() for f in feats.values())
+            names = [n for n, p in net.named_parameters() if p.requires_grad and n.endswith("weight") and p.dim() == 4]
+            params = [dict(net.named_parameters())[n] for n in names]
+            res[mode] = dict(zip(names, torch.autograd.grad(loss, params)))
+        finally:
+            convwrw.WGRAD_ANY_C, convwrw.WGRAD_S2 = prev
+    worst = []
+    for n in res[True]:
+        a, b = res[True][n].double(), res[False][n].double()
+        rel = float((a - b).norm() / b.norm().clamp_min(1e-30))
+        if rel > 2e-4:
+            worst.append((n, rel))
+    assert not worst, worst
