@@ -616,9 +616,8 @@ def main():
              8: ("gemm_nt3_kernel (1 bf16 product: --head-dtype bf16)", "mfma", 2500.0, "TFLOP/s", 1e12)}
     # HBM traffic per launch: PMC passes of tools/pmc_bench.sh, valid only for the kernels of the commit they were taken at
     pmc, pmc_note = {}, None
-    pmc_path = os.path.join(ROOT, "profiles", "r04_pmc.json")
-    if not os.path.exists(pmc_path):
-        pmc_path = os.path.join(ROOT, "profiles", "r03_pmc.json")
+    pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc.json") for r in (5, 4, 3)) if os.path.exists(q)),
+                    os.path.join(ROOT, "profiles", "r05_pmc.json"))
     if os.path.exists(pmc_path):
         with open(pmc_path) as f:
             pmc = json.load(f)

@@ -38,6 +38,7 @@ _SIGNATURES = {
     "combo_relu_grad_f32": [c_void_p, c_void_p, c_longlong, c_void_p, c_void_p],
     "combo_relu_grad2_f32": [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_void_p],
     "combo_relu_grad3_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_void_p],
+    "combo_expand_stride2_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "combo_msda_backward_needs_zero": [c_int] * 6,
     "combo_msda_forward_f32": [c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_int, c_void_p],
     "combo_msda_forward_f64": [c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_int, c_void_p],

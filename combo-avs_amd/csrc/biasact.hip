@@ -97,6 +97,27 @@ relu_grad3_f32_kernel(const float* __restrict__ dy1, const float* __restrict__ d
                                                  v.z > 0.f ? a.z + b.z + c.z : 0.f, v.w > 0.f ? a.w + b.w + c.w : 0.f);
 }
 
+// Input gradient of a 1x1 stride-2 convolution from its compact form: dst [B, H, W, C] = src [B, ceil(H/2), ceil(W/2), C] at the even
+// pixels, zero elsewhere - one write-only pass (the GEMM dY . W over the OUTPUT tokens produced `src`; round 5: the shortcut
+// convolutions of res3.0 / res4.0 / res5.0 leave the library's backward-data kernel).  One float4 of dst per thread.
+__global__ void __launch_bounds__(256)
+expand_stride2_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int C4, long long n4) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const long long tok = fast_div(i, C4);
+  const int c4 = (int)(i - tok * C4);
+  const long long row = fast_div(tok, W);
+  const int x = (int)(tok - row * W);
+  const long long b = fast_div(row, H);
+  const int y = (int)(row - b * H);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!((x | y) & 1)) {
+    const int Ho = (H + 1) >> 1, Wo = (W + 1) >> 1;
+    v = reinterpret_cast<const float4*>(src)[((b * Ho + (y >> 1)) * Wo + (x >> 1)) * C4 + c4];
+  }
+  reinterpret_cast<float4*>(dst)[i] = v;
+}
+
 // fp32 variant of bias_act_kernel (the reference's S4 recipe runs the backbones in fp32: SOLVER.AMP.ENABLED False); 4 channels per thread
 __global__ void __launch_bounds__(256)
 bias_act_f32_kernel(float* __restrict__ y, const float* __restrict__ bias, const float* __restrict__ res, long long n4, int C4, int relu) {
@@ -150,6 +171,13 @@ int combo_relu_grad3_f32(const float* dy1, const float* dy2, const float* dy3, c
   const long long n4 = n / 4;
   hipLaunchKernelGGL(relu_grad3_f32_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy1, dy2, dy3, y, n4,
                      dx);
+  return (int)hipGetLastError();
+}
+
+int combo_expand_stride2_f32(const float* src, float* dst, int B, int H, int W, int C, combo_stream_t stream) {
+  if (!src || !dst || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 != 0 || (((uintptr_t)src | (uintptr_t)dst) & 15)) return COMBO_EINVAL;
+  const long long n4 = (long long)B * H * W * (C / 4);
+  hipLaunchKernelGGL(expand_stride2_f32_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, H, W, C / 4, n4);
   return (int)hipGetLastError();
 }
 

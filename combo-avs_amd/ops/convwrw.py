@@ -39,6 +39,9 @@ MASK_1X1 = True  # the same for conv2's output in conv3's (1x1) input-gradient G
 # combo_conv_wgrad_x3_f32): the 64-channel 3x3 layers of res2, and the stride-2 3x3 / 1x1 shortcut layers of res3.0 / res4.0 / res5.0
 WGRAD_ANY_C = True
 WGRAD_S2 = True
+# input gradient of the 1x1 stride-2 shortcut convolutions: GEMM over the output tokens on the 3-product kernel + one expansion
+# pass (csrc/biasact.hip expand_stride2) instead of the library's backward-data kernel
+DX_S2_1X1 = True
 
 
 def kind(x, w, stride, padding):
@@ -77,7 +80,8 @@ def weight_images(weights, geometry):
     (forward image [cout, k*k*cin] with K ordered (ky, kx, cin), input-gradient image [cin, k*k*cout] with the taps flipped).
     A 3x3 weight in NCHW order is ONE problem per image whose threads read the 9 contiguous taps of 8 (cout, cin) pairs."""
     kinds = [weight_kind(w, s, p) if (w.is_cuda and w.dtype == torch.float32) else 0 for w, (s, p) in zip(weights, geometry)]
-    total = sum((2 if k < 20 else 1) * w.numel() for w, k in zip(weights, kinds) if k)
+    two = lambda k: k < 20 or (k == 21 and DX_S2_1X1)  # layers whose input gradient runs on the own kernel: a second image
+    total = sum((2 if two(k) else 1) * w.numel() for w, k in zip(weights, kinds) if k)
     if total == 0:
         return [None] * len(weights)
     buf = torch.empty(total, device=weights[0].device, dtype=torch.float32)
@@ -88,15 +92,15 @@ def weight_images(weights, geometry):
             continue
         cout, cin = w.shape[:2]
         n, ks = w.numel(), w.shape[2]
-        if k < 20:
+        if two(k):
             out.append((buf[off:off + n].view(cout, ks * ks * cin), buf[off + n:off + 2 * n].view(cin, ks * ks * cout)))
         else:
-            out.append((buf[off:off + n].view(cout, ks * ks * cin), None))  # stride 2: forward only
+            out.append((buf[off:off + n].view(cout, ks * ks * cin), None))  # stride-2 3x3: forward only
         spans.append(w)
-        off += (2 if k < 20 else 1) * n
+        off += (2 if two(k) else 1) * n
     # addresses recycle (the folded weights are fresh tensors every step): the key also carries everything else a problem encodes -
     # shape, strides (contiguous vs channels_last taps), the layer kind (decides which images exist, i.e. every offset) and FWD_X3
-    key = (buf.data_ptr(), FWD_X3) + tuple((w.data_ptr(), tuple(w.shape), tuple(w.stride()), k) for w, k in zip(weights, kinds) if k)
+    key = (buf.data_ptr(), FWD_X3, DX_S2_1X1) + tuple((w.data_ptr(), tuple(w.shape), tuple(w.stride()), k) for w, k in zip(weights, kinds) if k)
     pr = _problem_cache.get(key)
     if pr is None:
         plist = []
@@ -201,8 +205,16 @@ class _ConvWrw(Function):
         if ctx.k > 20:  # stride 2 (the first block of res3 / res4 / res5): input gradient the library's, weight gradient own
             assert not ctx.mask_dx
             own_dw = WGRAD_S2 and ctx.needs_input_grad[1] and cin % 4 == 0 and cout >= 64 and cout % 4 == 0 and dy.shape[0] * dy.shape[2] * dy.shape[3] >= 256
-            dx, dw, _ = torch.ops.aten.convolution_backward(dy, x, w, None, (2, 2), (pad, pad), (1, 1), False, (0, 0), 1,
-                                                            (ctx.needs_input_grad[0], ctx.needs_input_grad[1] and not own_dw, False))
+            own_dx = DX_S2_1X1 and ctx.k == 21 and ctx.needs_input_grad[0] and ctx.img_dx is not None and cin % 4 == 0
+            dx, dw = None, None
+            if (ctx.needs_input_grad[0] and not own_dx) or (ctx.needs_input_grad[1] and not own_dw):
+                dx, dw, _ = torch.ops.aten.convolution_backward(dy, x, w, None, (2, 2), (pad, pad), (1, 1), False, (0, 0), 1,
+                                                                (ctx.needs_input_grad[0] and not own_dx, ctx.needs_input_grad[1] and not own_dw, False))
+            if own_dx:
+                dxc = L.gemm_nt_x3(C3._tokens(dy), ctx.img_dx, img=ctx.img_dx)  # [B * Ho * Wo, cin]: the gradient at the even pixels
+                dx = torch.empty((B, cin, H, W), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+                _lib.check(_lib.lib().combo_expand_stride2_f32(dxc.data_ptr(), dx.data_ptr(), B, H, W, cin, _lib.current_stream()),
+                           "combo_expand_stride2_f32")
             if own_dw:
                 dw = C3._wgrad_tokens(C3._tokens(dy), C3._tokens(x), B, H, W, cin, cout, ksize=3 if ctx.k == 23 else 1, stride=2)
             return dx, dw, None, None, None, None, None, None

@@ -142,6 +142,10 @@ int combo_relu_grad2_f32(const float* dy1, const float* dy2, const float* y, lon
 /* ... of a block output with three consumers (the last block of a ResNet stage also feeds the head): dx = (dy1 + dy2 + dy3) . [y > 0] */
 int combo_relu_grad3_f32(const float* dy1, const float* dy2, const float* dy3, const float* y, long long n, float* dx,
                          combo_stream_t stream);
+/* dst [B, H, W, C] = src [B, ceil(H/2), ceil(W/2), C] at the even pixels, zero elsewhere: the input gradient of a 1x1 stride-2
+ * convolution (d2 BottleneckBlock's shortcut, built at models/maskformer_model.py:138,145) from the GEMM dY . W over the output
+ * tokens; every element of dst is written. */
+int combo_expand_stride2_f32(const float* src, float* dst, int B, int H, int W, int C, combo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * PVTv2 depth-wise 3x3 convolution on token-major bf16 activations (models/modeling/backbone/pvtv2.py:377-388, DWConv:

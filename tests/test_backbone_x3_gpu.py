@@ -294,10 +294,10 @@ def test_mask_logits_of_the_whole_model_stay_within_the_north_star_bound_with_th
 @pytest.mark.parametrize("B,H,W,cin,cout,ksize,stride", [
     (2, 56, 56, 64, 64, 3, 1),      # res2's 64-channel 3x3 layers: a 128-column K tile spans two taps, K = 576 is ragged
     (3, 28, 28, 128, 128, 3, 2),    # res3.0 conv2 (stride 2)
-    (2, 15, 13, 256, 256, 3, 2),    # odd map: output ceil(H / 2) x ceil(W / 2), taps leaving the map on every side
+    (6, 15, 13, 256, 256, 3, 2),    # odd map: output ceil(H / 2) x ceil(W / 2), taps leaving the map on every side
     (2, 28, 28, 256, 512, 1, 2),    # res3.0 shortcut (1x1, stride 2)
     (2, 14, 14, 1024, 2048, 1, 2),  # res5.0 shortcut
-    (2, 9, 11, 64, 192, 3, 1),
+    (3, 9, 11, 64, 192, 3, 1),
 ])
 def test_generalised_weight_gradient_kernel_vs_fp64(B, H, W, cin, cout, ksize, stride):
     """combo_conv_wgrad_x3_f32 (round 5: any Cin % 4 == 0, kernel size 1 / 3, stride 1 / 2) against torch's convolution weight
@@ -320,25 +320,26 @@ def test_generalised_weight_gradient_kernel_vs_fp64(B, H, W, cin, cout, ksize, s
 
 
 def test_resnet_weight_gradients_own_kernels_vs_library_for_every_layer():
-    """every convolution weight gradient of the fp32 ResNet-50 with the round-5 switches on (64-channel and stride-2 layers on the
-    own kernel) against the same backward pass with them off (the library's kernels for those layers)"""
+    """every convolution weight gradient of the fp32 ResNet-50 (and the gradient of its input) with the round-5 switches on (64-channel
+    and stride-2 weight gradients, the 1x1 stride-2 input gradients on the own kernels) against the same backward pass with them
+    off (the library's kernels for those layers)"""
     from combo_avs_amd.backbone import ResNet
     from combo_avs_amd.ops import convwrw
     torch.manual_seed(0)
     net = ResNet(50).cuda().train()
-    x = torch.randn(2, 3, 96, 96, device="cuda")
+    x = torch.randn(2, 3, 96, 96, device="cuda", requires_grad=True)  # (its gradient passes through every input-gradient kernel)
     res = {}
     for mode in (True, False):
-        prev = convwrw.WGRAD_ANY_C, convwrw.WGRAD_S2
-        convwrw.WGRAD_ANY_C = convwrw.WGRAD_S2 = mode
+        prev = convwrw.WGRAD_ANY_C, convwrw.WGRAD_S2, convwrw.DX_S2_1X1
+        convwrw.WGRAD_ANY_C = convwrw.WGRAD_S2 = convwrw.DX_S2_1X1 = mode
         try:
             feats = net(x)
             loss = sum(f.float().pow(2).mean() for f in feats.values())
             names = [n for n, p in net.named_parameters() if p.requires_grad and n.endswith("weight") and p.dim() == 4]
             params = [dict(net.named_parameters())[n] for n in names]
-            res[mode] = dict(zip(names, torch.autograd.grad(loss, params)))
+            res[mode] = dict(zip(names + ["input"], torch.autograd.grad(loss, params + [x])))
         finally:
-            convwrw.WGRAD_ANY_C, convwrw.WGRAD_S2 = prev
+            convwrw.WGRAD_ANY_C, convwrw.WGRAD_S2, convwrw.DX_S2_1X1 = prev
     worst = []
     for n in res[True]:
         a, b = res[True][n].double(), res[False][n].double()
@@ -346,3 +347,15 @@ def test_resnet_weight_gradients_own_kernels_vs_library_for_every_layer():
         if rel > 2e-4:
             worst.append((n, rel))
     assert not worst, worst
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 28, 28, 256), (3, 15, 13, 64), (1, 7, 7, 1024)])
+def test_expand_stride2_places_the_compact_gradient_on_the_even_pixels(B, H, W, C):
+    from combo_avs_amd import _lib
+    Ho, Wo = -(-H // 2), -(-W // 2)
+    src = torch.randn(B, Ho, Wo, C, device="cuda")
+    dst = torch.full((B, H, W, C), float("nan"), device="cuda")
+    _lib.check(_lib.lib().combo_expand_stride2_f32(src.data_ptr(), dst.data_ptr(), B, H, W, C, _lib.current_stream()), "combo_expand_stride2_f32")
+    ref = torch.zeros(B, H, W, C, device="cuda")
+    ref[:, ::2, ::2] = src
+    assert torch.equal(dst, ref)

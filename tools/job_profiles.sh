@@ -10,4 +10,4 @@ python tools/bench_r50_x3.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r50_x3.txt
 python tools/bench_pointlogits.py 2>&1 | grep -v amdgpu.ids > gpurun_out/pointlogits.txt
 python tools/bench_nt3.py --shapes all 2>&1 | grep -v amdgpu.ids > gpurun_out/nt3_bench.txt
 python tools/bench_r50_convs.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r50_convs.txt
-ls -la gpurun_out/kstats.csv gpurun_out/steady_graph.csv gpurun_out/steady_pvt_ms3_t10.csv gpurun_out/steady_pvt_avss_512.csv gpurun_out/r04_pmc.json gpurun_out/prof_bench_line.json
+ls -la gpurun_out/kstats.csv gpurun_out/steady_graph.csv gpurun_out/steady_pvt_ms3_t10.csv gpurun_out/steady_pvt_avss_512.csv gpurun_out/r05_pmc.json gpurun_out/prof_bench_line.json
