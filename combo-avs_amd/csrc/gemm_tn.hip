@@ -621,7 +621,7 @@ int combo_conv_wgrad_x3_f32(const float* dY, long long ldy, const float* X, long
   const long long M = (long long)B * H * W, Min = (long long)B * Hin * Win;
   const int K = ksize * ksize * Cin;
   if (!dY || !X || !out_partials || B <= 0 || (ksize == 3 && (Hin < 2 || Win < 2)) || M * (H > W ? H : W) >= (1LL << 32) || Min > 0x7fffffffLL / 4 ||
-      M < 256 || Cin <= 0 || Cin % 4 != 0 || K < 64 || Cout < 64 || Cout % 4 != 0 || splits <= 0 || ldy % 4 != 0 || ldx % 4 != 0 ||
+      Cin <= 0 || Cin % 4 != 0 || Cout < 64 || Cout % 4 != 0 || splits <= 0 || ldy % 4 != 0 || ldx % 4 != 0 ||
       ((uintptr_t)dY & 15) || ((uintptr_t)X & 15))
     return COMBO_EINVAL;
   int mchunk = (int)((M + splits - 1) / splits);

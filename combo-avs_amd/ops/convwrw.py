@@ -204,7 +204,7 @@ class _ConvWrw(Function):
             dy = dy.contiguous(memory_format=torch.channels_last)
         if ctx.k > 20:  # stride 2 (the first block of res3 / res4 / res5): input gradient the library's, weight gradient own
             assert not ctx.mask_dx
-            own_dw = WGRAD_S2 and ctx.needs_input_grad[1] and cin % 4 == 0 and cout >= 64 and cout % 4 == 0 and dy.shape[0] * dy.shape[2] * dy.shape[3] >= 256
+            own_dw = WGRAD_S2 and ctx.needs_input_grad[1] and cin % 4 == 0 and cout >= 64 and cout % 4 == 0
             own_dx = DX_S2_1X1 and ctx.k == 21 and ctx.needs_input_grad[0] and ctx.img_dx is not None and cin % 4 == 0
             dx, dw = None, None
             if (ctx.needs_input_grad[0] and not own_dx) or (ctx.needs_input_grad[1] and not own_dw):

@@ -25,8 +25,9 @@ def test_weight_images_equal_the_single_weight_presplit():
     geo = [((1, 1), (0, 0)), ((1, 1), (1, 1)), ((1, 1), (1, 1)), ((2, 2), (3, 3)), ((2, 2), (0, 0))]
     imgs = convwrw.weight_images(ws, geo)
     assert imgs[3] is None  # the 7x7 stem stays with the library
-    assert imgs[4][1] is None  # the stride-2 shortcut: forward image only (its backward is the library's)
+    # the stride-2 shortcut: forward image and - round 5: its input gradient is a GEMM over the output tokens - the transposed one
     assert torch.equal(imgs[4][0].view(torch.int32), L.presplit(ws[4].view(512, 256)).view(torch.int32))
+    assert torch.equal(imgs[4][1].view(torch.int32), L.presplit(ws[4].view(512, 256).t().contiguous()).view(torch.int32))
     for w, im in zip(ws[:3], imgs[:3]):
         cout, cin, k, _ = w.shape
         fwd = L.presplit(w.permute(0, 2, 3, 1).reshape(cout, k * k * cin).contiguous())
@@ -153,7 +154,8 @@ def test_resnet_features_and_gradients_own_forward_vs_library():
 def test_stride2_forward_on_the_own_kernel(B, H, W, cin, cout, k):
     """the first block of res3 / res4 / res5: 3x3 / stride 2 / pad 1 and the 1x1 / stride 2 shortcut (odd map sizes included),
     forward + bias + ReLU within 2e-5 of the output range of an fp64 evaluation; bit-identical from call to call; the backward
-    pass is the library's (compared against autograd of F.conv2d)"""
+    pass (round 5: weight gradients and the 1x1 input gradient on own kernels, the 3x3 input gradient the library's) against
+    autograd of F.conv2d"""
     import combo_avs_amd  # noqa: F401
     from combo_avs_amd.ops import convwrw
     g = torch.Generator().manual_seed(H * 10 + k)
@@ -163,7 +165,7 @@ def test_stride2_forward_on_the_own_kernel(B, H, W, cin, cout, k):
     geo = ((2, 2), (k // 2, k // 2))
     assert convwrw.weight_kind(w, *geo) == 20 + k
     images = convwrw.weight_images([w.detach()], [geo])[0]
-    assert images[1] is None
+    assert (images[1] is None) == (k == 3)  # the 3x3 stride-2 input gradient stays the library's; the 1x1 one is own (round 5)
     xx = x.clone().requires_grad_(True)
     y = convwrw.conv_bias_act(xx, w, b, 2, k // 2, images)
     ref = F.conv2d(x.double(), w.detach().double(), b.double(), 2, k // 2).relu_()
