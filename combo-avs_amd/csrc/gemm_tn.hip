@@ -377,6 +377,9 @@ gemm_tn_glds_kernel(const float* __restrict__ dY, long long ldy, const float* __
   gemm_tn_glds_body<WN, kStages>(dY, ldy, X, ldx, out, db_part, M, N, K, mchunk, bx, by, bz);
 }
 
+// WN = 2: 256 (cout) x 128 (k) block tiles; WN = 1 (round 5): 128 x 256 - the 64- and 128-channel layers of res2 / res3 waste
+// 3/4 and 1/2 of a 256-wide cout tile (clamped DMA columns, MFMAs on duplicates)
+template <int WN>
 __global__ void __launch_bounds__(256, 2)
 conv3x3_wgrad_kernel(const float* __restrict__ dY, long long ldy, const float* __restrict__ X, long long ldx,
                      float* __restrict__ out, int M, int N, int K, int mchunk, int remap, TnConvGeom cg) {
@@ -386,7 +389,7 @@ conv3x3_wgrad_kernel(const float* __restrict__ dY, long long ldy, const float* _
     const int l = xcd_contiguous(bx + gx * (by + gy * bz), gx * gy * (int)gridDim.z);
     bx = l % gx; by = (l / gx) % gy; bz = l / (gx * gy);
   }
-  gemm_tn_glds_body<2, 3, true>(dY, ldy, X, ldx, out, nullptr, M, N, K, mchunk, bx, by, bz, cg);
+  gemm_tn_glds_body<WN, 3, true>(dY, ldy, X, ldx, out, nullptr, M, N, K, mchunk, bx, by, bz, cg);
 }
 
 // Grouped launch: many independent weight-gradient problems in ONE kernel.  The decoder's dW GEMMs (M = BT*100 tokens)
@@ -630,16 +633,23 @@ int combo_conv_wgrad_x3_f32(const float* dY, long long ldy, const float* X, long
   constexpr int lds = 3 * (kTS * 256 * 4 + kTS * 128 * 4);
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
   const int remap = 1;  // XCD-contiguous tile order
   TnConvGeom cg{H, W, Cin, (unsigned)(0xffffffffu / (unsigned)W + 1u), (unsigned)(0xffffffffu / (unsigned)H + 1u), Hin, Win, stride, ksize};
-  const dim3 grid((K + 127) / 128, (Cout + 255) / 256, splits);
-  hipLaunchKernelGGL(conv3x3_wgrad_kernel, grid, dim3(256), lds, (hipStream_t)stream, dY, ldy, X, ldx, out_partials, (int)M,
-                     Cout, K, mchunk, remap, cg);
+  if (tn_variant(Cout, K) == 2) {  // the less padded tile shape
+    const dim3 grid((K + 127) / 128, (Cout + 255) / 256, splits);
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, dY, ldy, X, ldx, out_partials, (int)M, Cout, K,
+                       mchunk, remap, cg);
+  } else {
+    const dim3 grid((K + 255) / 256, (Cout + 127) / 128, splits);
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, dY, ldy, X, ldx, out_partials, (int)M, Cout, K,
+                       mchunk, remap, cg);
+  }
   return (int)hipGetLastError();
 }
 

@@ -120,12 +120,14 @@ msda_bwd_win_d32(const float* __restrict__ gout, const float* __restrict__ value
 
   // ---- stage the level's value rows with LDS-DMA (whole-level windows); clear the accumulators --------------------------------
   {
-    // position p of row r holds the 16-byte chunk p ^ (r & 7): the gather reads chunk c of 64 DIFFERENT rows at once - un-swizzled,
+    // position p of row r holds the 16-byte chunk p ^ ((r >> 1) & 7) (round 5; before: p ^ (r & 7), whose bank slot depended on r & 7
+    // only - 8 classes for the 16 lanes of a ds_read_b128 service group; now (r & 1, (r >> 1) & 7): 16 classes, 16 consecutive rows
+    // conflict-free): the gather reads chunk c of 64 DIFFERENT rows at once - un-swizzled,
     // all of them in the same 4 banks
     const int p = lane & 7;
     for (int r0 = wave * 8; r0 < NR && !(dbg & 128); r0 += NW * 8) {  // (ablation bit 128: no slab staging)
       const int r = r0 + (lane >> 3);
-      if (r < NR) lds_dma16(value + (((long long)b * S + row0 + r) * M + m) * kD + ((p ^ (r & 7)) * 4), slab + r0 * kD);
+      if (r < NR) lds_dma16(value + (((long long)b * S + row0 + r) * M + m) * kD + ((p ^ ((r >> 1) & 7)) * 4), slab + r0 * kD);
     }
     if (tid < 8) *reinterpret_cast<float4*>(slab + NR * kD + tid * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
@@ -336,7 +338,7 @@ msda_bwd_win_d32(const float* __restrict__ gout, const float* __restrict__ value
       for (int k = 0; k < 4; ++k) {
         const int row = grow[k];  // NR: the zero row (tap outside the map, or a sample owned elsewhere)
         const float* vr = slab + row * kD;
-        const int sw7 = row & 7;  // LDS slab: chunk c sits at position c ^ (row & 7)
+        const int sw7 = (row >> 1) & 7;  // LDS slab: chunk c sits at position c ^ ((row >> 1) & 7)
         float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {  // two halves of the 128-byte row: 16 registers of value in flight, not 32

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """A/B of a module constant inside the bench step (the COMBO_* environment switches of round 3 are gone):
     python tools/ab_const.py combo_avs_amd.ops.convwrw.DX_OWN=3 [more assignments] -- [bench.py arguments]
-sets the constants after importing the package, then runs bench.main() in this process."""
+sets the constants after importing the package, then runs bench.main() in this process.  `call:<c_abi_setter>=<int>` calls an
+int-argument setter of the C ABI instead (e.g. call:combo_gemm_tn_tile256=0)."""
 import importlib
 import os
 import sys
@@ -17,6 +18,11 @@ if "--" in args:
     args, rest = args[:i], args[i + 1:]
 for a in args:
     path, val = a.split("=", 1)
+    if path.startswith("call:"):  # call:combo_gemm_tn_tile256=0 -> an int-argument setter of the C ABI (host-side kernel state)
+        from combo_avs_amd import _lib
+        prev = getattr(_lib.lib(), path[5:])(int(val))
+        print(f"[ab_const] {path[5:]}({val}) (was {prev})", file=sys.stderr)
+        continue
     mod, name = path.rsplit(".", 1)
     try:
         m = importlib.import_module(mod)
