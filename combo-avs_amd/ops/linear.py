@@ -36,6 +36,9 @@ def f32_ok(a, w):
             and a.shape[0] * w.shape[0] * 4 < 2 ** 31 - 1)
 
 
+SPLITK_F32 = True  # K slices + finishing sum for long reductions with few output tiles (tools/bench_f32.py --no-splitk: A/B)
+
+
 def gemm_nt_f32(a, w, bias=None, relu=False, out=None):
     """C[M,N] = a[M,K] @ w[N,K]^T (+ bias) (+ ReLU), exact fp32 on the matrix cores.  `out` may be a column block of a wider
     row-major matrix (stride(1) == 1)."""
@@ -44,7 +47,7 @@ def gemm_nt_f32(a, w, bias=None, relu=False, out=None):
     if out is None:
         out = torch.empty(M, N, device=a.device, dtype=torch.float32)
     lib = _lib.lib()
-    splits = lib.combo_gemm_nt_splitk_plan(M, N, K) if (K >= 1024 and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0) else 1
+    splits = lib.combo_gemm_nt_splitk_plan(M, N, K) if (SPLITK_F32 and K >= 1024 and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0) else 1
     if splits > 1:  # a long reduction with few output tiles: K slices as the batch entries of one launch + a finishing sum
         ws = torch.empty(splits, M, N, device=a.device, dtype=torch.float32)
         with _lib.timed("gemm_nt_f32", (M, N, K)):

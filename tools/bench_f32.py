@@ -16,12 +16,17 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=50)
 ap.add_argument("--shapes", default="all")
 ap.add_argument("--no-lib", action="store_true")
+ap.add_argument("--no-splitk", action="store_true")
 args = ap.parse_args()
 
 SHAPES = [(41160, 256, 1024), (41160, 1024, 256), (41160, 256, 256), (41160, 256, 288), (125440, 256, 256), (31360, 256, 256),
-          (4000, 256, 256), (4000, 256, 2048), (4000, 2048, 256), (4000, 256, 512), (7840, 256, 256), (1960, 256, 256)]
+          (4000, 256, 256), (4000, 256, 2048), (4000, 2048, 256), (4000, 256, 512), (7840, 256, 256), (1960, 256, 256),
+          (16384, 2048, 256), (7840, 1024, 256), (1960, 2048, 256), (41160, 256, 96)]
 if args.shapes == "small":
     SHAPES = SHAPES[:2]
+if args.shapes == "fixed":  # one round of wide tiles at growing K: the intercept is the per-launch fixed cost
+    SHAPES = [(65536, 16, 128), (65536, 64, 128), (65536, 256, 128), (65536, 512, 128), (65536, 1024, 128), (65536, 2048, 128),
+              (131072, 256, 128), (131072, 1024, 128)]
 
 
 def timeit(fn, n):
@@ -42,6 +47,9 @@ def timeit(fn, n):
     return s.elapsed_time(e) / n * 1e3
 
 
+if args.no_splitk:
+    import combo_avs_amd.ops.linear as _L
+    _L.SPLITK_F32 = False
 torch.manual_seed(0)
 for M, K, N in SHAPES:
     a = torch.randn(M, K, device="cuda")
