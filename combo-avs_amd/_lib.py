@@ -51,6 +51,7 @@ _SIGNATURES = {
     "combo_event_elapsed_us": [c_void_p, c_void_p, c_void_p],
     "combo_event_destroy": [c_void_p],
     "combo_upsample2x_bilinear_nhwc_f32": [c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "combo_upsample2x_bilinear_add_nhwc_f32": [c_void_p, c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "combo_upsample2x_bilinear_nhwc_backward_f32": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_longlong, c_void_p],
     "combo_groupnorm_nhwc_slices": [c_int],
     "combo_groupnorm_nhwc_forward_f32": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],

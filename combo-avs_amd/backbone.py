@@ -34,16 +34,25 @@ class FrozenBatchNorm2d(nn.Module):
         return x * scale.to(x.dtype)[None, :, None, None] + shift.to(x.dtype)[None, :, None, None]
 
 
+GRAD_IN_PLACE = True  # gradients of the folded convolution weights are written into the optimiser's flat buffer (A/B: tools/ab_const.py)
+
+
 class _FoldAll(torch.autograd.Function):
     """folded_i = (weight_i * scale_i).to(dtype) for every convolution of a backbone, as one node."""
 
     @staticmethod
     def forward(ctx, dtype, scales, *weights):
         ctx.scales = scales
+        ctx.wptrs = [w.data_ptr() for w in weights]
         if weights[0].is_cuda and all(w.is_contiguous() for w in weights):
             from .ops.foldcast import fold_cast  # ONE launch per 56 tensors (csrc/foldcast.hip)
             out = [torch.empty_like(w, dtype=dtype) for w in weights]
             fold_cast([w.detach() for w in weights], out, scales)
+            if GRAD_IN_PLACE and dtype == torch.float32 and any(ctx.needs_input_grad[2:]):
+                # the gradient of a folded weight may be written where its parameter's gradient lives (the optimiser's flat
+                # buffer): this node scales it in place
+                from .ops.linear import register_grad_aliases
+                register_grad_aliases(out, weights)
             return tuple(out)
         folded = torch._foreach_mul(weights, scales)
         if dtype != torch.float32:
@@ -69,9 +78,14 @@ class _FoldAll(torch.autograd.Function):
                 for i in late:
                     out[i] = grads[i]
                 idx = [i for i in idx if i not in set(late)]
-        g32 = [torch.empty(grads[i].shape, dtype=torch.float32, device=grads[i].device) for i in idx]
+        g32 = [None] * len(idx)
         if idx and grads[idx[0]].is_cuda:
+            from .ops import linear as L
             from .ops.foldcast import fold_cast
+            for j, i in enumerate(idx):  # straight into the optimiser's flat gradient buffer where the parameter is registered
+                g32[j] = L.grad_target(ctx.wptrs[i], grads[i].shape, torch.float32)
+        g32 = [g if g is not None else torch.empty(grads[i].shape, dtype=torch.float32, device=grads[i].device) for g, i in zip(g32, idx)]
+        if idx and grads[idx[0]].is_cuda:
             fold_cast([grads[i].contiguous() for i in idx], g32, [ctx.scales[i] for i in idx])
         elif idx:
             torch._foreach_copy_(g32, [grads[i] for i in idx])

@@ -15,7 +15,8 @@ __device__ __forceinline__ void taps(int o, int n_in, int& i0, int& i1, float& l
 }
 
 __global__ void __launch_bounds__(256)
-up2_fwd_kernel(const float* __restrict__ x, long long x_bstride4, int B, int H, int W, int C4, float* __restrict__ y) {
+up2_fwd_kernel(const float* __restrict__ x, long long x_bstride4, int B, int H, int W, int C4, float* __restrict__ y,
+               const float* __restrict__ add) {  // add (nullable): the lateral branch of the FPN step, y = add + up(x)
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   const int OH = 2 * H, OW = 2 * W;
   if (i >= (long long)B * OH * OW * C4) return;
@@ -30,10 +31,15 @@ up2_fwd_kernel(const float* __restrict__ x, long long x_bstride4, int B, int H, 
   const float4 v00 = xb[((long long)y0 * W + x0) * C4], v01 = xb[((long long)y0 * W + x1) * C4];
   const float4 v10 = xb[((long long)y1 * W + x0) * C4], v11 = xb[((long long)y1 * W + x1) * C4];
   const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
-  reinterpret_cast<float4*>(y)[i] = make_float4(w00 * v00.x + w01 * v01.x + w10 * v10.x + w11 * v11.x,
-                                                w00 * v00.y + w01 * v01.y + w10 * v10.y + w11 * v11.y,
-                                                w00 * v00.z + w01 * v01.z + w10 * v10.z + w11 * v11.z,
-                                                w00 * v00.w + w01 * v01.w + w10 * v10.w + w11 * v11.w);
+  float4 r = make_float4(w00 * v00.x + w01 * v01.x + w10 * v10.x + w11 * v11.x,
+                         w00 * v00.y + w01 * v01.y + w10 * v10.y + w11 * v11.y,
+                         w00 * v00.z + w01 * v01.z + w10 * v10.z + w11 * v11.z,
+                         w00 * v00.w + w01 * v01.w + w10 * v10.w + w11 * v11.w);
+  if (add) {  // the interpolated value is rounded to fp32 first, then added: bitwise `add + F.interpolate(x)`
+    const float4 a = reinterpret_cast<const float4*>(add)[i];
+    r.x = a.x + r.x; r.y = a.y + r.y; r.z = a.z + r.z; r.w = a.w + r.w;
+  }
+  reinterpret_cast<float4*>(y)[i] = r;
 }
 
 __global__ void __launch_bounds__(256)
@@ -69,14 +75,20 @@ up2_bwd_kernel(const float* __restrict__ dy, int B, int H, int W, int C4, float*
 
 extern "C" {
 
-int combo_upsample2x_bilinear_nhwc_f32(const float* x, long long x_batch_stride, int B, int H, int W, int C, float* y,
-                                       combo_stream_t stream) {
+int combo_upsample2x_bilinear_add_nhwc_f32(const float* x, long long x_batch_stride, const float* add, int B, int H, int W, int C,
+                                           float* y, combo_stream_t stream) {
   if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 != 0 || x_batch_stride % 4 != 0 || ((uintptr_t)x & 15) ||
-      ((uintptr_t)y & 15))
+      ((uintptr_t)y & 15) || ((uintptr_t)add & 15))
     return COMBO_EINVAL;
   const long long n = (long long)B * 4 * H * W * (C / 4);
-  hipLaunchKernelGGL(up2_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, x_batch_stride / 4, B, H, W, C / 4, y);
+  hipLaunchKernelGGL(up2_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, x_batch_stride / 4, B, H, W, C / 4, y,
+                     add);
   return (int)hipGetLastError();
+}
+
+int combo_upsample2x_bilinear_nhwc_f32(const float* x, long long x_batch_stride, int B, int H, int W, int C, float* y,
+                                       combo_stream_t stream) {
+  return combo_upsample2x_bilinear_add_nhwc_f32(x, x_batch_stride, nullptr, B, H, W, C, y, stream);
 }
 
 int combo_upsample2x_bilinear_nhwc_backward_f32(const float* dy, int B, int H, int W, int C, float* dx,

@@ -275,8 +275,11 @@ class MaskFormer(nn.Module):
             gt_masks = _field(t, "gt_masks").to(self.device)
             if hasattr(gt_masks, "tensor"):
                 gt_masks = gt_masks.tensor
-            padded = torch.zeros((gt_masks.shape[0], h_pad, w_pad), dtype=gt_masks.dtype, device=gt_masks.device)
-            padded[:, : gt_masks.shape[1], : gt_masks.shape[2]] = gt_masks
+            if tuple(gt_masks.shape[1:]) == (h_pad, w_pad):
+                padded = gt_masks  # nothing to pad (every shipped recipe: fixed-size inputs): no zero-fill + copy per clip
+            else:
+                padded = torch.zeros((gt_masks.shape[0], h_pad, w_pad), dtype=gt_masks.dtype, device=gt_masks.device)
+                padded[:, : gt_masks.shape[1], : gt_masks.shape[2]] = gt_masks
             new_targets.append({"labels": _field(t, "gt_classes").to(self.device), "masks": padded})
         return new_targets
 

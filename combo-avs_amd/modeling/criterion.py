@@ -280,11 +280,15 @@ class SetCriterion(nn.Module):
             extra = torch.stack(extra).view(L * Nm, n_rand, 2) if n_rand > 0 else None
         # ---- Hungarian matching: batched costs, one host sync -------------------------------------------------
         H, W = targets[0]["masks"].shape[-2:]
-        gt = torch.zeros(F_, Gmax, H, W, device=dev)
-        lab = torch.zeros(F_, Gmax, dtype=torch.int64, device=dev)
-        for f, t in enumerate(targets):
-            gt[f, : G[f]] = t["masks"].to(gt)
-            lab[f, : G[f]] = t["labels"]
+        if all(g == Gmax for g in G) and Gmax > 0:  # equal target counts: two stacks instead of two fills + two copies per frame
+            gt = torch.stack([t["masks"] for t in targets]).to(device=dev, dtype=torch.float32)
+            lab = torch.stack([t["labels"] for t in targets]).to(device=dev, dtype=torch.int64)
+        else:
+            gt = torch.zeros(F_, Gmax, H, W, device=dev)
+            lab = torch.zeros(F_, Gmax, dtype=torch.int64, device=dev)
+            for f, t in enumerate(targets):
+                gt[f, : G[f]] = t["masks"].to(gt)
+                lab[f, : G[f]] = t["labels"]
         with torch.no_grad():
             if fused:
                 C = self.matcher.batched_cost(logits.reshape(L * F_, Q, -1), xall, lab.repeat(L, 1), gt.repeat(L, 1, 1, 1), mpts,

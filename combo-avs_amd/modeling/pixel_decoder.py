@@ -20,7 +20,7 @@ from torch.nn.init import constant_, normal_, xavier_uniform_
 from ..msda import MSDeformAttnFunction
 from ..registry import SEM_SEG_HEADS_REGISTRY, ShapeSpec
 from ..ops.linear import Linear, ffn, linear
-from ..ops.upsample import upsample_bilinear
+from ..ops.upsample import upsample_bilinear, upsample_bilinear_add  # noqa: F401
 from .layers import conv1x1_or_conv, norm_act, Conv2d, c2_xavier_fill, get_norm, position_embedding_sine
 
 
@@ -280,14 +280,13 @@ class MSDeformAttnPixelDecoder(nn.Module):
                 pos.append(position_embedding_sine(1, x.shape[2], x.shape[3], x.device, self.conv_dim // 2))
             y, spatial_shapes, level_start_index, shapes_list = self.transformer(srcs, pos)
             bs = y.shape[0]
-            out, start = [], 0
-            for (H, W) in shapes_list:
-                out.append(y[:, start:start + H * W].transpose(1, 2).reshape(bs, -1, H, W))
-                start += H * W
+            # (one split node: its backward is ONE concatenation - three slices cost three zero-filled [BT, S, C] gradients
+            # and two accumulation adds)
+            out = [lv.transpose(1, 2).reshape(bs, -1, H, W) for lv, (H, W) in zip(y.split([H * W for H, W in shapes_list], 1), shapes_list)]
             for idx, f in enumerate(self.in_features[: self.num_fpn_levels][::-1]):
                 x = features[f].float()
                 cur_fpn = self.lateral_convs[idx](x)
-                y = cur_fpn + upsample_bilinear(out[-1], cur_fpn.shape[-2:])  # :349-350 (HIP kernels for the exact-2x case)
+                y = upsample_bilinear_add(cur_fpn, out[-1])  # :349-350 cur_fpn + F.interpolate(out[-1]) (one HIP pass for exact 2x)
                 out.append(self.output_convs[idx](y))
             multi_scale_features = out[: self.maskformer_num_feature_levels]
             return self.mask_features(out[-1]), out[0], multi_scale_features

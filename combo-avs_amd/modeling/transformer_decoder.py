@@ -133,6 +133,9 @@ class FFNLayer(nn.Module):
         return self.norm(t_res, y, fanout=2, pos=query_pos)
 
 
+BATCH_CLASS_HEADS = True  # (tools/ab_const.py flips it for the A/B)
+
+
 @TRANSFORMER_DECODER_REGISTRY.register()
 class MultiScaleMaskedTransformerDecoder(nn.Module):
     _version = 2
@@ -190,6 +193,11 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         # test hook: a list that receives the PackedMask of every prediction head of the next forward (what attn_mask_override
         # accepts: a second run with the first run's masks injected has no discrete choice left in the decoder)
         self.record_attn_masks = None
+        # the class logits are not needed inside the layer loop (only the mask embedding is, for the next layer's attention
+        # mask): with this switch the 10 heads' `class_embed` calls become ONE call on the stacked decoder outputs after the
+        # loop - one forward, one dX, one dW launch instead of ten each, and no accumulation of ten weight / bias gradients
+        self.batch_class_heads = BATCH_CLASS_HEADS
+        self._dec_list = None
 
     @classmethod
     def from_config(cls, cfg, in_channels, mask_classification):
@@ -260,6 +268,7 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         self._mfd = {sz: masklogit.downsample_tokens(mf_tok, (h_m, w_m), sz) for sz in set(size_list)}
         predictions_class, mask_embeds = [], []
         self._head_no = 0
+        self._dec_list = [] if self.batch_class_heads else None
         outputs_class, mask_embed, blocked = self.forward_prediction_heads(output, mf_tok, (h_m, w_m), size_list[0], logit_buf[0])
         predictions_class.append(outputs_class)
         mask_embeds.append(mask_embed)
@@ -281,6 +290,9 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
             predictions_class.append(outputs_class)
             mask_embeds.append(mask_embed)
         assert len(predictions_class) == self.num_layers + 1
+        if self._dec_list is not None:  # (:495 for all heads at once; rows are independent: the same values per head)
+            predictions_class = list(self.class_embed(torch.stack(self._dec_list)).unbind(0))
+            self._dec_list = None
         masklogit.mask_logits_all_into(mask_embeds, mf_tok, logit_buf)  # all heads' full-resolution logits: one launch
         self._mfd = {}
         # ... and ONE autograd node carries the gradient of all heads back to mask_features / the mask embeddings
@@ -301,8 +313,17 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         """:493-509 -> (class logits [BT,Q,K+1], mask embedding [BT,Q,C], blocked bool [BT,Q,h*w]); the mask logits
         [BT,Q,H*W] are written into `logits_out` (their gradient is attached later by one node for all heads)."""
         from ..ops import masklogit
-        dec = self.decoder_norm(output)
-        outputs_class = self.class_embed(dec)
+        if self._dec_list is not None and hasattr(self.decoder_norm, "defer_dw"):
+            # two handles on the normalised output (class head, mask-embedding MLP): their gradients are summed inside the
+            # LayerNorm backward kernel, not by autograd's accumulation (a clone + an add per head)
+            dec_c, dec = self.decoder_norm(output, fanout=2)
+        else:
+            dec_c = dec = self.decoder_norm(output)
+        if self._dec_list is not None:
+            self._dec_list.append(dec_c)
+            outputs_class = None  # filled in by forward() after the loop
+        else:
+            outputs_class = self.class_embed(dec_c)
         mask_embed = self.mask_embed(dec)
         # (the mask of the LAST head is never used - the reference computes it anyway, transformer_decoder.py:474-478)
         blocked = masklogit.mask_bits(mask_embed, self._mfd[tuple(attn_mask_target_size)]) if self._head_no < self.num_layers else None

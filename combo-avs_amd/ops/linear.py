@@ -17,6 +17,8 @@ import ctypes
 import weakref
 import os as _os
 
+import math
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -529,13 +531,38 @@ class grad_targets:
         _grad_targets = self.prev
 
 
+_grad_alias = {}  # {address of a derived weight (the FrozenBN-folded copy a convolution runs on): address of its parameter}
+
+
+def register_grad_aliases(derived, params):
+    """backbone._FoldAll.forward: `derived[i]` is computed from the parameter `params[i]` by a per-channel scale, and its
+    gradient node hands the scaled gradient on in place - so the gradient of `derived[i]` may be written where the gradient of
+    `params[i]` lives.  Every call replaces the previous generation of aliases of the same parameters (the derived tensors of
+    an earlier forward pass are gone; a recycled address must not resolve to a flat-buffer view)."""
+    fresh = {p.data_ptr() for p in params}
+    for k in [k for k, v in _grad_alias.items() if v in fresh]:
+        del _grad_alias[k]
+    for d, p in zip(derived, params):
+        _grad_alias[d.data_ptr()] = p.data_ptr()
+
+
+def grad_target(ptr, shape, dtype):
+    """the registered flat-buffer view for the parameter (or aliased derived weight) at address `ptr`, viewed as `shape`; None
+    when there is none (no grad_targets() open, an unknown address, another dtype / element count)"""
+    if _grad_targets is None:
+        return None
+    v = _grad_targets.get(ptr)
+    if v is None and ptr in _grad_alias:
+        v = _grad_targets.get(_grad_alias[ptr])
+    if v is None or v.dtype != dtype or v.numel() != math.prod(shape):
+        return None
+    return v if tuple(v.shape) == tuple(shape) else v.view(shape)
+
+
 def grad_buffer_like(weight):
     """destination of a full weight gradient: the registered flat-buffer view of `weight`, else a fresh tensor"""
-    if _grad_targets is not None:
-        v = _grad_targets.get(weight.data_ptr())
-        if v is not None and v.shape == weight.shape and v.dtype == weight.dtype:
-            return v
-    return torch.empty_like(weight)
+    v = grad_target(weight.data_ptr(), weight.shape, weight.dtype) if weight.is_contiguous() else None
+    return v if v is not None else torch.empty_like(weight)
 
 
 def weight_grad(weight, dy, x2d, want_db, defer):

@@ -141,7 +141,9 @@ class FlatAdamW:
     def _grad(self, outputs, inputs, grad_outputs):
         from .ops.linear import deferred_dw, grad_targets
         in_place = self.flat_grad.dtype == torch.float32 and self.flat_grad.is_cuda
-        targets = {p.data_ptr(): v for p, v in zip(self.params, self.grad_views) if p.dim() == 2} if in_place else {}
+        # matrices (dense layers) and 4-D convolution weights (1x1 layers run as dense layers; the backbones' FrozenBN-folded
+        # weights resolve to their parameters through ops.linear.register_grad_aliases)
+        targets = {p.data_ptr(): v for p, v in zip(self.params, self.grad_views) if p.dim() in (2, 4)} if in_place else {}
         with grad_targets(targets), deferred_dw():  # latency-bound decoder weight gradients: one grouped launch when the context closes
             return torch.autograd.grad(outputs, inputs, grad_outputs, allow_unused=True)
 

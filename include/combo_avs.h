@@ -237,6 +237,10 @@ int combo_upsample2x_bilinear_nhwc_f32(const float* x, long long x_batch_stride,
                                        combo_stream_t stream);
 int combo_upsample2x_bilinear_nhwc_backward_f32(const float* dy, int B, int H, int W, int C, float* dx,
                                                 long long dx_batch_stride, combo_stream_t stream);
+/*   the whole step `y = cur_fpn + F.interpolate(out[-1], ...)` (msdeformattn.py:350) in one pass: add [B,2H,2W,C] (nullable),
+ *   bitwise the two-pass result (the interpolated value is rounded to fp32, then added) */
+int combo_upsample2x_bilinear_add_nhwc_f32(const float* x, long long x_batch_stride, const float* add, int B, int H, int W, int C,
+                                           float* y, combo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a5  MSDeformAttn prologue (ops/modules/ms_deform_attn.py:101-118)

@@ -400,6 +400,30 @@ def test_upsample2x_bilinear_nhwc_vs_torch(B, C, H, W):
     assert (dx - dxr).abs().max() <= 1e-5 * dxr.abs().max() + 1e-6
 
 
+@pytest.mark.parametrize("B,C,H,W", [(3, 256, 28, 28), (2, 8, 5, 7)])
+def test_fpn_step_lateral_plus_upsampled_in_one_pass(B, C, H, W):
+    """ops.upsample.upsample_bilinear_add(lateral, x) == lateral + F.interpolate(x) (msdeformattn.py:350): bitwise the two-pass
+    result of the own kernels, within round-off of ATen's; the lateral branch receives dy itself, x the gathered gradient."""
+    import combo_avs_amd  # noqa: F401
+    from combo_avs_amd.ops.upsample import upsample_bilinear, upsample_bilinear_add
+    torch.manual_seed(H + W)
+    x = torch.randn(B, C, H, W, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    lat = torch.randn(B, C, 2 * H, 2 * W, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = upsample_bilinear_add(lat, x)
+    two = lat + upsample_bilinear(x, (2 * H, 2 * W))
+    assert torch.equal(y, two)
+    ref = lat + torch.nn.functional.interpolate(x, size=(2 * H, 2 * W), mode="bilinear", align_corners=False)
+    assert (y - ref).abs().max() < 1e-6
+    g = torch.randn_like(ref).contiguous(memory_format=torch.channels_last)
+    dlat, dx = torch.autograd.grad(y, (lat, x), g)
+    dlat_r, dx_r = torch.autograd.grad(ref, (lat, x), g)
+    assert torch.equal(dlat, dlat_r)
+    assert (dx - dx_r).abs().max() <= 1e-5 * dx_r.abs().max() + 1e-6
+    # a lateral map that is not channels_last takes the two-pass route and gives the same values
+    lat2 = lat.detach().contiguous()
+    assert (upsample_bilinear_add(lat2, x.detach()) - ref).abs().max() < 1e-6
+
+
 @pytest.mark.parametrize("rows,C,with_res", [(41160, 256, True), (4000, 256, True), (4000, 256, False), (37, 128, True), (5, 512, False)])
 def test_add_layernorm_forward_backward_vs_torch(rows, C, with_res):
     """ops.layernorm.LayerNorm(x, residual): LN(x + r) in one pass (csrc/layernorm.hip) == nn.LayerNorm(x + r) in float64,

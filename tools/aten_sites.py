@@ -41,12 +41,14 @@ class Spy(TorchDispatchMode):
         if name in WATCH:
             t = out if torch.is_tensor(out) else (args[0] if args and torch.is_tensor(args[0]) else None)
             if t is not None and t.is_cuda:
-                site = "autograd engine"
+                node = torch._C._current_autograd_node() if hasattr(torch._C, "_current_autograd_node") else None
+                site = "autograd engine" + (f" ({node.name()})" if node is not None else "")
                 for fr in reversed(traceback.extract_stack()[:-1]):
                     if "combo-avs_amd" in fr.filename and "trainer.py" not in fr.filename:
                         site = f"{fr.filename.split('combo-avs_amd/')[-1]}:{fr.lineno} {(fr.line or '')[:60]}"
                         break
-                shapes = str([tuple(a.shape) for a in args if torch.is_tensor(a)][:3])[:60]
+                flat = [a for x in args for a in (x if isinstance(x, (list, tuple)) else [x])]
+                shapes = str([tuple(a.shape) for a in flat if torch.is_tensor(a)][:3])[:60]
                 k = (name, shapes, site)
                 agg[k][0] += 1
                 agg[k][1] += t.numel() * t.element_size()

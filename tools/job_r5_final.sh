@@ -1,0 +1,15 @@
+#!/bin/bash
+# round 5, final evidence at one commit: PMC traffic first (bench.py reads profiles/r05_pmc.json of the same csrc digest), the whole
+# GPU test suite, the default bench run, the rocprofv3 kernel trace + steady-state summary.  Everything lands in gpurun_out/.
+mkdir -p gpurun_out profiles
+export COMBO_COMMIT=$(git rev-parse --short HEAD 2>/dev/null || cat .combo_commit 2>/dev/null || echo unknown)
+bash tools/pmc_bench.sh > gpurun_out/pmc_bench.log 2>&1
+cp gpurun_out/r05_pmc.json profiles/r05_pmc.json 2>/dev/null   # (on the box: the bench below then reports `traffic`)
+timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/final_tests.log 2>&1
+echo "tests exit $?" >> gpurun_out/final_tests.log
+tail -3 gpurun_out/final_tests.log
+timeout 900 python bench.py > gpurun_out/final_bench.json 2> gpurun_out/final_bench.err
+tail -c 400 gpurun_out/final_bench.json
+bash tools/final_profile.sh --profile-only > gpurun_out/final_profile.log 2>&1
+python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-workloads --dump-slots 2 > gpurun_out/slots_bench.json 2> gpurun_out/slots_bench.err
+ls -la gpurun_out/kstats.csv gpurun_out/steady_graph.csv gpurun_out/r05_pmc.json gpurun_out/prof_bench_line.json
