@@ -244,7 +244,8 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
         # for all three (ops/linear.py memory_kv; their gradients come back through one [tokens, 3 x 256] buffer per level)
         nl = self.num_feature_levels
         attn = [layer.multihead_attn for layer in self.transformer_cross_attention_layers]
-        kv = memory_kv(src_k, src, [[(a.in_proj_weight, a.in_proj_bias) for a in attn[l::nl]] for l in range(nl)], defer=True)
+        kv = memory_kv(src_k, src, [[(a.in_proj_weight, a.in_proj_bias) for a in attn[l::nl]] for l in range(nl)], defer=True,
+                       key_from_value=not any(p_.requires_grad for p_ in pos))  # src_k = src + (sine embedding): see memory_kv
         query_embed = self.query_embed.weight.unsqueeze(0)  # [1,Q,C]
         output = self.query_feat.weight.unsqueeze(0).expand(bt, -1, -1)
         if self.queries_fuse_type == "add":

@@ -302,25 +302,28 @@ def forward_gemm(x2d, weight, bias, relu, out=None):
     return y
 
 
-def input_grad_gemm(dy, weight, relu_mask=None):
+def input_grad_gemm(dy, weight, relu_mask=None, add=None):
     """dX = dy @ weight (weight [N,K] as stored, or a tuple of weights standing for their row concatenation), optionally
-    multiplied by [relu_mask > 0]"""
+    + add (another gradient arriving at the same tensor, summed in the GEMM's epilogue), optionally multiplied by
+    [relu_mask > 0]"""
     ws = weight if isinstance(weight, tuple) else (weight,)
     dyc = dy if _aligned_rows(dy) else dy.contiguous()
     if x3_ok(dyc, ws[0].shape[1]) and ws[0].dtype == torch.float32:
         img = _expected_image(*ws)
         if img is not None:
-            return gemm_nt_x3(dyc, img, relu_mask=relu_mask, img=img)  # img [K, N] has the shape of the operand view
-        return gemm_nt_x3(dyc, (ws[0] if len(ws) == 1 else torch.cat(ws, 0)).t(), relu_mask=relu_mask)
+            return gemm_nt_x3(dyc, img, relu_mask=relu_mask, img=img, add=add)  # img [K, N] has the shape of the operand view
+        return gemm_nt_x3(dyc, (ws[0] if len(ws) == 1 else torch.cat(ws, 0)).t(), relu_mask=relu_mask, add=add)
     w = ws[0] if len(ws) == 1 else torch.cat(ws, 0)
     if (dy.is_cuda and dy.dtype == torch.float32 and w.dtype == torch.float32 and dy.dim() == 2 and dy.shape[1] <= 16 and dy.stride(1) == 1
-            and w.shape[1] % 4 == 0 and w.is_contiguous() and w.data_ptr() % 16 == 0 and relu_mask is None):
+            and w.shape[1] % 4 == 0 and w.is_contiguous() and w.data_ptr() % 16 == 0 and relu_mask is None and add is None):
         # a tiny reduction length (class_embed: K + 1 classes): outer-product kernel instead of a BLAS tile GEMM
         dx = torch.empty(dy.shape[0], w.shape[1], device=dy.device, dtype=torch.float32)
         _lib.check(_lib.lib().combo_gemm_smallk_f32(dy.data_ptr(), dy.stride(0), w.data_ptr(), w.stride(0), dx.data_ptr(), dx.stride(0),
                                                     dy.shape[0], w.shape[1], dy.shape[1], _lib.current_stream()), "combo_gemm_smallk_f32")
         return dx
     dx = dy @ w
+    if add is not None:
+        dx = dx + add
     return relu_grad(dx, relu_mask) if relu_mask is not None else dx
 
 
@@ -771,6 +774,7 @@ class _MemoryKV(Function):
         bv [n E]: the k / v rows of the n layers' packed projections, concatenated (copies, not differentiated); Wb = W_0, b_0,
         W_1, b_1, ...: the packed [3E, E] / [3E] parameters themselves -> k_0, v_0, k_1, v_1, ...: [rows, E] column blocks."""
         from . import attention as A
+        defer, ctx.key_from_value = defer if isinstance(defer, tuple) else (defer, False)
         Ws = Wb[0::2]
         n, E = len(Ws), Ws[0].shape[1]
         K_all = forward_gemm(mem_k, Wk, bk, False)
@@ -810,7 +814,12 @@ class _MemoryKV(Function):
                 elif g.data_ptr() != dst.data_ptr() or g.stride() != dst.stride():
                     dst.copy_(g)  # a gradient that was not written in place by the strided attention backward
         dxk = input_grad_gemm(dK, tuple(W[E:2 * E] for W in Ws)) if ctx.needs_input_grad[0] else None
-        dxv = input_grad_gemm(dV, tuple(W[2 * E:] for W in Ws)) if ctx.needs_input_grad[1] else None
+        if ctx.key_from_value and dxk is not None and ctx.needs_input_grad[1]:
+            # mem_k = mem_v + (a constant): both gradients belong to mem_v - the second GEMM's epilogue sums them, the key
+            # input's own edge carries nothing (autograd would add two [rows, E] tensors per level)
+            dxv, dxk = input_grad_gemm(dV, tuple(W[2 * E:] for W in Ws), add=dxk if dxk.is_contiguous() else dxk.contiguous()), None
+        else:
+            dxv = input_grad_gemm(dV, tuple(W[2 * E:] for W in Ws)) if ctx.needs_input_grad[1] else None
         out = [dxk, dxv, None, None, None, None, None]
         for j, W in enumerate(Ws):
             if not ctx.needs_input_grad[7 + 2 * j]:
@@ -823,8 +832,10 @@ class _MemoryKV(Function):
         return tuple(out)
 
 
-def memory_kv(mem_k, mem_v, level_params, defer=False):
+def memory_kv(mem_k, mem_v, level_params, defer=False, key_from_value=False):
     """The k / v projections of every cross-attention layer, one pair of GEMMs per memory level.
+    key_from_value: the caller guarantees mem_k[l] = mem_v[l] + (a tensor that needs no gradient): the gradient of both inputs is
+    then returned once, through mem_v.
     mem_k / mem_v: per level, the key input (memory + position) and the value input (memory), [B, hw, E];
     level_params: per level, [(in_proj_weight [3E, E], in_proj_bias [3E])] of the layers that attend to that level, in layer order
     -> per level, [(k, v)] as ROW VIEWS [B * hw, E] (row pitch layers * E) for ops.attention.attention."""
@@ -843,7 +854,7 @@ def memory_kv(mem_k, mem_v, level_params, defer=False):
         flat = [t for pair in params for t in pair]
         rk, rv = slice(off, off + n * E), slice(off + n * E, off + 2 * n * E)
         off += 2 * n * E
-        o = _MemoryKV.apply(xk.reshape(-1, E), xv.reshape(-1, E), defer, Wcat[rk], bcat[rk], Wcat[rv], bcat[rv], *flat)
+        o = _MemoryKV.apply(xk.reshape(-1, E), xv.reshape(-1, E), (defer, key_from_value), Wcat[rk], bcat[rk], Wcat[rv], bcat[rv], *flat)
         out.append([(o[2 * j], o[2 * j + 1]) for j in range(n)])
     return out
 
