@@ -34,6 +34,7 @@ class FrozenBatchNorm2d(nn.Module):
         return x * scale.to(x.dtype)[None, :, None, None] + shift.to(x.dtype)[None, :, None, None]
 
 
+CHAIN_RELU = True  # block-to-block ReLU gradient + fan-out sum inside the next block's first dX GEMM (A/B: tools/ab_const.py)
 GRAD_IN_PLACE = True  # gradients of the folded convolution weights are written into the optimiser's flat buffer (A/B: tools/ab_const.py)
 
 
@@ -126,9 +127,11 @@ class Bottleneck(nn.Module):
         """the order `forward` consumes the folded weights in"""
         return [self.conv1, self.conv2, self.conv3] + ([self.shortcut] if self.shortcut is not None else [])
 
-    def forward(self, x, folded=None, x_res=None, fanout=False):
+    def forward(self, x, folded=None, x_res=None, fanout=False, chain_in=False):
         """x_res: the same values as x as a second autograd output of the producing block (its identity / shortcut consumer);
-        fanout: hand the output over in that form (-> a pair)."""
+        fanout: hand the output over in that form (-> a pair); fanout == "chain": hand over ONE output whose gradient comes
+        back complete and ReLU-masked (the next block is called with chain_in=True: its first convolution's input-gradient GEMM
+        sums the identity branch's gradient and applies this block's ReLU mask, ops.convwrw.conv_bias_act(passthrough=True))."""
         if folded is None:
             out = F.relu_(self.conv1(x))
             out = F.relu_(self.conv2(out))
@@ -154,13 +157,20 @@ class Bottleneck(nn.Module):
             k3 = convwrw.weight_kind(f3[0], c3.stride, c3.padding, (B_, f3[0].shape[1], (H_ - 1) // s2 + 1, (W_ - 1) // s2 + 1)) if (ok and f3[0].requires_grad) else 0
             fold1 = convwrw.ENABLED and convwrw.MASK_3X3 and k2 == 3 and bool(convwrw.DX_OWN & 1) and f2[3] is not None
             fold2 = convwrw.ENABLED and convwrw.MASK_1X1 and k3 == 1
-            out = cba(x, f1[0], f1[2], c1.stride, c1.padding, f1[3], grad_masked=fold1)
+            chain_out = fanout == "chain"
+            fo = False if chain_out else fanout
+            if chain_in:
+                assert self.shortcut is None and x_res is None
+                out, xr = cba(x, f1[0], f1[2], c1.stride, c1.padding, f1[3], grad_masked=fold1, passthrough=True)
+            else:
+                out = cba(x, f1[0], f1[2], c1.stride, c1.padding, f1[3], grad_masked=fold1)
             out = cba(out, f2[0], f2[2], c2.stride, c2.padding, f2[3], grad_masked=fold2, mask_dx=fold1)
             if self.shortcut is not None:
                 fs = next(folded)
                 sc = cba(xr, fs[0], None, self.shortcut.stride, self.shortcut.padding, fs[3])
-                return cba(out, f3[0], self._merged_shift(f3[2], fs[2]), c3.stride, c3.padding, f3[3], residual=sc, fanout=fanout, mask_dx=fold2)
-            return cba(out, f3[0], f3[2], c3.stride, c3.padding, f3[3], residual=xr, fanout=fanout, mask_dx=fold2)
+                return cba(out, f3[0], self._merged_shift(f3[2], fs[2]), c3.stride, c3.padding, f3[3], residual=sc, fanout=fo,
+                           grad_masked=chain_out, mask_dx=fold2)
+            return cba(out, f3[0], f3[2], c3.stride, c3.padding, f3[3], residual=xr, fanout=fo, grad_masked=chain_out, mask_dx=fold2)
         from .ops.biasact import bias_act
         out = bias_act(self.conv1(x, f1, bias=False), f1[2])
         out = bias_act(self.conv2(out, f2, bias=False), f2[2])
@@ -260,13 +270,21 @@ class ResNet(nn.Module):
             # fp32: a block output goes to the next block twice (first convolution, identity / shortcut branch); handed over as
             # two autograd outputs, the two gradients are added inside the block's ReLU-gradient pass (ops/biasact.py)
             blocks = [(name, blk) for name in ("res2", "res3", "res4", "res5") for blk in getattr(self, name)]
-            x_res = None
+            x_res, chain_in = None, False
             for i, (name, blk) in enumerate(blocks):
                 fan = dtype == torch.float32 and i + 1 < len(blocks) and torch.is_grad_enabled()
                 is_out = name in self._out_features and (i + 1 == len(blocks) or blocks[i + 1][0] != name)
+                # a block inside a stage (next block: no shortcut convolution, same map size): ONE output, "chain" - the sum of its
+                # two consumers' gradients and its ReLU mask ride in the next block's first input-gradient GEMM
+                chain = (fan and CHAIN_RELU and not is_out and blocks[i + 1][0] == name and blocks[i + 1][1].shortcut is None
+                         and x.is_cuda and x.requires_grad)
                 # (a stage's last block has a third consumer - the head: a third alias, summed in the same ReLU-gradient pass)
-                y = blk(x, folded, x_res, (3 if is_out else 2) if fan else False)
-                x, x_res = (y[0], y[1]) if fan else (y, None)
+                y = blk(x, folded, x_res, "chain" if chain else ((3 if is_out else 2) if fan else False), chain_in=chain_in)
+                if chain:
+                    x, x_res = y, None
+                else:
+                    x, x_res = (y[0], y[1]) if fan else (y, None)
+                chain_in = chain
                 if is_out:
                     out[name] = y[2] if fan else x
         return out

@@ -68,6 +68,39 @@ class _BiasAct(Function):
         return dx, None, (dx if ctx.has_res else None), None, None, None, None
 
 
+class _MaskedFan(Function):
+    """x (a ReLU output whose producer was told grad_masked=True) -> two aliases for its two consumers; the gradients come back
+    summed and multiplied by [x > 0] in one pass - the producer-side fan-out of _BiasAct moved to the consumer, for the layers
+    ops.convwrw._ConvWrw's `passthrough` form does not take."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d1, d2):
+        (x,) = ctx.saved_tensors
+        got = [g.contiguous(memory_format=torch.channels_last) for g in (d1, d2) if g is not None]
+        if not got:
+            return None
+        lib, st = _lib.lib(), _lib.current_stream()
+        dx = torch.empty_like(got[0])
+        if len(got) == 2 and all(g.dtype == torch.float32 for g in got) and x.dtype == torch.float32:
+            _lib.check(lib.combo_relu_grad2_f32(got[0].data_ptr(), got[1].data_ptr(), x.data_ptr(), dx.numel(), dx.data_ptr(), st),
+                       "combo_relu_grad2_f32")
+            return dx
+        dy = got[0] if len(got) == 1 else (got[0] + got[1]).contiguous(memory_format=torch.channels_last)
+        fn = lib.combo_relu_grad_f32 if dy.dtype == torch.float32 else lib.combo_relu_grad_bf16
+        _lib.check(fn(dy.data_ptr(), x.data_ptr(), dy.numel(), dx.data_ptr(), st), "combo_relu_grad")
+        return dx
+
+
+def masked_fan(x):
+    return _MaskedFan.apply(x)
+
+
 def bias_act(y, bias, residual=None, relu=True, fanout=False, grad_masked=False, precomputed=False):
     """y: convolution output WITHOUT bias (modified in place); bias: fp32 [C]; residual: same shape as y or None.
     fanout: return the result twice (True / 2) or three times (two / three autograd outputs over the same memory) for its

@@ -179,7 +179,7 @@ def _x3_tokens(x_tok, k, img, bias, aux, aux_mode, relu, y_tok, B, H, W, cin, co
 
 class _ConvWrw(Function):
     @staticmethod
-    def forward(ctx, x, w, k, mask_dx=False, images=None, bias=None, residual=None, relu=False):
+    def forward(ctx, x, w, k, mask_dx=False, images=None, bias=None, residual=None, relu=False, passthrough=False):
         """mask_dx: x is the ReLU output of the producing layer and feeds nothing else - the input gradient is returned already
         multiplied by [x > 0] (folded into the dX GEMM's epilogue); the producer then skips its ReLU-gradient pass
         (ops.biasact.bias_act(grad_masked=True)).  Set in pairs by backbone.Bottleneck.
@@ -188,22 +188,30 @@ class _ConvWrw(Function):
         ctx.k, ctx.mask_dx = k, mask_dx
         ctx.img_dx = images[1] if images is not None else None
         ctx.save_for_backward(x, w)
+        ctx.passthrough = passthrough
         if images is not None and FWD_X3:
-            return _x3_forward(x, k, images[0], bias, residual, relu)
-        assert bias is None and residual is None and not relu
-        return F.conv2d(x, w, None, 2 if k > 20 else 1, 1 if k % 10 == 3 else 0)
+            y = _x3_forward(x, k, images[0], bias, residual, relu)
+        else:
+            assert bias is None and residual is None and not relu
+            y = F.conv2d(x, w, None, 2 if k > 20 else 1, 1 if k % 10 == 3 else 0)
+        # passthrough (with mask_dx, stride 1): x has a SECOND consumer (the block's identity branch) - it reads this node's second
+        # output, an alias of x, so that its gradient arrives HERE and is summed in the input-gradient GEMM's epilogue, before the
+        # ReLU mask: dx = (dy . W + d_alias) * [x > 0] - one GEMM instead of GEMM + (add, mask) pass (csrc/biasact.hip relu_grad2)
+        return (y, x.view_as(x)) if passthrough else y
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, dy):
+    def backward(ctx, dy, d_alias=None):
         x, w = ctx.saved_tensors
+        if d_alias is not None and not d_alias.is_contiguous(memory_format=torch.channels_last):
+            d_alias = d_alias.contiguous(memory_format=torch.channels_last)
         B, cin, H, W = x.shape
         cout = w.shape[0]
         pad = 1 if ctx.k % 10 == 3 else 0
         if not dy.is_contiguous(memory_format=torch.channels_last):
             dy = dy.contiguous(memory_format=torch.channels_last)
         if ctx.k > 20:  # stride 2 (the first block of res3 / res4 / res5): input gradient the library's, weight gradient own
-            assert not ctx.mask_dx
+            assert not ctx.mask_dx and not ctx.passthrough
             own_dw = WGRAD_S2 and ctx.needs_input_grad[1] and cin % 4 == 0 and cout >= 64 and cout % 4 == 0
             own_dx = DX_S2_1X1 and ctx.k == 21 and ctx.needs_input_grad[0] and ctx.img_dx is not None and cin % 4 == 0
             dx, dw = None, None
@@ -217,21 +225,24 @@ class _ConvWrw(Function):
                            "combo_expand_stride2_f32")
             if own_dw:
                 dw = C3._wgrad_tokens(C3._tokens(dy), C3._tokens(x), B, H, W, cin, cout, ksize=3 if ctx.k == 23 else 1, stride=2)
-            return dx, dw, None, None, None, None, None, None
+            return dx, dw, None, None, None, None, None, None, None
         dx = dw = None
-        if ctx.needs_input_grad[0] and ctx.k == 3 and (DX_OWN & 1) and ctx.img_dx is not None:
+        if ctx.needs_input_grad[0] and ctx.k == 3 and (DX_OWN & 1) and ctx.img_dx is not None and d_alias is None:
             dx = torch.empty((B, cin, H, W), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
             _x3_tokens(C3._tokens(dy), 3, ctx.img_dx, None, C3._tokens(x) if ctx.mask_dx else None, 2, False, C3._tokens(dx), B, H, W, cout, cin)
         elif ctx.needs_input_grad[0] and ctx.k == 1 and (DX_OWN & 2) and min(cin, cout) >= DX_MIN_C:
             mask = C3._tokens(x) if ctx.mask_dx else None
+            add = C3._tokens(d_alias) if d_alias is not None else None
             if ctx.img_dx is not None:
-                dx = L.gemm_nt_x3(C3._tokens(dy), ctx.img_dx, relu_mask=mask, img=ctx.img_dx)
+                dx = L.gemm_nt_x3(C3._tokens(dy), ctx.img_dx, relu_mask=mask, img=ctx.img_dx, add=add)
             else:
-                dx = L.input_grad_gemm(C3._tokens(dy), w.view(cout, cin), relu_mask=mask)
+                dx = L.input_grad_gemm(C3._tokens(dy), w.view(cout, cin), relu_mask=mask, add=add)
             dx = dx.view(B, H, W, cin).permute(0, 3, 1, 2)
         elif ctx.needs_input_grad[0]:  # input gradient: the library's kernel
             dx = torch.ops.aten.convolution_backward(dy, x, w, None, (1, 1), (pad, pad), (1, 1), False, (0, 0), 1,
                                                      (True, False, False))[0]
+            if d_alias is not None:
+                dx = dx + d_alias
             if ctx.mask_dx:
                 dx = L.relu_grad(C3._tokens(dx.contiguous(memory_format=torch.channels_last)), C3._tokens(x)).view(B, H, W, cin).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
@@ -244,7 +255,7 @@ class _ConvWrw(Function):
             else:  # the library's weight gradient
                 dw = torch.ops.aten.convolution_backward(dy, x, w, None, (1, 1), (pad, pad), (1, 1), False, (0, 0), 1,
                                                          (False, True, False))[1]
-        return dx, dw, None, None, None, None, None, None
+        return dx, dw, None, None, None, None, None, None, None
 
 
 class _MaskedInput(Function):
@@ -270,12 +281,27 @@ def _forward_ok(x, w, residual):
                                       and residual.is_contiguous(memory_format=torch.channels_last))))
 
 
-def conv_bias_act(x, w, bias, stride, padding, images=None, residual=None, relu=True, fanout=False, grad_masked=False, mask_dx=False):
+def conv_bias_act(x, w, bias, stride, padding, images=None, residual=None, relu=True, fanout=False, grad_masked=False, mask_dx=False,
+                  passthrough=False):
     """relu(conv2d(x, w) + bias (+ residual)) of a FrozenBN-folded backbone convolution (bias: fp32 [cout] or None = no epilogue
     at all).  With `images` (weight_images) the whole expression is ONE launch of the 3-product kernel; otherwise the library's
     convolution followed by the fused bias / ReLU pass (ops/biasact.py).  fanout / grad_masked / mask_dx: see
-    ops.biasact.bias_act and _ConvWrw.forward."""
+    ops.biasact.bias_act and _ConvWrw.forward.  passthrough: x is a ReLU output whose producer skips its ReLU-gradient pass, with
+    TWO consumers - this convolution and the reader of the second return value (an alias of x); the two gradients are summed and
+    masked in this layer's input-gradient GEMM where it is an own kernel, else by ops.biasact.masked_fan -> (y, x_alias)."""
     from .biasact import bias_act, fusable
+    if passthrough:
+        if not (torch.is_grad_enabled() and x.requires_grad):
+            return conv_bias_act(x, w, bias, stride, padding, images, residual, relu, fanout, grad_masked, False), x
+        k = kind(x, w, stride, padding)
+        if (k == 1 and images is not None and FWD_X3 and bias is not None and residual is None and fanout is False
+                and (DX_OWN & 2) and min(w.shape[0], w.shape[1]) >= DX_MIN_C):
+            z, x_alias = _ConvWrw.apply(x, w, k, True, images, bias, None, relu, True)
+            assert fusable(z, None)
+            return bias_act(z, bias, None, relu, False, grad_masked, precomputed=True), x_alias
+        from .biasact import masked_fan
+        x1, x2 = masked_fan(x)
+        return conv_bias_act(x1, w, bias, stride, padding, images, residual, relu, fanout, grad_masked, False), x2
     if images is not None and FWD_X3 and not (torch.is_grad_enabled() and (w.requires_grad or x.requires_grad)) and _forward_ok(x, w, residual):
         # no gradient (evaluation): the same kernel without an autograd node - the features of an evaluation forward are
         # bit-identical to the training forward's
