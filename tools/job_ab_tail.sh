@@ -1,11 +1,11 @@
 #!/bin/bash
 # tests touched by the round-5 tail items + a bench line on the same box with and without them
 mkdir -p gpurun_out
-timeout 2400 python -m pytest tests/test_backbone_x3_gpu.py tests/test_graph_gpu.py tests/test_model_gpu.py tests/test_dp_gpu.py -x -q > gpurun_out/tail_tests.log 2>&1
+timeout 2400 python -m pytest tests/test_head_gpu.py tests/test_graph_gpu.py tests/test_model_gpu.py -x -q > gpurun_out/tail_tests.log 2>&1
 echo "tests exit $?" >> gpurun_out/tail_tests.log
 B="--no-cpu-baseline --no-other-workloads --steps 30 --warmup 5"
 rm -f gpurun_out/tail_ab.txt
-for v in "x.y=0" "combo_avs_amd.backbone.CHAIN_RELU=0" "x.y=0" "combo_avs_amd.backbone.CHAIN_RELU=0"; do
+for v in "x.y=0" "combo_avs_amd.modeling.layers.MLP_FUSED_RELU_GRAD=0" "x.y=0" "combo_avs_amd.modeling.layers.MLP_FUSED_RELU_GRAD=0"; do
   if [ "$v" = "x.y=0" ]; then
     timeout 400 python bench.py $B > gpurun_out/tail_tmp.json 2> gpurun_out/tail_tmp.err
   else
