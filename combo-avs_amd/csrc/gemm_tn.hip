@@ -448,9 +448,19 @@ splitk_reduce_kernel(const float* __restrict__ part, int splits, long long n, fl
                      const float* __restrict__ db_part, int nb, float* __restrict__ db) {
   const long long n4 = n >> 2;
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  // eight partials in flight per thread, summed in the same fixed order: a tiny output (the class head: 3 x 256 values from
+  // 157 token slices) is ONE workgroup walking the splits - one memory latency per split (281 us) without the batching
   if (i < n4) {
     float4 a = reinterpret_cast<const float4*>(part)[i];
-    for (int z = 1; z < splits; ++z) {
+    int z = 1;
+    for (; z + 8 <= splits; z += 8) {
+      float4 b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) b[u] = reinterpret_cast<const float4*>(part + (long long)(z + u) * n)[i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a.x += b[u].x; a.y += b[u].y; a.z += b[u].z; a.w += b[u].w; }
+    }
+    for (; z < splits; ++z) {
       const float4 b = reinterpret_cast<const float4*>(part + (long long)z * n)[i];
       a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
@@ -458,7 +468,15 @@ splitk_reduce_kernel(const float* __restrict__ part, int splits, long long n, fl
   } else if (i - n4 < nb) {
     const int j = (int)(i - n4);
     float a = db_part[j];
-    for (int z = 1; z < splits; ++z) a += db_part[(long long)z * nb + j];
+    int z = 1;
+    for (; z + 8 <= splits; z += 8) {
+      float b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) b[u] = db_part[(long long)(z + u) * nb + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += b[u];
+    }
+    for (; z < splits; ++z) a += db_part[(long long)z * nb + j];
     db[j] = a;
   }
 }

@@ -133,6 +133,20 @@ class FFNLayer(nn.Module):
         return self.norm(t_res, y, fanout=2, pos=query_pos)
 
 
+class _Scramble(torch.autograd.Function):
+    """audio [BT, C] -> audio[idx] [BT, Q, C]; inv [BT, Q]: the flat (frame, query) positions that read frame f's token."""
+
+    @staticmethod
+    def forward(ctx, audio, idx, inv):
+        ctx.save_for_backward(inv)
+        return audio[idx]
+
+    @staticmethod
+    def backward(ctx, dy):
+        (inv,) = ctx.saved_tensors
+        return dy.reshape(-1, dy.shape[-1])[inv].sum(1), None, None
+
+
 BATCH_CLASS_HEADS = True  # (tools/ab_const.py flips it for the A/B)
 
 
@@ -222,10 +236,16 @@ class MultiScaleMaskedTransformerDecoder(nn.Module):
             q = torch.arange(Q, device=audio_features.device)[None, :]
             b = torch.arange(bt, device=audio_features.device)[:, None]
             idx = torch.div(q * bt + b, Q, rounding_mode="floor")  # [BT,Q]
+            # every frame's token is used by exactly Q (frame, query) pairs: their flat positions, frame by frame - the gather's
+            # backward is then itself a gather + a sum over Q (deterministic; ATen's index backward sorts the 4 000 indices and
+            # walks the segments: 72 us + the sort)
+            inv = torch.argsort(idx.flatten(), stable=True).view(bt, Q)
+            assert bool((idx.flatten()[inv] == torch.arange(bt, device=idx.device)[:, None]).all())
+            idx = (idx, inv)
             if not hasattr(self, "_scramble_idx"):
                 self._scramble_idx = {}
             self._scramble_idx[key] = idx
-        return audio_features[:, 0][idx]  # [BT,Q,C]
+        return _Scramble.apply(audio_features[:, 0], idx[0], idx[1])  # [BT,Q,C]
 
     def forward(self, x, audio_features, mask_features, mask=None):
         bt, c_m, h_m, w_m = mask_features.shape
