@@ -84,7 +84,7 @@ class _FoldAll(torch.autograd.Function):
             from .ops import linear as L
             from .ops.foldcast import fold_cast
             for j, i in enumerate(idx):  # straight into the optimiser's flat gradient buffer where the parameter is registered
-                g32[j] = L.grad_target(ctx.wptrs[i], grads[i].shape, torch.float32)
+                g32[j] = L.grad_target(ctx.wptrs[i], grads[i].shape, torch.float32) if GRAD_IN_PLACE else None
         g32 = [g if g is not None else torch.empty(grads[i].shape, dtype=torch.float32, device=grads[i].device) for g, i in zip(g32, idx)]
         if idx and grads[idx[0]].is_cuda:
             fold_cast([grads[i].contiguous() for i in idx], g32, [ctx.scales[i] for i in idx])
