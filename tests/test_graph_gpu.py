@@ -158,7 +158,10 @@ def test_graphed_training_actually_learns(rig):
             losses = step(batches[0])
             totals.append(float(sum(losses.values())))
         assert all(t == t for t in totals)
-        assert totals[-1] < 0.97 * totals[0], (totals[0], totals[-1])
+        # (at 20 x the learning rate the curve is noisy and, through the atomics of the library kernels, differs from run to run:
+        # 85.1 -> 75.0 +- 0.2 after 10 steps in every run, 71.8 ... 78.8 after 40 (tools/learn_probe.py); a capture that froze
+        # the weights would stay at 85.1)
+        assert min(totals[5:]) < 0.95 * totals[0], (totals[0], min(totals[5:]), totals[-1])
         assert len(step.graphs) == 1
     finally:
         for s, o in zip(opt.segments, old):
