@@ -728,7 +728,10 @@ def main():
             "other_kernels": kernels,
         }
         if dist.is_initialized():
-            out["rccl_world_size"] = dist.get_world_size()
+            backend = dist.get_backend()
+            out["dist_backend"] = "rccl (torch backend 'nccl')" if backend == "nccl" else backend
+            # (the name says RCCL only when RCCL carried the collectives; the shared-GPU functional runs use gloo)
+            out["rccl_world_size" if backend == "nccl" else "world_size"] = dist.get_world_size()
             out["ranks"] = rank_table["ranks"]
             out["distinct_devices"] = rank_table["distinct_devices"]
             if rank_table["shared_device_run"]:

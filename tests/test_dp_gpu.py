@@ -29,7 +29,10 @@ def test_two_ranks_sharing_the_gpu_run_the_bench_flow():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and out["config"]["global_batch_clips"] == 4
     # the line proves what ran: every rank's device identity, the process group's size, the measured all-reduce time
-    assert out["rccl_world_size"] == 2 and [r_["rank"] for r_ in out["ranks"]] == [0, 1]
+    # (two ranks on one GPU cannot use RCCL - "Duplicate GPU detected" - so this functional run travels over gloo and the line
+    # says so: `world_size` + `dist_backend`; `rccl_world_size` appears only when RCCL carried the collectives)
+    assert out["dist_backend"] == "gloo" and out["world_size"] == 2 and "rccl_world_size" not in out
+    assert [r_["rank"] for r_ in out["ranks"]] == [0, 1]
     assert all(r_["pci"] and r_["name"] and r_["pid"] > 0 for r_ in out["ranks"]) and out["ranks"][0]["pid"] != out["ranks"][1]["pid"]
     assert out["distinct_devices"] == 1 and out["shared_device_run"] is True  # two ranks on ONE GPU: allowed only by COMBO_SINGLE_DEVICE=1
     ar = out["all_reduce"]
