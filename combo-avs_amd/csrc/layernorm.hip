@@ -23,6 +23,38 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// VEC consecutive floats of a lane as the widest accesses their count allows (rows are 16-byte aligned: C % 4 == 0 wherever
+// VEC % 4 == 0).  Round 5: the scalar form compiled to 4 dword loads / stores per tensor and lane (16-byte stride between
+// lanes: four partial-line requests where one full one does) - the 41 160-row encoder launches ran at 2.0 TB/s.
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float* __restrict__ p, float (&v)[VEC]) {
+  if constexpr (VEC % 4 == 0) {
+#pragma unroll
+    for (int i = 0; i < VEC; i += 4) {
+      const float4 t = *reinterpret_cast<const float4*>(p + i);
+      v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w;
+    }
+  } else if constexpr (VEC == 2) {
+    const float2 t = *reinterpret_cast<const float2*>(p);
+    v[0] = t.x; v[1] = t.y;
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) v[i] = p[i];
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* __restrict__ p, const float (&v)[VEC]) {
+  if constexpr (VEC % 4 == 0) {
+#pragma unroll
+    for (int i = 0; i < VEC; i += 4) *reinterpret_cast<float4*>(p + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
+  } else if constexpr (VEC == 2) {
+    *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) p[i] = v[i];
+  }
+}
+
 template <int VEC>  // channels per lane: C = 64 * VEC, VEC in {1, 2, 4, 5, 8} (64 / 320 = PVTv2's widths)
 __global__ void __launch_bounds__(256)
 add_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ w, const float* __restrict__ b,
@@ -34,12 +66,17 @@ add_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ r, cons
   const int lane = threadIdx.x & 63;
   const long long off = row * C + lane * VEC;
   float v[VEC];
-#pragma unroll
-  for (int i = 0; i < VEC; ++i) v[i] = x[off + i];
+  load_vec<VEC>(x + off, v);
   if (r) {
+    float rv[VEC];
+    load_vec<VEC>(r + off, rv);
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) v[i] += r[off + i];
+    for (int i = 0; i < VEC; ++i) v[i] += rv[i];
   }
+  float wv[VEC], bv[VEC], pv[VEC];
+  load_vec<VEC>(w + lane * VEC, wv);
+  load_vec<VEC>(b + lane * VEC, bv);
+  if (yp) load_vec<VEC>(pos + (long long)fast_mod(row, (int)pos_rows) * C + lane * VEC, pv);
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < VEC; ++i) s += v[i];
@@ -48,12 +85,15 @@ add_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ r, cons
 #pragma unroll
   for (int i = 0; i < VEC; ++i) q += (v[i] - mu) * (v[i] - mu);
   const float rs = rsqrtf(wave_sum(q) * (1.f / C) + eps);
+  if (z) store_vec<VEC>(z + off, v);
+  float o[VEC];
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) {
-    if (z) z[off + i] = v[i];
-    const float o = (v[i] - mu) * rs * w[lane * VEC + i] + b[lane * VEC + i];
-    y[off + i] = o;
-    if (yp) yp[off + i] = o + pos[(long long)fast_mod(row, (int)pos_rows) * C + lane * VEC + i];
+  for (int i = 0; i < VEC; ++i) o[i] = (v[i] - mu) * rs * wv[i] + bv[i];
+  store_vec<VEC>(y + off, o);
+  if (yp) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) o[i] += pv[i];
+    store_vec<VEC>(yp + off, o);
   }
   if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
@@ -70,24 +110,40 @@ ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z, const f
   const int lane = threadIdx.x & 63;
   const long long off = row * C + lane * VEC;
   const float mu = mean[row], rs = rstd[row];
-  float g[VEC], xh[VEC];
+  float g[VEC], xh[VEC], d[VEC], t[VEC], wv[VEC];
   float s1 = 0.f, s2 = 0.f;
+  load_vec<VEC>(dy + off, d);
+  if (dy2) {
+    load_vec<VEC>(dy2 + off, t);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) d[i] += t[i];
+  }
+  if (dy3) {
+    load_vec<VEC>(dy3 + off, t);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) d[i] += t[i];
+  }
+  if (dy4) {
+    load_vec<VEC>(dy4 + off, t);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) d[i] += t[i];
+  }
+  if (dy_sum) store_vec<VEC>(dy_sum + off, d);  // the summed output gradient, for the deferred parameter-gradient launch
+  load_vec<VEC>(z + off, t);
+  load_vec<VEC>(w + lane * VEC, wv);
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
-    float d = dy[off + i];
-    if (dy2) d += dy2[off + i];
-    if (dy3) d += dy3[off + i];
-    if (dy4) d += dy4[off + i];
-    if (dy_sum) dy_sum[off + i] = d;  // the summed output gradient, for the deferred parameter-gradient launch
-    g[i] = d * w[lane * VEC + i];
-    xh[i] = (z[off + i] - mu) * rs;
+    g[i] = d[i] * wv[i];
+    xh[i] = (t[i] - mu) * rs;
     s1 += g[i];
     s2 += g[i] * xh[i];
   }
   s1 = wave_sum(s1) * (1.f / C);
   s2 = wave_sum(s2) * (1.f / C);
+  float o[VEC];
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) dz[off + i] = rs * (g[i] - s1 - xh[i] * s2);
+  for (int i = 0; i < VEC; ++i) o[i] = rs * (g[i] - s1 - xh[i] * s2);
+  store_vec<VEC>(dz + off, o);
 }
 
 inline bool c_ok(int C) { return C == 64 || C == 128 || C == 256 || C == 320 || C == 512; }

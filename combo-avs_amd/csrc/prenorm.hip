@@ -9,6 +9,10 @@
 // the LayerNorm forward, and their four counterparts backward: ~1 900 launches and ~20 ms of a 160 ms PVTv2-B5 step at
 // 4 clips x 10 frames.  HBM-bound: forward reads 4 + 2 and writes 4 + 2 bytes per element, backward reads 2 + 4 + 4 and
 // writes 4 + 2 (+ 4).  One wave per row, C = 64 * VEC, statistics in registers (two-pass variance), as csrc/layernorm.hip.
+// Round 5: a lane owns the channels {lane, 64 + lane, ...} (it owned VEC consecutive ones): a wave-wide dword / ushort access is
+// then 256 / 128 contiguous bytes.  The consecutive form compiled to VEC scalar accesses per tensor with a VEC-element stride
+// between lanes (C = 320: 20 bytes - no vector form exists), i.e. VEC partial-line requests where one full one does; these
+// kernels were 10 % of the `pvt_avss_512` step.
 #include "combo_common.h"
 
 namespace {
@@ -39,14 +43,14 @@ prenorm_fwd_kernel(const PreArgs a) {
   const long long row = blockIdx.x * 4LL + (threadIdx.x >> 6);
   if (row >= a.rows) return;
   const int lane = threadIdx.x & 63;
-  const long long off = row * C + lane * VEC;
+  const long long off = row * C + lane;  // element i of a lane is channel 64 i + lane: every access of a wave is one contiguous run
   float v[VEC];
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) v[i] = a.x[off + i];
+  for (int i = 0; i < VEC; ++i) v[i] = a.x[off + 64 * i];
   if (a.r) {
     const float s = a.scale ? a.scale[fast_div(row, (int)a.rows_per_sample)] : 1.f;
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) v[i] += s * bf2f(a.r[off + i]);
+    for (int i = 0; i < VEC; ++i) v[i] += s * bf2f(a.r[off + 64 * i]);
   }
   float sum = 0.f;
 #pragma unroll
@@ -58,10 +62,10 @@ prenorm_fwd_kernel(const PreArgs a) {
   const float rs = rsqrtf(wsum(q) * (1.f / C) + a.eps);
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
-    if (a.z) a.z[off + i] = v[i];
-    const float o = (v[i] - mu) * rs * a.w[lane * VEC + i] + a.b[lane * VEC + i];
-    if (a.y_bf16) reinterpret_cast<unsigned short*>(a.y)[off + i] = f2bf(o);
-    else reinterpret_cast<float*>(a.y)[off + i] = o;
+    if (a.z) a.z[off + 64 * i] = v[i];
+    const float o = (v[i] - mu) * rs * a.w[64 * i + lane] + a.b[64 * i + lane];
+    if (a.y_bf16) reinterpret_cast<unsigned short*>(a.y)[off + 64 * i] = f2bf(o);
+    else reinterpret_cast<float*>(a.y)[off + 64 * i] = o;
   }
   if (lane == 0) { a.mean[row] = mu; a.rstd[row] = rs; }
 }
@@ -79,7 +83,7 @@ prenorm_bwd_kernel(const PreBwdArgs a) {
   const long long row = blockIdx.x * 4LL + (threadIdx.x >> 6);
   if (row >= a.rows) return;
   const int lane = threadIdx.x & 63;
-  const long long off = row * C + lane * VEC;
+  const long long off = row * C + lane;  // element i of a lane is channel 64 i + lane: every access of a wave is one contiguous run
   float d[VEC];
   if (a.dy) {
     const float mu = a.mean[row], rs = a.rstd[row];
@@ -87,12 +91,12 @@ prenorm_bwd_kernel(const PreBwdArgs a) {
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-      float t = a.dy_bf16 ? bf2f(reinterpret_cast<const unsigned short*>(a.dy)[off + i]) : reinterpret_cast<const float*>(a.dy)[off + i];
+      float t = a.dy_bf16 ? bf2f(reinterpret_cast<const unsigned short*>(a.dy)[off + 64 * i]) : reinterpret_cast<const float*>(a.dy)[off + 64 * i];
       if (a.dy2)  // the second consumer of y (fan-out: the autograd node hands out two aliases of y)
-        t += a.dy_bf16 ? bf2f(reinterpret_cast<const unsigned short*>(a.dy2)[off + i]) : reinterpret_cast<const float*>(a.dy2)[off + i];
-      if (a.dy32) a.dy32[off + i] = t;
-      g[i] = t * a.w[lane * VEC + i];
-      xh[i] = (a.z[off + i] - mu) * rs;
+        t += a.dy_bf16 ? bf2f(reinterpret_cast<const unsigned short*>(a.dy2)[off + 64 * i]) : reinterpret_cast<const float*>(a.dy2)[off + 64 * i];
+      if (a.dy32) a.dy32[off + 64 * i] = t;
+      g[i] = t * a.w[64 * i + lane];
+      xh[i] = (a.z[off + 64 * i] - mu) * rs;
       s1 += g[i];
       s2 += g[i] * xh[i];
     }
@@ -106,13 +110,13 @@ prenorm_bwd_kernel(const PreBwdArgs a) {
   }
   if (a.dz) {
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) d[i] += a.dz[off + i];
+    for (int i = 0; i < VEC; ++i) d[i] += a.dz[off + 64 * i];
   }
   const float s = (a.dr && a.scale) ? a.scale[fast_div(row, (int)a.rows_per_sample)] : 1.f;
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
-    a.dx[off + i] = d[i];
-    if (a.dr) a.dr[off + i] = f2bf(s * d[i]);
+    a.dx[off + 64 * i] = d[i];
+    if (a.dr) a.dr[off + 64 * i] = f2bf(s * d[i]);
   }
 }
 
@@ -133,13 +137,13 @@ bias_ln_kernel(const BiasLnArgs a) {
   const long long row = blockIdx.x * 4LL + (threadIdx.x >> 6);
   if (row >= a.rows) return;
   const int lane = threadIdx.x & 63;
-  const long long off = row * C + lane * VEC;
+  const long long off = row * C + lane;  // element i of a lane is channel 64 i + lane: every access of a wave is one contiguous run
   float v[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
-    const int c = lane * VEC + i;
+    const int c = 64 * i + lane;
     const float xb = !a.xb ? 0.f : a.xb_bf16 ? bf2f(reinterpret_cast<const unsigned short*>(a.xb)[c]) : reinterpret_cast<const float*>(a.xb)[c];
-    v[i] = bf2f(a.x[off + i]) + xb;
+    v[i] = bf2f(a.x[off + 64 * i]) + xb;
   }
   if (!BWD) {
     float sum = 0.f;
@@ -151,7 +155,7 @@ bias_ln_kernel(const BiasLnArgs a) {
     for (int i = 0; i < VEC; ++i) q += (v[i] - mu) * (v[i] - mu);
     const float rs = rsqrtf(wsum(q) * (1.f / C) + a.eps);
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) a.y[off + i] = f2bf((v[i] - mu) * rs * a.w[lane * VEC + i] + a.b[lane * VEC + i]);
+    for (int i = 0; i < VEC; ++i) a.y[off + 64 * i] = f2bf((v[i] - mu) * rs * a.w[64 * i + lane] + a.b[64 * i + lane]);
     if (lane == 0) { a.mean[row] = mu; a.rstd[row] = rs; }
   } else {
     const float mu = a.mean[row], rs = a.rstd[row];
@@ -159,9 +163,9 @@ bias_ln_kernel(const BiasLnArgs a) {
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-      const float t = bf2f(a.dy[off + i]);
-      if (a.dy32) { a.dy32[off + i] = t; a.z32[off + i] = v[i]; }  // (dy, z) in fp32 for the deferred parameter-gradient launch
-      g[i] = t * a.w[lane * VEC + i];
+      const float t = bf2f(a.dy[off + 64 * i]);
+      if (a.dy32) { a.dy32[off + 64 * i] = t; a.z32[off + 64 * i] = v[i]; }  // (dy, z) in fp32 for the deferred parameter-gradient launch
+      g[i] = t * a.w[64 * i + lane];
       xh[i] = (v[i] - mu) * rs;
       s1 += g[i];
       s2 += g[i] * xh[i];
@@ -169,7 +173,7 @@ bias_ln_kernel(const BiasLnArgs a) {
     s1 = wsum(s1) * (1.f / C);
     s2 = wsum(s2) * (1.f / C);
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) a.dx[off + i] = f2bf(rs * (g[i] - s1 - xh[i] * s2));
+    for (int i = 0; i < VEC; ++i) a.dx[off + 64 * i] = f2bf(rs * (g[i] - s1 - xh[i] * s2));
   }
 }
 
