@@ -18,6 +18,7 @@ _SIGNATURES = {
     "combo_build_arch": [],
     "combo_dwconv3x3_bf16": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "combo_dwconv3x3_wgrad_slices": [c_int] * 4,
+    "combo_dwconv3x3_wgrad_strips": [c_int],
     "combo_dwconv3x3_wgrad_finish_f32": [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "combo_dwconv3x3_wgrad_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "combo_fold_cast_grouped": [c_void_p, c_int, c_void_p],

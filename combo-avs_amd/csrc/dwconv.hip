@@ -231,6 +231,92 @@ dwconv3x3_wgrad2_kernel(const u16* __restrict__ x, const u16* __restrict__ dy, i
   }
 }
 
+// v3 of the weight gradient (round 5): v2's token lane re-reads the 3 x 3 neighbourhood of every token - 10 16-byte loads per
+// token and channel group, 9 of them through L1 / L2 again (104 launches, 5.7 ms of a 108 ms `pvt_ms3_t10` step).  Here a token
+// lane walks a vertical STRIP of R rows at one (frame, column), as the forward kernel does: the window slides down, 3 new x loads
+// + 1 dy load per token (R = 4: 5.5 loads per token with the two rows that prime the window, R = 8: 4.75).  Workgroup, partial
+// layout, the reduction over the 32 token lanes and the finish kernel are v2's.
+template <int R>
+__global__ void __launch_bounds__(512)
+dwconv3x3_wgrad3_kernel(const u16* __restrict__ x, const u16* __restrict__ dy, int B, int H, int W, int C8, int slices,
+                        int strips_per_slice, float* __restrict__ partial) {
+  __shared__ float red[8][32][8];  // 512 threads: 32 channel groups x 16 token lanes (80 accumulators + a 3 x 3 window of
+                                   // 16-byte vectors per thread: 1024 threads would cap a thread at 128 registers and spill)
+  const int c8l = threadIdx.x & 31, tl = threadIdx.x >> 5, wave = threadIdx.x >> 6;
+  const int c8 = blockIdx.x * 32 + c8l, s = blockIdx.y;
+  const int HS = (H + R - 1) / R;
+  const long long strips = (long long)B * HS * W;
+  const long long q0 = (long long)s * strips_per_slice, q1 = min(strips, q0 + strips_per_slice);
+  float acc[10][8];
+#pragma unroll
+  for (int t = 0; t < 10; ++t)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[t][k] = 0.f;
+  const long long rs = (long long)W * C8 * 8;  // elements per image row
+  const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+  for (long long q = q0 + tl; q < q1; q += 16) {
+    // strip q = (b, hs, w), w fastest: the 16 token lanes of a workgroup read neighbouring columns
+    const int w = (int)(q % W);
+    const long long t2 = q / W;
+    const int hs = (int)(t2 % HS), b = (int)(t2 / HS);
+    const int h0 = hs * R;
+    const bool lok = w > 0, rok = w < W - 1;
+    const u16* xc = x + (((long long)b * H * W + w) * C8 + c8) * 8;   // token (b, 0, w)
+    const u16* gc = dy + (((long long)b * H * W + w) * C8 + c8) * 8;
+    uint4 win[3][3];
+    auto load_row = [&](int hh, uint4 (&row)[3]) {
+      if (hh < 0 || hh >= H) { row[0] = row[1] = row[2] = zero; return; }
+      const u16* p = xc + hh * rs;
+      row[0] = lok ? *reinterpret_cast<const uint4*>(p - C8 * 8) : zero;
+      row[1] = *reinterpret_cast<const uint4*>(p);
+      row[2] = rok ? *reinterpret_cast<const uint4*>(p + C8 * 8) : zero;
+    };
+    load_row(h0 - 1, win[0]);
+    load_row(h0, win[1]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int h = h0 + r;
+      if (h >= H) break;
+      load_row(h + 1, win[2]);
+      float g[8];
+      unpack8(*reinterpret_cast<const uint4*>(gc + h * rs), g);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[9][k] += g[k];
+#pragma unroll
+      for (int iy = 0; iy < 3; ++iy)
+#pragma unroll
+        for (int ix = 0; ix < 3; ++ix) {
+          float xv[8];
+          unpack8(win[iy][ix], xv);  // (a tap outside the map is a zero vector: it adds nothing, as v2's `continue`)
+#pragma unroll
+          for (int k = 0; k < 8; ++k) acc[iy * 3 + ix][k] += g[k] * xv[k];
+        }
+#pragma unroll
+      for (int ix = 0; ix < 3; ++ix) { win[0][ix] = win[1][ix]; win[1][ix] = win[2][ix]; }
+    }
+  }
+  const int C = C8 * 8;
+  float* o = partial + (long long)s * 10 * C;
+#pragma unroll
+  for (int t = 0; t < 10; ++t) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[t][k] += __shfl_xor(acc[t][k], 32, 64);  // the wave's two token lanes
+    if ((threadIdx.x & 32) == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) red[wave][c8l][k] = acc[t][k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {  // (channel group, k): fixed order over the 16 waves
+      const int cl = threadIdx.x >> 3, k = threadIdx.x & 7;
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v += red[q][cl][k];
+      o[t * C + (blockIdx.x * 32 + cl) * 8 + k] = v;
+    }
+    __syncthreads();
+  }
+}
+
 // dw[c][tap] = sum_s partial[s][tap][c], db[c] = sum_s partial[s][9][c]: the weight gradient in the parameter's layout [C][9]
 // and the bias gradient in ONE launch (v1: two levels of the generic split-K reduce + a transpose copy).  Block = 32 channels
 // x 8 slice lanes, grid = (C / 32, 10 taps); fixed summation order.
@@ -287,10 +373,29 @@ int combo_dwconv3x3_wgrad_finish_f32(const float* partials, int slices, int C, f
   return (int)hipGetLastError();
 }
 
-static bool wgrad_v2() { return true; }  // (v1 below stays for channel counts that are not a multiple of 256)
+static bool wgrad_v2() { return true; }
+static int g_wgrad_strips = 1;  // (v1 below stays for channel counts that are not a multiple of 256)
+
+int combo_dwconv3x3_wgrad_strips(int on) {  // host-side switch of the launches that follow; returns the previous value
+  const int prev = g_wgrad_strips;
+  g_wgrad_strips = on ? 1 : 0;
+  return prev;
+}
 
 int combo_dwconv3x3_wgrad_slices(int B, int H, int W, int C) {
   const long long tokens = (long long)B * H * W;
+  if (wgrad_v2() && C % 256 == 0 && g_wgrad_strips) {  // v3: a token lane takes whole strips; a slice = a multiple of 16 strips (16 token lanes)
+    const int R = H >= 32 ? 8 : 4;
+    const long long strips = (long long)B * ((H + R - 1) / R) * W;
+    long long s = 512 / (C / 256);
+    const long long maxs = (strips + 15) / 16;
+    if (s > maxs) s = maxs;
+    if (s < 1) s = 1;
+    long long sps = (strips + s - 1) / s;
+    sps = (sps + 15) / 16 * 16;
+    s = (strips + sps - 1) / sps;
+    return (int)(s < 1 ? 1 : s);
+  }
   if (wgrad_v2() && C % 256 == 0) {  // v2: 32 channel groups x 32 token lanes per workgroup, ~512 workgroups
     long long s = 512 / (C / 256);
     if (s > tokens / 128) s = tokens / 128;  // at least 4 tokens per token lane
@@ -310,6 +415,20 @@ int combo_dwconv3x3_wgrad_bf16(const void* x, const void* dy, int B, int H, int 
   const long long tokens = (long long)B * H * W;
   const int tps = (int)((tokens + slices - 1) / slices);
   if (wgrad_v2() && C % 256 == 0) {
+    if (g_wgrad_strips) {  // v3: strips of R rows per token lane (combo_dwconv3x3_wgrad_strips(0) brings v2 back, for A/B)
+      const int R = H >= 32 ? 8 : 4;
+      const long long strips = (long long)B * ((H + R - 1) / R) * W;
+      int sps = (int)((strips + slices - 1) / slices);
+      sps = (sps + 15) / 16 * 16;  // (as combo_dwconv3x3_wgrad_slices plans it; a caller's own slice count still covers every strip)
+      if ((long long)sps * slices < strips) return COMBO_EINVAL;
+      if (R == 8)
+        hipLaunchKernelGGL(dwconv3x3_wgrad3_kernel<8>, dim3(C / 256, slices), dim3(512), 0, (hipStream_t)stream, (const u16*)x,
+                           (const u16*)dy, B, H, W, C / 8, slices, sps, partials);
+      else
+        hipLaunchKernelGGL(dwconv3x3_wgrad3_kernel<4>, dim3(C / 256, slices), dim3(512), 0, (hipStream_t)stream, (const u16*)x,
+                           (const u16*)dy, B, H, W, C / 8, slices, sps, partials);
+      return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(dwconv3x3_wgrad2_kernel, dim3(C / 256, slices), dim3(1024), 0, (hipStream_t)stream, (const u16*)x,
                        (const u16*)dy, B, H, W, C / 8, slices, tps, partials);
     return (int)hipGetLastError();

@@ -160,6 +160,9 @@ int combo_dwconv3x3_bf16(const void* x, const float* w_tap_major, const float* b
 /* the finish of the weight gradient: dw[c][tap] = sum_s partials[s][tap][c] (nn.Conv2d's own [C,1,3,3] layout),
  * db[c] = sum_s partials[s][9][c] (db may be NULL) in one launch, fixed order */
 int combo_dwconv3x3_wgrad_finish_f32(const float* partials, int slices, int C, float* dw, float* db, combo_stream_t stream);
+/*   host-side switch (A/B): 1 = the strip-form weight-gradient kernel (round 5, default), 0 = round 3's per-token form; returns the
+ *   previous value; combo_dwconv3x3_wgrad_slices plans for the form that is on */
+int combo_dwconv3x3_wgrad_strips(int on);
 int combo_dwconv3x3_wgrad_slices(int B, int H, int W, int C);
 int combo_dwconv3x3_wgrad_bf16(const void* x, const void* dy, int B, int H, int W, int C, int slices, float* partials,
                                combo_stream_t stream);
