@@ -15,8 +15,13 @@ struct LnGroupArgs {
   combo_ln_grad_problem p[kMaxLnGroup];
 };
 
+// Round 5: (a) eight tokens in flight per thread - the serial walk had ONE pair of loads outstanding per thread and ran at
+// 1.4 TB/s (1.8 ms of a `pvt_ms3_t10` step, 8 launches); (b) narrow rows use token sub-lanes: C = 64 / 128 kept 64 / 128 of the
+// 256 threads busy - now thread (tl, c) takes the tokens t0 + tl, t0 + tl + ntl, ... (ntl = 256 / C) and the sub-lanes are summed
+// through LDS in a fixed order.
 __global__ void __launch_bounds__(256)
 ln_param_grad_grouped_kernel(const LnGroupArgs args) {
+  __shared__ float red[2][256];
   const int b = blockIdx.x;
   int pi = 0;
   for (int i = 1; i < args.count; ++i)
@@ -25,16 +30,51 @@ ln_param_grad_grouped_kernel(const LnGroupArgs args) {
   const int slice = b - args.block_start[pi];
   const long long t0 = (long long)slice * pr.tokens_per_slice, t1 = min(pr.tokens, t0 + pr.tokens_per_slice);
   const int C = pr.C;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+  const float* __restrict__ dy = pr.dy;
+  const float* __restrict__ x = pr.x;
+  const float* __restrict__ mean = pr.mean;
+  const float* __restrict__ rstd = pr.rstd;
+  const int ntl = (C <= 128 && 256 % C == 0) ? 256 / C : 1;  // token sub-lanes (uniform per workgroup)
+  const int tl = ntl > 1 ? (int)threadIdx.x / C : 0;
+  const int c0 = ntl > 1 ? (int)threadIdx.x % C : (int)threadIdx.x;
+  float* o = pr.partials + (long long)slice * 2 * C;
+  for (int c = c0; c < C; c += 256) {  // (ntl > 1: exactly one pass, every thread takes part in the barrier below)
     float dg = 0.f, db = 0.f;
-    for (long long t = t0; t < t1; ++t) {
-      const float g = pr.dy[t * C + c];
-      dg += g * (pr.x[t * C + c] - pr.mean[t]) * pr.rstd[t];
+    long long t = t0 + tl;
+    for (; t + 7LL * ntl < t1; t += 8LL * ntl) {
+      float g[8], xv[8], mu[8], rs[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const long long tt = t + (long long)u * ntl;
+        g[u] = dy[tt * C + c];
+        xv[u] = x[tt * C + c];
+        mu[u] = mean[tt];
+        rs[u] = rstd[tt];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        dg += g[u] * (xv[u] - mu[u]) * rs[u];
+        db += g[u];
+      }
+    }
+    for (; t < t1; t += ntl) {
+      const float g = dy[t * C + c];
+      dg += g * (x[t * C + c] - mean[t]) * rstd[t];
       db += g;
     }
-    float* o = pr.partials + (long long)slice * 2 * C;
-    o[c] = dg;
-    o[C + c] = db;
+    if (ntl > 1) {
+      red[0][threadIdx.x] = dg;
+      red[1][threadIdx.x] = db;
+      __syncthreads();
+      if (tl == 0) {
+        for (int k = 1; k < ntl; ++k) { dg += red[0][k * C + c]; db += red[1][k * C + c]; }
+        o[c] = dg;
+        o[C + c] = db;
+      }
+    } else {
+      o[c] = dg;
+      o[C + c] = db;
+    }
   }
 }
 

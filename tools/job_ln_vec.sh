@@ -1,7 +1,7 @@
 #!/bin/bash
-# vectorised / lane-strided LayerNorm kernels: tests, then the three workloads
+# LayerNorm kernels (access width, parameter-gradient kernel): tests, then the three workloads
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q -k "prenorm or bias_ln or layernorm or pvt" > gpurun_out/ln_tests.log 2>&1
+timeout 1200 python -m pytest tests/test_kernels_gpu.py tests/test_graph_gpu.py -x -q -k "prenorm or bias_ln or layernorm or pvt or graph or ln" > gpurun_out/ln_tests.log 2>&1
 echo "tests exit $?" >> gpurun_out/ln_tests.log
 tail -3 gpurun_out/ln_tests.log
 for c in r50_s4 pvt_ms3_t10 pvt_avss_512; do
