@@ -275,11 +275,19 @@ def csrc_digest():
 
 def device_identity(index):
     """what distinguishes one physical GPU from another on this node: the device's UUID (when this torch exposes it) and its PCI
-    domain:bus:device address"""
+    domain:bus:device address.  A torch build that exposes NEITHER yields `verifiable: False` with (hostname, visible-device
+    environment, device index) as the key - the census then warns instead of refusing a genuine N-GPU run."""
+    import socket
     p = torch.cuda.get_device_properties(index)
     uuid = getattr(p, "uuid", None)
-    pci = "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0))
-    return {"device_index": int(index), "name": p.name, "uuid": str(uuid) if uuid is not None else None, "pci": pci}
+    has_pci = all(hasattr(p, f) for f in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+    pci = ("%04x:%02x:%02x" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)) if has_pci else None
+    verifiable = uuid is not None or has_pci
+    if not verifiable:
+        vis = ",".join("%s=%s" % (k, os.environ.get(k, "")) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+        pci = "unverifiable:%s:%s:%d" % (socket.gethostname(), vis, int(index))
+    return {"device_index": int(index), "name": p.name, "uuid": str(uuid) if uuid is not None else None, "pci": pci,
+            "verifiable": bool(verifiable)}
 
 
 def device_census(rank, local_rank, dev):
@@ -294,6 +302,14 @@ def device_census(rank, local_rank, dev):
 
 def census_verdict(table, shared):
     keys = [(t["uuid"] or "", t["pci"]) for t in table]
+    if not all(t.get("verifiable", True) for t in table):
+        # no UUID and no PCI address from this torch build: the keys are (host, visible devices, index) - distinct indices are
+        # the best available evidence; say so in the line instead of refusing the run
+        print("[bench] WARNING: this torch build exposes neither device UUIDs nor PCI addresses - the rank -> device table is "
+              "built from (hostname, visible-device environment, device index) and is NOT a proof of distinct GPUs", file=sys.stderr, flush=True)
+        if len(set(keys)) != len(keys) and not shared:
+            raise RuntimeError("bench.py: %d ranks but only %d distinct (host, visible devices, index) keys: %s" % (len(keys), len(set(keys)), table))
+        return {"ranks": table, "distinct_devices": len(set(keys)), "shared_device_run": bool(shared), "device_identity": "unverifiable"}
     if len(set(keys)) != len(keys) and not shared:
         raise RuntimeError("bench.py: %d ranks but only %d distinct devices: %s (COMBO_SINGLE_DEVICE=1 allows a functional run on a "
                            "shared device)" % (len(keys), len(set(keys)), table))

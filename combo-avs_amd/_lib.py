@@ -192,6 +192,23 @@ def torch_channels_last():
 
 
 # ---- kernel timing (bench.py): HIP events from the C ABI around selected launches -------------------------------
+_noticed = set()
+
+
+def fallback_notice(site, why):
+    """One line on stderr, once per call site and process, whenever an op of this package hands CUDA work to a LIBRARY kernel
+    (ATen / hipBLASLt / MIOpen) because its operands do not meet the own kernel's conditions.  SURVEY 8(b): the reference's
+    module-level `except` swallowed such routing silently (ms_deform_attn.py:123) and hid performance bugs; here the result is
+    still correct, but the user is told which path ran.  COMBO_QUIET_FALLBACK=1 silences the notices."""
+    if site in _noticed:
+        return
+    _noticed.add(site)
+    if os.environ.get("COMBO_QUIET_FALLBACK") == "1":
+        return
+    import sys
+    print(f"[combo_avs_amd] {site}: running on a library kernel, not the package's HIP kernel ({why})", file=sys.stderr, flush=True)
+
+
 _timing = None  # {kind: [(start_event, stop_event, meta)]} while a measurement is running
 
 

@@ -93,6 +93,12 @@ class _FoldAll(torch.autograd.Function):
             torch._foreach_mul_(g32, [ctx.scales[i] for i in idx])
         for i, g in zip(idx, g32):
             out[i] = g
+        if GRAD_IN_PLACE:
+            # every consumer of the folded copies has run its weight-gradient kernel by now (their gradients arrived here): the
+            # aliases "folded copy -> parameter" end with this backward pass, so a recycled address of a dead folded copy can never
+            # resolve to another parameter's flat-buffer view in a later step (eval forward, frozen backbone, switch flipped)
+            from .ops.linear import drop_grad_aliases
+            drop_grad_aliases(ctx.wptrs)
         return (None, None) + tuple(out)
 
 

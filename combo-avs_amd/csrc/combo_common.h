@@ -4,7 +4,24 @@
 
 #include "combo_avs.h"  // the public C ABI (include/combo_avs.h)
 
+#include <atomic>
+
 #define COMBO_WAVE 64
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a property of a function ON ONE DEVICE: a launcher that opted in once per
+// process (`static bool`) launches its > 64 KiB-LDS kernel without the opt-in on every other device the process touches, and the
+// launch fails.  One bit per device ordinal, set after a successful opt-in on the current device; atomic, because launches may
+// come from several host threads (setting the attribute twice is harmless).
+struct ComboDevFlag {
+  std::atomic<unsigned long long> bits{0ull};
+  static unsigned long long bit() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return 1ull << (dev & 63);
+  }
+  bool is_set() const { return (bits.load(std::memory_order_acquire) & bit()) != 0ull; }
+  void mark() { bits.fetch_or(bit(), std::memory_order_release); }
+};
 
 // Workgroups are dispatched round-robin over the 8 XCDs (blockIdx % 8), each with a private L2.  Maps blockIdx to a
 // logical index such that every XCD owns a contiguous range of the n logical indices (bijective): neighbours in the

@@ -451,12 +451,12 @@ int n_cu_cached() {
 
 template <bool CONV, typename Cfg>
 int launch_cfg(F32Args a, hipStream_t stream) {
-  static bool attr = false;
-  if (!attr) {
+  static ComboDevFlag attr;
+  if (!attr.is_set()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_f32_kernel<CONV, Cfg>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     if (e != hipSuccess) return (int)e;
-    attr = true;
+    attr.mark();
   }
   const long long tiles = ((a.M + Cfg::BM - 1LL) / Cfg::BM) * ((a.N + Cfg::BN - 1LL) / Cfg::BN) * a.batch;
   if (tiles > 0x7fffffffLL) return COMBO_EINVAL;

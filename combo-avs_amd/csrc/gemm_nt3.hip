@@ -643,12 +643,12 @@ int dbg_bits3() {
 
 template <bool CONV, typename Cfg, bool P3, int ABL, bool AUX>
 int launch_inst3x(const N3Args& a, int grid, hipStream_t stream) {
-  static bool attr = false;
-  if (!attr) {
+  static ComboDevFlag attr;
+  if (!attr.is_set()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt3_kernel<CONV, Cfg, P3, ABL, AUX>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     if (e != hipSuccess) return (int)e;
-    attr = true;
+    attr.mark();
   }
   hipLaunchKernelGGL((gemm_nt3_kernel<CONV, Cfg, P3, ABL, AUX>), dim3((unsigned)grid), dim3(Cfg::NW * 64), Cfg::LDS, stream, a);
   return (int)hipGetLastError();

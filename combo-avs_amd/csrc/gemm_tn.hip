@@ -603,15 +603,15 @@ int combo_gemm_tn_x3_f32(const float* dY, long long ldy, const float* X, long lo
   if (glds_ok(dY, ldy, X, ldx, M, N, K)) {  // (else: the direct-from-global kernel below, any alignment)
     constexpr int stage_bytes = kTS * 256 * 4 + kTS * 128 * 4;  // both variants: 24 KiB
     const int stages = 3;  // 3 stages x 2 workgroups/CU (measured against 5 stages x 1 workgroup/CU: the instances stay for tools)
-    static bool attr = false;
-    if (!attr) {
+    static ComboDevFlag attr;
+    if (!attr.is_set()) {
       const void* fns[4] = {reinterpret_cast<const void*>(gemm_tn_glds_kernel<2, 3>), reinterpret_cast<const void*>(gemm_tn_glds_kernel<1, 3>),
                             reinterpret_cast<const void*>(gemm_tn_glds_kernel<2, 5>), reinterpret_cast<const void*>(gemm_tn_glds_kernel<1, 5>)};
       for (int i = 0; i < 4; ++i) {
         hipError_t e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (i < 2 ? 3 : 5) * stage_bytes);
         if (e != hipSuccess) return (int)e;
       }
-      attr = true;
+      attr.mark();
     }
     const int lds = stages * stage_bytes;
     const int remap = 1;  // XCD-contiguous tile order
@@ -649,13 +649,13 @@ int combo_conv_wgrad_x3_f32(const float* dY, long long ldy, const float* X, long
   mchunk = (mchunk + 15) / 16 * 16;
   if ((M + mchunk - 1) / mchunk != splits) return COMBO_EINVAL;
   constexpr int lds = 3 * (kTS * 256 * 4 + kTS * 128 * 4);
-  static bool attr = false;
-  if (!attr) {
+  static ComboDevFlag attr;
+  if (!attr.is_set()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess)
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    attr = true;
+    attr.mark();
   }
   const int remap = 1;  // XCD-contiguous tile order
   TnConvGeom cg{H, W, Cin, (unsigned)(0xffffffffu / (unsigned)W + 1u), (unsigned)(0xffffffffu / (unsigned)H + 1u), Hin, Win, stride, ksize};
@@ -679,12 +679,12 @@ int combo_conv3x3_wgrad_x3_f32(const float* dY, long long ldy, const float* X, l
 int combo_gemm_tn_x3_grouped_f32(const combo_gemm_tn_problem* problems, int count, combo_stream_t stream) {
   if (!problems || count <= 0) return COMBO_EINVAL;
   constexpr int lds = 3 * (kTS * 256 * 4 + kTS * 128 * 4);
-  static bool attr = false;
-  if (!attr) {
+  static ComboDevFlag attr;
+  if (!attr.is_set()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_grouped_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    attr = true;
+    attr.mark();
   }
   const int remap = 1;  // XCD-contiguous tile order
   for (int base = 0; base < count; base += kMaxGroup) {

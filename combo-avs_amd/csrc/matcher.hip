@@ -137,12 +137,12 @@ extern "C" int combo_matcher_cost_f32(const float* logits, const float* masks, c
   const long long tot = (long long)N * G * P;
   hipLaunchKernelGGL(gt_sample_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, gt, points, N, G, H, W, P, t_ws);
   const size_t lds = (size_t)h * w * 4;
-  static bool attr = false;
-  if (!attr && lds > 64 * 1024) {
+  static ComboDevFlag attr;
+  if (lds > 64 * 1024 && !attr.is_set()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(matcher_cost_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    attr = true;
+    attr.mark();
   }
   hipLaunchKernelGGL(matcher_cost_kernel, dim3(N * Q), dim3(WAVES * 64), lds, st, logits, masks, mask_base, labels, t_ws,
                      points, N, Q, K1, G, h, w, P, w_class, w_mask, w_dice, cost);

@@ -1047,22 +1047,22 @@ int msda_forward(const T* value, const int64_t* shapes, const int64_t* lsi, cons
       const int grid = NS >= n_cu ? n_cu : (NS * QT < n_cu ? NS * QT : n_cu);
       const size_t lds = fwd_tap_lds_bytes(S, L * P, nw);
       const int dbg = 0;  // (the kernel's ablation bits - 1: staging only, 3: no coordinate phase, 4: no gather - are compiled in)
-      static bool attr12 = false, attr16 = false;
+      static ComboDevFlag attr12, attr16;
       if (L * P == 12) {
-        if (!attr12) {
+        if (!attr12.is_set()) {
           hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_fwd_tap_d32<12>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
           if (e != hipSuccess) return (int)e;
-          attr12 = true;
+          attr12.mark();
         }
         hipLaunchKernelGGL(msda_fwd_tap_d32<12>, dim3(grid), dim3(nw * 64), lds, stream, value, shapes, lsi, loc, aw, B,
                            S, M, L, Lq, P, QT, out, dbg, combo_timing_next_slot(COMBO_TS_MSDA_FWD, (double)B * ((double)(S + Lq) * M * D + 3.0 * Lq * M * L * P) * 4.0));
       } else {
-        if (!attr16) {
+        if (!attr16.is_set()) {
           hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_fwd_tap_d32<16>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
           if (e != hipSuccess) return (int)e;
-          attr16 = true;
+          attr16.mark();
         }
         hipLaunchKernelGGL(msda_fwd_tap_d32<16>, dim3(grid), dim3(nw * 64), lds, stream, value, shapes, lsi, loc, aw, B,
                            S, M, L, Lq, P, QT, out, dbg, combo_timing_next_slot(COMBO_TS_MSDA_FWD, (double)B * ((double)(S + Lq) * M * D + 3.0 * Lq * M * L * P) * 4.0));
@@ -1075,12 +1075,12 @@ int msda_forward(const T* value, const int64_t* shapes, const int64_t* lsi, cons
       int QT = 1;
       while ((long long)B * M * QT < 1024 && QT < 8 && Lq / (QT * 2) >= nw * kQW) QT *= 2;
       const size_t lds = fwd_lds_bytes(S, L, P, nw);
-      static bool attr_set = false;
-      if (!attr_set) {
+      static ComboDevFlag attr_set;
+      if (!attr_set.is_set()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_fwd_lds_d32),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        attr_set.mark();
       }
       const int dbg = 0;
       hipLaunchKernelGGL(msda_fwd_lds_d32, dim3(B * M * QT), dim3(nw * 64), lds, stream, value, shapes, lsi, loc,
@@ -1131,15 +1131,15 @@ int msda_backward(const T* gout, const T* value, const int64_t* shapes, const in
   if (algo == 2 && !lds_ok) return COMBO_EINVAL;
   if constexpr (sizeof(T) == 4) {
     if (lds_ok && algo != 1) {
-      static bool attr_set = false;
-      if (!attr_set) {
+      static ComboDevFlag attr_set;
+      if (!attr_set.is_set()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_value_lds_d32<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
         if (e != hipSuccess) return (int)e;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_locw_lds_d32),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        attr_set.mark();
       }
       // query stride: ~Lq/16 and coprime with Lq, so the 16 queries of one wave instruction are far apart
       int mult = Lq / 16 + 1;
@@ -1163,12 +1163,12 @@ int msda_backward(const T* gout, const T* value, const int64_t* shapes, const in
   }
   if constexpr (sizeof(T) == 4) {
     if (bwd_windowed_ok(S, D, L, P, 4) && algo != 1) {
-      static bool attr_w = false;
-      if (!attr_w) {
+      static ComboDevFlag attr_w;
+      if (!attr_w.is_set()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_value_lds_d32<true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
         if (e != hipSuccess) return (int)e;
-        attr_w = true;
+        attr_w.mark();
       }
       const int n_parts = (S + kBwdWindowRows - 1) / kBwdWindowRows;
       const int rows = (S + n_parts - 1) / n_parts;

@@ -511,13 +511,13 @@ int combo_msda_backward_win_f32(const float* grad_out, const float* value, const
   // term - the forward's output, which the backward pass never touches: 263.4 MB.)
   const double bytes = 4.0 * B * ((2.0 * (double)S + Lq) * M * kD + 2.0 * 3.0 * (double)Lq * M * L * P);
   unsigned long long* ts = combo_timing_next_slot(COMBO_TS_MSDA_BWD, bytes, bytes);
-  static bool attr = false;
-  if (!attr) {
+  static ComboDevFlag attr;
+  if (!attr.is_set()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_win_d32<8>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     if (e == hipSuccess)
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(msda_bwd_win_d32<16>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     if (e != hipSuccess) return (int)e;
-    attr = true;
+    attr.mark();
   }
   if (nw == 16)
     hipLaunchKernelGGL(msda_bwd_win_d32<16>, dim3((unsigned)grid), dim3(1024), lds_max, (hipStream_t)stream, grad_out, value,

@@ -551,8 +551,8 @@ int combo_sra_attention_forward_bf16(const void* q, const void* kv, void* out, f
   int e = 0;
 #define SRA_FWD(NB_)                                                                                                      \
   {                                                                                                                       \
-    static bool attr = false;                                                                                             \
-    if (!attr) { e = set_lds(sra_fwd_kernel<NB_>, lds); attr = e == 0; }                                                   \
+    static ComboDevFlag attr;                                                                                             \
+    if (!attr.is_set()) { e = set_lds(sra_fwd_kernel<NB_>, lds); if (e == 0) attr.mark(); }                                                   \
     if (e == 0) hipLaunchKernelGGL(sra_fwd_kernel<NB_>, dim3((unsigned)grid), dim3(512), lds, (hipStream_t)stream, a);     \
   }
   if (NB == 2) SRA_FWD(2) else if (NB == 4) SRA_FWD(4) else SRA_FWD(8)
@@ -582,8 +582,8 @@ int combo_sra_attention_backward_bf16(const void* q, const void* kv, const void*
   size_t lds = (size_t)2 * 32 * NB * 128 + (size_t)64 * (64 * NB + 8);
 #define SRA_DQ(NB_)                                                                                                          \
   {                                                                                                                          \
-    static bool attr = false;                                                                                                \
-    if (!attr) { e = set_lds(sra_bwd_dq_kernel<NB_>, lds); attr = e == 0; }                                                   \
+    static ComboDevFlag attr;                                                                                                \
+    if (!attr.is_set()) { e = set_lds(sra_bwd_dq_kernel<NB_>, lds); if (e == 0) attr.mark(); }                                                   \
     if (e == 0) hipLaunchKernelGGL(sra_bwd_dq_kernel<NB_>, dim3((unsigned)grid), dim3(512), lds, (hipStream_t)stream, a);     \
   }
   if (NB == 2) SRA_DQ(2) else if (NB == 4) SRA_DQ(4) else SRA_DQ(8)
@@ -596,8 +596,8 @@ int combo_sra_attention_backward_bf16(const void* q, const void* kv, const void*
   lds = (size_t)nwq * 2 * (2 * 4096 + 2 * 64 * 72 + 256);
 #define SRA_DKV(NB_)                                                                                                          \
   {                                                                                                                           \
-    static bool attr = false;                                                                                                 \
-    if (!attr) { e = set_lds(sra_bwd_dkv_kernel<NB_>, lds); attr = e == 0; }                                                   \
+    static ComboDevFlag attr;                                                                                                 \
+    if (!attr.is_set()) { e = set_lds(sra_bwd_dkv_kernel<NB_>, lds); if (e == 0) attr.mark(); }                                                   \
     if (e == 0) hipLaunchKernelGGL(sra_bwd_dkv_kernel<NB_>, dim3((unsigned)grid), dim3(512), lds, (hipStream_t)stream, a);     \
   }
   if (NB == 2) SRA_DKV(2) else if (NB == 4) SRA_DKV(4) else SRA_DKV(8)

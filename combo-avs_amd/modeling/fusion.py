@@ -49,19 +49,6 @@ class BiMultiHeadAttention(nn.Module):
             lin.bias.data.fill_(0)
 
 
-def bilateral_attention_tokens(xn, pos, u, c, z, b_ov, gamma_v, drop_v=None, drop_a=None):
-    """Pure-tensor form of the collapsed bilateral attention on token-major activations.
-    xn [B,N,C] (LayerNormed), pos [1,N,C], u [B,h,C], c [B,h], z [B,h,C] -> (y [B,N,C], pooled [B,h,C], spa [B,h], p)."""
-    s = torch.einsum("bic,bhc->bhi", xn + pos, u) + c[..., None]
-    s = s.clamp(min=-50000, max=50000)  # fuse_helper.py:190-193
-    p = torch.softmax(s, dim=-1)  # over HW, both directions (:202-203)
-    pv = p if drop_v is None else p * drop_v
-    pa = p if drop_a is None else p * drop_a
-    y = xn + gamma_v * (torch.einsum("bhi,bhc->bic", pv, z) + b_ov)
-    pooled = torch.einsum("bhi,bic->bhc", pa, xn)
-    return y, pooled, pa.sum(-1), p
-
-
 class BiAttentionBlock(nn.Module):
     """fuse_helper.py:240-332"""
 

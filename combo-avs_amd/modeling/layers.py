@@ -46,6 +46,11 @@ def conv1x1_or_conv(conv, x):
         from ..ops import conv3x3
         if conv3x3.ENABLED and conv3x3.usable(conv, x):
             return conv3x3.conv3x3(x, conv.weight, conv.bias)  # implicit GEMM on csrc/gemm_nt.hip / gemm_tn.hip
+    if x.is_cuda:
+        from .. import _lib
+        _lib.fallback_notice(f"modeling.layers.conv1x1_or_conv[w {tuple(conv.weight.shape)}]",
+                             f"x {x.dtype} {tuple(x.shape)}, channels_last {x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)}, "
+                             f"autocast {torch.is_autocast_enabled()}: MIOpen convolution")
     return F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, conv.groups)
 
 

@@ -212,7 +212,10 @@ class _ConvWrw(Function):
             dy = dy.contiguous(memory_format=torch.channels_last)
         if ctx.k > 20:  # stride 2 (the first block of res3 / res4 / res5): input gradient the library's, weight gradient own
             assert not ctx.mask_dx and not ctx.passthrough
-            own_dw = WGRAD_S2 and ctx.needs_input_grad[1] and cin % 4 == 0 and cout >= 64 and cout % 4 == 0
+            # (the geometry limits of combo_conv_wgrad_x3_f32: maps of at least 2 x 2 input pixels, int32 token indices - anything
+            #  else goes to the library instead of raising COMBO_EINVAL out of a backward pass)
+            own_dw = (WGRAD_S2 and ctx.needs_input_grad[1] and cin % 4 == 0 and cout >= 64 and cout % 4 == 0 and H >= 2 and W >= 2
+                      and B * H * W < 2 ** 29)
             own_dx = DX_S2_1X1 and ctx.k == 21 and ctx.needs_input_grad[0] and ctx.img_dx is not None and cin % 4 == 0
             dx, dw = None, None
             if (ctx.needs_input_grad[0] and not own_dx) or (ctx.needs_input_grad[1] and not own_dw):
@@ -274,6 +277,14 @@ class _MaskedInput(Function):
         return dy * (x > 0).to(dy.dtype)
 
 
+def _library_notice(site, x, w, stride):
+    """one stderr line per (site, layer geometry): this convolution runs on MIOpen.  By design for the backbones' 7x7 stems
+    (3 input channels) - DESIGN.md section 6b; anything else listed is a layout / dtype condition of kind() that was not met."""
+    _lib.fallback_notice(f"ops.convwrw.{site}[w {tuple(w.shape)}, stride {stride}]",
+                         f"x {x.dtype} {'channels_last' if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) else 'NCHW'}, "
+                         f"grad {torch.is_grad_enabled() and w.requires_grad}, autocast {torch.is_autocast_enabled()}")
+
+
 def _forward_ok(x, w, residual):
     return (ENABLED and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and not torch.is_autocast_enabled() and x.dim() == 4
             and x.is_contiguous(memory_format=torch.channels_last)
@@ -320,6 +331,8 @@ def conv_bias_act(x, w, bias, stride, padding, images=None, residual=None, relu=
     if mask_dx and not k:  # the caller planned on an own dX kernel that does not take this layer after all (a layout / size
         # condition of kind()): unmasked library dX + an explicit ReLU-gradient pass instead of an assertion
         x, mask_dx = _MaskedInput.apply(x), False
+    if not k and x.is_cuda:
+        _library_notice("conv_bias_act", x, w, stride)
     y = _ConvWrw.apply(x, w, k, mask_dx, images) if k else F.conv2d(x, w, None, stride, padding)
     if bias is None:
         return y
@@ -334,4 +347,6 @@ def conv2d(x, w, stride, padding, mask_dx=False):
         return _ConvWrw.apply(x, w, k, mask_dx)
     if mask_dx:
         x = _MaskedInput.apply(x)
+    if x.is_cuda:
+        _library_notice("conv2d", x, w, stride)
     return F.conv2d(x, w, None, stride, padding)

@@ -549,6 +549,13 @@ def register_grad_aliases(derived, params):
         _grad_alias[d.data_ptr()] = p.data_ptr()
 
 
+def drop_grad_aliases(param_ptrs):
+    """backbone._FoldAll.backward: the aliases of these parameters' derived weights are no longer needed"""
+    dead = set(param_ptrs)
+    for k in [k for k, v in _grad_alias.items() if v in dead]:
+        del _grad_alias[k]
+
+
 def grad_target(ptr, shape, dtype):
     """the registered flat-buffer view for the parameter (or aliased derived weight) at address `ptr`, viewed as `shape`; None
     when there is none (no grad_targets() open, an unknown address, another dtype / element count)"""
@@ -955,7 +962,12 @@ def linear(x, weight, bias=None, relu=False, defer=False, mask_dx=False, grad_ma
         rows = x.numel() // K
         y = _Linear.apply(x.reshape(rows, K), weight, bias, relu, defer, mask_dx, grad_masked)
         return y.view(*x.shape[:-1], N)
-    y = torch.nn.functional.linear(x, weight, bias)  # autocast / CPU / non-fp32 callers (host-PyTorch backbones)
+    # autocast / non-fp32 callers (the host-PyTorch backbones' bf16 linears do not come through here: backbone_pvt._linear);
+    # CPU tensors are the multi-process host-logic tests.  A CUDA caller landing here is told so, once.
+    if x.is_cuda:
+        _lib.fallback_notice("ops.linear.linear", f"x {x.dtype}, weight {weight.dtype}, autocast {torch.is_autocast_enabled()}: "
+                             "the own GEMMs take fp32 operands outside autocast")
+    y = torch.nn.functional.linear(x, weight, bias)
     return torch.relu(y) if relu else y
 
 

@@ -157,6 +157,8 @@ class _MaskLogitsAll(torch.autograd.Function):
                 rc = _lib.lib().combo_gemm_tn_x3_grouped_f32(ctypes.cast(prob, ctypes.c_void_p), bt, _lib.current_stream())
             _lib.check(rc, "combo_gemm_tn_x3_grouped_f32")
             return (dMF, None) + tuple(dME[:, i * Q:(i + 1) * Q] for i in range(nh))
+        _lib.fallback_notice("ops.masklogit._MaskLogitsAll.backward", f"HW {HW}, C {C}, heads*Q {nh * Q}: the batched 3-product "
+                             "kernels take HW % 16 == 0, C % 4 == 0, C >= 64, heads*Q >= 256")
         with torch.autocast("cuda", enabled=False):
             dME = torch.bmm(dL2, mf_tok)  # [BT, nh*Q, C]
             dMF = torch.bmm(dL2.transpose(1, 2), ME)  # [BT, HW, C]

@@ -477,6 +477,7 @@ class GraphedTrainStep:
         # eager_only: the step is NOT captured (every call runs trainer.train_step) because this process replays hipGraph
         # memset nodes wrongly - callers that report a graphed number (bench.py) read this flag
         self.eager_only = False
+        self._overflow_noticed = False
         dev = getattr(model, "device", None)
         if dev is not None and torch.device(dev).type == "cuda" and os.environ.get("COMBO_ALLOW_PACKET_CAPTURE") != "1":
             if not graph_memset_selftest(torch.device(dev)):
@@ -649,6 +650,7 @@ class GraphedTrainStep:
             return train_step(self.model, self.opt, batched_inputs)
         flags = self._avss_flags(batched_inputs)
         counts = None
+        original_batch = batched_inputs  # (the eager fallback below takes the caller's batch, not the padded one)
         if self.pad_targets_to:
             padded = self._pad_instances(batched_inputs)
             if padded is None:  # a frame with more instances than the padded length
@@ -658,9 +660,15 @@ class GraphedTrainStep:
         key = (tuple((tuple(t.shape), t.dtype) for t in tensors), rest, self.model.training, flags)
         if key not in self.graphs:
             if len(self.graphs) >= self.max_graphs:
-                if counts is not None:
-                    raise RuntimeError("GraphedTrainStep: more input signatures than max_graphs with padded targets")
-                return train_step(self.model, self.opt, batched_inputs)
+                # AVSS: the flag VALUES are part of the key (three patterns per clip in the real data: v1s / v1m / v2,
+                # register_avss_sem.py:36-43) - more signatures than graphs is the normal case there, not an error: such a
+                # batch runs the eager step on the caller's own (unpadded) batch
+                if not self._overflow_noticed:
+                    self._overflow_noticed = True
+                    import sys
+                    print(f"[combo_avs_amd] GraphedTrainStep: more than max_graphs = {self.max_graphs} input signatures - further new "
+                          "signatures run the eager (un-captured) step", file=sys.stderr, flush=True)
+                return train_step(self.model, self.opt, original_batch)
             self.graphs[key] = self._capture(batched_inputs, num_masks, flags, counts)
         graph, static_batch, static_num, static_losses, static_counts, _keep = self.graphs[key]
         if static_counts is not None:

@@ -61,3 +61,10 @@ def test_census_refuses_ranks_that_share_a_device():
     # no UUID exposed by this torch: the PCI address alone decides
     c, d = {"rank": 0, "uuid": None, "pci": "0000:05:00"}, {"rank": 1, "uuid": None, "pci": "0000:25:00"}
     assert bench.census_verdict([c, d], shared=False)["distinct_devices"] == 2
+    # a torch build that exposes neither: the run is NOT refused (advisor, round 5) - the line says the identity is unverifiable
+    e = {"rank": 0, "uuid": None, "pci": "unverifiable:host:HIP_VISIBLE_DEVICES=:0", "verifiable": False}
+    f = {"rank": 1, "uuid": None, "pci": "unverifiable:host:HIP_VISIBLE_DEVICES=:1", "verifiable": False}
+    v = bench.census_verdict([e, f], shared=False)
+    assert v["distinct_devices"] == 2 and v["device_identity"] == "unverifiable"
+    with pytest.raises(RuntimeError, match="distinct"):
+        bench.census_verdict([e, dict(e, rank=1)], shared=False)
