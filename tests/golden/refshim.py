@@ -237,7 +237,7 @@ def ref():
 
 
 def build_head(num_classes=2, channels=(256, 512, 1024, 2048), num_queries=100, dec_layers=9, enc_layers=6,
-               use_cosine_loss=True):
+               use_cosine_loss=True, num_frames=5, dataset_name="avss4"):
     """Construct the reference MaskFormerHead exactly as COMBO_R50_bs8_90k.yaml would
     (mask_former_head.py:94-136, msdeformattn.py:299-313, transformer_decoder.py:366-403)."""
     R = ref()
@@ -249,9 +249,9 @@ def build_head(num_classes=2, channels=(256, 512, 1024, 2048), num_queries=100, 
     fusion = R.AVFuse(fused_type="MHA-B", audio_dim=128, fused_backbone=["res2"], fused_backbone_dim=[256])
     amlp = R.audio_mlp(in_dim=128, middle_dim=4096, out_dim=256)
     predictor = R.MultiScaleMaskedTransformerDecoder(
-        256, True, num_classes=num_classes, hidden_dim=256, num_queries=num_queries, num_frames=5,
+        256, True, num_classes=num_classes, hidden_dim=256, num_queries=num_queries, num_frames=num_frames,
         queries_fuse_type="add", audio_out_dim=256, nheads=8, dim_feedforward=2048, dec_layers=dec_layers,
-        pre_norm=False, mask_dim=256, enforce_input_project=False, dataset_name="avss4",
+        pre_norm=False, mask_dim=256, enforce_input_project=False, dataset_name=dataset_name,
         use_cosine_loss=use_cosine_loss)
     head = R.MaskFormerHead(shapes, num_classes=num_classes, pixel_decoder=pixel_decoder, fusion_module=fusion,
                             audio_transformation=amlp, loss_weight=1.0, ignore_value=255,
