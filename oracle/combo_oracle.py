@@ -636,14 +636,85 @@ def vggish(P, pre, x):
     return x
 
 
+# PVTv2-B5 (round 6; pinned by tests/golden/pvt.npz, generated from the reference's own module: tests/golden/gen_golden_pvt.py)
+# models/modeling/backbone/pvtv2.py:391-409: embed_dims 64 / 128 / 320 / 512, heads 1 / 2 / 5 / 8, depths 3 / 6 / 40 / 3,
+# sr_ratios 8 / 4 / 2 / 1, mlp_ratio 4, qkv_bias, LayerNorm eps 1e-6 for the blocks' and stages' norms (norm_layer partial, :403)
+# but the DEFAULT 1e-5 for the patch embeddings' and the spatial-reduction norms (plain nn.LayerNorm: :76, :203).
+PVT_B5 = dict(dims=(64, 128, 320, 512), heads=(1, 2, 5, 8), depths=(3, 6, 40, 3), sr=(8, 4, 2, 1))
+
+
+def _ln(P, pre, x, eps):
+    return F.layer_norm(x, (x.shape[-1],), P[pre + "weight"], P[pre + "bias"], eps)
+
+
+def pvt_attention(P, pre, x, H, W, heads, sr):
+    """Attention.forward, pvtv2.py:104-132 (linear = False): queries from all N tokens, keys / values from the map reduced by a
+    stride-sr convolution + LayerNorm; softmax(q k^T * d^-0.5) v; output projection."""
+    B, N, C = x.shape
+    d = C // heads
+    q = F.linear(x, P[pre + "q.weight"], P[pre + "q.bias"]).reshape(B, N, heads, d).permute(0, 2, 1, 3)
+    if sr > 1:
+        x_ = x.permute(0, 2, 1).reshape(B, C, H, W)
+        x_ = F.conv2d(x_, P[pre + "sr.weight"], P[pre + "sr.bias"], stride=sr).reshape(B, C, -1).permute(0, 2, 1)
+        x_ = _ln(P, pre + "norm.", x_, 1e-5)
+    else:
+        x_ = x
+    kv = F.linear(x_, P[pre + "kv.weight"], P[pre + "kv.bias"]).reshape(B, -1, 2, heads, d).permute(2, 0, 3, 1, 4)
+    attn = ((q @ kv[0].transpose(-2, -1)) * d ** -0.5).softmax(dim=-1)
+    y = (attn @ kv[1]).transpose(1, 2).reshape(B, N, C)
+    return F.linear(y, P[pre + "proj.weight"], P[pre + "proj.bias"])
+
+
+def pvt_mlp(P, pre, x, H, W):
+    """Mlp.forward, pvtv2.py:48-57: fc1 -> 3x3 depth-wise convolution on the token map (DWConv, :377-386) -> GELU -> fc2"""
+    B, N, _ = x.shape
+    h = F.linear(x, P[pre + "fc1.weight"], P[pre + "fc1.bias"])
+    C = h.shape[-1]
+    h = F.conv2d(h.transpose(1, 2).reshape(B, C, H, W), P[pre + "dwconv.dwconv.weight"], P[pre + "dwconv.dwconv.bias"], padding=1, groups=C)
+    h = F.gelu(h.flatten(2).transpose(1, 2))
+    return F.linear(h, P[pre + "fc2.weight"], P[pre + "fc2.bias"])
+
+
+def pvtv2_b5(P, pre, x, drop_path=None):
+    """PyramidVisionTransformerV2.forward_features, pvtv2.py:343-362 -> {"res2".."res5"} NCHW.  Evaluation semantics (stochastic
+    depth off) unless `drop_path` gives, per block, a pair of per-sample multipliers [B] (mask / keep probability) for its two
+    residual branches (timm DropPath, pvtv2.py:162-175)."""
+    outs = {}
+    B = x.shape[0]
+    k = 0
+    for i, (dim, heads, depth, sr) in enumerate(zip(PVT_B5["dims"], PVT_B5["heads"], PVT_B5["depths"], PVT_B5["sr"])):
+        pe = f"{pre}patch_embed{i + 1}."
+        ks = 7 if i == 0 else 3
+        x = F.conv2d(x, P[pe + "proj.weight"], P[pe + "proj.bias"], stride=4 if i == 0 else 2, padding=ks // 2)  # :214-219
+        H, W = x.shape[-2:]
+        x = _ln(P, pe + "norm.", x.flatten(2).transpose(1, 2), 1e-5)
+        for j in range(depth):
+            bp = f"{pre}block{i + 1}.{j}."
+            a = pvt_attention(P, bp + "attn.", _ln(P, bp + "norm1.", x, 1e-6), H, W, heads, sr)
+            m1 = 1.0 if drop_path is None else drop_path[k][0].view(B, 1, 1)
+            x = x + m1 * a
+            m = pvt_mlp(P, bp + "mlp.", _ln(P, bp + "norm2.", x, 1e-6), H, W)
+            m2 = 1.0 if drop_path is None else drop_path[k][1].view(B, 1, 1)
+            x = x + m2 * m
+            k += 1
+        x = _ln(P, f"{pre}norm{i + 1}.", x, 1e-6)
+        x = x.reshape(B, H, W, -1).permute(0, 3, 1, 2)
+        outs[f"res{i + 2}"] = x
+    return outs
+
+
 # MaskFormer.forward                                    models/maskformer_model.py:274-441
 PIXEL_MEAN = (123.675, 116.280, 103.530)
 PIXEL_STD = (58.395, 57.120, 57.375)
 
 
-def maskformer_forward(P, batched_inputs, num_classes=2, training=True, rand=torch.rand, world_size=1, record=None):
-    """Full model step on CPU: normalise, VGGish (no grad), dual R50, SEM mix, head, then the weighted
-    39-term loss (training) or the per-frame sem_seg maps (eval).  S4/MS3 path (is_avss_data False).
+def maskformer_forward(P, batched_inputs, num_classes=2, training=True, rand=torch.rand, world_size=1, record=None, backbone="r50",
+                       avss=False, attn_override=None, frozen=None):
+    """Full model step on CPU: normalise, VGGish (no grad), dual R50 / dual PVTv2-B5 (`backbone`), SEM mix, head, then the weighted
+    39-term loss (training) or the per-frame sem_seg maps (eval).  avss (round 6): the AVSS data path - the flag tensors of the
+    clips are concatenated, the audio rows of the frames that exist are kept (maskformer_model.py:300-331) and the criterion
+    selects the annotated frames (criterion_ss.py:246-257); the inference tail multiplies by the frame flag (:466-471).
+    attn_override / frozen: test hooks handed to the decoder / criterion (the reference's or another run's discrete choices).
     record: test hook - a dict that receives this run's discrete choices: "attn_masks" (list of 9 bool [BT,Q,hw], the form
     `transformer_decoder(attn_override=...)` accepts), the criterion's "match_src" / "match_tgt" / "topk", and the 10 heads'
     "pred_masks" [BT,Q,H/4,W/4] / "pred_logits" [BT,Q,K+1] (transformer_decoder.py:481-509)."""
@@ -656,17 +727,24 @@ def maskformer_forward(P, batched_inputs, num_classes=2, training=True, rand=tor
     pre_masks = (pre_masks - mean) / std  # :338
     with torch.no_grad():
         audio = vggish(P, "audio_backbone.", mel).unsqueeze(1)  # :327-329
-    feats = resnet50(P, "backbone.", images)  # :333
-    pfeats = resnet50(P, "pre_sam_backbone.", pre_masks)  # :341
+    vid_flag = gt_flag = None
+    if avss:
+        vid_flag = torch.cat([b["vid_temporal_mask_flag"] for b in batched_inputs])  # :300-312
+        gt_flag = torch.cat([b["gt_temporal_mask_flag"] for b in batched_inputs])
+        audio = audio[vid_flag.bool()]  # :330-331
+    net = resnet50 if backbone == "r50" else pvtv2_b5
+    feats = net(P, "backbone.", images)  # :333
+    pfeats = net(P, "pre_sam_backbone.", pre_masks)  # :341
     feats = sem_mix(P, "scale_factor_module.", feats, pfeats)  # :345-352
-    out = head_forward(P, "sem_seg_head.", feats, audio)  # :363
+    out = head_forward(P, "sem_seg_head.", feats, audio, attn_override=attn_override)  # :363
     if not training:
-        return semantic_inference(out["pred_logits"], out["pred_masks"], images.shape[-2:])
+        return semantic_inference(out["pred_logits"], out["pred_masks"], images.shape[-2:], vid_flag=vid_flag)
     targets = []
     for b in batched_inputs:  # prepare_targets :443-458 (no padding needed at 224)
         for inst in b["instances"]:
             targets.append({"labels": inst["gt_classes"], "masks": inst["gt_masks"]})
-    losses = set_criterion(out, targets, num_classes, None, world_size, rand, record=record)
+    gt_index = torch.where(gt_flag == 1)[0] if avss else None  # criterion_ss.py:246
+    losses = set_criterion(out, targets, num_classes, gt_index, world_size, rand, record=record, frozen=frozen)
     if record is not None:
         record["attn_masks"] = [a[::8].clone() for a in out["attn_masks"][:9]]  # one of the 8 identical head replicas
         # the north-star's compared quantity: mask / class logits of all 10 prediction heads (9 auxiliary + the final one)

@@ -98,7 +98,7 @@ def per_parameter(opt, g, ref_g):
     return out
 
 
-def failures(report, rel_l2=REL_L2, frac=FRAC):
+def failures(report, rel_l2=REL_L2, frac=FRAC, lib_frac=None):
     """parameters beyond the bound.  A gradient that is mathematically zero (the bilateral fusion's v_proj bias cancels in its
     soft-max: RMS 1e-13 against 1e-2 .. 1e-1 elsewhere) has no relative error: such a tensor only has to stay below 1e-6 of
     the table's typical RMS."""
@@ -110,7 +110,10 @@ def failures(report, rel_l2=REL_L2, frac=FRAC):
             if r[3] != float("inf") and r[3] * r[2] < floor * 10:  # ||got - ref|| / sqrt(n) stays tiny as well
                 continue
         lib = r[0].startswith(("backbone.", "pre_sam_backbone."))
-        if not (r[3] <= (max(rel_l2, LIB_REL_L2) if lib else rel_l2) and r[4] <= (max(frac, LIB_FRAC) if lib else frac)):
+        # lib_frac: the entry fraction allowed for the backbones' parameters (bf16 recipe: a 2e-3 element-wise bound means nothing
+        # against bf16 round-off - 83 % of the entries of a 64-entry norm weight - so that recipe passes 1.0 and keeps the L2 bound)
+        lf = max(frac, LIB_FRAC) if lib_frac is None else lib_frac
+        if not (r[3] <= (max(rel_l2, LIB_REL_L2) if lib else rel_l2) and r[4] <= (lf if lib else frac)):
             out.append(r)
     return out
 

@@ -20,13 +20,23 @@ def rig():
     return GC.build("r50")
 
 
-PVT_REL_L2, PVT_FRAC = 2e-1, 1.0  # bf16 backbones, frozen choices: measured <= 1.7e-2 (norm affines of the backbones) in 11 of 12 runs
-# and ONE run in which every parameter of the last decoder layer moved by 1.1e-1 (the library's bf16 kernels differ between an eager
-# and a captured step; what this test has to catch - a gradient written by a memset node of a replayed graph - is an error of ~1); the 2e-3
-# element-wise fraction means nothing against bf16 round-off (83 % of a 64-entry norm weight) and is not applied
+# Round 6: the PVT recipe's bound is the R50 recipe's again (head 5e-3 / 25 %, backbones 2e-2).  Round 5 had widened it to 2e-1 for "one run
+# in twelve in which every parameter of the last decoder layer moved by 1.1e-1".  Root cause (tools/pvt_forward_states.py,
+# tools/graph_outlier_probe.py, profiles/r06_pvt_eager_vs_replay_states.txt): MIOpen's DEFAULT (immediate-mode) solver for the bf16
+# spatial-reduction convolutions of PVTv2 (`Attention.sr`, kernel = stride, pvtv2.py:76) is not run-to-run reproducible - the
+# convolution's output is the first tensor of a forward pass that differs bitwise between two runs on identical inputs (6 % of the
+# passes; block2.2's 128 -> 128, k = 4 layer), bf16 re-rounding in the 40 blocks behind it turns that into a different
+# forward pass (losses 2e-4 apart), and eager / replayed steps fall into 2 - 4 reproducible clusters 2 - 6e-3 apart over the head's
+# parameters (up to 5e-2 .. 1.1e-1 on single tensors) - between two EAGER steps as well, with the package's own bf16 kernels (SRA
+# attention, pre-norm, deferred column sums) on or off, and never with fp32 backbones or the R50 recipe.  With deterministic
+# library solvers (`torch.backends.cudnn.deterministic = True`, PyTorch's own switch) 4 eager steps, 16 replays of 8 separate
+# captures and one more eager step agree to 1.4e-6 over the head's parameters (backbones: <= 5.3e-3, the library's bf16 weight-
+# gradient GEMMs); with MIOpen's find mode (`cudnn.benchmark`, what bench.py runs) to 4.6e-4.  The test below therefore runs under
+# `torch.backends.cudnn.flags(deterministic=True)` and holds the head to the strict bound.
+PVT_LIB_FRAC = 1.0  # bf16 backbones: relative L2 <= 2e-2 per parameter; the 2e-3 element-wise fraction is not applied to them
 
 
-def _check_pair(i, ref_l, got_l, report, ref_p, got_p, rel_l2=GC.REL_L2, frac=GC.FRAC):
+def _check_pair(i, ref_l, got_l, report, ref_p, got_p, rel_l2=GC.REL_L2, frac=GC.FRAC, lib_frac=None, param_frac=None):
     assert len(got_l) == 39
     for k, v in got_l.items():
         assert abs(v - ref_l[k]) <= (2e-4 if rel_l2 == GC.REL_L2 else 5e-3) * abs(ref_l[k]) + 1e-5, (i, k, v, ref_l[k])
@@ -35,7 +45,7 @@ def _check_pair(i, ref_l, got_l, report, ref_p, got_p, rel_l2=GC.REL_L2, frac=GC
     # measured <= 2.3e-3 / 16 % on pre_sam_backbone.stem.conv1.weight, median 5e-5).  A whole-buffer fraction cannot see the
     # biases / level embeddings / norm affines (together far below 1 % of the 87 M entries) - which is how the wrong memset-node
     # gradients of rounds 1-2 (relative error ~1) got through.
-    bad = GC.failures(report, rel_l2, frac)
+    bad = GC.failures(report, rel_l2, frac, lib_frac)
     worst = sorted(report, key=lambda r: -r[3])[:5]
     print(f"[graph vs eager, batch {i}] {len(report)} parameters, worst rel L2: " + ", ".join(f"{r[0]} {r[3]:.2e}" for r in worst))
     assert not bad, [(r[0], r[1], f"rel_l2 {r[3]:.3e}", f"frac {r[4]:.4f}") for r in bad[:20]]
@@ -43,8 +53,8 @@ def _check_pair(i, ref_l, got_l, report, ref_p, got_p, rel_l2=GC.REL_L2, frac=GC
     # AdamW step 1 moves every parameter by lr * g / (|g| + eps): parameters whose gradient is ~eps (1e-8) amplify
     # round-off differences, up to 2 * lr for a sign flip; everything else must agree
     d = (got_p - ref_p).abs()
-    assert d.max() <= 2.1e-4 and float((d > 1e-5).float().mean()) < (1e-3 if rel_l2 == GC.REL_L2 else 2e-2), \
-        (float(d.max()), float((d > 1e-5).float().mean()))
+    pf = param_frac if param_frac is not None else (1e-3 if rel_l2 == GC.REL_L2 else 2e-2)
+    assert d.max() <= 2.1e-4 and float((d > 1e-5).float().mean()) < pf, (float(d.max()), float((d > 1e-5).float().mean()))
 
 
 FLIP_REL_L2, FLIP_FRAC = 5e-2, 1.0  # un-frozen R50 step: ONE discrete event - an attention-mask cell or an FFN unit within round-off
@@ -83,14 +93,17 @@ def test_graphed_step_equals_eager_step_pvt_recipe():
     grouped column sums, the pre-norm kernels, stochastic depth off).  The discrete choices of a recorded step are injected into
     both runs (GC.freeze_choices): un-frozen, bf16 round-off in the backbones flips attention-mask cells between an eager
     and a replayed step and whole gradient rows move by 3-8 % (measured: median relative L2 2.8e-2 over the 2 438 parameters)."""
-    model, opt, batches, state = GC.build("pvt")
-    GC.freeze_choices(model, opt, batches[0])
-    try:
-        graphed, out = GC.eager_and_graphed(model, opt, batches[:1])
-    finally:
-        GC.unfreeze_choices(model)
+    with torch.backends.cudnn.flags(enabled=True, benchmark=False, deterministic=True):  # (MIOpen: see the note above PVT_LIB_FRAC)
+        model, opt, batches, state = GC.build("pvt")
+        GC.freeze_choices(model, opt, batches[0])
+        try:
+            graphed, out = GC.eager_and_graphed(model, opt, batches[:1])
+        finally:
+            GC.unfreeze_choices(model)
     ref_l, got_l, report, ref_p, got_p, _, _ = out[0]
-    _check_pair(0, ref_l, got_l, report, ref_p, got_p, rel_l2=PVT_REL_L2, frac=PVT_FRAC)
+    # head: the R50 recipe's strict bound; the bf16 backbones' parameters: relative L2 <= 2e-2 (measured <= 5.3e-3), and the AdamW
+    # sign-flip share of the update among their ~160 M entries <= 2 %
+    _check_pair(0, ref_l, got_l, report, ref_p, got_p, lib_frac=PVT_LIB_FRAC, param_frac=2e-2)
     assert len(graphed.graphs) == 1
 
 

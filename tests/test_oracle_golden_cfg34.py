@@ -126,3 +126,26 @@ def test_oracle_gradients_at_ms3_t10_geometry():
             # (0.5 %: twice the frames of head.npz - twice the ReLU cells of the FPN output convolution within round-off of 0, each
             #  moving a 3 x 3 x 64 patch of d loss / d res2; measured 0.39 % on feat.res2, <= 0.1 % elsewhere)
             synth.check_digest(g, d, f"{case}/grad/{n}", rtol=2e-3, atol=2e-3 * scale + 1e-9, k=2048, frac_bad=0.005)
+
+
+def test_oracle_pvtv2_b5_matches_the_reference_golden():
+    """oracle.pvtv2_b5 (functional restatement of backbone/pvtv2.py:60-175, 343-409) against tests/golden/pvt.npz - features and
+    eight parameter gradients of the reference's own PyramidVisionTransformerV2 on name-seeded weights (gen_golden_pvt.py).  This
+    pins the backbone half of oracle.maskformer_forward(backbone="pvt")."""
+    z = np.load(os.path.join(G, "pvt.npz"), allow_pickle=False)
+    spec = [(n, tuple(int(v) for v in s.split(","))) for n, s in zip(z["spec_names"].tolist(), z["spec_shapes"].tolist())]
+    P = synth.synth_state_dict(spec, seed=0)
+    probe = z["probe"].tolist()
+    for p in probe:
+        P[p].requires_grad_(True)
+    x = synth.synth_tensor("pvt.x", (2, 3, 64, 64), 0)
+    out = O.pvtv2_b5(P, "", x)
+    names = ["res2", "res3", "res4", "res5"]
+    assert [",".join(map(str, out[n].shape)) for n in names] == z["out_shapes"].tolist()
+    for n in names:
+        synth.check_digest(out[n], synth.unpack(f"out.{n}", z), f"pvt.out.{n}", rtol=2e-4, atol=2e-4)
+    loss = sum((out[n] * synth.synth_tensor(f"pvt.g.{n}", tuple(out[n].shape), 0)).sum() for n in names)
+    grads = torch.autograd.grad(loss, [P[p] for p in probe])
+    for p, g in zip(probe, grads):
+        d = synth.unpack(f"grad.{p}", z)
+        synth.check_digest(g, d, f"pvt.grad.{p}", rtol=2e-3, atol=2e-4 * max(1.0, float(np.abs(d["sample"]).max())))

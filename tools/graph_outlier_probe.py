@@ -63,6 +63,10 @@ def main():
     if "ffnfuse" in sw:
         from combo_avs_amd.ops import linear
         linear.FFN_FUSED_RELU_GRAD = False
+    if "det" in sw:  # MIOpen: deterministic solvers only (tools/pvt_forward_states.py: the default immediate-mode solver of the
+        torch.backends.cudnn.deterministic = True  # PVT spatial-reduction convolutions is not run-to-run reproducible)
+    if "find" in sw:
+        torch.backends.cudnn.benchmark = True
     from combo_avs_amd.trainer import GraphedTrainStep, train_step
     model, opt, batches, state = GC.build(recipe)
     if "fp32bb" in sw:
