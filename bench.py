@@ -587,7 +587,7 @@ def main():
                 d["bytes"] += nbytes.value * n_l
                 d["nodes"] += 1
                 # the launch's own roofline: the longer of its matrix-pipe time and its HBM time at the peaks (GEMM kinds)
-                ceil = {1: 157.3e12, 2: 2500.0e12 / 3, 8: 2500.0e12}.get(kind.value)
+                ceil = {1: 157.3e12, 2: 2500.0e12 / 3, 8: 2500.0e12, 9: 2500.0e12 / 3}.get(kind.value)
                 if ceil:
                     d["floor_us"] += n_l * max(work.value / ceil, nbytes.value / 8e12) * 1e6
                 if work.value >= 2e9:  # launches of >= 2 GFLOP (GB for the HBM-bound kinds): the layers that can fill the chip
@@ -629,11 +629,12 @@ def main():
              2: ("gemm_nt3_kernel", "mfma", X3, "TFLOP/s", 1e12), 3: ("gemm_tn_grouped_kernel", "hbm", 8000.0, "GB/s", 1e9),
              4: ("attn_fwd_kernel", "mfma", 157.3, "TFLOP/s", 1e12), 5: ("attn_bwd_dq/dkv_kernel", "mfma", 157.3, "TFLOP/s", 1e12),
              6: ("msda_bwd", "hbm", 8000.0, "GB/s", 1e9), 7: ("bifuse", "hbm", 8000.0, "GB/s", 1e9),
-             8: ("gemm_nt3_kernel (1 bf16 product: --head-dtype bf16)", "mfma", 2500.0, "TFLOP/s", 1e12)}
+             8: ("gemm_nt3_kernel (1 bf16 product: --head-dtype bf16)", "mfma", 2500.0, "TFLOP/s", 1e12),
+             9: ("conv3x3_wgrad_kernel", "mfma", X3, "TFLOP/s", 1e12)}  # implicit-GEMM weight gradients of the 3x3 / strided convolutions
     # HBM traffic per launch: PMC passes of tools/pmc_bench.sh, valid only for the kernels of the commit they were taken at
     pmc, pmc_note = {}, None
-    pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc.json") for r in (5, 4, 3)) if os.path.exists(q)),
-                    os.path.join(ROOT, "profiles", "r05_pmc.json"))
+    pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_pmc.json") for r in (6, 5, 4, 3)) if os.path.exists(q)),
+                    os.path.join(ROOT, "profiles", "r06_pmc.json"))
     if os.path.exists(pmc_path):
         with open(pmc_path) as f:
             pmc = json.load(f)
@@ -667,7 +668,7 @@ def main():
             r["traffic_note"] = pmc_note
         if timing_truncated:
             r["timing_truncated"] = True  # the slot buffer ran out: figures cover the slotted launches only
-        if d["big_launches"] and kind in (1, 2, 4, 5):
+        if d["big_launches"] and kind in (1, 2, 4, 5, 9):
             big = d["big_work"] / (d["big_us"] * 1e-6) / scale
             r["large_launches"] = {"min_gflop": 2, "launches_per_step": d["big_launches"] // max(args.steps, 1),
                                    "ms_per_step": round(d["big_us"] / max(args.steps, 1) / 1e3, 3), "achieved": round(big, 1),
@@ -676,16 +677,40 @@ def main():
             # every launch against ITS binding roofline (a third of the 3-product launches are HBM-bound 64 .. 256-channel layers:
             # `frac` prices them against the matrix pipe)
             r["frac_of_binding_roofline"] = round(d["floor_us"] / d["us"], 4)
-        if kind in (1, 2, 3) and d["bytes"] > 0:  # the GEMM families also report the other side of their roofline
+        if kind in (1, 2, 3, 9) and d["bytes"] > 0:  # the GEMM families also report the other side of their roofline
             useful = d["work"] / secs / 1e12
             r["hbm"] = {"algorithmic_bytes_per_step": d["bytes"] / max(args.steps, 1), "achieved_gbs": round(d["bytes"] / secs / 1e9, 1),
                         "frac_of_8tbs": round(d["bytes"] / secs / 8e12, 4)}
-            if kind in (2, 3):
+            if kind in (2, 3, 9):
                 r["mfma"] = {"useful_tflops": round(useful, 1), "ceiling_useful_tflops": round(X3, 1), "frac": round(useful / X3, 4),
                              "issued_tflops_bf16": round(3 * useful, 1),
                              "note": "3 bf16 MFMA products per fp32 multiply-add: the ceiling of useful flops is 2500 / 3 TFLOP/s"}
         rooflines.append(r)
     rooflines.sort(key=lambda r: -r["ms_per_step"])
+    # The north-star's "≥ 40 % of the CDNA4 bf16 MFMA peak on the bilateral-fusion + MSDeformAttn decoder", as numbers (round 6):
+    #  (a) hot_path: SURVEY 8(d)'s algorithmic flops of the hot path (fusion + pixel decoder + masked decoder, forward + backward = 3 x
+    #      forward) / the WHOLE step's time - a lower bound of the head's rate (the step also runs two backbones, VGGish, the losses
+    #      and the optimiser);
+    #  (b) matrix_kernels: the useful flops of all instrumented matrix kernels of a step (GEMM families, attention: head AND the
+    #      backbones' convolutions on the own kernels) / the sum of their durations - the rate while a matrix kernel runs.
+    gf_frame = {("r50_s4", 224): 63.5, ("pvt_s4", 224): 61.8, ("pvt_ms3_t10", 224): 61.8, ("pvt_avss_512", 512): 283.0}.get((args.config, H))
+    north = {"target": "fraction of the 2 500 TFLOP/s dense bf16 MFMA peak; north-star target >= 0.40", "peak_tflops": 2500.0}
+    if gf_frame:
+        hp = gf_frame * 1e9 * bt  # per step and GPU
+        north["hot_path"] = {"useful_tflop_per_step": round(hp / 1e12, 3), "source": "SURVEY.md 8(d): GFLOP per frame forward x 3",
+                             "tflops_over_whole_step": round(hp / (elapsed / args.steps) / 1e12, 1),
+                             "frac_of_bf16_peak": round(hp / (elapsed / args.steps) / 2500e12, 4)}
+    mk = [(k, d) for k, d in per_kind.items() if k in (1, 2, 4, 5, 8, 9) or (k == 3 and d["work"] > 0)]
+    if mk:
+        w = sum(d["work"] for _, d in mk)
+        us = sum(d["us"] for _, d in mk)
+        north["matrix_kernels"] = {"useful_tflop_per_step": round(w / max(args.steps, 1) / 1e12, 3), "ms_per_step": round(us / max(args.steps, 1) / 1e3, 3),
+                                   "useful_tflops": round(w / (us * 1e-6) / 1e12, 1), "frac_of_bf16_peak": round(w / (us * 1e-6) / 2500e12, 4),
+                                   "families": sorted(KINDS[k][0] for k, _ in mk)}
+    north["why_below_target"] = ("the 1e-3 bound on mask logits (and the attention-mask thresholds behind them) holds the head's forward to "
+                                 "exact fp32 (v_mfma_f32: 157 TFLOP/s peak = 6.3 % of the bf16 peak) and the gradients to 3 bf16 products per "
+                                 "multiply-add (ceiling 833 TFLOP/s useful = 33 %); most launches are K = 64 .. 256 layers whose roofline is "
+                                 "HBM, not the matrix pipe (frac_of_binding_roofline per family)")
     roof = rooflines[0] if rooflines else None
     kernels = {r["kernel"]: r for r in rooflines[1:]}
     if args.no_graph and kt.get("fwd_us"):  # eager run: HIP events on the launch stream around the MSDeformAttn core
@@ -742,6 +767,7 @@ def main():
                                        "head forward in exact fp32 (fp32 MFMA), gradients with the 3-product split")},
             "roofline": roof,
             "other_kernels": kernels,
+            "north_star_target": north,
         }
         if dist.is_initialized():
             backend = dist.get_backend()

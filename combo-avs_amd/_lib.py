@@ -16,6 +16,7 @@ c_void_p, c_int, c_float, c_longlong = ctypes.c_void_p, ctypes.c_int, ctypes.c_f
 _SIGNATURES = {
     "combo_abi_version": [],
     "combo_build_arch": [],
+    "combo_set_cu_limit": [c_int],
     "combo_dwconv3x3_bf16": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "combo_dwconv3x3_wgrad_slices": [c_int] * 4,
     "combo_dwconv3x3_wgrad_strips": [c_int],
@@ -192,6 +193,21 @@ def torch_channels_last():
 
 
 # ---- kernel timing (bench.py): HIP events from the C ABI around selected launches -------------------------------
+class cu_limit:
+    """`with cu_limit(n):` the persistent GEMM launches issued by this thread inside the block use at most n CUs (csrc/abi.hip);
+    n = 0 / None: no change"""
+
+    def __init__(self, n):
+        self.n = int(n or 0)
+
+    def __enter__(self):
+        self.prev = lib().combo_set_cu_limit(self.n) if self.n else None
+
+    def __exit__(self, *exc):
+        if self.n:
+            lib().combo_set_cu_limit(self.prev)
+
+
 _noticed = set()
 
 

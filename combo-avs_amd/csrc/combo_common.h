@@ -43,6 +43,8 @@ __device__ __forceinline__ int fast_mod(long long a, int b) {
   return ((unsigned long long)a >> 32) == 0 ? (int)((unsigned)a % (unsigned)b) : (int)(a % b);
 }
 
+int combo_cu_limit(void);  // abi.hip: 0 = no limit; else the CU budget of the persistent GEMM launches of this host thread
+
 // ---- device-side launch timing (works inside a replayed hipGraph, where HIP refuses event records) ----
 // A slot = COMBO_TS_SLOT_U64 x u64: 16 sub-slots, one 128-byte line each, {earliest workgroup start, latest workgroup end}
 // in wall-clock ticks; sub-slot 0 also carries {sum of durations, launches} at +2 / +3.  The host hands every instrumented
@@ -53,7 +55,7 @@ __device__ __forceinline__ int fast_mod(long long a, int b) {
 // each, returning or not - a "last workgroup adds the duration" protocol cost 25 us on a 1280-workgroup launch, and plain
 // min / max on a single pair of words still 18 us; spread over 16 lines it is ~1 us.
 enum { COMBO_TS_MSDA_FWD = 0, COMBO_TS_GEMM_F32 = 1, COMBO_TS_GEMM_X3 = 2, COMBO_TS_GEMM_TN = 3, COMBO_TS_ATTN_FWD = 4,
-       COMBO_TS_ATTN_BWD = 5, COMBO_TS_MSDA_BWD = 6, COMBO_TS_BIFUSE = 7, COMBO_TS_GEMM_BF16 = 8, COMBO_TS_KINDS = 9 };
+       COMBO_TS_ATTN_BWD = 5, COMBO_TS_MSDA_BWD = 6, COMBO_TS_BIFUSE = 7, COMBO_TS_GEMM_BF16 = 8, COMBO_TS_CONV_WGRAD = 9, COMBO_TS_KINDS = 10 };
 enum { COMBO_TS_SUBS = 16, COMBO_TS_SUB_U64 = 16, COMBO_TS_SLOT_U64 = 256 };
 // host; nullptr when timing is off (timing.hip).  work: flops (bytes for the HBM-bound kinds); bytes: algorithmic HBM bytes
 // of the launch (operands read once + result written once) for the kinds that report a second, HBM-side fraction

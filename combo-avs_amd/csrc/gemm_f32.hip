@@ -446,7 +446,8 @@ int n_cu_cached() {
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     return cus > 0 ? cus : 256;
   }();
-  return n_cu;
+  const int lim = combo_cu_limit();  // (abi.hip: a caller running two launch chains side by side hands each a share of the CUs)
+  return lim > 0 && lim < n_cu ? lim : n_cu;
 }
 
 template <bool CONV, typename Cfg>

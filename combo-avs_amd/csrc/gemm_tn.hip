@@ -382,7 +382,8 @@ gemm_tn_glds_kernel(const float* __restrict__ dY, long long ldy, const float* __
 template <int WN>
 __global__ void __launch_bounds__(256, 2)
 conv3x3_wgrad_kernel(const float* __restrict__ dY, long long ldy, const float* __restrict__ X, long long ldx,
-                     float* __restrict__ out, int M, int N, int K, int mchunk, int remap, TnConvGeom cg) {
+                     float* __restrict__ out, int M, int N, int K, int mchunk, int remap, TnConvGeom cg, unsigned long long* ts) {
+  combo_ts_begin(ts);
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   if (remap) {
     const int gx = gridDim.x, gy = gridDim.y;
@@ -390,6 +391,7 @@ conv3x3_wgrad_kernel(const float* __restrict__ dY, long long ldy, const float* _
     bx = l % gx; by = (l / gx) % gy; bz = l / (gx * gy);
   }
   gemm_tn_glds_body<WN, 3, true>(dY, ldy, X, ldx, out, nullptr, M, N, K, mchunk, bx, by, bz, cg);
+  combo_ts_end(ts);
 }
 
 // Grouped launch: many independent weight-gradient problems in ONE kernel.  The decoder's dW GEMMs (M = BT*100 tokens)
@@ -658,15 +660,18 @@ int combo_conv_wgrad_x3_f32(const float* dY, long long ldy, const float* X, long
     attr.mark();
   }
   const int remap = 1;  // XCD-contiguous tile order
+  // timing slot (bench.py `other_kernels`): useful flops 2 M Cout K; algorithmic bytes = dY and X read once + the partials written
+  unsigned long long* ts = combo_timing_next_slot(COMBO_TS_CONV_WGRAD, 2.0 * M * Cout * K,
+                                                  4.0 * ((double)M * Cout + (double)Min * Cin + (double)splits * Cout * K));
   TnConvGeom cg{H, W, Cin, (unsigned)(0xffffffffu / (unsigned)W + 1u), (unsigned)(0xffffffffu / (unsigned)H + 1u), Hin, Win, stride, ksize};
   if (tn_variant(Cout, K) == 2) {  // the less padded tile shape
     const dim3 grid((K + 127) / 128, (Cout + 255) / 256, splits);
     hipLaunchKernelGGL(conv3x3_wgrad_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, dY, ldy, X, ldx, out_partials, (int)M, Cout, K,
-                       mchunk, remap, cg);
+                       mchunk, remap, cg, ts);
   } else {
     const dim3 grid((K + 255) / 256, (Cout + 127) / 128, splits);
     hipLaunchKernelGGL(conv3x3_wgrad_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, dY, ldy, X, ldx, out_partials, (int)M, Cout, K,
-                       mchunk, remap, cg);
+                       mchunk, remap, cg, ts);
   }
   return (int)hipGetLastError();
 }

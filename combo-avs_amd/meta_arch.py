@@ -120,6 +120,7 @@ class MaskFormer(nn.Module):
     # measured (bs = 8, hipGraph step, A/B in one session): 67.4 ms with the two encoders on two streams vs 66.7 ms on one -
     # the replayed graph does not overlap the branches and the fork/join costs a little; kept as an opt-in experiment
     parallel_backbones = False
+    parallel_backbones_split = True  # (with parallel_backbones) half of the CUs per encoder
 
     def _loss_weights(self, keys, device):
         cache = self.__dict__.setdefault("_loss_weight_cache", {})
@@ -179,11 +180,15 @@ class MaskFormer(nn.Module):
                 # the two backward passes overlap as well; the late stages (14x14, 7x7 maps) do not fill 256 CUs alone.
                 cur, side = torch.cuda.current_stream(), self._side_stream(images.device)
                 side.wait_stream(cur)
-                with torch.cuda.stream(side):
+                # round 6: each encoder's persistent GEMM launches take HALF of the CUs (ops.convwrw.backbone_cus): full-size
+                # launches of the two streams only queue behind each other (measured in round 4: 50.87 vs 50.89 ms)
+                from .ops.convwrw import backbone_cus
+                half = torch.cuda.get_device_properties(images.device).multi_processor_count // 2 if self.parallel_backbones_split else 0
+                with torch.cuda.stream(side), backbone_cus(half):
                     pre.record_stream(side)
                     with amp:
                         pre_sam_features = self.pre_sam_backbone(pre)
-                with amp:
+                with amp, backbone_cus(half):
                     features = self.backbone(images)
                 cur.wait_stream(side)
                 for v in pre_sam_features.values():

@@ -44,6 +44,25 @@ WGRAD_S2 = True
 DX_S2_1X1 = True
 
 
+# CU budget of the launches issued for the convolutions of ONE backbone while the Siam pair runs side by side on two streams
+# (meta_arch.MaskFormer.parallel_backbones; csrc/abi.hip combo_set_cu_limit).  The forward pass records the budget in the autograd
+# node, the backward pass (issued by autograd's thread on the forward's stream) applies the same one.
+_cu_scope = 0
+
+
+class backbone_cus:
+    def __init__(self, n):
+        self.n = int(n or 0)
+
+    def __enter__(self):
+        global _cu_scope
+        self.prev, _cu_scope = _cu_scope, self.n
+
+    def __exit__(self, *exc):
+        global _cu_scope
+        _cu_scope = self.prev
+
+
 def kind(x, w, stride, padding):
     """0: not handled; 1: 1x1 stride 1; 3: 3x3 stride 1 pad 1; 21 / 23: the same with stride 2 (forward only)"""
     if not (ENABLED and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and not torch.is_autocast_enabled()
@@ -189,8 +208,10 @@ class _ConvWrw(Function):
         ctx.img_dx = images[1] if images is not None else None
         ctx.save_for_backward(x, w)
         ctx.passthrough = passthrough
+        ctx.cus = _cu_scope
         if images is not None and FWD_X3:
-            y = _x3_forward(x, k, images[0], bias, residual, relu)
+            with _lib.cu_limit(ctx.cus):
+                y = _x3_forward(x, k, images[0], bias, residual, relu)
         else:
             assert bias is None and residual is None and not relu
             y = F.conv2d(x, w, None, 2 if k > 20 else 1, 1 if k % 10 == 3 else 0)
@@ -202,6 +223,11 @@ class _ConvWrw(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dy, d_alias=None):
+        with _lib.cu_limit(ctx.cus):
+            return _ConvWrw._backward(ctx, dy, d_alias)
+
+    @staticmethod
+    def _backward(ctx, dy, d_alias=None):
         x, w = ctx.saved_tensors
         if d_alias is not None and not d_alias.is_contiguous(memory_format=torch.channels_last):
             d_alias = d_alias.contiguous(memory_format=torch.channels_last)
@@ -318,7 +344,8 @@ def conv_bias_act(x, w, bias, stride, padding, images=None, residual=None, relu=
         # bit-identical to the training forward's
         k = weight_kind(w, stride, padding, x.shape)
         if k:
-            y = _x3_forward(x, k, images[0], bias, residual, relu and bias is not None)
+            with _lib.cu_limit(_cu_scope):
+                y = _x3_forward(x, k, images[0], bias, residual, relu and bias is not None)
             return (y,) * max(int(fanout), 2) if (fanout and bias is not None) else y
     k = kind(x, w, stride, padding)
     if k and images is not None and FWD_X3 and (residual is None or (residual.dtype == torch.float32 and residual.shape[1] == w.shape[0]

@@ -38,6 +38,9 @@ typedef void* combo_stream_t;
 
 /* Library / device introspection (host only, no GPU needed). */
 int combo_abi_version(void);
+/* CU budget of the calling host thread's persistent GEMM launches (0 = whole device); returns the previous value.  For callers that run
+ * two independent launch chains on two streams (the reference runs its Siam pair of backbones back to back: maskformer_model.py:333-341). */
+int combo_set_cu_limit(int n);
 
 /* Measurement aid (bench.py): device-side timing of the instrumented kernels.  HIP refuses event records inside a
  * captured hipGraph on ROCm 7, so the kernels take wall-clock timestamps themselves: `buf` = slots x 256 uint64 on the
