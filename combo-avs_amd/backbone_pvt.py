@@ -32,6 +32,11 @@ def drop_path(x, p, training):
     return x * (mask / keep)
 
 
+# (round 6) the spatial-reduction convolution (kernel = stride = sr, no padding: pvtv2.py:76) as a GEMM over non-overlapping patches:
+# [B * Ho * Wo, sr * sr * C] x [Cout, sr * sr * C]^T.  Two reasons: MIOpen's default (immediate-mode) bf16 solver for these layers
+# is not run-to-run reproducible (profiles/r06_pvt_eager_vs_replay_states.txt - it was the source of the eager-vs-replay "states" of
+# the PVT recipe), and its weight-gradient kernels are the slowest part of the layer.  False: F.conv2d as before.
+SR_PATCH_GEMM = True
 PRENORM = True  # False: the per-op formulation (the reference of tests/test_kernels_gpu.py::test_pvt_prenorm_path_matches_per_op_path)
 
 
@@ -124,6 +129,19 @@ def _conv(x, mod, wts):
         from .ops.colsum import add_channel_vector
         return add_channel_vector(F.conv2d(x, w, None, mod.stride, mod.padding, mod.dilation, mod.groups), _p(mod.bias, wts), 1)
     return F.conv2d(x, w, None if mod.bias is None else _p(mod.bias, wts), mod.stride, mod.padding, mod.dilation, mod.groups)
+
+
+def _sr_patch_gemm(xs, w, B, H, W, C, sr):
+    """conv2d(x, w, stride = kernel = sr) on token-major x [B, H * W, C] -> [B, Ho * Wo, Cout]: the non-overlapping sr x sr patches
+    are the rows of a GEMM (one gather copy of x, one library GEMM; rows / columns beyond Ho * sr, Wo * sr are dropped as the
+    convolution drops them)"""
+    Ho, Wo = H // sr, W // sr
+    x4 = xs.view(B, H, W, C)
+    if Ho * sr != H or Wo * sr != W:
+        x4 = x4[:, :Ho * sr, :Wo * sr]
+    patches = x4.reshape(B, Ho, sr, Wo, sr, C).permute(0, 1, 3, 2, 4, 5).reshape(B * Ho * Wo, sr * sr * C)
+    w2 = w.permute(0, 2, 3, 1).reshape(w.shape[0], sr * sr * C)  # [Cout, (ky, kx, c)]
+    return F.linear(patches, w2).view(B, Ho * Wo, w.shape[0])
 
 
 def _ln(x, mod, wts):
@@ -219,8 +237,11 @@ class Attention(nn.Module):
             if wts is not None and PRENORM and xs.is_cuda and xs.dtype == w_sr.dtype == torch.bfloat16 and torch.is_grad_enabled():
                 # reduced-precision training path: the convolution without its bias, then bias + LayerNorm -> bf16 in one pass
                 from .ops.prenorm import bias_ln
-                x_ = F.conv2d(xs.view(B, H, W, C).permute(0, 3, 1, 2), w_sr, None, self.sr.stride)
-                x_ = bias_ln(x_.flatten(2).transpose(1, 2), _p(self.sr.bias, wts), self.norm)
+                if SR_PATCH_GEMM:
+                    x_ = _sr_patch_gemm(xs, w_sr, B, H, W, C, self.sr_ratio)  # [B, Ho * Wo, C], token-major
+                else:
+                    x_ = F.conv2d(xs.view(B, H, W, C).permute(0, 3, 1, 2), w_sr, None, self.sr.stride).flatten(2).transpose(1, 2)
+                x_ = bias_ln(x_, _p(self.sr.bias, wts), self.norm)
             else:
                 x_ = _conv(xs.view(B, H, W, C).permute(0, 3, 1, 2), self.sr, wts)  # [B,C,H/sr,W/sr]
                 x_ = _ln(x_.flatten(2).transpose(1, 2), self.norm, wts)

@@ -7,6 +7,8 @@
 import os
 from typing import Tuple
 
+import contextlib
+
 import torch
 from torch import nn
 from torch.nn import functional as F
@@ -117,10 +119,19 @@ class MaskFormer(nn.Module):
     def device(self):
         return self.pixel_mean.device
 
-    # measured (bs = 8, hipGraph step, A/B in one session): 67.4 ms with the two encoders on two streams vs 66.7 ms on one -
-    # the replayed graph does not overlap the branches and the fork/join costs a little; kept as an opt-in experiment
-    parallel_backbones = False
-    parallel_backbones_split = True  # (with parallel_backbones) half of the CUs per encoder
+    # The Siam pair of encoders is independent until the SEM mix: the second one runs on its own HIP stream (fork / join with events,
+    # also inside a captured hipGraph; autograd replays each backward pass on its forward stream, so the two backward chains run
+    # side by side as well).  Round 1 (library convolutions): 67.4 vs 66.7 ms - no gain, opt-in.  Round 6 (own persistent kernels,
+    # ~200 launches of 10 - 60 us per encoder and direction): 46.0 -> 43.9 ms per step, same box, A B A B
+    # (profiles/r06_ab_parallel_backbones.txt) - a launch's fixed costs (dispatch, ring priming, drain of the last stores: ~8 us)
+    # overlap with the other chain's streaming.  Giving each chain HALF of the CUs (ops.convwrw.backbone_cus, csrc/abi.hip
+    # combo_set_cu_limit) measured the same as full-size launches (43.90 vs 43.87 ms): off.
+    parallel_backbones = True
+    parallel_backbones_split = False  # (with parallel_backbones) half of the CUs per encoder
+    # VGGish (no gradient) on a third stream: 44.35 -> 44.05 ms (profiles/r06_ab_parallel_backbones.txt).  Measured and NOT kept: the
+    # head's deferred weight gradients launched on a side stream at the head / backbone boundary of the backward pass instead of as a
+    # serial tail after it (44.35 vs 44.40 ms: two throughput-bound streams gain nothing from running side by side)
+    parallel_audio = True
 
     def _loss_weights(self, keys, device):
         cache = self.__dict__.setdefault("_loss_weight_cache", {})
@@ -129,9 +140,9 @@ class MaskFormer(nn.Module):
             cache[ck] = torch.tensor([float(self.criterion.weight_dict[k]) for k in keys], dtype=torch.float32, device=device)
         return cache[ck]
 
-    def _side_stream(self, device):
+    def _side_stream(self, device, index=0):
         streams = self.__dict__.setdefault("_side_streams", {})
-        key = str(device)
+        key = (str(device), index)
         if key not in streams:
             streams[key] = torch.cuda.Stream(device=device)
         return streams[key]
@@ -162,10 +173,20 @@ class MaskFormer(nn.Module):
         images = self._pad(images.sub(self.pixel_mean).div_(self.pixel_std) if images.dtype == torch.uint8
                            else (images.float() - self.pixel_mean) / self.pixel_std)
         amp = torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.backbone_dtype == torch.bfloat16)
-        with torch.no_grad(), amp:
+        audio_stream = None
+        if images.is_cuda and self.parallel_audio:
+            audio_stream = self._side_stream(images.device, 1)
+            audio_stream.wait_stream(torch.cuda.current_stream())
+        with torch.no_grad(), amp, (torch.cuda.stream(audio_stream) if audio_stream is not None else contextlib.nullcontext()):
+            if audio_stream is not None:
+                audio_log_mels.record_stream(audio_stream)
             audio_feature = self.audio_backbone(audio_log_mels).float()  # :327-328
         audio_feature = audio_feature.unsqueeze(1)
         if self.is_avss_data:
+            if audio_stream is not None:
+                torch.cuda.current_stream().wait_stream(audio_stream)
+                audio_feature.record_stream(torch.cuda.current_stream())
+                audio_stream = None
             # maskformer_model.py:330-331: the audio rows of the frames that exist.  Boolean indexing reads the flag VALUES on the
             # host (a synchronisation: not capturable); trainer.GraphedTrainStep reads them once per step before the graph
             # launch, keys its graphs by them and hands over the same selection as constant index tensors
@@ -206,6 +227,9 @@ class MaskFormer(nn.Module):
         # (recorded only on request: holding them keeps the step's autograd graph alive beyond the backward pass)
         self._head_inputs = ([v for v in features.values() if torch.is_tensor(v) and v.requires_grad]
                              if self.training and getattr(self, "record_head_inputs", False) else None)
+        if audio_stream is not None:
+            torch.cuda.current_stream().wait_stream(audio_stream)
+            audio_feature.record_stream(torch.cuda.current_stream())
         outputs = self.sem_seg_head(features, audio_feature)
         if self.training:
             if "instances" not in batched_inputs[0]:
