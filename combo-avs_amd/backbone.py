@@ -208,6 +208,10 @@ class BasicStem(nn.Module):
 
 
 class ResNet(nn.Module):
+    # the convolutions of this backbone run on the package's own kernels, none of which waits for another workgroup: two instances
+    # may run side by side on two HIP streams (meta_arch.MaskFormer.parallel_backbones)
+    concurrent_safe = True
+
     def __init__(self, depth=50, out_features=("res2", "res3", "res4", "res5")):
         super().__init__()
         blocks = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}[depth]
@@ -328,11 +332,18 @@ class VGGish(nn.Module):
                 raise NotImplementedError("wav->log-mel preprocessing / PCA post-processing are offline steps (disabled in all shipped configs)")
 
     def forward(self, x):
-        if x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and not torch.is_autocast_enabled():
-            x = self._features_own(x)
-        else:
-            x = self.features(x)
+        own = x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and not torch.is_autocast_enabled()
+        x = self._features_own(x) if own else self.features(x)
         x = x.permute(0, 2, 3, 1).reshape(x.size(0), -1)  # vggish.py:21-25
+        if own:
+            # (round 6) the three dense layers on the head's weight-streaming kernel (csrc/gemm_smallm.hip, <= 64 rows) instead of a
+            # library GEMM: the extractor may run on a side stream next to the encoders (meta_arch.parallel_audio), and a library
+            # solution may be a stream-K kernel whose workgroups wait for each other
+            from .ops.linear import linear
+            for m in self.embeddings:
+                if isinstance(m, nn.Linear):
+                    x = linear(x, m.weight, m.bias, relu=True)  # every Linear of vggish.py:13-19 is followed by a ReLU
+            return x
         return self.embeddings(x)
 
     def _features_own(self, x):

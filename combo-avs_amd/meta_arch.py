@@ -126,6 +126,10 @@ class MaskFormer(nn.Module):
     # (profiles/r06_ab_parallel_backbones.txt) - a launch's fixed costs (dispatch, ring priming, drain of the last stores: ~8 us)
     # overlap with the other chain's streaming.  Giving each chain HALF of the CUs (ops.convwrw.backbone_cus, csrc/abi.hip
     # combo_set_cu_limit) measured the same as full-size launches (43.90 vs 43.87 ms): off.
+    # ONLY for backbones marked `concurrent_safe` (backbone.ResNet): the PVTv2 encoders run library GEMMs, and the solutions
+    # TunableOp / hipBLASLt pick for them include stream-K kernels (`..._SK3_...`), whose workgroups spin-wait for each other - two
+    # of those on two streams each hold part of the chip waiting for workgroups that cannot be scheduled: the replayed graph of
+    # `pvt_ms3_t10` never finished (tools/run_with_dump.py: torch.cuda.synchronize after the first replay).  PVT stays on one stream.
     parallel_backbones = True
     parallel_backbones_split = False  # (with parallel_backbones) half of the CUs per encoder
     # VGGish (no gradient) on a third stream: 44.35 -> 44.05 ms (profiles/r06_ab_parallel_backbones.txt).  Measured and NOT kept: the
@@ -174,7 +178,8 @@ class MaskFormer(nn.Module):
                            else (images.float() - self.pixel_mean) / self.pixel_std)
         amp = torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.backbone_dtype == torch.bfloat16)
         audio_stream = None
-        if images.is_cuda and self.parallel_audio:
+        side_ok = images.is_cuda and getattr(self.backbone, "concurrent_safe", False)  # (see parallel_backbones)
+        if side_ok and self.parallel_audio:
             audio_stream = self._side_stream(images.device, 1)
             audio_stream.wait_stream(torch.cuda.current_stream())
         with torch.no_grad(), amp, (torch.cuda.stream(audio_stream) if audio_stream is not None else contextlib.nullcontext()):
@@ -195,7 +200,7 @@ class MaskFormer(nn.Module):
             pre = torch.cat([b["pre_masks"].to(dev, non_blocking=True) for b in batched_inputs], dim=0)
             pre = self._pad(pre.sub(self.pixel_mean).div_(self.pixel_std) if pre.dtype == torch.uint8
                             else (pre.float() - self.pixel_mean) / self.pixel_std)
-            if images.is_cuda and self.parallel_backbones:
+            if side_ok and self.parallel_backbones:
                 # the Siam pair is independent until the SEM mix: run the second encoder on its own HIP stream (fork/join
                 # with events, also inside a captured hipGraph).  Autograd replays each backward on its forward stream, so
                 # the two backward passes overlap as well; the late stages (14x14, 7x7 maps) do not fill 256 CUs alone.
