@@ -182,6 +182,10 @@ def main():
             return x.view(A, C, L).sum((0, 2), dtype=torch.float32).to(out_dtype or x.dtype)
         colsum.channel_sum = aten_channel_sum
         colsum.DEFER = False
+    if "--single-stream" in sys.argv:  # the launch order of rounds 1-5: one stream, a linear graph (the form whose memset nodes the
+        import combo_avs_amd  # noqa: F401  # runtime's packet capture replays wrongly; a graph with parallel branches takes another path)
+        from combo_avs_amd.meta_arch import MaskFormer
+        MaskFormer.parallel_backbones = MaskFormer.parallel_audio = False
     model, opt, batches, _ = build(recipe)
     from combo_avs_amd.trainer import graph_memset_selftest
     selftest = graph_memset_selftest(torch.device("cuda", 0))

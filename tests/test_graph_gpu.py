@@ -114,7 +114,9 @@ def test_per_parameter_comparison_catches_a_bypassed_colsum():
     import json
     import subprocess
     env = dict(os.environ, DEBUG_CLR_GRAPH_PACKET_CAPTURE="1", COMBO_ALLOW_PACKET_CAPTURE="1")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "graph_compare.py"), "r50", "--bypass-colsum"],
+    # --single-stream: since round 6 the two encoders run on two streams and the captured step has parallel branches - the runtime
+    # replays the memset nodes of THAT graph correctly (measured: no parameter flagged); the hazard is the linear graph's
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "graph_compare.py"), "r50", "--bypass-colsum", "--single-stream"],
                          capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])

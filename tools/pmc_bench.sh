@@ -2,13 +2,13 @@
 # HBM traffic (and MFMA / LDS counters) of the head's instrumented kernels inside the BENCH step, per launch, as
 # MI355X_MICROARCH.md prescribes: separate rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit together), kernel trace
 # only; FETCH_SIZE is doubled (gfx950 counts 128-B requests of wide coalesced reads at 64 B).  The step runs eagerly
-# (--no-graph) so that every launch is its own dispatch record.  Writes gpurun_out/r05_pmc.json, stamped with $COMBO_COMMIT;
+# (--no-graph) so that every launch is its own dispatch record.  Writes gpurun_out/r06_pmc.json, stamped with $COMBO_COMMIT;
 # copy it to profiles/ - bench.py reports its numbers in `roofline.traffic`.
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_bench.txt
 : > $OUT
 for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT"; do
-  COMBO_MIOPEN_BENCHMARK=0 COMBO_GEMM_TUNING=0 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc -o p -- python3 $GRAFT_REPO_ROOT/bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  COMBO_MIOPEN_BENCHMARK=0 COMBO_GEMM_TUNING=0 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc -o p -- python3 $GRAFT_REPO_ROOT/bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline --no-other-workloads > /dev/null 2>&1
   python3 - <<PY | tee -a $OUT
 import csv,glob,collections,re
 fs=glob.glob("/tmp/pmc/**/*counter_collection.csv", recursive=True)
@@ -39,6 +39,6 @@ for line in open("$OUT"):
 for name,rec in out.items():
     if isinstance(rec, dict) and "FETCH_SIZE" in rec and "WRITE_SIZE" in rec:
         rec["hbm_bytes_per_launch"]=int((2.0*rec["FETCH_SIZE"]+rec["WRITE_SIZE"])*1024)
-json.dump(out, open(os.path.join("$GRAFT_REPO_ROOT","gpurun_out","r05_pmc.json"),"w"), indent=1)
+json.dump(out, open(os.path.join("$GRAFT_REPO_ROOT","gpurun_out","r06_pmc.json"),"w"), indent=1)
 print(json.dumps({k:(v.get("hbm_bytes_per_launch") if isinstance(v,dict) else v) for k,v in out.items()}))
 PY
