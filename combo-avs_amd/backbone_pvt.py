@@ -35,8 +35,10 @@ def drop_path(x, p, training):
 # (round 6) the spatial-reduction convolution (kernel = stride = sr, no padding: pvtv2.py:76) as a GEMM over non-overlapping patches:
 # [B * Ho * Wo, sr * sr * C] x [Cout, sr * sr * C]^T.  Two reasons: MIOpen's default (immediate-mode) bf16 solver for these layers
 # is not run-to-run reproducible (profiles/r06_pvt_eager_vs_replay_states.txt - it was the source of the eager-vs-replay "states" of
-# the PVT recipe), and its weight-gradient kernels are the slowest part of the layer.  False: F.conv2d as before.
-SR_PATCH_GEMM = True
+# the PVT recipe).  An OPTION for reproducible runs without `torch.backends.cudnn.deterministic`: measured 105.9 vs 105.1 ms per
+# `pvt_ms3_t10` step against MIOpen's find-mode kernels (same box, A B A B: profiles/r06_ab_pvt_sr_patch_gemm.txt), so the default
+# stays F.conv2d.
+SR_PATCH_GEMM = False
 PRENORM = True  # False: the per-op formulation (the reference of tests/test_kernels_gpu.py::test_pvt_prenorm_path_matches_per_op_path)
 
 
