@@ -185,7 +185,7 @@ def other_workloads(budget_s=400):
         if left < 45:
             out.append({"name": name, "error": f"skipped: the {budget_s} s budget of the side workloads is spent"})
             continue
-        cmd = [sys.executable, os.path.abspath(__file__)] + extra + ["--no-cpu-baseline", "--no-other-workloads"]
+        cmd = [sys.executable, os.path.abspath(__file__)] + extra + ["--no-cpu-baseline", "--no-other-workloads", "--no-exclusive"]
         t0 = time.perf_counter()
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=left, cwd=ROOT)
@@ -259,6 +259,11 @@ def _pmc_stale(pmc):
     if csrc_digest() != want:
         return f"kernel sources changed since the PMC passes of commit {pmc.get('commit')}: traffic withheld"
     return None
+
+
+def ran_eager_probe(graphed):
+    """True when the timed steps did not replay a captured graph"""
+    return graphed is None or graphed.eager_only or not graphed.graphs
 
 
 def csrc_digest():
@@ -380,6 +385,10 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="no device-side timing slots (the instrumented kernels' 2 atomics per workgroup + the fold launch per step): the "
                          "plain step, without `roofline` / `other_kernels` - measures what the instrumentation costs")
+    ap.add_argument("--single-stream", action="store_true", help="round 5's launch order: the two encoders and VGGish on ONE stream (the timed "
+                                                                  "region then is what `roofline` reports without a second pass)")
+    ap.add_argument("--no-exclusive", action="store_true", help="skip the single-stream pass after the timed region (per-family figures "
+                                                                 "with the chip to themselves + the step time without stream overlap)")
     ap.add_argument("--dump-slots", default="", help="comma-separated timing-slot kinds (csrc/combo_common.h COMBO_TS_*): print every "
                                                      "instrumented launch of those kinds (work, bytes, average duration) to stderr")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
@@ -427,6 +436,9 @@ def main():
     from combo_avs_amd.meta_arch import build_model
     from combo_avs_amd.trainer import FlatAdamW, GraphedTrainStep, train_step
 
+    if args.single_stream:
+        from combo_avs_amd.meta_arch import MaskFormer as _MF
+        _MF.parallel_backbones = _MF.parallel_audio = False
     if args.library_backbone_forward:
         from combo_avs_amd.ops import convwrw as _cw
         _cw.FWD_X3 = False
@@ -558,16 +570,17 @@ def main():
     model.criterion.matcher.check_status()  # a diverged step (non-finite matching cost) is an error, not a number
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     median_ms = step_ms[len(step_ms) // 2] if step_ms else None
-    per_kind = {}
     timing_truncated = False
-    if slot_timing:
+
+    def collect_slots(buf, dump):
+        """-> {kind: sums over the slots of `buf`} from the device-side timestamps the instrumented launches left there"""
+        import ctypes
+        out_k = {}
         torch.cuda.synchronize()
-        tsv = ts_buf.cpu()
+        tsv = buf.cpu()
         lib = _clib.lib()
         used = lib.combo_timing_slots_used()
-        timing_truncated = bool(lib.combo_timing_truncated())
         khz = lib.combo_wall_clock_khz()
-        import ctypes
         lib.combo_timing_slot_info.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]
         lib.combo_timing_slot_bytes.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
         for sl in range(min(used, n_slots)):
@@ -575,11 +588,11 @@ def main():
             lib.combo_timing_slot_info(sl, ctypes.byref(kind), ctypes.byref(work))
             lib.combo_timing_slot_bytes(sl, ctypes.byref(nbytes))
             n_l = int(tsv[sl, 3])
-            if khz > 0 and n_l > 0 and args.dump_slots and str(kind.value) in args.dump_slots.split(","):
+            if khz > 0 and n_l > 0 and dump and str(kind.value) in dump.split(","):
                 print(f"[slot {sl}] kind {kind.value} work {work.value:.4g} bytes {nbytes.value:.4g} avg_us {float(tsv[sl, 2]) / khz * 1e3 / n_l:.1f}", file=sys.stderr)
             if khz > 0 and n_l > 0:
-                d = per_kind.setdefault(kind.value, {"us": 0.0, "launches": 0, "work": 0.0, "bytes": 0.0, "nodes": 0, "big_us": 0.0,
-                                                     "big_work": 0.0, "big_launches": 0, "floor_us": 0.0})
+                d = out_k.setdefault(kind.value, {"us": 0.0, "launches": 0, "work": 0.0, "bytes": 0.0, "nodes": 0, "big_us": 0.0,
+                                                  "big_work": 0.0, "big_launches": 0, "floor_us": 0.0})
                 us = float(tsv[sl, 2]) / khz * 1e3
                 d["us"] += us
                 d["launches"] += n_l
@@ -594,9 +607,52 @@ def main():
                     d["big_us"] += us
                     d["big_work"] += work.value * n_l
                     d["big_launches"] += n_l
+        return out_k
+
+    per_kind, per_kind_excl, single_stream = {}, {}, None
+    if slot_timing:
+        per_kind = collect_slots(ts_buf, args.dump_slots)
+        timing_truncated = bool(_clib.lib().combo_timing_truncated())
         # the graph's kernel nodes keep raw pointers into ts_buf: the buffer lives as long as the graphs do
         graphed._timing_buffer = ts_buf
-        lib.combo_timing_set_buffer(None, 0)
+        _clib.lib().combo_timing_set_buffer(None, 0)
+        # Round 6: the Siam pair of encoders (and VGGish) run on their own HIP streams - inside the timed region a launch of one
+        # chain shares the CUs with the other chain's launches, so its device-side duration is longer than the same launch alone on
+        # the chip although the step is shorter.  A second, SINGLE-STREAM capture of the same step (5 replays, outside the timed
+        # region) gives every family's figures with the chip to itself (`exclusive`) and the step time without the overlap.
+        from combo_avs_amd.meta_arch import MaskFormer
+        streams_on = (MaskFormer.parallel_backbones or MaskFormer.parallel_audio) and getattr(model.backbone, "concurrent_safe", False)
+        if streams_on and not ran_eager_probe(graphed) and world == 1 and not args.no_exclusive:
+            saved = (MaskFormer.parallel_backbones, MaskFormer.parallel_audio)
+            MaskFormer.parallel_backbones = MaskFormer.parallel_audio = False
+            try:
+                ts2 = torch.zeros(n_slots, 256, dtype=torch.int64, device=dev)
+                ts2[:, 0::16] = -1
+                _clib.check(_clib.lib().combo_timing_set_buffer(ts2.data_ptr(), n_slots), "combo_timing_set_buffer")
+                g2 = GraphedTrainStep(model, opt, pad_targets_to=4 if wl["avss"] else None)
+                for i in range(3):
+                    g2(batches[i % len(batches)])
+                _clib.lib().combo_timing_fold(_clib.current_stream())
+                sync()
+                ts2[:, 2:4] = 0
+                sync()
+                n_ex = 5
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_ex + 1)]
+                ev[0].record()
+                for i in range(n_ex):
+                    g2(batches[i % len(batches)])
+                    _clib.lib().combo_timing_fold(_clib.current_stream())
+                    ev[i + 1].record()
+                sync()
+                ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(n_ex))
+                per_kind_excl = collect_slots(ts2, "")
+                single_stream = {"ms_per_step_median": round(ms[n_ex // 2], 3), "steps": n_ex,
+                                 "what": "the same step captured with ONE stream (round 5's launch order): MaskFormer.parallel_backbones / "
+                                         "parallel_audio off; 5 replays after the timed region"}
+                g2._timing_buffer = ts2
+            finally:
+                MaskFormer.parallel_backbones, MaskFormer.parallel_audio = saved
+                _clib.lib().combo_timing_set_buffer(None, 0)
     kt = {"fwd_us": [], "bwd_us": [], "kernels": {}}
     if args.no_graph:
         kt = msda.stop_timing()
@@ -641,51 +697,77 @@ def main():
         pmc_note = _pmc_stale(pmc)
         if pmc_note:
             pmc = {}
-    rooflines = []
-    for kind, d in per_kind.items():
-        name, bound, peak, unit, scale = KINDS.get(kind, (f"kind{kind}", "mfma", X3, "TFLOP/s", 1e12))
-        secs = d["us"] * 1e-6
-        if kind == 3:  # weight-gradient GEMM: a long-M reduction that streams dY and X once - HBM-bound (`work` holds flops)
-            ach = d["bytes"] / secs / scale
-        else:
-            ach = d["work"] / secs / scale
-        rec = pmc.get(name, {}) if pmc.get("frames_per_launch") == bt else {}
-        if not rec and pmc.get("frames_per_launch") == bt:
-            # families whose launches are several kernels of the PMC file: the mean over the family's launches of one step
-            members = {"msda_bwd": ("msda_bwd_win_d32",),
-                       "bifuse": ("bifuse_scores", "bifuse_apply", "bifuse_bwd1", "bifuse_bwd2")}.get(name, ())
-            got = [pmc[m]["hbm_bytes_per_launch"] for m in members if isinstance(pmc.get(m), dict) and "hbm_bytes_per_launch" in pmc[m]]
-            if got and len(got) == len(members):
-                rec = {"hbm_bytes_per_launch": int(sum(got) / len(got))}
-        r = {"kernel": name, "bound": bound, "achieved": round(ach, 1), "peak": round(peak, 1), "unit": unit, "frac": round(ach / peak, 4),
-             "traffic": rec.get("hbm_bytes_per_launch"), "traffic_commit": pmc.get("commit") if rec else None,
-             "avg_launch_us": round(d["us"] / d["launches"], 2), "launches": d["launches"],
-             "launches_per_step": d["launches"] // max(args.steps, 1), "ms_per_step": round(d["us"] / max(args.steps, 1) / 1e3, 3),
-             "algorithmic_work_per_step": (d["bytes"] if kind == 3 else d["work"]) / max(args.steps, 1),
-             "timing": "device-side wall-clock timestamps of the kernel over the launches of the timed "
-                       + ("eager steps" if eager_slots else "graph replays")}
-        if pmc_note and r["traffic"] is None:
-            r["traffic_note"] = pmc_note
-        if timing_truncated:
-            r["timing_truncated"] = True  # the slot buffer ran out: figures cover the slotted launches only
-        if d["big_launches"] and kind in (1, 2, 4, 5, 9):
-            big = d["big_work"] / (d["big_us"] * 1e-6) / scale
-            r["large_launches"] = {"min_gflop": 2, "launches_per_step": d["big_launches"] // max(args.steps, 1),
-                                   "ms_per_step": round(d["big_us"] / max(args.steps, 1) / 1e3, 3), "achieved": round(big, 1),
-                                   "frac": round(big / peak, 4)}
-        if d.get("floor_us"):
-            # every launch against ITS binding roofline (a third of the 3-product launches are HBM-bound 64 .. 256-channel layers:
-            # `frac` prices them against the matrix pipe)
-            r["frac_of_binding_roofline"] = round(d["floor_us"] / d["us"], 4)
-        if kind in (1, 2, 3, 9) and d["bytes"] > 0:  # the GEMM families also report the other side of their roofline
-            useful = d["work"] / secs / 1e12
-            r["hbm"] = {"algorithmic_bytes_per_step": d["bytes"] / max(args.steps, 1), "achieved_gbs": round(d["bytes"] / secs / 1e9, 1),
-                        "frac_of_8tbs": round(d["bytes"] / secs / 8e12, 4)}
-            if kind in (2, 3, 9):
-                r["mfma"] = {"useful_tflops": round(useful, 1), "ceiling_useful_tflops": round(X3, 1), "frac": round(useful / X3, 4),
-                             "issued_tflops_bf16": round(3 * useful, 1),
-                             "note": "3 bf16 MFMA products per fp32 multiply-add: the ceiling of useful flops is 2500 / 3 TFLOP/s"}
-        rooflines.append(r)
+    def family_records(pk, n_steps, timing):
+        recs = []
+        for kind, d in pk.items():
+            name, bound, peak, unit, scale = KINDS.get(kind, (f"kind{kind}", "mfma", X3, "TFLOP/s", 1e12))
+            secs = d["us"] * 1e-6
+            if kind == 3:  # weight-gradient GEMM: a long-M reduction that streams dY and X once - HBM-bound (`work` holds flops)
+                ach = d["bytes"] / secs / scale
+            else:
+                ach = d["work"] / secs / scale
+            rec = pmc.get(name, {}) if pmc.get("frames_per_launch") == bt else {}
+            if not rec and pmc.get("frames_per_launch") == bt:
+                # families whose launches are several kernels of the PMC file: the mean over the family's launches of one step
+                members = {"msda_bwd": ("msda_bwd_win_d32",),
+                           "bifuse": ("bifuse_scores", "bifuse_apply", "bifuse_bwd1", "bifuse_bwd2")}.get(name, ())
+                got = [pmc[m]["hbm_bytes_per_launch"] for m in members if isinstance(pmc.get(m), dict) and "hbm_bytes_per_launch" in pmc[m]]
+                if got and len(got) == len(members):
+                    rec = {"hbm_bytes_per_launch": int(sum(got) / len(got))}
+            r = {"kernel": name, "bound": bound, "achieved": round(ach, 1), "peak": round(peak, 1), "unit": unit, "frac": round(ach / peak, 4),
+                 "traffic": rec.get("hbm_bytes_per_launch"), "traffic_commit": pmc.get("commit") if rec else None,
+                 "avg_launch_us": round(d["us"] / d["launches"], 2), "launches": d["launches"],
+                 "launches_per_step": d["launches"] // max(n_steps, 1), "ms_per_step": round(d["us"] / max(n_steps, 1) / 1e3, 3),
+                 "algorithmic_work_per_step": (d["bytes"] if kind == 3 else d["work"]) / max(n_steps, 1), "timing": timing, "_kind": kind}
+            if pmc_note and r["traffic"] is None:
+                r["traffic_note"] = pmc_note
+            if timing_truncated:
+                r["timing_truncated"] = True  # the slot buffer ran out: figures cover the slotted launches only
+            if d["big_launches"] and kind in (1, 2, 4, 5, 9):
+                big = d["big_work"] / (d["big_us"] * 1e-6) / scale
+                r["large_launches"] = {"min_gflop": 2, "launches_per_step": d["big_launches"] // max(n_steps, 1),
+                                       "ms_per_step": round(d["big_us"] / max(n_steps, 1) / 1e3, 3), "achieved": round(big, 1),
+                                       "frac": round(big / peak, 4)}
+            if d.get("floor_us"):
+                # every launch against ITS binding roofline (a third of the 3-product launches are HBM-bound 64 .. 256-channel layers:
+                # `frac` prices them against the matrix pipe)
+                r["frac_of_binding_roofline"] = round(d["floor_us"] / d["us"], 4)
+            if kind in (1, 2, 3, 9) and d["bytes"] > 0:  # the GEMM families also report the other side of their roofline
+                useful = d["work"] / secs / 1e12
+                r["hbm"] = {"algorithmic_bytes_per_step": d["bytes"] / max(n_steps, 1), "achieved_gbs": round(d["bytes"] / secs / 1e9, 1),
+                            "frac_of_8tbs": round(d["bytes"] / secs / 8e12, 4)}
+                if kind in (2, 3, 9):
+                    r["mfma"] = {"useful_tflops": round(useful, 1), "ceiling_useful_tflops": round(X3, 1), "frac": round(useful / X3, 4),
+                                 "issued_tflops_bf16": round(3 * useful, 1),
+                                 "note": "3 bf16 MFMA products per fp32 multiply-add: the ceiling of useful flops is 2500 / 3 TFLOP/s"}
+            recs.append(r)
+        return recs
+
+    timed_label = "device-side wall-clock timestamps of the kernel over the launches of the timed " + ("eager steps" if eager_slots else "graph replays")
+    rooflines = family_records(per_kind, args.steps, timed_label)
+    if per_kind_excl:
+        # The encoders' launch chains overlap inside the timed region: a launch's duration there includes the time it shares the CUs
+        # with another chain's launch and prices nothing about the kernel.  Primary figures = the SINGLE-STREAM capture of the same step
+        # (5 replays right after the timed region, same process, same device-side timestamps); the timed region's figures ride along
+        # under `timed_region`.  `bench.py --single-stream` times the single-stream step itself (the rocprofv3 summary of that
+        # command is the one whose per-kernel averages these figures agree with).
+        excl = {r["_kind"]: r for r in family_records(
+            per_kind_excl, single_stream["steps"],
+            "device-side wall-clock timestamps of the kernel over 5 replays of a single-stream capture of the same step, taken right "
+            "after the timed region (the timed region overlaps the encoders' launch chains on separate HIP streams: `timed_region`)")}
+        merged = []
+        for r in rooflines:
+            e = excl.get(r["_kind"])
+            if e is None:
+                merged.append(r)
+                continue
+            e["timed_region"] = {k: r[k] for k in ("ms_per_step", "avg_launch_us", "achieved", "frac", "frac_of_binding_roofline", "launches") if k in r}
+            e["timed_region"]["note"] = ("launch chains of the two encoders (and VGGish) overlap on separate HIP streams: durations include "
+                                          "the time a launch shares the CUs with another chain's launch")
+            merged.append(e)
+        rooflines = merged
+    for r in rooflines:
+        r.pop("_kind", None)
     rooflines.sort(key=lambda r: -r["ms_per_step"])
     # The north-star's "≥ 40 % of the CDNA4 bf16 MFMA peak on the bilateral-fusion + MSDeformAttn decoder", as numbers (round 6):
     #  (a) hot_path: SURVEY 8(d)'s algorithmic flops of the hot path (fusion + pixel decoder + masked decoder, forward + backward = 3 x
@@ -700,11 +782,12 @@ def main():
         north["hot_path"] = {"useful_tflop_per_step": round(hp / 1e12, 3), "source": "SURVEY.md 8(d): GFLOP per frame forward x 3",
                              "tflops_over_whole_step": round(hp / (elapsed / args.steps) / 1e12, 1),
                              "frac_of_bf16_peak": round(hp / (elapsed / args.steps) / 2500e12, 4)}
-    mk = [(k, d) for k, d in per_kind.items() if k in (1, 2, 4, 5, 8, 9) or (k == 3 and d["work"] > 0)]
+    pk_n, st_n = (per_kind_excl, single_stream["steps"]) if per_kind_excl else (per_kind, args.steps)  # (single-stream figures when taken)
+    mk = [(k, d) for k, d in pk_n.items() if k in (1, 2, 4, 5, 8, 9) or (k == 3 and d["work"] > 0)]
     if mk:
         w = sum(d["work"] for _, d in mk)
         us = sum(d["us"] for _, d in mk)
-        north["matrix_kernels"] = {"useful_tflop_per_step": round(w / max(args.steps, 1) / 1e12, 3), "ms_per_step": round(us / max(args.steps, 1) / 1e3, 3),
+        north["matrix_kernels"] = {"useful_tflop_per_step": round(w / max(st_n, 1) / 1e12, 3), "ms_per_step": round(us / max(st_n, 1) / 1e3, 3),
                                    "useful_tflops": round(w / (us * 1e-6) / 1e12, 1), "frac_of_bf16_peak": round(w / (us * 1e-6) / 2500e12, 4),
                                    "families": sorted(KINDS[k][0] for k, _ in mk)}
     north["why_below_target"] = ("the 1e-3 bound on mask logits (and the attention-mask thresholds behind them) holds the head's forward to "
@@ -746,11 +829,14 @@ def main():
                            "hipGraph (fwd+loss+bwd captured; all-reduce + AdamW eager)"
                            + ("; per-frame instance lists padded to 4 (real counts in a device tensor): one graph for all batches"
                               if graphed is not None and graphed.pad_targets_to else "")),
+                       "streams": ("one" if (args.single_stream or not getattr(model.backbone, "concurrent_safe", False)) else
+                                   "three: the Siam pair of ResNet-50 encoders on two HIP streams (forward and, through autograd, backward), "
+                                   "VGGish on a third; the head on the main stream"),
                        "instrumentation": "the instrumented kernels' timing atomics (2 per workgroup) and one fold launch per step run "
                                           "inside the timed region" if slot_timing else "HIP events around the MSDeformAttn core",
                        "arithmetic": "forward GEMMs / convolutions / attention of the head in exact fp32 on v_mfma_f32_* (peak 157.3 "
                                      "TFLOP/s): the north-star's 1e-3 bound on the mask logits rules bf16 products out (DESIGN section 2), so "
-                                     "its '>= 40 % of the bf16 MFMA peak' target does not apply to this line; gradient GEMMs issue 3 bf16 "
+                                     "its '>= 40 % of the bf16 MFMA peak' target is not reachable on this line (`north_star_target` has the numbers); gradient GEMMs issue 3 bf16 "
                                      "products per fp32 multiply-add (ceiling 833 TFLOP/s useful)",
                        "grad_all_reduce": args.grad_comm,
                        "collective": ("none (one rank)" if not dist.is_initialized() else
@@ -769,6 +855,9 @@ def main():
             "other_kernels": kernels,
             "north_star_target": north,
         }
+        if single_stream:
+            single_stream["speedup_from_stream_overlap"] = round(single_stream["ms_per_step_median"] / median_ms, 4) if median_ms else None
+            out["single_stream"] = single_stream
         if dist.is_initialized():
             backend = dist.get_backend()
             out["dist_backend"] = "rccl (torch backend 'nccl')" if backend == "nccl" else backend

@@ -136,3 +136,24 @@ def test_pvt_backbone_features_and_gradients_own_attention_vs_library():
     # gradients move from run to run): measured 0.05 - 0.082 relative L2 on the attention weights of the first blocks
     for a, b in zip(res[True][1], res[False][1]):
         assert rel_l2(a, b) <= 1.5e-1, rel_l2(a, b)
+
+
+@pytest.mark.parametrize("B,H,W,C,sr", [(10, 56, 56, 64, 8), (4, 28, 28, 128, 4), (2, 32, 32, 320, 2), (2, 30, 27, 64, 4)])
+def test_sr_patch_gemm_equals_the_strided_convolution(B, H, W, C, sr):
+    """backbone_pvt._sr_patch_gemm (round 6 option: the spatial-reduction convolution, kernel = stride, as a gather + GEMM over
+    non-overlapping patches - reproducible without cudnn.deterministic) against F.conv2d on the same bf16 operands: forward and both
+    gradients within bf16 round-off of the fp32 evaluation (pvtv2.py:76, :106-108); ragged maps drop the same border rows / columns."""
+    import torch.nn.functional as F
+    from combo_avs_amd import backbone_pvt as BP
+    torch.manual_seed(B * 131 + C)
+    x = (0.5 * torch.randn(B, H * W, C, device="cuda")).bfloat16().requires_grad_(True)
+    w = (torch.randn(C, C, sr, sr, device="cuda") / (C * sr * sr) ** 0.5).bfloat16().requires_grad_(True)
+    a = BP._sr_patch_gemm(x, w, B, H, W, C, sr)
+    ref = F.conv2d(x.float().view(B, H, W, C).permute(0, 3, 1, 2), w.float(), None, sr).flatten(2).transpose(1, 2)
+    assert a.shape == ref.shape and a.dtype == torch.bfloat16
+    g = torch.randn_like(ref)
+    ga = torch.autograd.grad(a, (x, w), g.bfloat16())
+    gr = torch.autograd.grad(ref, (x, w), g)
+    for got, want in ((a, ref), (ga[0], gr[0]), (ga[1], gr[1])):
+        err = (got.float() - want).norm() / want.norm()
+        assert float(err) < 8e-3, float(err)  # bf16 operands / results: 2^-9 per element
