@@ -295,6 +295,10 @@ class OverlapPatchEmbed(nn.Module):
 
 
 class PyramidVisionTransformerV2(nn.Module):
+    # two instances on two HIP streams (meta_arch.MaskFormer.parallel_backbones): NOT safe - the captured `pvt_ms3_t10` step with the two
+    # encoders side by side never finished its first replay (tools/job_pvt_parallel_probe.sh)
+    concurrent_safe = False
+
     def __init__(self, in_chans=3, embed_dims=(64, 128, 256, 512), num_heads=(1, 2, 4, 8), mlp_ratios=(4, 4, 4, 4),
                  qkv_bias=False, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.0, norm_eps=1e-5,
                  depths=(3, 4, 6, 3), sr_ratios=(8, 4, 2, 1), num_stages=4, out_features=None):
