@@ -611,7 +611,10 @@ def main():
 
     per_kind, per_kind_excl, single_stream = {}, {}, None
     if slot_timing:
-        per_kind = collect_slots(ts_buf, args.dump_slots)
+        from combo_avs_amd.meta_arch import MaskFormer
+        will_excl = ((MaskFormer.parallel_backbones or MaskFormer.parallel_audio) and getattr(model.backbone, "concurrent_safe", False)
+                     and not ran_eager_probe(graphed) and world == 1 and not args.no_exclusive)
+        per_kind = collect_slots(ts_buf, "" if will_excl else args.dump_slots)  # (--dump-slots lists the single-stream pass when there is one)
         timing_truncated = bool(_clib.lib().combo_timing_truncated())
         # the graph's kernel nodes keep raw pointers into ts_buf: the buffer lives as long as the graphs do
         graphed._timing_buffer = ts_buf
@@ -620,9 +623,7 @@ def main():
         # chain shares the CUs with the other chain's launches, so its device-side duration is longer than the same launch alone on
         # the chip although the step is shorter.  A second, SINGLE-STREAM capture of the same step (5 replays, outside the timed
         # region) gives every family's figures with the chip to itself (`exclusive`) and the step time without the overlap.
-        from combo_avs_amd.meta_arch import MaskFormer
-        streams_on = (MaskFormer.parallel_backbones or MaskFormer.parallel_audio) and getattr(model.backbone, "concurrent_safe", False)
-        if streams_on and not ran_eager_probe(graphed) and world == 1 and not args.no_exclusive:
+        if will_excl:
             saved = (MaskFormer.parallel_backbones, MaskFormer.parallel_audio)
             MaskFormer.parallel_backbones = MaskFormer.parallel_audio = False
             try:
@@ -645,7 +646,7 @@ def main():
                     ev[i + 1].record()
                 sync()
                 ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(n_ex))
-                per_kind_excl = collect_slots(ts2, "")
+                per_kind_excl = collect_slots(ts2, args.dump_slots)
                 single_stream = {"ms_per_step_median": round(ms[n_ex // 2], 3), "steps": n_ex,
                                  "what": "the same step captured with ONE stream (round 5's launch order): MaskFormer.parallel_backbones / "
                                          "parallel_audio off; 5 replays after the timed region"}
