@@ -15,7 +15,7 @@ fi
 timeout 900 python bench.py > gpurun_out/final_bench.json 2> gpurun_out/final_bench.err
 tail -c 400 gpurun_out/final_bench.json
 bash tools/final_profile.sh --profile-only > gpurun_out/final_profile.log 2>&1
-python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-workloads --dump-slots 2 > gpurun_out/slots_bench.json 2> gpurun_out/slots_bench.err
+python bench.py --single-stream --steps 10 --warmup 3 --no-cpu-baseline --no-other-workloads --dump-slots 2 > gpurun_out/slots_single.json 2> gpurun_out/slots_single.err
 ls -la gpurun_out/kstats.csv gpurun_out/steady_graph.csv gpurun_out/r06_pmc.json gpurun_out/prof_bench_line.json
 bash tools/prof_config.sh pvt_ms3_t10 > gpurun_out/prof_ms3.log 2>&1
 bash tools/prof_config.sh pvt_avss_512 3 2 > gpurun_out/prof_avss.log 2>&1
