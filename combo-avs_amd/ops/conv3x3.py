@@ -19,6 +19,7 @@ import os
 from .. import _lib
 
 ENABLED = True  # (module constant: tools flip it in-process for A/B measurements against MIOpen)
+WGRAD_MAX_PARTIAL_MB = 64  # cap on the split-K partials of one weight-gradient launch in MiB (0 = the planner's split count); same-box A/B: profiles/r06_ab_conv_wgrad_partial_cap.txt
 
 
 def usable(conv, x):
@@ -69,6 +70,11 @@ def _wgrad_tokens(dy_tok, x_tok, B, H, W, cin, cout, ksize=3, stride=1):
     taps = ksize * ksize
     M, K = B * (-(-H // stride)) * (-(-W // stride)), taps * cin
     splits = lib.combo_gemm_tn_splits(M, cout, K)
+    if WGRAD_MAX_PARTIAL_MB:
+        # (round 6) the planner aims at two workgroups per CU; for the few-token / wide layers (res5: 1 960 tokens, 512 x 4 608 outputs)
+        # that is 8 partial copies of a 9.4 MB gradient - written and re-read cold inside the step (147 us for 9.25 GFLOP against 81 us
+        # warm in tools/bench_conv_wgrad_splits.py).  Cap the bytes of partials instead.
+        splits = max(1, min(splits, int(WGRAD_MAX_PARTIAL_MB * (1 << 20)) // (cout * K * 4)))
     mchunk = (-(-M // splits) + 15) // 16 * 16
     splits = -(-M // mchunk)
     part = torch.empty(splits, cout, K, device=x_tok.device, dtype=torch.float32)
