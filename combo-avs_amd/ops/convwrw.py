@@ -63,6 +63,19 @@ class backbone_cus:
         _cu_scope = self.prev
 
 
+# (tools/ab_const.py) split counts of the backbone launches by token count, overriding the C planners: {("c", M): 1 | 3 | 9} for the 3x3
+# tap split, {("g", M, cout, cin): s} for the K split of a 1x1 layer - the planners' cost models were fitted on warm micro-benchmarks
+SPLIT_OVERRIDE = {}
+
+
+def _plan3x3(lib, M, cout, cin):
+    return SPLIT_OVERRIDE.get(("c", M)) or lib.combo_conv3x3_x3_splitk_plan(M, cout, cin)
+
+
+def _plan1x1(lib, M, cout, cin):
+    return SPLIT_OVERRIDE.get(("g", M, cout, cin)) or lib.combo_gemm_nt_x3_splitk_plan(M, cout, cin)
+
+
 def kind(x, w, stride, padding):
     """0: not handled; 1: 1x1 stride 1; 3: 3x3 stride 1 pad 1; 21 / 23: the same with stride 2 (forward only)"""
     if not (ENABLED and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and not torch.is_autocast_enabled()
@@ -159,7 +172,7 @@ def _x3_forward(x, k, img, bias, residual, relu):
         ho, wo = (H + 1) // 2, (W + 1) // 2
         y = torch.empty((B, cout, ho, wo), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
         lib, M, ks = _lib.lib(), B * ho * wo, k - 20
-        splits = lib.combo_conv3x3_x3_splitk_plan(M, cout, cin) if ks == 3 else 1
+        splits = _plan3x3(lib, M, cout, cin) if ks == 3 else 1
         ws = torch.empty(splits, M, cout, device=x.device, dtype=torch.float32) if splits > 1 else None
         x_tok, y_tok = C3._tokens(x), C3._tokens(y)
         aux = C3._tokens(residual) if residual is not None else None
@@ -178,7 +191,7 @@ def _x3_tokens(x_tok, k, img, bias, aux, aux_mode, relu, y_tok, B, H, W, cin, co
     lib, st = _lib.lib(), _lib.current_stream()
     M = B * H * W
     if k == 1:
-        splits = lib.combo_gemm_nt_x3_splitk_plan(M, cout, cin)
+        splits = _plan1x1(lib, M, cout, cin)
         ws = torch.empty(splits, M, cout, device=x_tok.device, dtype=torch.float32) if splits > 1 else None
         with _lib.timed("gemm_nt_x3", (M, cout, cin)):
             rc = lib.combo_gemm_nt_x3_epi_f32(x_tok.data_ptr(), x_tok.stride(0), img.data_ptr(), _lib.ptr(bias), _lib.ptr(aux),
@@ -186,7 +199,7 @@ def _x3_tokens(x_tok, k, img, bias, aux, aux_mode, relu, y_tok, B, H, W, cin, co
                                               1 if relu else 0, splits, _lib.ptr(ws), st)
         _lib.check(rc, "combo_gemm_nt_x3_epi_f32")
     else:
-        splits = lib.combo_conv3x3_x3_splitk_plan(M, cout, cin)
+        splits = _plan3x3(lib, M, cout, cin)
         ws = torch.empty(splits, M, cout, device=x_tok.device, dtype=torch.float32) if splits > 1 else None
         with _lib.timed("conv3x3_x3", (M, cout, 9 * cin)):
             rc = lib.combo_conv3x3_nhwc_x3_epi_f32(x_tok.data_ptr(), x_tok.stride(0), img.data_ptr(), _lib.ptr(bias), _lib.ptr(aux),
