@@ -3,6 +3,12 @@
 #pragma once
 #include "combo_avs.h"
 
+// fp16 pieces: the B image (the weight) is split from 2^COMBO_F16_BSCALE_LOG2 . w and the kernel's epilogue multiplies the accumulator by
+// 2^-COMBO_F16_BSCALE_LOG2 (both exact): the lo pieces of typical weights (|w| ~ 0.01 ... 0.1) would otherwise be fp16 SUBNORMALS with an absolute
+// floor of 2^-25 (1.5e-6 relative at |w| = 0.02, as coarse as the bf16 split at |w| = 0.005); range: 2^8 |w| < 65 504
+#define COMBO_F16_BSCALE_LOG2 8
+enum { COMBO_PRODUCTS_F16X3 = 19 };  // `products` value: 3 products on fp16 hi / lo pieces (16 + 3); 3 = bf16 pieces, 1 = plain bf16
+
 struct combo_nt3_conv {
   int H, W, Cin;  // input map and channels
   int tap_step;   // split convolution: batch entry b computes taps b * tap_step .. (b + 1) * tap_step - 1 (K = tap_step * Cin); else 0
@@ -11,7 +17,7 @@ struct combo_nt3_conv {
 };
 
 // C_b[M,N] = A_b[M,K] . Bimg_b[N,K]^T (+ bias) (+ ReLU) (mask_b > 0 ? . : 0), `batch` problems at base + b * stride (elements; the
-// mask shares C's pitch and stride; add: C += add before the ReLU, same layout); products: 3 = fp32-accurate split, 1 = plain bf16; conv != nullptr: implicit-GEMM 3x3
+// mask shares C's pitch and stride; add: C += add before the ReLU, same layout); products: 3 = fp32-accurate split (bf16 pieces), COMBO_PRODUCTS_F16X3 = the same on fp16 pieces (Bimg from the fp16 pre-split), 1 = plain bf16; conv != nullptr: implicit-GEMM 3x3
 // convolution (A = NHWC tokens, K = 9 * Cin); force_cfg: 0 auto, 1 wide (256 x 128), 2 mid (128 x 128), 3 skinny (64 x 64), 4 tall (256 x 64).
 int combo_nt3_launch(const float* A, long long lda, const float* Bimg, long long ldb, const float* bias, const float* mask, float* C,
                      long long ldc, long long M, int N, int K, int relu, int products, int batch, long long sA, long long sB,

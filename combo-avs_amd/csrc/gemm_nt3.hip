@@ -51,6 +51,35 @@ __device__ __forceinline__ unsigned pack_rne(float a, float b) {
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+// fp16 pieces (round 6: the fp32-GRADE forward mode).  hi = rne_f16(x), lo = rne_f16(x - hi): 22 mantissa bits, the dropped lo.lo
+// term and the rounding of lo are ~2^-22 |x.w| (bf16 pieces: 2^-16 / 2^-17) - at the price of fp16's RANGE: |x| < 65 504, and the
+// pieces of small operands are fp16 subnormals (absolute floor 2^-25; v_cvt_pk_f16_f32 and v_mfma_*_f16 keep subnormals on gfx950:
+// tools/ubench/mfma_f16_denorm.hip).  Forward activations / weights of the normalised head only - gradients stay on bf16 pieces.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+__device__ __forceinline__ unsigned pack_rne_f16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+template <bool F16>
+__device__ __forceinline__ unsigned pack2(float a, float b) { return F16 ? pack_rne_f16(a, b) : pack_rne(a, b); }
+template <bool F16>
+__device__ __forceinline__ void unpack2(unsigned h, float& f0, float& f1) {
+  if constexpr (F16) {
+    const f16x2 v = __builtin_bit_cast(f16x2, h);
+    f0 = (float)v[0];
+    f1 = (float)v[1];
+  } else {
+    f0 = __uint_as_float(h << 16);
+    f1 = __uint_as_float(h & 0xffff0000u);
+  }
+}
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 template <int OFF>
 __device__ __forceinline__ f4v lds_read128(unsigned addr) {  // inline asm: hipcc drains the LDS-DMA queue before a visible ds_read
   f4v r;
@@ -86,6 +115,7 @@ __device__ __forceinline__ void glds16(const float* g, char* l) {
 }
 
 constexpr int kBK = 16;
+constexpr float kF16Unscale = 1.0f / (float)(1 << COMBO_F16_BSCALE_LOG2);
 constexpr int kMaxBiasN = 2048;  // the bias vector lives in LDS (ordinary global loads next to the LDS-DMA stream drain the ring)
 
 __device__ __attribute__((aligned(64))) float g_zero_row3[16];  // zero-initialised: the source of padded conv taps
@@ -119,6 +149,7 @@ struct N3Args {
                                    // bottleneck block; the other gradient arriving at a block input)
   float* C; long long ldc;
   int M, N, K, relu, c_bytes, batch, vec_store, dbg, products;
+  int f16;                         // 1: fp16 pieces (the image was made by the fp16 pre-split), 0: bf16
   long long sA, sB, sC;
   combo_nt3_conv cg;
   unsigned long long* ts;
@@ -127,7 +158,7 @@ struct N3Args {
 // P3: three products (fp32-accurate) or one (plain bf16); ABL: ablation bits, COMPILE-TIME (a run-time test per bit costs a scalar
 // branch per use, ~1 000 cycles per stage in total - more than the stage itself): 1 no DMA, 2 no LDS reads, 4 no barrier, 8 no
 // stores, 16 no split, 32 no MFMA; the instances listed in launch_cfg3 exist (COMBO_NT3_DBG, tools/bench_nt3.py)
-template <bool CONV, typename Cfg, bool P3, int ABL, bool AUX>
+template <bool CONV, typename Cfg, bool P3, int ABL, bool AUX, bool F16 = false>
 __global__ void __launch_bounds__(Cfg::NW * 64, Cfg::NW / 4)
 gemm_nt3_kernel(const N3Args p) {
   constexpr int NW = Cfg::NW;
@@ -345,9 +376,11 @@ gemm_nt3_kernel(const N3Args p) {
     const float v0 = q < 2 ? ra[i][0][2 * q] : ra[i][1][2 * (q - 2)];
     const float v1 = q < 2 ? ra[i][0][2 * q + 1] : ra[i][1][2 * (q - 2) + 1];
     if (dbg & 16) { hw_[i][q] = __float_as_uint(v0); lw_[i][q] = __float_as_uint(v1); return; }
-    const unsigned h = pack_rne(v0, v1);  // hi = rne_bf16(x): the dropped lo.lo term is <= 2^-16 |x.w| and unbiased
+    const unsigned h = pack2<F16>(v0, v1);  // hi = rne_bf16(x): the dropped lo.lo term is <= 2^-16 |x.w| and unbiased
     hw_[i][q] = h;
-    lw_[i][q] = pack_rne(v0 - __uint_as_float(h << 16), v1 - __uint_as_float(h & 0xffff0000u));
+    float h0, h1;
+    unpack2<F16>(h, h0, h1);
+    lw_[i][q] = pack2<F16>(v0 - h0, v1 - h1);
   };
   auto split_commit = [&](bf16x8 (&dh)[TI], bf16x8 (&dl)[TI]) __attribute__((always_inline)) {
 #pragma unroll
@@ -427,6 +460,7 @@ gemm_nt3_kernel(const N3Args p) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             v[q] = f4v{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+            if constexpr (F16) v[q] *= kF16Unscale;  // (the image holds 2^8 . w: gemm_nt3.h)
             if (p.bias) v[q] += bv[q];
           }
           u4v mv[4];
@@ -482,6 +516,7 @@ gemm_nt3_kernel(const N3Args p) {
           for (int e = 0; e < 16; ++e) {
             const int n = nb + 8 * (e >> 2) + (e & 3);
             float v = acc[i][j][e];
+            if constexpr (F16) v *= kF16Unscale;
             if (p.bias) {
               float b;
               asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(b) : "v"(bias_lds + (unsigned)min(n, n_pad - 1) * 4u) : "memory");
@@ -534,10 +569,10 @@ gemm_nt3_kernel(const N3Args p) {
             const int idx = (h * TI + i) * TJ + j;
             if (!(dbg & 32)) {
               if (h == 0) {
-                if (FIRST) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[PAR][j], ah[PAR][i], zero16, 0, 0, 0);
-                else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[PAR][j], ah[PAR][i], acc[i][j], 0, 0, 0);
+                if (FIRST) acc[i][j] = mfma16<F16>(bh[PAR][j], ah[PAR][i], zero16);
+                else acc[i][j] = mfma16<F16>(bh[PAR][j], ah[PAR][i], acc[i][j]);
               } else if (p3) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[PAR][j], al[PAR][i], acc[i][j], 0, 0, 0);
+                acc[i][j] = mfma16<F16>(bh[PAR][j], al[PAR][i], acc[i][j]);
               }
             } else if (FIRST && h == 0) {
               acc[i][j] = zero16;
@@ -565,7 +600,7 @@ gemm_nt3_kernel(const N3Args p) {
 #pragma unroll
       for (int j = 0; j < TJ; ++j) {
         const int idx = i * TJ + j;
-        if (p3 && !(dbg & 32)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[j], ah[PAR][i], acc[i][j], 0, 0, 0);
+        if (p3 && !(dbg & 32)) acc[i][j] = mfma16<F16>(bl[j], ah[PAR][i], acc[i][j]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int qq = idx * QS / NM1; qq < (idx + 1) * QS / NM1; ++qq) split_q(qq / 4, qq % 4);
@@ -642,27 +677,27 @@ int dbg_bits3() {
   return d;
 }
 
-template <bool CONV, typename Cfg, bool P3, int ABL, bool AUX>
+template <bool CONV, typename Cfg, bool P3, int ABL, bool AUX, bool F16 = false>
 int launch_inst3x(const N3Args& a, int grid, hipStream_t stream) {
   static ComboDevFlag attr;
   if (!attr.is_set()) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt3_kernel<CONV, Cfg, P3, ABL, AUX>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt3_kernel<CONV, Cfg, P3, ABL, AUX, F16>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     if (e != hipSuccess) return (int)e;
     attr.mark();
   }
-  hipLaunchKernelGGL((gemm_nt3_kernel<CONV, Cfg, P3, ABL, AUX>), dim3((unsigned)grid), dim3(Cfg::NW * 64), Cfg::LDS, stream, a);
+  hipLaunchKernelGGL((gemm_nt3_kernel<CONV, Cfg, P3, ABL, AUX, F16>), dim3((unsigned)grid), dim3(Cfg::NW * 64), Cfg::LDS, stream, a);
   return (int)hipGetLastError();
 }
 
-template <bool CONV, typename Cfg, bool P3, int ABL>
+template <bool CONV, typename Cfg, bool P3, int ABL, bool F16 = false>
 int launch_inst3(const N3Args& a, int grid, hipStream_t stream) {
   // the early-auxiliary-operand instance: launches with a vector-store epilogue that adds or masks (not the ablation builds, not
   // the 8-wave convolution tile: no registers for it)
   if constexpr (ABL == 0 && !(CONV && Cfg::NW == 8)) {
-    if (a.vec_store && (a.add || a.mask)) return launch_inst3x<CONV, Cfg, P3, ABL, true>(a, grid, stream);
+    if (a.vec_store && (a.add || a.mask)) return launch_inst3x<CONV, Cfg, P3, ABL, true, F16>(a, grid, stream);
   }
-  return launch_inst3x<CONV, Cfg, P3, ABL, false>(a, grid, stream);
+  return launch_inst3x<CONV, Cfg, P3, ABL, false, F16>(a, grid, stream);
 }
 
 template <bool CONV, typename Cfg>
@@ -688,6 +723,7 @@ int launch_cfg3(N3Args a, hipStream_t stream) {
       }
     }
   }
+  if (a.products == 3 && a.f16) return launch_inst3<CONV, Cfg, true, 0, true>(a, grid, stream);  // fp16 pieces: 3 products only
   if (a.products == 3) return launch_inst3<CONV, Cfg, true, 0>(a, grid, stream);
   return launch_inst3<CONV, Cfg, false, 0>(a, grid, stream);
 }
@@ -761,11 +797,13 @@ int combo_nt3_launch(const float* A, long long lda, const float* Bimg, long long
                      long long sC, const combo_nt3_conv* conv, int force_cfg, combo_stream_t stream, const float* add) {
   if (!A || !Bimg || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || K % kBK != 0 || lda % 4 != 0 || ldb % 4 != 0 || sA % 4 != 0 ||
       sB % 4 != 0 || ((uintptr_t)A & 15) || ((uintptr_t)Bimg & 15) || M > 0x7fffffffLL || ((M - 1) * ldc + N) * 4 >= 0x7ffffff0LL ||
-      (bias && N > kMaxBiasN) || (products != 1 && products != 3))
+      (bias && N > kMaxBiasN) || (products != 1 && products != 3 && products != COMBO_PRODUCTS_F16X3))
     return COMBO_EINVAL;
+  const int f16 = products == COMBO_PRODUCTS_F16X3 ? 1 : 0;  // 3 products on fp16 pieces (the image holds fp16 pieces)
+  if (f16) products = 3;
   const int vec = (N % 4 == 0 && ldc % 4 == 0 && sC % 4 == 0 && !((uintptr_t)C & 15) && (!mask || !((uintptr_t)mask & 15)) && (!add || !((uintptr_t)add & 15))) ? 1 : 0;
   N3Args a{A, lda, Bimg, ldb, bias, mask, add, C, ldc, (int)M, N, K, relu, (int)(((M - 1) * ldc + N) * 4), batch, vec, dbg_bits3(), products,
-           sA, sB, sC, conv ? *conv : combo_nt3_conv{1, 1, K, 0, 1, 1}, nullptr};
+           f16, sA, sB, sC, conv ? *conv : combo_nt3_conv{1, 1, K, 0, 1, 1}, nullptr};
   if (force_cfg) return conv ? launch_one3<true>(a, (hipStream_t)stream, force_cfg) : launch_one3<false>(a, (hipStream_t)stream, force_cfg);
   return conv ? launch_nt3<true>(a, (hipStream_t)stream) : launch_nt3<false>(a, (hipStream_t)stream);
 }

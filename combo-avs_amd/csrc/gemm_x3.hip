@@ -20,13 +20,34 @@ __device__ __forceinline__ unsigned pack_rne(float a, float b) {
   return r;
 }
 
+__device__ __forceinline__ unsigned pack_rne_f16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+// one packed pair of `hi` pieces and of `lo` pieces of two fp32 values: bf16 (hi = rne(x), lo = rne(x - hi)) or, f16, the same on
+// fp16 pieces (csrc/gemm_nt3.hip: the fp32-grade forward mode; |x| < 65 504)
+__device__ __forceinline__ void split_pair(float a, float b, bool f16, unsigned& h, unsigned& l) {
+  if (f16) {
+    a *= (float)(1 << COMBO_F16_BSCALE_LOG2);  // (exact; undone by the GEMM's epilogue, csrc/gemm_nt3.hip)
+    b *= (float)(1 << COMBO_F16_BSCALE_LOG2);
+    h = pack_rne_f16(a, b);
+    const f16x2 v = __builtin_bit_cast(f16x2, h);
+    l = pack_rne_f16(a - (float)v[0], b - (float)v[1]);
+  } else {
+    h = pack_rne(a, b);
+    l = pack_rne(a - __uint_as_float(h << 16), b - __uint_as_float(h & 0xffff0000u));
+  }
+}
+
 constexpr int kBK = 16;
 
 // Weight image: element (n, k) = src[n*ld_row + k*ld_col]; per 8 consecutive k a 16-B group of bf16 `hi`
 // = rne(x) followed by a 16-B group of bf16 `lo` = rne(x - hi): 4 bytes per element, row stride K floats.
 __global__ void __launch_bounds__(256)
 presplit_kernel(const float* __restrict__ src, long long ld_row, long long ld_col, int N, int K, uint4* __restrict__ img,
-                long long batch_stride) {
+                long long batch_stride, int f16) {
   const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   const int kg = K >> 3;
   if (t >= (long long)N * kg) return;
@@ -41,10 +62,7 @@ presplit_kernel(const float* __restrict__ src, long long ld_row, long long ld_co
   for (int i = 0; i < 8; ++i) v[i] = src[(long long)n * ld_row + (long long)(g8 * 8 + i) * ld_col];
   unsigned h[4], l[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    h[i] = pack_rne(v[2 * i], v[2 * i + 1]);
-    l[i] = pack_rne(v[2 * i] - __uint_as_float(h[i] << 16), v[2 * i + 1] - __uint_as_float(h[i] & 0xffff0000u));
-  }
+  for (int i = 0; i < 4; ++i) split_pair(v[2 * i], v[2 * i + 1], f16 != 0, h[i], l[i]);
   const long long o = ((long long)n * kg + g8) * 2;
   img[o] = make_uint4(h[0], h[1], h[2], h[3]);
   img[o + 1] = make_uint4(l[0], l[1], l[2], l[3]);
@@ -55,7 +73,7 @@ presplit_kernel(const float* __restrict__ src, long long ld_row, long long ld_co
 // fill k ranges of one image (the two weights of a column-concatenated layer).
 constexpr int kMaxSplitGroup = 56;  // (the argument block of a launch stays below 4 KiB)
 struct SplitGroupArgs {
-  int count;
+  int count, f16;
   long long thread_start[kMaxSplitGroup + 1];
   combo_presplit_problem p[kMaxSplitGroup];
 };
@@ -84,10 +102,7 @@ presplit_grouped_kernel(const SplitGroupArgs args) {
     for (int i = 0; i < 8; ++i) v[i] = src[(long long)i * pr.ld_col + tap];
     unsigned h[4], l[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      h[i] = pack_rne(v[2 * i], v[2 * i + 1]);
-      l[i] = pack_rne(v[2 * i] - __uint_as_float(h[i] << 16), v[2 * i + 1] - __uint_as_float(h[i] & 0xffff0000u));
-    }
+    for (int i = 0; i < 4; ++i) split_pair(v[2 * i], v[2 * i + 1], args.f16 != 0, h[i], l[i]);
     const int col_tap = pr.flip ? taps - 1 - tap : tap;
     uint4* img = reinterpret_cast<uint4*>(pr.img) + (long long)n * (pr.img_ld >> 2) + ((long long)col_tap * kg + g8) * 2;
     img[0] = make_uint4(h[0], h[1], h[2], h[3]);
@@ -96,6 +111,7 @@ presplit_grouped_kernel(const SplitGroupArgs args) {
 }
 
 int g_products = 3;  // combo_gemm_nt2_products: bf16 products per multiply-add of the launches that follow (host state, read at launch)
+int g_split_f16 = 0;  // combo_presplit_pieces: the pre-split launches that follow write fp16 pieces (1) or bf16 pieces (0)
 
 }  // namespace
 
@@ -104,7 +120,16 @@ int g_products = 3;  // combo_gemm_nt2_products: bf16 products per multiply-add 
  * only).  Returns the previous value.  Host-side state, read when a launch is issued (a captured graph keeps what was set). */
 extern "C" int combo_gemm_nt2_products(int products) {
   const int prev = g_products;
-  if (products == 1 || products == 3) g_products = products;
+  if (products == 1 || products == 3 || products == COMBO_PRODUCTS_F16X3) g_products = products;
+  return prev;
+}
+
+/* Piece type of the combo_presplit_bf16x2_* launches that FOLLOW: 0 = bf16 hi / lo (the default: every gradient GEMM), 1 = fp16
+ * hi / lo (the image of a FORWARD weight for combo_gemm_nt2_products(19): 22 mantissa bits, |w| < 65 504).  Returns the previous
+ * value.  Host-side state, read when a launch is issued. */
+extern "C" int combo_presplit_pieces(int f16) {
+  const int prev = g_split_f16;
+  if (f16 == 0 || f16 == 1) g_split_f16 = f16;
   return prev;
 }
 
@@ -113,7 +138,7 @@ extern "C" int combo_presplit_bf16x2_f32(const float* src, long long ld_row, lon
   if (!src || !img || N <= 0 || K <= 0 || K % 8 != 0 || ((uintptr_t)img & 15)) return COMBO_EINVAL;
   const long long threads = (long long)N * (K / 8);
   hipLaunchKernelGGL(presplit_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, ld_row,
-                     ld_col, N, K, reinterpret_cast<uint4*>(img), 0LL);
+                     ld_col, N, K, reinterpret_cast<uint4*>(img), 0LL, g_split_f16);
   return (int)hipGetLastError();
 }
 
@@ -122,6 +147,7 @@ extern "C" int combo_presplit_bf16x2_grouped_f32(const combo_presplit_problem* p
   for (int base = 0; base < count; base += kMaxSplitGroup) {
     SplitGroupArgs a;
     a.count = count - base < kMaxSplitGroup ? count - base : kMaxSplitGroup;
+    a.f16 = g_split_f16;
     long long threads = 0;
     for (int i = 0; i < a.count; ++i) {
       const combo_presplit_problem& pr = problems[base + i];
@@ -145,7 +171,7 @@ extern "C" int combo_presplit_bf16x2_batched_f32(const float* src, long long ld_
   if (!src || !img || N <= 0 || K <= 0 || K % 8 != 0 || batch <= 0 || batch > 65535 || ((uintptr_t)img & 15)) return COMBO_EINVAL;
   const long long threads = (long long)N * (K / 8);
   hipLaunchKernelGGL(presplit_kernel, dim3((unsigned)((threads + 255) / 256), (unsigned)batch), dim3(256), 0, (hipStream_t)stream,
-                     src, ld_row, ld_col, N, K, reinterpret_cast<uint4*>(img), batch_stride);
+                     src, ld_row, ld_col, N, K, reinterpret_cast<uint4*>(img), batch_stride, g_split_f16);
   return (int)hipGetLastError();
 }
 

@@ -24,6 +24,16 @@ from ..ops.upsample import upsample_bilinear, upsample_bilinear_add  # noqa: F40
 from .layers import conv1x1_or_conv, norm_act, Conv2d, c2_xavier_fill, get_norm, position_embedding_sine
 
 
+# Arithmetic of the pixel decoder's forward GEMMs / convolutions (input projections, the 6 deformable encoder layers' linears, the
+# FPN lateral / output convolutions, the mask-feature projection): "fp32" = the exact fp32 matrix instruction (csrc/gemm_f32.hip),
+# "x3" = the fp32-grade 3-product bf16 split on csrc/gemm_nt3.hip (what the fp32 backbones' forward convolutions and every gradient
+# GEMM use).  Everything behind the pixel decoder - the masked transformer decoder, the mask-logit contraction, the thresholded
+# attention masks - keeps the exact instruction in both settings.  Environment: COMBO_PD_FORWARD.
+import os as _os
+PIXEL_DECODER_FORWARD = _os.environ.get("COMBO_PD_FORWARD", "fp32")          # the deformable transformer encoder's linears
+PIXEL_DECODER_FPN_FORWARD = _os.environ.get("COMBO_PD_FPN_FORWARD", "fp32")  # input projections, FPN lateral / output convolutions, mask features
+
+
 def _deferred_layer_norm(dim):
     """per-layer post-norm: applied once per forward, so its parameter gradients may join the grouped launch"""
     from ..ops.layernorm import LayerNorm
@@ -271,14 +281,16 @@ class MSDeformAttnPixelDecoder(nn.Module):
     def forward_features(self, features):
         """-> (mask_features [BT,mask_dim,H/4,W/4], out[0], multi_scale_features[3]); fp32 like the reference
         (msdeformattn.py:315: autocast disabled, inputs .float())."""
-        with torch.autocast(device_type="cuda", enabled=False):
+        from ..ops.linear import forward_precision_scope
+        with torch.autocast(device_type="cuda", enabled=False), forward_precision_scope(PIXEL_DECODER_FPN_FORWARD):
             srcs, pos = [], []
             for idx, f in enumerate(self.transformer_in_features[::-1]):
                 x = features[f].float()
                 proj = self.input_proj[idx]  # Sequential(1x1 conv, GroupNorm): the conv is a token-major GEMM (layers.py)
                 srcs.append(norm_act(conv1x1_or_conv(proj[0], x), proj[1]))
                 pos.append(position_embedding_sine(1, x.shape[2], x.shape[3], x.device, self.conv_dim // 2))
-            y, spatial_shapes, level_start_index, shapes_list = self.transformer(srcs, pos)
+            with forward_precision_scope(PIXEL_DECODER_FORWARD):
+                y, spatial_shapes, level_start_index, shapes_list = self.transformer(srcs, pos)
             bs = y.shape[0]
             # (one split node: its backward is ONE concatenation - three slices cost three zero-filled [BT, S, C] gradients
             # and two accumulation adds)

@@ -14,6 +14,7 @@ not take (K not a multiple of 16, misaligned views; the class head's 3-wide grad
 launches per step, counted in DESIGN section 5.
 """
 import ctypes
+import os
 import weakref
 import os as _os
 
@@ -64,12 +65,29 @@ def gemm_nt_f32(a, w, bias=None, relu=False, out=None):
     return out
 
 
-def presplit(b):
-    """bf16 hi/lo image of a 2-D fp32 view [N, K] (any strides: pass `w.t()` for W^T, no copy) for csrc/gemm_nt3.hip."""
+class split_pieces:
+    """`with split_pieces(f16):` the pre-split launches inside write fp16 hi / lo pieces (f16 true: the image of a FORWARD weight
+    in the "f16x3" mode) instead of bf16 ones (csrc/gemm_x3.hip combo_presplit_pieces; host-side state of the library)."""
+
+    def __init__(self, f16):
+        self.f16 = 1 if f16 else 0
+
+    def __enter__(self):
+        self.prev = _lib.lib().combo_presplit_pieces(self.f16)
+
+    def __exit__(self, *exc):
+        _lib.lib().combo_presplit_pieces(self.prev)
+        return False
+
+
+def presplit(b, f16=False):
+    """hi/lo image of a 2-D fp32 view [N, K] (any strides: pass `w.t()` for W^T, no copy) for csrc/gemm_nt3.hip: bf16 pieces
+    (every gradient GEMM, the "x3" forward mode) or, f16, fp16 pieces (the "f16x3" forward mode)."""
     N, K = b.shape
     img = torch.empty(N, K, device=b.device, dtype=torch.float32)
-    _lib.check(_lib.lib().combo_presplit_bf16x2_f32(b.data_ptr(), b.stride(0), b.stride(1), N, K, img.data_ptr(),
-                                                    _lib.current_stream()), "combo_presplit_bf16x2_f32")
+    with split_pieces(f16):
+        _lib.check(_lib.lib().combo_presplit_bf16x2_f32(b.data_ptr(), b.stride(0), b.stride(1), N, K, img.data_ptr(),
+                                                        _lib.current_stream()), "combo_presplit_bf16x2_f32")
     return img
 
 
@@ -233,30 +251,73 @@ def gemm_smallm_f32(a, w, bias=None, relu=False):
 # accumulation): ~1/16 of the matrix-pipe time of the exact-fp32 instruction.  It is NOT the default: bf16 products move a
 # mask logit by ~3e-3 of its scale, the north-star's 1e-3 bound needs the fp32 path.  Stated tolerance
 # and its test: tests/test_head_gpu.py::test_bf16_forward_mode_stated_tolerance.  Gradient GEMMs keep the 3-product split.
-FORWARD_PRECISION = "fp32"
+DEFAULT_FORWARD_PRECISION = os.environ.get("COMBO_HEAD_FORWARD", "f16x3")  # (round 6: was "fp32"; see "f16x3" below)
+FORWARD_PRECISION = DEFAULT_FORWARD_PRECISION
 _fwd_images = None  # {weight view key: bf16 hi/lo image [N, K]} of the current step (grouped_presplit context)
+
+
+# "f16x3" (round 6): the 3-product split on fp16 pieces - 22 mantissa bits per operand instead of bf16's 16, i.e. fp32-GRADE products
+# (error ~2^-22 |x.w| per term against 2^-16 for "x3") at the same matrix-pipe cost; needs |x| < 65 504: forward activations and
+# weights of the normalised head, never gradients.
+FORWARD_MODES = ("fp32", "f16x3", "x3", "bf16")  # from exact to cheap
 
 
 def set_forward_precision(mode):
     global FORWARD_PRECISION
-    if mode not in ("fp32", "bf16", "x3"):
+    if mode not in FORWARD_MODES:
         raise ValueError(mode)
     FORWARD_PRECISION = mode
 
 
+class forward_precision_scope:
+    """`with forward_precision_scope("x3"):` - the forward GEMMs issued inside run in `mode` unless the global mode is already a
+    cheaper one ("bf16" stays "bf16"); restores the previous mode on exit.  Used by the pixel decoder (modeling/pixel_decoder.py
+    PIXEL_DECODER_FORWARD): its forward GEMMs sit in FRONT of the first thresholded attention mask, like the backbones'."""
+    _rank = {m: i for i, m in enumerate(FORWARD_MODES)}
+
+    def __init__(self, mode):
+        if mode not in self._rank:
+            raise ValueError(mode)
+        self.mode = mode
+
+    _base = None  # the mode in force outside the outermost open scope (nested scopes are judged against IT, not against each other)
+
+    def __enter__(self):
+        global FORWARD_PRECISION
+        cls = forward_precision_scope
+        self.prev, self.outer = FORWARD_PRECISION, cls._base is None
+        if self.outer:
+            cls._base = FORWARD_PRECISION
+        FORWARD_PRECISION = self.mode if self._rank[self.mode] > self._rank[cls._base] else cls._base
+        return self
+
+    def __exit__(self, *exc):
+        global FORWARD_PRECISION
+        FORWARD_PRECISION = self.prev
+        if self.outer:
+            forward_precision_scope._base = None
+        return False
+
+
 def forward_products():
-    """bf16 products per multiply-add of the head's forward GEMMs in the current mode ("bf16": 1; "x3": the fp32-grade split)"""
-    return 1 if FORWARD_PRECISION == "bf16" else 3
+    """`products` argument of the head's forward GEMMs in the current mode (combo_gemm_nt2_products): "bf16": 1; "x3": the 3-product
+    split on bf16 pieces; "f16x3": 19 = the same on fp16 pieces"""
+    return 1 if FORWARD_PRECISION == "bf16" else 19 if FORWARD_PRECISION == "f16x3" else 3
+
+
+def forward_f16():
+    return FORWARD_PRECISION == "f16x3"
 
 
 def forward_image(weight):
-    """bf16 image of a forward weight [N, K] (cached for the step inside grouped_presplit())"""
+    """hi/lo image of a forward weight [N, K] in the current mode's piece type (cached for the step inside grouped_presplit())"""
+    f16 = forward_f16()
     if _fwd_images is None:
-        return presplit(weight)
-    key = _split_key(weight)
+        return presplit(weight, f16)
+    key = (_split_key(weight), f16)
     img = _fwd_images.get(key)
     if img is None:
-        img = _fwd_images[key] = presplit(weight)
+        img = _fwd_images[key] = presplit(weight, f16)
     return img
 
 

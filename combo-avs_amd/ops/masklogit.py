@@ -15,14 +15,17 @@ def _hip_ok(*ts):
     return all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0 for t in ts)
 
 
-def presplit_batched(x, transpose):
-    """bf16 hi/lo image (csrc/gemm_nt3.hip) of a contiguous [B, R, C] tensor: [B, R, C] (K = C) or, transposed, [B, C, R]."""
+def presplit_batched(x, transpose, f16=False):
+    """hi/lo image (csrc/gemm_nt3.hip; bf16 pieces, or fp16 ones for the "f16x3" forward mode) of a contiguous [B, R, C] tensor:
+    [B, R, C] (K = C) or, transposed, [B, C, R]."""
+    from .linear import split_pieces
     B, R, C = x.shape
     N, K = (C, R) if transpose else (R, C)
     img = torch.empty(B, N, K, device=x.device, dtype=torch.float32)
     ld_row, ld_col = (1, C) if transpose else (C, 1)
-    _lib.check(_lib.lib().combo_presplit_bf16x2_batched_f32(x.data_ptr(), ld_row, ld_col, R * C, N, K, B, img.data_ptr(),
-                                                            _lib.current_stream()), "combo_presplit_bf16x2_batched_f32")
+    with split_pieces(f16):
+        _lib.check(_lib.lib().combo_presplit_bf16x2_batched_f32(x.data_ptr(), ld_row, ld_col, R * C, N, K, B, img.data_ptr(),
+                                                                _lib.current_stream()), "combo_presplit_bf16x2_batched_f32")
     return img
 
 
@@ -84,7 +87,7 @@ def mask_logits_all_into(mask_embeds, mf_tok, out):
     from . import linear as L
     mf = mf_tok.detach()
     if L.FORWARD_PRECISION != "fp32":  # the head's bf16 throughput mode: per head, one bf16 product per multiply-add
-        img = presplit_batched(mf, transpose=False)
+        img = presplit_batched(mf, transpose=False, f16=L.forward_f16())
         lib = _lib.lib()
         prev = lib.combo_gemm_nt2_products(L.forward_products())
         try:

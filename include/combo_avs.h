@@ -321,9 +321,12 @@ int combo_gemm_nt_batched_f32(const float* A, long long lda, long long sA, const
  *   projections): combo_gemm_nt_splitk_plan -> number of K slices (1: do not split); combo_gemm_nt_splitk_f32 runs the slices
  *   as the batch entries of one launch into workspace [splits, M, N] and finishes with a fixed-order sum + bias + ReLU. */
 /*   bf16 products per fp32 multiply-add of the combo_gemm_nt_x3_* / combo_conv3x3_nhwc_x3_* launches that follow: 3 (default)
- *   = the fp32-accurate split, 1 = plain bf16 inputs, fp32 accumulation (the head's bf16 throughput mode).  Returns the
- *   previous value. */
+ *   = the fp32-accurate split, 1 = plain bf16 inputs, fp32 accumulation (the head's bf16 throughput mode), 19 = the 3-product
+ *   split on fp16 hi / lo pieces (22 mantissa bits instead of 16: the fp32-grade FORWARD mode; operands |x| < 65 504; the weight
+ *   image must come from a pre-split issued under combo_presplit_pieces(1)).  Returns the previous value. */
 int combo_gemm_nt2_products(int products);
+/*   Piece type written by the combo_presplit_bf16x2_* launches that follow: 0 = bf16 (default), 1 = fp16.  Returns the previous value. */
+int combo_presplit_pieces(int f16);
 int combo_gemm_nt_x3_splitk_plan(int M, int N, int K);  /* K slices of a few-tile, long-K input-gradient GEMM (1 = none) */
 int combo_gemm_nt_x3_splitk_f32(const float* A, long long lda, const float* Bimg, const float* mask, float* C, long long ldc,
                                 int M, int N, int K, int splits, float* workspace /* [splits, M, N] */, combo_stream_t stream);

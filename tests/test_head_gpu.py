@@ -442,7 +442,7 @@ def test_x3_forward_mode_stated_tolerance():
             out = head(dict(feats), audio.cuda())
         torch.cuda.synchronize()
     finally:
-        L.set_forward_precision("fp32")
+        L.set_forward_precision(L.DEFAULT_FORWARD_PRECISION)
     masks = [a["pred_masks"] for a in out["aux_outputs"]] + [out["pred_masks"]]
     report = []
     for i, m in enumerate(masks):
@@ -492,7 +492,7 @@ def test_bf16_forward_mode_stated_tolerance():
             out = head(dict(feats), audio.cuda())
         torch.cuda.synchronize()
     finally:
-        L.set_forward_precision("fp32")
+        L.set_forward_precision(L.DEFAULT_FORWARD_PRECISION)
     masks = [a["pred_masks"] for a in out["aux_outputs"]] + [out["pred_masks"]]
     report = []
     for i, m in enumerate(masks):

@@ -38,7 +38,7 @@ def hazards(asm_text):
         states = 0
         for j in range(i - 1, max(i - 4, -1), -1):
             p = lines[j]
-            if p.startswith("v_cvt_pk_bf16_f32"):
+            if p.startswith(("v_cvt_pk_bf16_f32", "v_cvt_pk_f16_f32")):  # (fp16 pieces: round 6, csrc/gemm_nt3.hip F16)
                 if _regs(p.split(None, 1)[1].split(",")[0].strip()) & src and states < 2:
                     found.append((i, ln, p))
                     break

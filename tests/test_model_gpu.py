@@ -554,7 +554,7 @@ def test_configs4_bf16_head_mode_at_full_size():
         assert all(torch.isfinite(v) for v in losses.values()) and bool(torch.isfinite(opt.flat_param).all())
         model.criterion.matcher.check_status()
     finally:
-        L.set_forward_precision("fp32")
+        L.set_forward_precision(L.DEFAULT_FORWARD_PRECISION)
         model.criterion.point_source = None
 
 
