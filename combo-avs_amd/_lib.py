@@ -104,6 +104,8 @@ _SIGNATURES = {
     "combo_conv3x3_nhwc_f32": [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_longlong] + [c_int] * 6 + [c_void_p],
     "combo_wall_clock_khz": [],
     "combo_gemm_nt_x3_pre_f32": [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_void_p],
+    "combo_gemm_nt_x3_pre_splitk_f32": [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_int,
+                                        c_void_p, c_void_p],
     "combo_conv3x3_nhwc_x3_pre_f32": [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_longlong] + [c_int] * 6 + [c_void_p],
     "combo_gemm_nt_x3_epi_f32": [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_longlong] + [c_int] * 5 + [c_void_p, c_void_p],
     "combo_gemm_nt_x3_epi2_f32": [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong] + [c_int] * 5 + [c_void_p, c_void_p],

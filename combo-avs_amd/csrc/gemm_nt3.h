@@ -7,7 +7,10 @@
 // 2^-COMBO_F16_BSCALE_LOG2 (both exact): the lo pieces of typical weights (|w| ~ 0.01 ... 0.1) would otherwise be fp16 SUBNORMALS with an absolute
 // floor of 2^-25 (1.5e-6 relative at |w| = 0.02, as coarse as the bf16 split at |w| = 0.005); range: 2^8 |w| < 65 504
 #define COMBO_F16_BSCALE_LOG2 8
-enum { COMBO_PRODUCTS_F16X3 = 19 };  // `products` value: 3 products on fp16 hi / lo pieces (16 + 3); 3 = bf16 pieces, 1 = plain bf16
+// `products` values: 3 = 3 products on bf16 hi / lo pieces, 1 = plain bf16, 19 (16 + 3) = 3 products on fp16 pieces with a WEIGHT image (split
+// from 2^8 . w: the epilogue multiplies by 2^-8), 35 (32 + 3) = the same with an ACTIVATION image (split unscaled: the per-frame mask features
+// of the mask-logit contraction, whose range is the activations' 65 504, not a weight's 255)
+enum { COMBO_PRODUCTS_F16X3 = 19, COMBO_PRODUCTS_F16X3_UNSCALED = 35 };
 
 struct combo_nt3_conv {
   int H, W, Cin;  // input map and channels
@@ -22,3 +25,9 @@ struct combo_nt3_conv {
 int combo_nt3_launch(const float* A, long long lda, const float* Bimg, long long ldb, const float* bias, const float* mask, float* C,
                      long long ldc, long long M, int N, int K, int relu, int products, int batch, long long sA, long long sB,
                      long long sC, const combo_nt3_conv* conv, int force_cfg, combo_stream_t stream, const float* add = nullptr);
+
+// split-K form (K slices as the batch entries of one launch into workspace [splits, M, N] + the fixed-order finishing sum with the epilogue):
+// csrc/gemm_nt3.hip; products as above (the forward modes pass theirs, every gradient GEMM 3)
+int nt3_split_launch(const float* A, long long lda, const float* Bimg, const float* bias, const float* add, const float* mask, float* C,
+                     long long ldc, long long M, int N, int K, int relu, int splits, float* workspace, const combo_nt3_conv* conv,
+                     combo_stream_t stream, int products = 3);

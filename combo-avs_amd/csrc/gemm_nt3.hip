@@ -150,6 +150,7 @@ struct N3Args {
   float* C; long long ldc;
   int M, N, K, relu, c_bytes, batch, vec_store, dbg, products;
   int f16;                         // 1: fp16 pieces (the image was made by the fp16 pre-split), 0: bf16
+  float unscale;                   // fp16 pieces: the epilogue's factor (2^-8 for a weight image split from 2^8 . w, else 1)
   long long sA, sB, sC;
   combo_nt3_conv cg;
   unsigned long long* ts;
@@ -460,7 +461,7 @@ gemm_nt3_kernel(const N3Args p) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             v[q] = f4v{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-            if constexpr (F16) v[q] *= kF16Unscale;  // (the image holds 2^8 . w: gemm_nt3.h)
+            if constexpr (F16) v[q] *= p.unscale;  // (a weight image holds 2^8 . w: gemm_nt3.h)
             if (p.bias) v[q] += bv[q];
           }
           u4v mv[4];
@@ -516,7 +517,7 @@ gemm_nt3_kernel(const N3Args p) {
           for (int e = 0; e < 16; ++e) {
             const int n = nb + 8 * (e >> 2) + (e & 3);
             float v = acc[i][j][e];
-            if constexpr (F16) v *= kF16Unscale;
+            if constexpr (F16) v *= p.unscale;
             if (p.bias) {
               float b;
               asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(b) : "v"(bias_lds + (unsigned)min(n, n_pad - 1) * 4u) : "memory");
@@ -797,13 +798,14 @@ int combo_nt3_launch(const float* A, long long lda, const float* Bimg, long long
                      long long sC, const combo_nt3_conv* conv, int force_cfg, combo_stream_t stream, const float* add) {
   if (!A || !Bimg || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || K % kBK != 0 || lda % 4 != 0 || ldb % 4 != 0 || sA % 4 != 0 ||
       sB % 4 != 0 || ((uintptr_t)A & 15) || ((uintptr_t)Bimg & 15) || M > 0x7fffffffLL || ((M - 1) * ldc + N) * 4 >= 0x7ffffff0LL ||
-      (bias && N > kMaxBiasN) || (products != 1 && products != 3 && products != COMBO_PRODUCTS_F16X3))
+      (bias && N > kMaxBiasN) || (products != 1 && products != 3 && products != COMBO_PRODUCTS_F16X3 && products != COMBO_PRODUCTS_F16X3_UNSCALED))
     return COMBO_EINVAL;
-  const int f16 = products == COMBO_PRODUCTS_F16X3 ? 1 : 0;  // 3 products on fp16 pieces (the image holds fp16 pieces)
+  const int f16 = products == COMBO_PRODUCTS_F16X3 || products == COMBO_PRODUCTS_F16X3_UNSCALED ? 1 : 0;  // 3 products on fp16 pieces
+  const float unscale = products == COMBO_PRODUCTS_F16X3 ? kF16Unscale : 1.0f;
   if (f16) products = 3;
   const int vec = (N % 4 == 0 && ldc % 4 == 0 && sC % 4 == 0 && !((uintptr_t)C & 15) && (!mask || !((uintptr_t)mask & 15)) && (!add || !((uintptr_t)add & 15))) ? 1 : 0;
   N3Args a{A, lda, Bimg, ldb, bias, mask, add, C, ldc, (int)M, N, K, relu, (int)(((M - 1) * ldc + N) * 4), batch, vec, dbg_bits3(), products,
-           f16, sA, sB, sC, conv ? *conv : combo_nt3_conv{1, 1, K, 0, 1, 1}, nullptr};
+           f16, unscale, sA, sB, sC, conv ? *conv : combo_nt3_conv{1, 1, K, 0, 1, 1}, nullptr};
   if (force_cfg) return conv ? launch_one3<true>(a, (hipStream_t)stream, force_cfg) : launch_one3<false>(a, (hipStream_t)stream, force_cfg);
   return conv ? launch_nt3<true>(a, (hipStream_t)stream) : launch_nt3<false>(a, (hipStream_t)stream);
 }
@@ -857,9 +859,9 @@ extern "C" int combo_gemm_nt_x3_splitk_plan(int M, int N, int K) {
   return s < 1 ? 1 : s;
 }
 
-static int nt3_split_launch(const float* A, long long lda, const float* Bimg, const float* bias, const float* add, const float* mask,
-                            float* C, long long ldc, long long M, int N, int K, int relu, int splits, float* workspace,
-                            const combo_nt3_conv* conv, combo_stream_t stream) {
+int nt3_split_launch(const float* A, long long lda, const float* Bimg, const float* bias, const float* add, const float* mask,
+                     float* C, long long ldc, long long M, int N, int K, int relu, int splits, float* workspace,
+                     const combo_nt3_conv* conv, combo_stream_t stream, int products) {
   if (splits < 2 || !workspace || K % (splits * 32) != 0 || N % 4 != 0 || ((uintptr_t)workspace & 15) || ((uintptr_t)C & 15) ||
       (add && ((uintptr_t)add & 15)) || (mask && ((uintptr_t)mask & 15)) || (bias && ((uintptr_t)bias & 15)) || ldc % 4 != 0 ||
       M * N > 0x7fffffffLL / 4)
@@ -867,7 +869,7 @@ static int nt3_split_launch(const float* A, long long lda, const float* Bimg, co
   const int Ks = K / splits;
   // slice z: A columns [z Ks, (z + 1) Ks) (element offset z Ks; a convolution: taps z * tap_step ...), image rows keep their pitch K
   // and start z Ks floats in
-  if (int e = combo_nt3_launch(A, lda, Bimg, K, nullptr, nullptr, workspace, N, M, N, Ks, 0, 3, splits, conv ? 0 : Ks, Ks, M * N,
+  if (int e = combo_nt3_launch(A, lda, Bimg, K, nullptr, nullptr, workspace, N, M, N, Ks, 0, products, splits, conv ? 0 : Ks, Ks, M * N,
                                conv, 0, stream, nullptr))
     return e;
   const long long n4 = M * (N >> 2);

@@ -28,10 +28,13 @@ __device__ __forceinline__ unsigned pack_rne_f16(float a, float b) {
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 // one packed pair of `hi` pieces and of `lo` pieces of two fp32 values: bf16 (hi = rne(x), lo = rne(x - hi)) or, f16, the same on
 // fp16 pieces (csrc/gemm_nt3.hip: the fp32-grade forward mode; |x| < 65 504)
-__device__ __forceinline__ void split_pair(float a, float b, bool f16, unsigned& h, unsigned& l) {
+// f16: 0 = bf16 pieces, 1 = fp16 pieces of 2^8 . x (a weight image), 2 = fp16 pieces of x (an activation image)
+__device__ __forceinline__ void split_pair(float a, float b, int f16, unsigned& h, unsigned& l) {
   if (f16) {
-    a *= (float)(1 << COMBO_F16_BSCALE_LOG2);  // (exact; undone by the GEMM's epilogue, csrc/gemm_nt3.hip)
-    b *= (float)(1 << COMBO_F16_BSCALE_LOG2);
+    if (f16 == 1) {
+      a *= (float)(1 << COMBO_F16_BSCALE_LOG2);  // (exact; undone by the GEMM's epilogue, csrc/gemm_nt3.hip)
+      b *= (float)(1 << COMBO_F16_BSCALE_LOG2);
+    }
     h = pack_rne_f16(a, b);
     const f16x2 v = __builtin_bit_cast(f16x2, h);
     l = pack_rne_f16(a - (float)v[0], b - (float)v[1]);
@@ -62,7 +65,7 @@ presplit_kernel(const float* __restrict__ src, long long ld_row, long long ld_co
   for (int i = 0; i < 8; ++i) v[i] = src[(long long)n * ld_row + (long long)(g8 * 8 + i) * ld_col];
   unsigned h[4], l[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) split_pair(v[2 * i], v[2 * i + 1], f16 != 0, h[i], l[i]);
+  for (int i = 0; i < 4; ++i) split_pair(v[2 * i], v[2 * i + 1], f16, h[i], l[i]);
   const long long o = ((long long)n * kg + g8) * 2;
   img[o] = make_uint4(h[0], h[1], h[2], h[3]);
   img[o + 1] = make_uint4(l[0], l[1], l[2], l[3]);
@@ -102,7 +105,7 @@ presplit_grouped_kernel(const SplitGroupArgs args) {
     for (int i = 0; i < 8; ++i) v[i] = src[(long long)i * pr.ld_col + tap];
     unsigned h[4], l[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) split_pair(v[2 * i], v[2 * i + 1], args.f16 != 0, h[i], l[i]);
+    for (int i = 0; i < 4; ++i) split_pair(v[2 * i], v[2 * i + 1], args.f16, h[i], l[i]);
     const int col_tap = pr.flip ? taps - 1 - tap : tap;
     uint4* img = reinterpret_cast<uint4*>(pr.img) + (long long)n * (pr.img_ld >> 2) + ((long long)col_tap * kg + g8) * 2;
     img[0] = make_uint4(h[0], h[1], h[2], h[3]);
@@ -171,7 +174,7 @@ extern "C" int combo_presplit_bf16x2_batched_f32(const float* src, long long ld_
   if (!src || !img || N <= 0 || K <= 0 || K % 8 != 0 || batch <= 0 || batch > 65535 || ((uintptr_t)img & 15)) return COMBO_EINVAL;
   const long long threads = (long long)N * (K / 8);
   hipLaunchKernelGGL(presplit_kernel, dim3((unsigned)((threads + 255) / 256), (unsigned)batch), dim3(256), 0, (hipStream_t)stream,
-                     src, ld_row, ld_col, N, K, reinterpret_cast<uint4*>(img), batch_stride, g_split_f16);
+                     src, ld_row, ld_col, N, K, reinterpret_cast<uint4*>(img), batch_stride, g_split_f16 ? 2 : 0);  // (activations: unscaled)
   return (int)hipGetLastError();
 }
 
@@ -187,7 +190,9 @@ extern "C" int combo_gemm_nt_x3_pre_batched_f32(const float* A, long long lda, l
   const int pad256 = (M + 255) / 256 * 256, pad128 = (M + 127) / 128 * 128;
   // M = 100 queries per frame pads to 128, not 256: 128 x 128 tiles; otherwise the planner weighs tile rounds (M = 1000 rows of 10
   // heads x 40 frames: 320 wide tiles are 2 rounds on 256 CUs, 640 mid tiles 3 cheaper ones)
-  return combo_nt3_launch(A, lda, Bimg, K, nullptr, nullptr, C, ldc, M, N, K, relu, g_products, batch, sA, sB, sC, nullptr,
+  // (fp16 pieces: the batched form's images are ACTIVATIONS - combo_presplit_bf16x2_batched_f32 splits them unscaled)
+  return combo_nt3_launch(A, lda, Bimg, K, nullptr, nullptr, C, ldc, M, N, K, relu,
+                          g_products == COMBO_PRODUCTS_F16X3 ? COMBO_PRODUCTS_F16X3_UNSCALED : g_products, batch, sA, sB, sC, nullptr,
                           pad128 < pad256 ? 2 : 0, stream);
 }
 
@@ -197,6 +202,17 @@ extern "C" int combo_gemm_nt_x3_pre_f32(const float* A, long long lda, const flo
       ((uintptr_t)Bimg & 15))
     return COMBO_EINVAL;
   return combo_nt3_launch(A, lda, Bimg, K, bias, nullptr, C, ldc, M, N, K, relu, g_products, 1, 0, 0, 0, nullptr, 0, stream);
+}
+
+/* combo_gemm_nt_x3_pre_f32 with split-K (splits = combo_gemm_nt_x3_splitk_plan(M, N, K) > 1; workspace [splits, M, N]): the forward
+ * GEMMs with a long reduction and few output tiles (the decoder FFN's linear2 4000 x 2048 -> 256, the res5 / res4 input projections)
+ * in the 3-product forward modes - what combo_gemm_nt_splitk_f32 is to the exact path. */
+extern "C" int combo_gemm_nt_x3_pre_splitk_f32(const float* A, long long lda, const float* Bimg, const float* bias, float* C,
+                                               long long ldc, int M, int N, int K, int relu, int splits, float* workspace,
+                                               combo_stream_t stream) {
+  if (!A || !Bimg || !C || M <= 0 || N <= 0 || K <= 0 || K % kBK != 0 || lda % 4 != 0 || ((uintptr_t)A & 15) || ((uintptr_t)Bimg & 15))
+    return COMBO_EINVAL;
+  return nt3_split_launch(A, lda, Bimg, bias, nullptr, nullptr, C, ldc, M, N, K, relu, splits, workspace, nullptr, stream, g_products);
 }
 
 extern "C" int combo_gemm_nt_x3_pre_masked_f32(const float* A, long long lda, const float* Bimg, const float* mask, float* C,

@@ -281,13 +281,14 @@ class MSDeformAttnPixelDecoder(nn.Module):
     def forward_features(self, features):
         """-> (mask_features [BT,mask_dim,H/4,W/4], out[0], multi_scale_features[3]); fp32 like the reference
         (msdeformattn.py:315: autocast disabled, inputs .float())."""
-        from ..ops.linear import forward_precision_scope
+        from ..ops.linear import forward_precision_scope, range_safe
         with torch.autocast(device_type="cuda", enabled=False), forward_precision_scope(PIXEL_DECODER_FPN_FORWARD):
             srcs, pos = [], []
             for idx, f in enumerate(self.transformer_in_features[::-1]):
                 x = features[f].float()
                 proj = self.input_proj[idx]  # Sequential(1x1 conv, GroupNorm): the conv is a token-major GEMM (layers.py)
-                srcs.append(norm_act(conv1x1_or_conv(proj[0], x), proj[1]))
+                with range_safe():  # (x: the backbone's own ReLU feature, not a normalised activation)
+                    srcs.append(norm_act(conv1x1_or_conv(proj[0], x), proj[1]))
                 pos.append(position_embedding_sine(1, x.shape[2], x.shape[3], x.device, self.conv_dim // 2))
             with forward_precision_scope(PIXEL_DECODER_FORWARD):
                 y, spatial_shapes, level_start_index, shapes_list = self.transformer(srcs, pos)
@@ -297,7 +298,8 @@ class MSDeformAttnPixelDecoder(nn.Module):
             out = [lv.transpose(1, 2).reshape(bs, -1, H, W) for lv, (H, W) in zip(y.split([H * W for H, W in shapes_list], 1), shapes_list)]
             for idx, f in enumerate(self.in_features[: self.num_fpn_levels][::-1]):
                 x = features[f].float()
-                cur_fpn = self.lateral_convs[idx](x)
+                with range_safe():
+                    cur_fpn = self.lateral_convs[idx](x)
                 y = upsample_bilinear_add(cur_fpn, out[-1])  # :349-350 cur_fpn + F.interpolate(out[-1]) (one HIP pass for exact 2x)
                 out.append(self.output_convs[idx](y))
             multi_scale_features = out[: self.maskformer_num_feature_levels]

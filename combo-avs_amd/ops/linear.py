@@ -127,17 +127,20 @@ class grouped_presplit:
     the weights whose input-gradient GEMMs will run (expect_input_grad), the first of those GEMMs splits all of them at once."""
 
     def __enter__(self):
-        global _split_images, _fwd_images
+        global _split_images, _fwd_images, _fwd_plan_next, _fwd_plan_flushed
         self.prev, _split_images = (_split_images, _split_pending[:]), {}
-        self.prev_fwd, _fwd_images = _fwd_images, {}
+        self.prev_fwd, _fwd_images = (_fwd_images, _fwd_plan_next, _fwd_plan_flushed), {}
+        _fwd_plan_next, _fwd_plan_flushed = {}, False
         del _split_pending[:]
         return self
 
     def __exit__(self, *exc):
-        global _split_images, _fwd_images
+        global _split_images, _fwd_images, _fwd_plan, _fwd_plan_next, _fwd_plan_flushed
         _split_images = self.prev[0]
         _split_pending[:] = self.prev[1]
-        _fwd_images = self.prev_fwd
+        if exc[0] is None and self.prev_fwd[0] is None:  # the outermost context of a completed step: what it used is the next step's plan
+            _fwd_plan = _fwd_plan_next
+        _fwd_images, _fwd_plan_next, _fwd_plan_flushed = self.prev_fwd
         return False
 
 
@@ -299,6 +302,25 @@ class forward_precision_scope:
         return False
 
 
+class range_safe:
+    """`with range_safe():` - forward GEMMs / convolutions whose operand is NOT a normalised activation (the pixel decoder's input
+    projections and lateral convolutions read the backbones' ReLU features as they come): the fp16 pieces of "f16x3" end at 65 504
+    (hi = inf, lo = x - inf: NaN), so inside the block that mode gives way to the exact fp32 instruction; the other modes (bf16
+    pieces share fp32's range) stay.  tools/probe_f16_range.py: 40 steps at 20 x the learning rate drive res5 to 6.6e4."""
+
+    def __enter__(self):
+        global FORWARD_PRECISION
+        self.prev = FORWARD_PRECISION
+        if FORWARD_PRECISION == "f16x3":
+            FORWARD_PRECISION = "fp32"
+        return self
+
+    def __exit__(self, *exc):
+        global FORWARD_PRECISION
+        FORWARD_PRECISION = self.prev
+        return False
+
+
 def forward_products():
     """`products` argument of the head's forward GEMMs in the current mode (combo_gemm_nt2_products): "bf16": 1; "x3": the 3-product
     split on bf16 pieces; "f16x3": 19 = the same on fp16 pieces"""
@@ -309,6 +331,46 @@ def forward_f16():
     return FORWARD_PRECISION == "f16x3"
 
 
+# Forward images of a step, grouped (round 6).  With the forward GEMMs on the 3-product kernel every forward weight needs its hi / lo
+# image once per step: 117 launches of ~6 us in the S4 step (0.7 ms).  The set of weights is the same every step, so a step REMEMBERS
+# the weights it split (`_fwd_plan`: parameters and views of parameters only - their memory is final when the step starts; a tensor
+# computed during the step, e.g. a concatenated or re-laid-out weight, could be read before it is written) and the next step splits all
+# of them with ONE grouped launch per piece type when the first one is asked for.  Only the weight views are kept from step to step;
+# the images are allocated per step (inside a captured graph: from the graph's pool), so a replayed graph never depends on a buffer
+# the plan owns.  A planned weight that a step does not use costs its split and leaves the plan at the end of that step.
+FORWARD_PLAN = os.environ.get("COMBO_FORWARD_PLAN", "1") == "1"
+_fwd_plan = {}        # (view key, f16) -> weight view: the forward weights of the previous completed step
+_fwd_plan_next = {}   # ... of the step in progress
+_fwd_plan_flushed = False
+
+
+def _plannable(w):
+    base = w._base if w._base is not None else w
+    return isinstance(base, torch.nn.Parameter) and w.dim() == 2 and w.dtype == torch.float32 and w.shape[1] % 8 == 0
+
+
+def _flush_forward_plan():
+    """one grouped pre-split launch per piece type for every weight of the plan -> _fwd_images"""
+    global _fwd_plan_flushed
+    _fwd_plan_flushed = True
+    for f16 in (False, True):
+        todo = [(k, w) for k, w in _fwd_plan.items() if k[1] == f16 and k not in _fwd_images and k[0] == _split_key(w)]
+        if not todo:
+            continue
+        buf = torch.empty(sum(w.shape[0] * w.shape[1] for _, w in todo), device=todo[0][1].device, dtype=torch.float32)
+        pr, off = (_SplitProblem * len(todo))(), 0
+        for i, (k, w) in enumerate(todo):
+            N, K = w.shape
+            img = buf[off:off + N * K].view(N, K)
+            off += N * K
+            pr[i] = _SplitProblem(w.data_ptr(), img.data_ptr(), w.stride(0), w.stride(1), K, N, K)
+            _fwd_images[k] = img
+            _fwd_plan_next[k] = w
+        with split_pieces(f16):
+            _lib.check(_lib.lib().combo_presplit_bf16x2_grouped_f32(ctypes.cast(pr, ctypes.c_void_p), len(todo), _lib.current_stream()),
+                       "combo_presplit_bf16x2_grouped_f32 (forward images)")
+
+
 def forward_image(weight):
     """hi/lo image of a forward weight [N, K] in the current mode's piece type (cached for the step inside grouped_presplit())"""
     f16 = forward_f16()
@@ -316,8 +378,13 @@ def forward_image(weight):
         return presplit(weight, f16)
     key = (_split_key(weight), f16)
     img = _fwd_images.get(key)
+    if img is None and FORWARD_PLAN and not _fwd_plan_flushed and key in _fwd_plan and weight.is_cuda:
+        _flush_forward_plan()
+        img = _fwd_images.get(key)
     if img is None:
         img = _fwd_images[key] = presplit(weight, f16)
+        if FORWARD_PLAN and _plannable(weight):
+            _fwd_plan_next[key] = weight.detach()
     return img
 
 
@@ -330,15 +397,27 @@ def gemm_nt_bf16(a, w, bias=None, relu=False, out=None, img=None):
     if img is None:
         img = forward_image(w)
     lib, st = _lib.lib(), _lib.current_stream()
+    # a long reduction with few output tiles (the decoder FFN's linear2: 4000 x 2048 -> 256; the res5 / res4 input projections): K slices
+    # as the batch entries of one launch + the fixed-order finishing sum, as the exact path and the gradient GEMMs do
+    splits = lib.combo_gemm_nt_x3_splitk_plan(M, N, K) if (FORWARD_SPLITK and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0
+                                                           and (bias is None or bias.data_ptr() % 16 == 0)) else 1
+    ws = torch.empty(splits, M, N, device=a.device, dtype=torch.float32) if splits > 1 else None
     prev = lib.combo_gemm_nt2_products(forward_products())
     try:
         with _lib.timed("gemm_nt_bf16", (M, N, K)):
-            rc = lib.combo_gemm_nt_x3_pre_f32(a.data_ptr(), a.stride(0), img.data_ptr(), _lib.ptr(bias), out.data_ptr(), out.stride(0),
-                                              M, N, K, 1 if relu else 0, st)
+            if splits > 1:
+                rc = lib.combo_gemm_nt_x3_pre_splitk_f32(a.data_ptr(), a.stride(0), img.data_ptr(), _lib.ptr(bias), out.data_ptr(), out.stride(0),
+                                                         M, N, K, 1 if relu else 0, splits, ws.data_ptr(), st)
+            else:
+                rc = lib.combo_gemm_nt_x3_pre_f32(a.data_ptr(), a.stride(0), img.data_ptr(), _lib.ptr(bias), out.data_ptr(), out.stride(0),
+                                                  M, N, K, 1 if relu else 0, st)
     finally:
         lib.combo_gemm_nt2_products(prev)
-    _lib.check(rc, "combo_gemm_nt_x3_pre_f32 (bf16 mode)")
+    _lib.check(rc, "combo_gemm_nt_x3_pre_f32 (3-product / bf16 forward mode)")
     return out
+
+
+FORWARD_SPLITK = os.environ.get("COMBO_FORWARD_SPLITK", "1") == "1"  # (tools/ab_const.py flips it for the A/B)
 
 
 def _bf16_ok(x2d, weight, out):

@@ -384,6 +384,10 @@ int combo_presplit_bf16x2_f32(const float* src, long long ld_row, long long ld_c
                               combo_stream_t stream);
 int combo_gemm_nt_x3_pre_f32(const float* A, long long lda, const float* Bimg, const float* bias, float* C, long long ldc,
                              int M, int N, int K, int relu, combo_stream_t stream);
+/*   ... with split-K (splits from combo_gemm_nt_x3_splitk_plan; workspace [splits, M, N]): long reductions with few output tiles in the
+ *   3-product forward modes (the decoder FFN's linear2, transformer_decoder.py:178-182; the res5 / res4 input projections) */
+int combo_gemm_nt_x3_pre_splitk_f32(const float* A, long long lda, const float* Bimg, const float* bias, float* C, long long ldc,
+                                    int M, int N, int K, int relu, int splits, float* workspace, combo_stream_t stream);
 /*   combo_gemm_nt_x3_pre_f32 with the ReLU backward of the consumer folded into the epilogue: C = mask > 0 ? A.B^T : 0,
  *   mask of the shape and row pitch of C.  The input-gradient GEMM of an FFN's second layer, dH = (dY . W2) o [H > 0]
  *   (pixel_decoder/msdeformattn.py:125-134, transformer_decoder.py:178-182): the ReLU-gradient pass over the 1024- /
