@@ -795,10 +795,15 @@ def main():
         north["matrix_kernels"] = {"useful_tflop_per_step": round(w / max(st_n, 1) / 1e12, 3), "ms_per_step": round(us / max(st_n, 1) / 1e3, 3),
                                    "useful_tflops": round(w / (us * 1e-6) / 1e12, 1), "frac_of_bf16_peak": round(w / (us * 1e-6) / 2500e12, 4),
                                    "families": sorted(KINDS[k][0] for k, _ in mk)}
-    north["why_below_target"] = ("the 1e-3 bound on mask logits (and the attention-mask thresholds behind them) holds the head's forward to "
-                                 "exact fp32 (v_mfma_f32: 157 TFLOP/s peak = 6.3 % of the bf16 peak) and the gradients to 3 bf16 products per "
-                                 "multiply-add (ceiling 833 TFLOP/s useful = 33 %); most launches are K = 64 .. 256 layers whose roofline is "
-                                 "HBM, not the matrix pipe (frac_of_binding_roofline per family)")
+    north["why_below_target"] = (("the 1e-3 bound on mask logits (and the attention-mask thresholds behind them) needs fp32-grade products: every "
+                                  "GEMM of the step - forward (fp16 pieces, round 6) and gradients (bf16 pieces) - issues 3 matrix products per "
+                                  "multiply-add (ceiling 833 TFLOP/s useful = 33 % of the bf16 peak); attention and the fused mask bits stay on "
+                                  "v_mfma_f32 (157 TFLOP/s = 6.3 %); " if args.head_dtype == "f16x3" else
+                                  "the 1e-3 bound on mask logits (and the attention-mask thresholds behind them) holds the head's forward to "
+                                  "exact fp32 (v_mfma_f32: 157 TFLOP/s peak = 6.3 % of the bf16 peak) and the gradients to 3 bf16 products per "
+                                  "multiply-add (ceiling 833 TFLOP/s useful = 33 %); ")
+                                 + "most launches are K = 64 .. 256 layers whose roofline is HBM, not the matrix pipe "
+                                   "(frac_of_binding_roofline per family)")
     roof = rooflines[0] if rooflines else None
     kernels = {r["kernel"]: r for r in rooflines[1:]}
     if args.no_graph and kt.get("fwd_us"):  # eager run: HIP events on the launch stream around the MSDeformAttn core

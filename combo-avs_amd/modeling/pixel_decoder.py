@@ -24,14 +24,12 @@ from ..ops.upsample import upsample_bilinear, upsample_bilinear_add  # noqa: F40
 from .layers import conv1x1_or_conv, norm_act, Conv2d, c2_xavier_fill, get_norm, position_embedding_sine
 
 
-# Arithmetic of the pixel decoder's forward GEMMs / convolutions (input projections, the 6 deformable encoder layers' linears, the
-# FPN lateral / output convolutions, the mask-feature projection): "fp32" = the exact fp32 matrix instruction (csrc/gemm_f32.hip),
-# "x3" = the fp32-grade 3-product bf16 split on csrc/gemm_nt3.hip (what the fp32 backbones' forward convolutions and every gradient
-# GEMM use).  Everything behind the pixel decoder - the masked transformer decoder, the mask-logit contraction, the thresholded
-# attention masks - keeps the exact instruction in both settings.  Environment: COMBO_PD_FORWARD.
-import os as _os
-PIXEL_DECODER_FORWARD = _os.environ.get("COMBO_PD_FORWARD", "fp32")          # the deformable transformer encoder's linears
-PIXEL_DECODER_FPN_FORWARD = _os.environ.get("COMBO_PD_FPN_FORWARD", "fp32")  # input projections, FPN lateral / output convolutions, mask features
+# Finer-grained arithmetic switches of the pixel decoder's forward GEMMs / convolutions than the head-wide ops.linear.FORWARD_PRECISION
+# (ops.linear.forward_precision_scope: a scope can only move towards the cheaper mode): the deformable transformer encoder's linears, and
+# the input projections / FPN lateral + output convolutions / mask-feature projection.  "fp32" = no effect.  tools/probe_flip_luck.py sets
+# them to show how the count of flipped attention-mask cells moves with the arithmetic of single groups of layers.
+PIXEL_DECODER_FORWARD = "fp32"
+PIXEL_DECODER_FPN_FORWARD = "fp32"
 
 
 def _deferred_layer_norm(dim):

@@ -338,7 +338,7 @@ def forward_f16():
 # of them with ONE grouped launch per piece type when the first one is asked for.  Only the weight views are kept from step to step;
 # the images are allocated per step (inside a captured graph: from the graph's pool), so a replayed graph never depends on a buffer
 # the plan owns.  A planned weight that a step does not use costs its split and leaves the plan at the end of that step.
-FORWARD_PLAN = os.environ.get("COMBO_FORWARD_PLAN", "1") == "1"
+FORWARD_PLAN = True  # (tools/ab_const.py flips it for the A/B)
 _fwd_plan = {}        # (view key, f16) -> weight view: the forward weights of the previous completed step
 _fwd_plan_next = {}   # ... of the step in progress
 _fwd_plan_flushed = False
@@ -417,7 +417,7 @@ def gemm_nt_bf16(a, w, bias=None, relu=False, out=None, img=None):
     return out
 
 
-FORWARD_SPLITK = os.environ.get("COMBO_FORWARD_SPLITK", "1") == "1"  # (tools/ab_const.py flips it for the A/B)
+FORWARD_SPLITK = True  # (tools/ab_const.py flips it for the A/B)
 
 
 def _bf16_ok(x2d, weight, out):

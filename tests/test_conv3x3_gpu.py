@@ -53,6 +53,8 @@ def test_conv2d_wrapper_routes_3x3_to_the_hip_kernels():
     _lib.start_timing()
     y = conv(x)
     timed = _lib.stop_timing()
-    assert len(timed.get("conv3x3_f32", [])) == 1, timed  # the launch went through csrc/gemm_f32.hip (CONV), not MIOpen
+    # the launch went through the package's implicit GEMM - csrc/gemm_nt3.hip (CONV, the default 3 x fp16-piece forward mode) or
+    # csrc/gemm_f32.hip (CONV, `--head-dtype fp32`) - not MIOpen
+    assert len(timed.get("conv3x3_f32", [])) + len(timed.get("conv3x3_bf16", [])) == 1, timed
     ref = F.conv2d(x.double().cpu(), conv.weight.detach().double().cpu(), padding=1)
     assert rel_err(y, ref) < 1e-6  # forward = exact fp32 MFMA

@@ -655,12 +655,23 @@ def test_mask_logits_of_all_heads_in_one_launch_equal_per_head_launches():
     heads, BT, Q, HW, C = 10, 5, 100, 3136, 256
     mes = [torch.randn(BT, Q, C, device="cuda") for _ in range(heads)]
     mf = torch.randn(BT, HW, C, device="cuda")
+    from combo_avs_amd.ops import linear as L
     allb = torch.empty(heads, BT, Q, HW, device="cuda")
-    masklogit.mask_logits_all_into(mes, mf, allb)
+    L.set_forward_precision("fp32")  # the exact path (`--head-dtype fp32`): ONE launch of csrc/gemm_f32.hip for all heads
+    try:
+        masklogit.mask_logits_all_into(mes, mf, allb)
+    finally:
+        L.set_forward_precision(L.DEFAULT_FORWARD_PRECISION)
     one = torch.empty(BT, Q, HW, device="cuda")
     for h in range(heads):
         masklogit.mask_logits_into(mes[h], mf, one)
         assert torch.equal(one, allb[h])  # the same kernel, the same k order: bit for bit
+    # the default forward mode (3 fp16-piece products on csrc/gemm_nt3.hip, per head): the same values to fp32 round-off
+    dflt = torch.empty(heads, BT, Q, HW, device="cuda")
+    masklogit.mask_logits_all_into(mes, mf, dflt)
+    assert float((dflt - allb).norm() / allb.norm()) < 1e-6
+    ref = torch.stack([m.double() @ mf.double().transpose(1, 2) for m in mes])
+    assert float((dflt.double() - ref).norm() / ref.norm()) <= 1.5 * float((allb.double() - ref).norm() / ref.norm())
 
 
 # ---- channel sums (csrc/colsum.hip): the bias / level-embedding gradients that must not go through ATen's split reduction ----
