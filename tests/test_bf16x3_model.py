@@ -2,7 +2,8 @@
 operand is split into hi = round_to_nearest_bf16(x) and lo = round_to_nearest_bf16(x - hi), and a product x*w is the sum of
 the three bf16 products hi*hi + hi*lo + lo*hi accumulated in fp32 (the MFMA accumulator).  Pins the error model DESIGN.md
 quotes (operands exact to 2^-17, a single product to 2^-15.5 worst case, ~4e-6 on a K = 256 dot product: ~3x better than
-round 1's truncated `hi`, still ~15x fp32 - which is why the FORWARD GEMMs run on the exact fp32 MFMA instead) and the
+round 1's truncated `hi`, still ~15x fp32 - which is why the FORWARD GEMMs do not use this split: exact fp32 MFMA until round 5, three
+products on fp16 pieces since round 6, tests/test_f16x3_model.py) and the
 pre-split image layout of combo_presplit_bf16x2_f32 (per 8 k a 16-byte hi group followed by a 16-byte lo group)."""
 import numpy as np
 
@@ -65,7 +66,7 @@ def test_dot_products_land_between_fp32_and_plain_bf16():
     e16 = np.linalg.norm(rne_bf16(a).astype(np.float64) @ rne_bf16(w).astype(np.float64).T - ref) / np.linalg.norm(ref)
     assert e3 < 1e-5      # what tests/test_gemm_gpu.py demands of the kernels
     assert e3 < e16 / 100  # two orders of magnitude better than one bf16 product
-    assert e32 < e3 / 5    # and not fp32: the reason every forward GEMM runs on the exact fp32 MFMA kernel
+    assert e32 < e3 / 5    # and not fp32: the reason no forward GEMM runs on bf16 pieces
 
 
 def test_presplit_image_layout():
