@@ -263,6 +263,8 @@ _fwd_images = None  # {weight view key: bf16 hi/lo image [N, K]} of the current 
 # (error ~2^-22 |x.w| per term against 2^-16 for "x3") at the same matrix-pipe cost; needs |x| < 65 504: forward activations and
 # weights of the normalised head, never gradients.
 FORWARD_MODES = ("fp32", "f16x3", "x3", "bf16")  # from exact to cheap
+if DEFAULT_FORWARD_PRECISION not in FORWARD_MODES:
+    raise ValueError(f"COMBO_HEAD_FORWARD={DEFAULT_FORWARD_PRECISION!r}: one of {FORWARD_MODES} expected")
 
 
 def set_forward_precision(mode):
