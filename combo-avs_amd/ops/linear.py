@@ -346,6 +346,12 @@ _fwd_plan_next = {}   # ... of the step in progress
 _fwd_plan_flushed = False
 
 
+def reset_forward_plan():
+    """forget the forward weights of the previous step (the plan holds views of the parameters: call it when a model is dropped)"""
+    global _fwd_plan
+    _fwd_plan = {}
+
+
 def _plannable(w):
     base = w._base if w._base is not None else w
     return isinstance(base, torch.nn.Parameter) and w.dim() == 2 and w.dtype == torch.float32 and w.shape[1] % 8 == 0
@@ -355,8 +361,10 @@ def _flush_forward_plan():
     """one grouped pre-split launch per piece type for every weight of the plan -> _fwd_images"""
     global _fwd_plan_flushed
     _fwd_plan_flushed = True
+    dev = torch.cuda.current_device()
     for f16 in (False, True):
-        todo = [(k, w) for k, w in _fwd_plan.items() if k[1] == f16 and k not in _fwd_images and k[0] == _split_key(w)]
+        todo = [(k, w) for k, w in _fwd_plan.items()
+                if k[1] == f16 and k not in _fwd_images and k[0] == _split_key(w) and w.is_cuda and w.device.index == dev]
         if not todo:
             continue
         buf = torch.empty(sum(w.shape[0] * w.shape[1] for _, w in todo), device=todo[0][1].device, dtype=torch.float32)
