@@ -94,6 +94,7 @@ _SIGNATURES = {
     "combo_gemm_nt2_products": [c_int],
     "combo_presplit_pieces": [c_int],
     "combo_gemm_nt_x3_tile": [c_int],
+    "combo_gemm_nt_x3_prof_buffer": [c_void_p],
     "combo_gemm_nt_x3_splitk_plan": [c_int, c_int, c_int],
     "combo_gemm_nt_x3_splitk_f32": [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "combo_gemm_nt_splitk_plan": [c_int, c_int, c_int],

@@ -154,11 +154,12 @@ struct N3Args {
   long long sA, sB, sC;
   combo_nt3_conv cg;
   unsigned long long* ts;
+  unsigned long long* prof;         // ABL bit 128: per (workgroup, wave) cycle sums of the stage's three segments (tools/prof_nt3_stage.py)
 };
 
 // P3: three products (fp32-accurate) or one (plain bf16); ABL: ablation bits, COMPILE-TIME (a run-time test per bit costs a scalar
 // branch per use, ~1 000 cycles per stage in total - more than the stage itself): 1 no DMA, 2 no LDS reads, 4 no barrier, 8 no
-// stores, 16 no split, 32 no MFMA; the instances listed in launch_cfg3 exist (COMBO_NT3_DBG, tools/bench_nt3.py)
+// stores, 16 no split, 32 no MFMA, 128 (not an ablation: per-segment cycle stamps of every stage); the instances listed in launch_cfg3 exist (COMBO_NT3_DBG, tools/bench_nt3.py)
 template <bool CONV, typename Cfg, bool P3, int ABL, bool AUX, bool F16 = false>
 __global__ void __launch_bounds__(Cfg::NW * 64, Cfg::NW / 4)
 gemm_nt3_kernel(const N3Args p) {
@@ -537,12 +538,27 @@ gemm_nt3_kernel(const N3Args p) {
   // PAR: which register set holds this stage's operands (the next stage's go to set PAR ^ 1).  first: first stage of a tile (the
   // hi.hi products start the accumulators from zero).  `relaxed`: the epilogue stores of the previous tile may still be in
   // flight behind the ring loads we wait for.
+  // ABL bit 128 (tools/prof_nt3_stage.py): s_memtime at three points of every stage - top (before the counted wait), behind the barrier, behind
+  // phase 0's wait; a mark CONSUMES the time stamp issued at the previous mark (long landed: no wait) and issues its own, so the stamps never
+  // stall the LDS / scalar-memory counter the kernel's own waits count on.  seg[0] = wait + barrier, seg[1] = phase 0, seg[2] = phase 1.
+  unsigned long long prof_seg[3] = {0ull, 0ull, 0ull}, prof_base = 0ull, prof_pend = 0ull;
+  if constexpr ((ABL & 128) != 0) prof_base = prof_pend = __builtin_amdgcn_s_memtime();  // (the first two marks then add the prologue's time once: 1 / stages)
+  auto prof_mark = [&](auto k_tag) __attribute__((always_inline)) {
+    if constexpr ((ABL & 128) != 0) {
+      constexpr int k = decltype(k_tag)::value;
+      const unsigned long long t = prof_pend;
+      prof_seg[(k + 1) % 3] += t - prof_base;
+      prof_base = t;
+      prof_pend = __builtin_amdgcn_s_memtime();
+    }
+  };
   constexpr int kYoung = (ST - 3) * PPW;
   constexpr bool p3 = P3;
   int c_slot = 0;  // ring slot of the stage being computed
   auto stage = [&](auto par_tag, bool first, bool relaxed, bool auxw) __attribute__((always_inline)) {
     constexpr int PAR = decltype(par_tag)::value;
     const int n_slot = c_slot == ST - 1 ? 0 : c_slot + 1;
+    prof_mark(std::integral_constant<int, 0>{});
     // stage s + 1 (a real one or a dummy of the stream's tail - nothing below needs to know) has landed once all but the ST - 3
     // younger stages (and, right after a tile boundary, the previous tile's stores, which are younger than every load waited
     // for here) are done
@@ -552,6 +568,7 @@ gemm_nt3_kernel(const N3Args p) {
     else if (auxw) wait_vm<kYoung + AUXN>();
     else wait_vm<kYoung>();
     if (!(dbg & 4)) __builtin_amdgcn_s_barrier();
+    prof_mark(std::integral_constant<int, 1>{});
     // ---- phase 0: B lo of this stage + raw A of the next -> registers; hi.hi and lo.hi products; the ring refill in between
     read_b(bl, b_lo + (unsigned)(c_slot * STAGE));
     read_a((unsigned)(n_slot * STAGE));
@@ -592,6 +609,7 @@ gemm_nt3_kernel(const N3Args p) {
       for (int u = (NM0 - 1) / STRIDE + 1; u <= PPW; ++u) issue_u(u);
     }
     wait_ab(bl);
+    prof_mark(std::integral_constant<int, 2>{});
     // ---- phase 1: B hi of the next stage -> the other register set; hi.lo products; the next stage's A split in between
     read_b(bh[PAR ^ 1], b_hi + (unsigned)(n_slot * STAGE));
     __builtin_amdgcn_sched_barrier(0);
@@ -658,6 +676,12 @@ gemm_nt3_kernel(const N3Args p) {
     epilogue(ec);
   }
   wait_vm<0>();  // the dummy stages of the stream's tail are still landing: no LDS-DMA may outlive its workgroup's LDS allocation
+  if constexpr ((ABL & 128) != 0) {
+    if (p.prof && lane == 0) {
+      unsigned long long* o = p.prof + ((long long)blockIdx.x * NW + wave) * 4;
+      o[0] = prof_seg[0]; o[1] = prof_seg[1]; o[2] = prof_seg[2]; o[3] = (unsigned long long)my_tiles * nst;
+    }
+  }
   combo_ts_end(p.ts);
 }
 
@@ -672,6 +696,8 @@ int n_cu_cached3() {
   const int lim = combo_cu_limit();  // (abi.hip: a caller running two launch chains side by side hands each a share of the CUs)
   return lim > 0 && lim < n_cu ? lim : n_cu;
 }
+
+unsigned long long* g_prof3 = nullptr;  // combo_gemm_nt_x3_prof_buffer
 
 int dbg_bits3() {
   static const int d = [] { const char* e = getenv("COMBO_NT3_DBG"); return e ? atoi(e) : 0; }();
@@ -720,6 +746,7 @@ int launch_cfg3(N3Args a, hipStream_t stream) {
         case 32: return launch_inst3<CONV, Cfg, true, 32>(a, grid, stream);
         case 41: return launch_inst3<CONV, Cfg, true, 41>(a, grid, stream);
         case 63: return launch_inst3<CONV, Cfg, true, 63>(a, grid, stream);
+        case 128: return launch_inst3<CONV, Cfg, true, 128>(a, grid, stream);
         default: break;
       }
     }
@@ -793,6 +820,13 @@ extern "C" int combo_gemm_nt_x3_tile(int cfg) {
   return prev;
 }
 
+/* COMBO_NT3_DBG=128 (the instrumented instance of the 8-wave tile): where the launches that follow write, per (workgroup, wave), the cycle sums
+ * of a stage's three segments + the stage count (4 x u64 each; 256 workgroups x 8 waves); NULL = off.  tools/prof_nt3_stage.py */
+extern "C" int combo_gemm_nt_x3_prof_buffer(unsigned long long* buf) {
+  g_prof3 = buf;
+  return 0;
+}
+
 int combo_nt3_launch(const float* A, long long lda, const float* Bimg, long long ldb, const float* bias, const float* mask, float* C,
                      long long ldc, long long M, int N, int K, int relu, int products, int batch, long long sA, long long sB,
                      long long sC, const combo_nt3_conv* conv, int force_cfg, combo_stream_t stream, const float* add) {
@@ -805,7 +839,7 @@ int combo_nt3_launch(const float* A, long long lda, const float* Bimg, long long
   if (f16) products = 3;
   const int vec = (N % 4 == 0 && ldc % 4 == 0 && sC % 4 == 0 && !((uintptr_t)C & 15) && (!mask || !((uintptr_t)mask & 15)) && (!add || !((uintptr_t)add & 15))) ? 1 : 0;
   N3Args a{A, lda, Bimg, ldb, bias, mask, add, C, ldc, (int)M, N, K, relu, (int)(((M - 1) * ldc + N) * 4), batch, vec, dbg_bits3(), products,
-           f16, unscale, sA, sB, sC, conv ? *conv : combo_nt3_conv{1, 1, K, 0, 1, 1}, nullptr};
+           f16, unscale, sA, sB, sC, conv ? *conv : combo_nt3_conv{1, 1, K, 0, 1, 1}, nullptr, g_prof3};
   if (force_cfg) return conv ? launch_one3<true>(a, (hipStream_t)stream, force_cfg) : launch_one3<false>(a, (hipStream_t)stream, force_cfg);
   return conv ? launch_nt3<true>(a, (hipStream_t)stream) : launch_nt3<false>(a, (hipStream_t)stream);
 }

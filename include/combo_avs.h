@@ -331,6 +331,7 @@ int combo_gemm_nt_x3_splitk_plan(int M, int N, int K);  /* K slices of a few-til
 int combo_gemm_nt_x3_splitk_f32(const float* A, long long lda, const float* Bimg, const float* mask, float* C, long long ldc,
                                 int M, int N, int K, int splits, float* workspace /* [splits, M, N] */, combo_stream_t stream);
 int combo_gemm_nt_x3_tile(int cfg);  /* 0 planner (default), 1 / 2 / 3 / 4: force 256x128 / 128x128 / 64x64 / 256x64 tiles (tests, tools); returns the previous value */
+int combo_gemm_nt_x3_prof_buffer(unsigned long long* buf); /* COMBO_NT3_DBG=128: device buffer (256 x 8 x 4 u64) for the per-wave cycle sums of a stage's segments (wait + barrier | phase 0 | phase 1 | stages); NULL = off (tools/prof_nt3_stage.py) */
 int combo_gemm_nt_splitk_plan(int M, int N, int K);
 int combo_gemm_nt_splitk_f32(const float* A, long long lda, const float* B, long long ldb, const float* bias, float* C,
                              long long ldc, int M, int N, int K, int relu, int splits, float* workspace, combo_stream_t stream);
