@@ -1,4 +1,5 @@
-"""GPU parity of the head's dense-layer kernels against float64 references: the exact-fp32 MFMA forward GEMM
+"""GPU parity of the head's dense-layer kernels against float64 references (the fp16-piece forward mode has its own file,
+tests/test_f16x3_gpu.py; `ops.linear.linear` below runs in the process's default forward mode): the exact-fp32 MFMA forward GEMM
 (csrc/gemm_f32.hip; must sit in fp32's own error class, not the bf16 split's), the 3-product bf16 input-gradient GEMM
 (csrc/gemm_nt3.hip) and weight-gradient GEMM (csrc/gemm_tn.hip): ragged M/N, strided operands, batched form, deferred /
 grouped weight gradients."""
@@ -29,7 +30,8 @@ def _t(fn, n=10):
                                           (1028, 256, 288, False), (31360, 256, 256, False), (516, 2048, 256, True),
                                           (40, 128, 4096, True), (4000, 256, 3, False)])
 def test_linear_forward_backward_vs_fp64(M, K, N, relu):
-    """ops.linear.linear: forward on the exact-fp32 MFMA kernel (error of fp32's own class: compared with the library's
+    """ops.linear.linear: forward at fp32 grade - the default fp16-piece products or, with COMBO_HEAD_FORWARD=fp32, the exact-fp32 MFMA
+    kernel (error of fp32's own class either way: compared with the library's
     fp32 GEMM on the same data), dX / dW / db on the 3-product bf16 kernels (2e-5)."""
     import combo_avs_amd  # noqa: F401
     from combo_avs_amd.ops.linear import linear

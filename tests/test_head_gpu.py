@@ -48,7 +48,9 @@ def test_decoder_outputs_match_reference(head_run):
     """BASELINE.json north_star: mask logits within 1e-3 rel (fp32) of the reference - checked at the stated bound on the
     PRODUCT DEFAULT path, no outlier budget: every sampled mask logit of all 10 prediction heads within
     1e-3 * RMS(head) + 1e-3 * |ref| (the logits have RMS ~5; near-zero entries are judged against the head's scale).
-    Forward dense layers run in exact fp32 (csrc/gemm_f32.hip), so attention-mask cells flip only where fp32 round-off
+    Forward dense layers run at fp32 grade (since round 6: three fp16-piece MFMA products per fp32 product, csrc/gemm_nt3.hip F16 - against
+    float64 no more error than the exact instruction of csrc/gemm_f32.hip, which `COMBO_HEAD_FORWARD=fp32` selects; this test passes with
+    either), so attention-mask cells flip only where fp32 round-off
     itself straddles 0 (transformer_decoder.py:493-509)."""
     z, head, feats, audio, out = head_run
     logits = [a["pred_logits"] for a in out["aux_outputs"]] + [out["pred_logits"]]
@@ -418,7 +420,7 @@ def test_fused_criterion_path_equals_unfused(head_run, mode):
 def test_x3_forward_mode_stated_tolerance():
     """The head's 3-product forward mode (ops.linear.set_forward_precision("x3"), bench.py --head-dtype x3): the forward GEMMs /
     convolutions / mask-logit contraction of the head on csrc/gemm_nt3.hip with the fp32-grade 3-product bf16 split (max error
-    ~5e-6 per layer) instead of the exact fp32 matrix instruction.  NOT the default: a cell of a decoder attention mask whose
+    ~5e-6 per layer) instead of an fp32-grade product (the default fp16 pieces or the exact fp32 matrix instruction).  NOT the default: a cell of a decoder attention mask whose
     logit lies within that error of 0 flips and re-routes its query for the rest of the decoder - the north-star bound then holds
     for all but a few entries instead of for all of them (the default path: 0 outliers).  Stated tolerance against the
     reference's fp32 outputs (golden head.npz):

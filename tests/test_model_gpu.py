@@ -94,7 +94,7 @@ def test_training_forward_bs8_matches_cpu_oracle(setup):
 @pytest.mark.parametrize("clips,seed", [(1, 3), (8, 13)])
 def test_mask_logits_of_the_whole_model_match_the_cpu_oracle(setup, clips, seed):
     """The north-star sentence, end to end: `pred_masks` of ALL 10 prediction heads out of `model(batch)` - the product's DEFAULT
-    path: 3-product R50 / VGGish backbones, SEM mix, HIP pixel decoder, bilateral fusion, exact-fp32 masked decoder - against the
+    path: 3-product R50 / VGGish backbones, SEM mix, HIP pixel decoder, bilateral fusion, fp32-grade masked decoder (fp16-piece products by default, tests/test_f16x3_gpu.py) - against the
     CPU oracle's `maskformer_forward` on identical weights and inputs, at BT = 5 (BASELINE configs[0]) and BT = 40 (configs[1]):
     EVERY mask logit within 1e-3 * RMS(head) + 1e-3 * |ref| (no outlier budget), class logits likewise.  The oracle's attention-mask
     bits are injected (a logit within round-off of 0 would otherwise re-route its query for the rest of the decoder: the chaotic
